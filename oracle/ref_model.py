@@ -1,0 +1,244 @@
+"""Oracle: CPU (PyTorch fp32) restatement of the DynaMask mask-head path.
+
+TEST INFRASTRUCTURE ONLY -- never imported by the product (dynamask_amd/).
+
+Every function is a functional restatement over a plain ``state_dict`` (same
+key names as the reference modules) and cites the reference
+lines it follows.  Pinned against golden vectors produced by the reference's
+own modules: tests/golden/make_golden.py, tests/test_oracle_golden.py.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import ref_ops
+
+STAGE_SUP_SIZE = (14, 28, 56, 112)
+
+
+# ----------------------------------------------------------------- mask head
+def sfm_stage(sd, pre, instance_feats, semantic_feat, rois, roi_labels, out_size,
+              spatial_scale, upsample=True):
+    """SFMStage.forward -- mask_heads/dynamask_head.py:102-125."""
+    sem = F.relu(F.conv2d(semantic_feat, sd[pre + 'semantic_transform_in.weight'],
+                          sd[pre + 'semantic_transform_in.bias']))
+    ins_sem = ref_ops.simple_roi_align(sem, rois, out_size, spatial_scale)
+    n = rois.shape[0]
+    ar = torch.arange(n)
+    ip = F.conv2d(instance_feats, sd[pre + 'instance_logits.weight'],
+                  sd[pre + 'instance_logits.bias'])[ar, roi_labels][:, None]
+    dp = F.conv2d(instance_feats, sd[pre + 'detail_logits.weight'],
+                  sd[pre + 'detail_logits.bias'])[ar, roi_labels][:, None]
+    fused = torch.cat([instance_feats, ins_sem, ip.sigmoid(), dp.sigmoid()], dim=1)
+    fused = F.relu(F.conv2d(fused, sd[pre + 'fuse_conv.0.weight'], sd[pre + 'fuse_conv.0.bias']))
+    fused = F.relu(ref_ops.deform_conv_pack(
+        fused, sd[pre + 'fuse_conv.1.weight'], sd[pre + 'fuse_conv.1.conv_offset.weight'],
+        sd[pre + 'fuse_conv.1.conv_offset.bias'], deform_groups=2))
+    fused = F.relu(F.conv2d(fused, sd[pre + 'fuse_transform_out.weight'],
+                            sd[pre + 'fuse_transform_out.bias']))
+    fused = torch.cat([fused, ip.sigmoid(), dp.sigmoid()], dim=1)
+    if upsample:
+        fused = F.relu(F.interpolate(fused, scale_factor=2, mode='bilinear', align_corners=False))
+    return ip, dp, fused
+
+
+def dynamask_head_forward(sd, instance_feats, semantic_feats, rois, roi_labels, pre='',
+                          num_convs_instance=2, stage_sup_size=STAGE_SUP_SIZE,
+                          semantic_out_stride=(16, 8, 4), stage_num_classes=(80, 80, 80, 1),
+                          pre_upsample_last_stage=False):
+    """DynaMaskHead.forward -- mask_heads/dynamask_head.py:220-244.
+
+    Quirk Q1: every stage samples with
+    spatial_scale = 1/semantic_out_stride[-1] (dynamask_head.py:192).
+    """
+    x = instance_feats
+    for i in range(num_convs_instance):
+        x = F.relu(F.conv2d(x, sd[f'{pre}instance_convs.{i}.conv.weight'],
+                            sd[f'{pre}instance_convs.{i}.conv.bias'], padding=1))
+    ips, dps = [], []
+    nst = len(stage_sup_size) - 1
+    scale = 1.0 / semantic_out_stride[-1]
+    for idx in range(nst):
+        up = pre_upsample_last_stage or idx < nst - 1
+        ip, dp, x = sfm_stage(sd, f'{pre}stages.{idx}.', x, semantic_feats[-idx - 3], rois,
+                              roi_labels, stage_sup_size[idx], scale, up)
+        ips.append(ip)
+        dps.append(dp)
+    if stage_num_classes[-1] == 1:
+        roi_labels = roi_labels.clamp(max=0)
+    ar = torch.arange(rois.shape[0])
+    ip = F.conv2d(x, sd[pre + 'final_instance_logits.weight'],
+                  sd[pre + 'final_instance_logits.bias'])[ar, roi_labels][:, None]
+    dp = F.conv2d(x, sd[pre + 'final_detail_logits.weight'],
+                  sd[pre + 'final_detail_logits.bias'])[ar, roi_labels][:, None]
+    if not pre_upsample_last_stage:
+        ip = F.interpolate(ip, scale_factor=2, mode='bilinear', align_corners=True)
+        dp = F.interpolate(dp, scale_factor=2, mode='bilinear', align_corners=True)
+    ips.append(ip)
+    dps.append(dp)
+    return ips, dps
+
+
+def mask_forward(sd, fpn_feats, rois, roi_labels, pre='mask_head.',
+                 featmap_strides=(4, 8, 16, 32), **kw):
+    """DynaMaskRoIHead._mask_forward -- roi_heads/dynamask_roi_head.py:75-81."""
+    ins = ref_ops.single_roi_extractor(list(fpn_feats[:len(featmap_strides)]), rois, 14,
+                                       featmap_strides)
+    return dynamask_head_forward(sd, ins, fpn_feats, rois, roi_labels, pre=pre, **kw)
+
+
+def fcn_mask_head_forward(sd, x, pre='', num_convs=4, upsample='deconv', scale=2, carafe_cfg=None):
+    """FCNMaskHead.forward -- mask_heads/fcn_mask_head.py:117-126."""
+    for i in range(num_convs):
+        x = F.relu(F.conv2d(x, sd[f'{pre}convs.{i}.conv.weight'], sd[f'{pre}convs.{i}.conv.bias'],
+                            padding=1))
+    if upsample == 'deconv':
+        x = F.relu(F.conv_transpose2d(x, sd[pre + 'upsample.weight'], sd[pre + 'upsample.bias'],
+                                      stride=scale))
+    elif upsample == 'carafe':
+        cfg = dict(up_kernel=5, up_group=1, encoder_kernel=3, encoder_dilation=1)
+        cfg.update(carafe_cfg or {})
+        x = ref_ops.carafe_pack(x, sd[pre + 'upsample.channel_compressor.weight'],
+                                sd[pre + 'upsample.channel_compressor.bias'],
+                                sd[pre + 'upsample.content_encoder.weight'],
+                                sd[pre + 'upsample.content_encoder.bias'], scale=scale, **cfg)
+    elif upsample in ('bilinear', 'nearest'):
+        x = F.interpolate(x, scale_factor=scale, mode=upsample,
+                          align_corners=(None if upsample == 'nearest' else False))
+    elif upsample is not None:
+        raise ValueError(upsample)
+    return F.conv2d(x, sd[pre + 'conv_logits.weight'], sd[pre + 'conv_logits.bias'])
+
+
+# ------------------------------------------------- resolution predictor/selector
+def mask_pre(sd, x, pre='mask_predictor.', training=True, eps=1e-5):
+    """MaskPre.forward -- roi_heads/base_roi_head.py:10-27 (BatchNorm in train
+    mode uses the batch statistics of this rank's RoIs: Quirk Q4)."""
+    def bn(t, name):
+        if training:
+            return F.batch_norm(t, None, None, sd[pre + name + '.weight'], sd[pre + name + '.bias'],
+                                True, 0.1, eps)
+        return F.batch_norm(t, sd[pre + name + '.running_mean'], sd[pre + name + '.running_var'],
+                            sd[pre + name + '.weight'], sd[pre + name + '.bias'], False, 0.1, eps)
+    x = F.conv2d(x, sd[pre + 'conv1.weight'], sd[pre + 'conv1.bias'])
+    x = F.max_pool2d(F.relu(bn(x, 'bn1')), stride=2, kernel_size=3, padding=1)
+    x = F.conv2d(x, sd[pre + 'conv2.weight'], sd[pre + 'conv2.bias'], padding=1)
+    x = F.max_pool2d(F.relu(bn(x, 'bn2')), stride=2, kernel_size=3, padding=1)
+    x = x.reshape(x.size(0), 3136)
+    x = F.relu(F.linear(x, sd[pre + 'fc1.weight'], sd[pre + 'fc1.bias']))
+    return F.linear(x, sd[pre + 'fc2.weight'], sd[pre + 'fc2.bias'])
+
+
+def gumbel_select(logits, U, temperature=0.5, eps=1e-20):
+    """ST-Gumbel-softmax (hard) -- roi_heads/dynamask_roi_head.py:84-114.
+    U is the explicit uniform noise the reference draws with torch.rand (:90).
+    Returns (one_hot_with_soft_grad [N,4], index [N] int64)."""
+    g = -torch.log(-torch.log(U + eps) + eps)
+    y = F.softmax((logits + g) / temperature, dim=-1)
+    _, ind = y.max(dim=-1)
+    y_hard = torch.zeros_like(y).scatter_(1, ind.view(-1, 1), 1)
+    return (y_hard - y).detach() + y, ind
+
+
+# --------------------------------------------------------------------- losses
+def binary_cross_entropy(pred, label):
+    """losses/cross_entropy_loss.py:56-87 (weight=None, reduction='mean')."""
+    return F.binary_cross_entropy_with_logits(pred, label.float(), reduction='none').mean()
+
+
+def mask_cross_entropy(pred, target, class_weight):
+    """losses/cross_entropy_loss.py:90-120 (the fork's eps-BCE form)."""
+    x = torch.sigmoid(pred)
+    eps = 1e-10
+    return -torch.mean((target * torch.log(x + eps) + (1 - target) * torch.log(1 - x + eps)) * class_weight)
+
+
+def detail_target(gtmasks, fuse_kernel=None):
+    """DetailTarget.forward -- losses/cross_entropy_loss.py:363-418."""
+    lap = torch.tensor([-1, -1, -1, -1, 8, -1, -1, -1, -1], dtype=torch.float32).reshape(1, 1, 3, 3)
+    if fuse_kernel is None:
+        fuse_kernel = torch.tensor([[7. / 10], [3. / 10]], dtype=torch.float32).reshape(1, 2, 1, 1)
+    g = gtmasks.unsqueeze(1).float()
+    b = F.conv2d(g, lap, padding=1).clamp(min=0)
+    b = (b > 0.1).float()
+    b2 = F.conv2d(g, lap, stride=2, padding=1).clamp(min=0)
+    b2 = F.interpolate(b2, b.shape[2:], mode='nearest')
+    b2 = (b2 > 0.1).float()
+    pyr = torch.stack((b, b2), dim=1).squeeze(2)
+    out = F.conv2d(pyr, fuse_kernel)
+    return (out > 0.1).float()
+
+
+def generate_block_target(mask_target, boundary_width=3):
+    """losses/cross_entropy_loss.py:123-154 -> int64 {0,1,2}."""
+    mask_target = mask_target.float()
+    k = 2 * boundary_width + 1
+    lap = -torch.ones(1, 1, k, k)
+    lap[0, 0, boundary_width, boundary_width] = k ** 2 - 1
+    pad = F.pad(mask_target.unsqueeze(1), (boundary_width,) * 4, 'constant', 0)
+    pos = F.conv2d(pad, lap).clamp(min=0) / float(k ** 2)
+    pos = (pos > 0.1).float().squeeze(1)
+    neg = F.conv2d(1 - pad, lap).clamp(min=0) / float(k ** 2)
+    neg = (neg > 0.1).float().squeeze(1)
+    block = torch.zeros_like(mask_target).long()
+    block[(pos + neg) > 0] = 1
+    block[(mask_target - pos) > 0] = 2
+    return block
+
+
+def dyna_loss(stage_instance_preds, stage_detail_preds, stage_instance_targets, mask_labels,
+              stage_detail_loss_weight=(0.5, 0.5, 0.5, 0.5), cb_loss_weight=0.8, start_stage=4,
+              fuse_kernel=None):
+    """DynaCrossEntropyLoss.forward -- losses/cross_entropy_loss.py:441-487.
+    Quirk Q2: only the last stage's instance BCE survives (variable is
+    overwritten); stage_instance_loss_weight is only length-checked."""
+    loss_detail_set = []
+    loss_mask = None
+    for idx in range(len(stage_instance_preds)):
+        ip = stage_instance_preds[idx].squeeze(1)
+        it = stage_instance_targets[idx]
+        dp = stage_detail_preds[idx].squeeze(1)
+        dt = detail_target(it, fuse_kernel).squeeze(1)
+        if idx <= start_stage:
+            loss_mask = binary_cross_entropy(ip, it)
+            ld = mask_cross_entropy(dp, dt, mask_labels[:, idx].view(-1, 1, 1)) * len(ip) / (
+                torch.sum(mask_labels[:, idx].detach()).item() + 1e-5)
+            loss_detail_set.append(ld)
+    cd = torch.sum(mask_labels, dim=0) / torch.sum(mask_labels)
+    loss_cb = torch.sum(cd * torch.log(cd + 1e-10))
+    loss_detail = sum(w * l for w, l in zip(stage_detail_loss_weight, loss_detail_set)) + cb_loss_weight * loss_cb
+    return loss_mask + loss_detail
+
+
+def flops_loss(mask_labels, flops=(0.23, 0.62, 1.01, 1.4), Lambda=0.3):
+    """roi_heads/dynamask_roi_head.py:68-70 (computed, never added: Quirk Q3)."""
+    f = torch.tensor(flops, dtype=torch.float32)
+    return Lambda * torch.clamp((torch.sum(mask_labels * f) / len(mask_labels) - 1.0) / (flops[-1] - flops[0]), min=0)
+
+
+# ------------------------------------------------------------------ inference
+def boundary_merge(stage_instance_preds):
+    """Boundary-aware coarse-to-fine merge of simple_test_mask --
+    roi_heads/dynamask_roi_head.py:138-149.  Input: the 4 stage logits
+    [n,1,S,S]; the 14x14 logits are not used (Quirk Q8).  Returns the merged
+    112x112 logits (clones; the reference overwrites in place)."""
+    preds = [p.clone() for p in stage_instance_preds[1:]]
+    for idx in range(len(preds) - 1):
+        inst = preds[idx].squeeze(1).sigmoid() >= 0.5
+        nb = (generate_block_target(inst, boundary_width=1) != 1).unsqueeze(1)
+        nb = F.interpolate(nb.float(), preds[idx + 1].shape[-2:], mode='bilinear', align_corners=True) >= 0.5
+        pre_pred = F.interpolate(preds[idx], preds[idx + 1].shape[-2:], mode='bilinear', align_corners=True)
+        preds[idx + 1][nb] = pre_pred[nb]
+    return preds[-1]
+
+
+def mask_forward_train(sd, fpn_feats, rois, roi_labels, stage_targets, U, **kw):
+    """DynaMaskRoIHead._mask_forward_train minus target generation --
+    roi_heads/dynamask_roi_head.py:48-73.  Returns (loss_masks, mask_labels,
+    selector index, predictor logits)."""
+    ips, dps = mask_forward(sd, fpn_feats, rois, roi_labels, **kw)
+    sem = ref_ops.single_roi_extractor([fpn_feats[0].detach()], rois, 56, (4,))
+    logits = mask_pre(sd, sem, training=True)
+    mask_labels, ind = gumbel_select(logits, U, 0.5)
+    fk = sd.get('mask_head.loss_func.detail_target.fuse_kernel')
+    loss = dyna_loss(ips, dps, stage_targets, mask_labels, fuse_kernel=fk)
+    return loss, mask_labels, ind, logits

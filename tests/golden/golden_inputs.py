@@ -1,0 +1,134 @@
+"""Seeded inputs shared by make_golden.py (reference side) and the tests
+(oracle / HIP side).  Pure data generation -- no DynaMask arithmetic."""
+import os
+import sys
+
+import torch
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+
+from dynamask_amd import synth  # noqa: E402
+
+GUMBEL_SEED = 1234
+
+# configs/dynamask/coco/r50-dynamask-1x.py:60-91
+MASK_ROI_EXTRACTOR_CFG = dict(
+    roi_layer=dict(type='RoIAlign', output_size=14, sampling_ratio=0),
+    out_channels=256, featmap_strides=[4, 8, 16, 32])
+LOSS_CFG = dict(
+    stage_instance_loss_weight=[0.5, 0.75, 0.75, 1.0],
+    stage_detail_loss_weight=[0.5, 0.5, 0.5, 0.5],
+    detail_loss_weight=1.0, cb_loss_weight=0.8, boundary_width=2, start_stage=4)
+MASK_HEAD_CFG = dict(
+    num_convs_instance=2, num_convs_semantic=4,
+    conv_in_channels_instance=256, conv_in_channels_semantic=256,
+    conv_kernel_size_instance=3, conv_kernel_size_semantic=3,
+    conv_out_channels_instance=256, conv_out_channels_semantic=256,
+    conv_cfg=None, norm_cfg=None, semantic_out_stride=[16, 8, 4],
+    mask_use_sigmoid=True, pre_upsample_last_stage=False,
+    stage_num_classes=[80, 80, 80, 1], stage_sup_size=[14, 28, 56, 112],
+    upsample_cfg=dict(type='bilinear', scale_factor=2),
+    loss_cfg=dict(type='DynaCrossEntropyLoss', **LOSS_CFG))
+# configs/_base_/models/mask_rcnn_r50_fpn.py:57-68
+FCN_HEAD_CFG = dict(num_convs=4, in_channels=256, conv_out_channels=256, num_classes=80,
+                    loss_mask=dict(type='CrossEntropyLoss', use_mask=True, loss_weight=1.0))
+
+GRAD_KEYS = [
+    'instance_convs.0.conv.weight', 'instance_convs.1.conv.bias',
+    'stages.0.semantic_transform_in.weight', 'stages.0.instance_logits.weight',
+    'stages.0.fuse_conv.0.weight', 'stages.0.fuse_conv.1.weight',
+    'stages.0.fuse_conv.1.conv_offset.weight', 'stages.0.fuse_conv.1.conv_offset.bias',
+    'stages.1.detail_logits.weight', 'stages.1.fuse_conv.1.weight', 'stages.1.fuse_transform_out.weight',
+    'stages.2.semantic_transform_in.weight', 'stages.2.fuse_conv.0.bias', 'stages.2.fuse_conv.1.weight',
+    'stages.2.fuse_transform_out.bias', 'final_instance_logits.weight', 'final_detail_logits.bias',
+]
+
+IMG_H, IMG_W = 256, 320
+
+
+def _g(seed):
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return g
+
+
+def head_inputs():
+    feats = synth.make_fpn(2, IMG_H, IMG_W, 256, seed=100)
+    rois = torch.tensor([
+        [0, 10.3, 20.7, 40.9, 61.2],          # level 0
+        [0, 50.5, 30.25, 210.75, 180.5],      # level 1
+        [0, -20.0, -10.0, 300.0, 250.0],      # level 2, sticks out of the image
+        [0, 100.0, 100.0, 101.5, 100.8],      # degenerate tiny box
+        [1, 0.0, 0.0, 319.0, 255.0],          # whole image
+        [1, -100.0, -80.0, 500.0, 400.0],     # level 3, far outside
+        [1, 200.2, 50.1, 310.6, 240.9],       # level 1, tall
+    ], dtype=torch.float32)
+    labels = torch.tensor([3, 17, 79, 0, 42, 5, 60], dtype=torch.long)
+    return dict(feats=feats, rois=rois, labels=labels)
+
+
+def head_state():
+    return synth.init_dynamask_head_state(seed=101, test_mode=True)
+
+
+def head_targets(n):
+    return synth.make_targets(n, seed=102)
+
+
+def head_mask_labels(n):
+    idx = torch.arange(n) % 4
+    return torch.nn.functional.one_hot(idx, 4).float()
+
+
+def mask_pre_state():
+    return synth.init_mask_pre_state(seed=103)
+
+
+def mask_pre_input():
+    return torch.randn(4, 256, 56, 56, generator=_g(104)) * 0.7
+
+
+def gumbel_logits():
+    return torch.randn(64, 4, generator=_g(105))
+
+
+def loss_inputs():
+    n = 6
+    g = _g(106)
+    targets = synth.make_targets(n, seed=107)
+    ips, dps = [], []
+    for t in targets:
+        ips.append(((t * 2 - 1) * 1.5 + torch.randn(t.shape, generator=g)).unsqueeze(1))
+        dps.append((torch.randn(t.shape, generator=g) * 2.0).unsqueeze(1))
+    idx = torch.tensor([0, 1, 2, 1, 1, 0])      # exit 3 never chosen: zero-count edge case
+    mask_labels = torch.nn.functional.one_hot(idx, 4).float()
+    return dict(ips=ips, dps=dps, targets=targets, mask_labels=mask_labels)
+
+
+def merge_inputs():
+    n = 5
+    g = _g(108)
+    targets = synth.make_targets(n, seed=109)
+    ips = [((t * 2 - 1) * 2.0 + torch.randn(t.shape, generator=g) * 1.5).unsqueeze(1) for t in targets]
+    return dict(ips=ips)
+
+
+def fcn_state(upsample):
+    return synth.init_fcn_head_state(seed=110, upsample=upsample if upsample in ('deconv', 'carafe') else None,
+                                     test_mode=True)
+
+
+def fcn_input():
+    return torch.relu(torch.randn(3, 256, 14, 14, generator=_g(111)))
+
+
+def grad_slice(g):
+    """Golden fixtures keep only the first 4 output channels of big param grads."""
+    return g[:4] if g.numel() > 4096 else g
+
+
+def feat_grad_slice(g):
+    """...and channels 0, 100 and 255 of the FPN-map grads."""
+    return g[:, [0, 100, 255]]

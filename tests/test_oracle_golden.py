@@ -1,0 +1,114 @@
+"""Oracle (oracle/ref_model.py) vs golden vectors produced by the REFERENCE's
+own modules (tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import torch
+
+import golden_inputs as gi
+from oracle import ref_model, ref_ops
+
+TOL = dict(atol=1e-5, rtol=1e-5)
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _close(a, b, **kw):
+    kw = kw or TOL
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else a
+    np.testing.assert_allclose(a, b, **kw)
+
+
+def test_losses_match_reference(golden_dir):
+    g = _load(golden_dir, 'g1_losses.npz')
+    li = gi.loss_inputs()
+    ips = [t.clone().requires_grad_(True) for t in li['ips']]
+    dps = [t.clone().requires_grad_(True) for t in li['dps']]
+    ml = li['mask_labels'].clone().requires_grad_(True)
+    loss = ref_model.dyna_loss(ips, dps, li['targets'], ml)
+    loss.backward()
+    _close(loss, g['loss_masks'])
+    _close(ml.grad, g['grad_mask_labels'])
+    for i in range(4):
+        _close(dps[i].grad, g[f'grad_dp{i}'])
+        gip = ips[i].grad if ips[i].grad is not None else torch.zeros_like(ips[i])
+        _close(gip, g[f'grad_ip{i}'])
+        # integer-valued stencil output: bit exact
+        assert np.array_equal(ref_model.detail_target(li['targets'][i]).numpy(), g[f'detail_target{i}'])
+    for bw in (1, 2, 3):
+        assert np.array_equal(ref_model.generate_block_target(li['targets'][1], bw).numpy(), g[f'block_target_bw{bw}'])
+    _close(ref_model.binary_cross_entropy(li['ips'][1].squeeze(1), li['targets'][1]), g['bce_stage1'])
+    _close(ref_model.mask_cross_entropy(li['dps'][1].squeeze(1), li['targets'][1],
+                                        li['mask_labels'][:, 1].view(-1, 1, 1)), g['epsbce_stage1'])
+
+
+def test_mask_pre_matches_reference(golden_dir):
+    g = _load(golden_dir, 'g2_maskpre.npz')
+    sd = gi.mask_pre_state()
+    x = gi.mask_pre_input()
+    _close(ref_model.mask_pre(sd, x, training=True), g['logits_train'], atol=2e-5, rtol=1e-4)
+    _close(ref_model.mask_pre(sd, x, training=False), g['logits_eval'], atol=2e-5, rtol=1e-4)
+
+
+def test_gumbel_selector_matches_reference(golden_dir):
+    g = _load(golden_dir, 'g3_gumbel.npz')
+    logits = gi.gumbel_logits().requires_grad_(True)
+    torch.manual_seed(gi.GUMBEL_SEED)
+    U = torch.rand(logits.shape)          # the draw the reference makes (dynamask_roi_head.py:90)
+    y, ind = ref_model.gumbel_select(logits, U, 0.5)
+    assert np.array_equal(ind.numpy(), g['index'])
+    _close(y, g['y_hard'])
+    (y * torch.arange(1, 5, dtype=torch.float32)).sum().backward()
+    _close(logits.grad, g['grad_logits'])
+
+
+def test_head_forward_matches_reference(golden_dir):
+    g = _load(golden_dir, 'g4_head.npz')
+    hi = gi.head_inputs()
+    sd = gi.head_state()
+    assert np.array_equal(ref_ops.map_roi_levels(hi['rois'], 4).numpy(), g['levels'])
+    assert set(g['levels'].tolist()) == {0, 1, 2, 3}
+    ins = ref_ops.single_roi_extractor(hi['feats'][:4], hi['rois'], 14, (4, 8, 16, 32))
+    _close(ins, g['ins_feats'])
+    with torch.no_grad():
+        ips, dps = ref_model.mask_forward(sd, hi['feats'], hi['rois'], hi['labels'])
+    for i in range(4):
+        _close(ips[i], g[f'ip{i}'], atol=2e-5, rtol=1e-4)
+        _close(dps[i], g[f'dp{i}'], atol=2e-5, rtol=1e-4)
+
+
+def test_boundary_merge_matches_reference(golden_dir):
+    g = _load(golden_dir, 'g5_merge.npz')
+    mi = gi.merge_inputs()
+    _close(ref_model.boundary_merge(mi['ips']), g['merged'])
+
+
+def test_fcn_head_matches_reference(golden_dir):
+    g = _load(golden_dir, 'g6_fcn.npz')
+    x = gi.fcn_input()
+    for up in ('deconv', 'carafe', 'bilinear'):
+        sd = gi.fcn_state(up)
+        with torch.no_grad():
+            out = ref_model.fcn_mask_head_forward(sd, x, pre='mask_head.', upsample=up)
+        _close(out, g[up], atol=2e-5, rtol=1e-4)
+
+
+def test_head_train_slice_matches_reference(golden_dir):
+    g = _load(golden_dir, 'g7_head_train.npz')
+    hi = gi.head_inputs()
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in gi.head_state().items()}
+    feats = [f.clone().requires_grad_(True) for f in hi['feats']]
+    ips, dps = ref_model.mask_forward(sd, feats, hi['rois'], hi['labels'])
+    n = hi['rois'].shape[0]
+    ml = gi.head_mask_labels(n).clone().requires_grad_(True)
+    loss = ref_model.dyna_loss(ips, dps, gi.head_targets(n), ml,
+                               fuse_kernel=sd['mask_head.loss_func.detail_target.fuse_kernel'])
+    loss.backward()
+    _close(loss, g['loss'], atol=1e-5, rtol=1e-5)
+    _close(ml.grad, g['grad_mask_labels'], atol=1e-5, rtol=1e-4)
+    for k in gi.GRAD_KEYS:
+        _close(gi.grad_slice(sd['mask_head.' + k].grad), g['grad.' + k], atol=2e-6, rtol=1e-3)
+    for i in range(4):
+        _close(gi.feat_grad_slice(feats[i].grad), g[f'grad_feat{i}'], atol=2e-6, rtol=1e-3)

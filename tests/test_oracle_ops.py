@@ -1,0 +1,89 @@
+"""Known-answer tests that pin the oracle's restatement of the mmcv operators
+(the third-party part: "parity unpinned" against mmcv itself)."""
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_ops
+
+
+def _g(seed):
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return g
+
+
+def test_roi_align_constant_map():
+    feat = torch.full((1, 3, 20, 30), 2.5)
+    rois = torch.tensor([[0, 3.2, 4.1, 50.7, 60.3], [0, 0., 0., 8., 8.]])
+    out = ref_ops.roi_align(feat, rois, 7, 0.25)
+    assert torch.allclose(out, torch.full_like(out, 2.5), atol=1e-6)
+
+
+def test_roi_align_linear_ramp():
+    # value = 2*x + 3*y on the pixel grid; bilinear interpolation reproduces
+    # a linear function, so each bin returns the ramp at the bin centre.
+    H, W = 40, 50
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing='ij')
+    feat = (2 * xx + 3 * yy)[None, None]
+    rois = torch.tensor([[0, 8.0, 12.0, 36.0, 40.0]])   # fully inside, scale 1
+    P = 7
+    out = ref_ops.roi_align(feat, rois, P, 1.0, 0, True)[0, 0]
+    bw = (36.0 - 8.0) / P
+    bh = (40.0 - 12.0) / P
+    cx = 8.0 - 0.5 + (torch.arange(P) + 0.5) * bw
+    cy = 12.0 - 0.5 + (torch.arange(P) + 0.5) * bh
+    exp = 2 * cx[None, :] + 3 * cy[:, None]
+    assert torch.allclose(out, exp, atol=1e-4)
+
+
+def test_roi_align_vs_float64_bruteforce():
+    feat = torch.randn(2, 3, 12, 17, generator=_g(0))
+    rois = torch.tensor([
+        [0, 1.3, 2.2, 30.1, 20.7], [1, -5.0, -3.0, 70.0, 60.0], [0, 10.0, 10.0, 10.5, 10.2],
+        [1, 20.0, 4.0, 66.0, 44.0], [0, 50.0, 30.0, 90.0, 70.0]])
+    for P, sr in ((7, 0), (4, 2), (14, 0)):
+        a = ref_ops.roi_align(feat, rois, P, 0.25, sr, True)
+        b = ref_ops.roi_align_bruteforce_f64(feat, rois, P, 0.25, sr, True)
+        assert torch.allclose(a.double(), b, atol=1e-5), (P, sr)
+
+
+def test_simple_roi_align_identity_box():
+    # RoI = whole feature map at scale 1 -> pixel centres -> identity
+    feat = torch.randn(1, 4, 6, 6, generator=_g(1))
+    rois = torch.tensor([[0, 0., 0., 6., 6.]])
+    out = ref_ops.simple_roi_align(feat, rois, 6, 1.0)
+    assert torch.allclose(out[0], feat[0], atol=1e-6)
+
+
+def test_deform_conv_zero_offset_equals_conv2d():
+    x = torch.randn(3, 8, 9, 11, generator=_g(2))
+    w = torch.randn(6, 8, 3, 3, generator=_g(3))
+    off = torch.zeros(3, 2 * 18, 9, 11)
+    out = ref_ops.deform_conv2d(x, off, w, 1, 1, 1, 2)
+    assert torch.allclose(out, F.conv2d(x, w, padding=1), atol=1e-5)
+
+
+def test_deform_conv_integer_offset_is_shift():
+    # offset (dh, dw) = (1, -2) everywhere == sampling a shifted image
+    x = torch.randn(1, 4, 10, 10, generator=_g(4))
+    w = torch.randn(5, 4, 3, 3, generator=_g(5))
+    off = torch.zeros(1, 18, 10, 10)
+    off[:, 0::2] = 1.0
+    off[:, 1::2] = -2.0
+    out = ref_ops.deform_conv2d(x, off, w, 1, 1, 1, 1)
+    xs = torch.zeros(1, 4, 14, 14)
+    xs[:, :, 2:12, 2:12] = x                      # zero-extended image
+    # sample (h+1, w-2): build shifted copy then plain conv
+    shifted = torch.zeros_like(xs)
+    shifted[:, :, 0:13, 2:14] = xs[:, :, 1:14, 0:12]
+    exp = F.conv2d(shifted, w, padding=1)[:, :, 2:12, 2:12]
+    assert torch.allclose(out, exp, atol=1e-5)
+
+
+def test_carafe_uniform_kernel_is_box_filter():
+    x = torch.randn(1, 2, 5, 5, generator=_g(6))
+    mask = torch.full((1, 25, 10, 10), 1.0 / 25)
+    out = ref_ops.carafe_reassemble(x, mask, 5, 1, 2)
+    box = F.avg_pool2d(F.pad(x, (2, 2, 2, 2)), 5, stride=1)
+    exp = box.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    assert torch.allclose(out, exp, atol=1e-6)
