@@ -1,0 +1,64 @@
+"""ctypes loader of libdynamask_hip.so (the C ABI of include/dynamask_hip.h)."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdynamask_hip.so')
+ABI_VERSION = 1
+
+_c_int = ctypes.c_int
+_c_float = ctypes.c_float
+_vp = ctypes.c_void_p
+
+# name -> argtypes  (every symbol declared in include/dynamask_hip.h)
+SIGNATURES = {
+    'dm_error_string': ([_c_int], ctypes.c_char_p),
+    'dm_abi_version': ([], _c_int),
+    'dm_roi_align_fwd': ([_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _c_float, _vp, _vp, _vp], _c_int),
+    'dm_roi_align_bwd': ([_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _c_float, _vp], _c_int),
+    'dm_conv_packed_cout': ([_c_int], _c_int),
+    'dm_conv_pack_weight': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp], _c_int),
+    'dm_conv2d_fwd': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp], _c_int),
+    'dm_point_sample_fwd': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_float, _vp, _vp], _c_int),
+    'dm_class_logits_fwd': ([_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp], _c_int),
+    'dm_deform_conv_fwd': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _vp, _vp], _c_int),
+    'dm_upsample2x_bilinear_fwd': ([_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp], _c_int),
+    'dm_boundary_merge': ([_vp, _vp, _c_int, _c_int, _vp], _c_int),
+    'dm_deconv_pack_weight': ([_vp, _c_int, _c_int, _vp, _vp], _c_int),
+    'dm_deconv2x2_fwd': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _vp, _vp], _c_int),
+    'dm_carafe_fwd': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp], _c_int),
+    'dm_gumbel_select_fwd': ([_vp, _vp, _c_int, _c_int, _c_float, _vp, _vp, _vp, _vp], _c_int),
+    'dm_detail_target': ([_vp, _c_int, _c_int, _c_float, _c_float, _vp, _vp], _c_int),
+    'dm_mask_loss_fwd_bwd': ([_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp], _c_int),
+}
+
+_LIB = None
+
+
+class DynaMaskLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the library once.  Fails loudly: there is no fallback path."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise DynaMaskLibraryError(
+                f'{LIB_PATH} not found: build it with `python -m dynamask_amd.build` '
+                '(or __graft_entry__.build()); dynamask_amd has no CPU/eager fallback')
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (argtypes, restype) in SIGNATURES.items():
+            fn = getattr(L, name)       # AttributeError if the symbol is missing
+            fn.argtypes = argtypes
+            fn.restype = restype
+        if L.dm_abi_version() != ABI_VERSION:
+            raise DynaMaskLibraryError('libdynamask_hip.so ABI version mismatch: rebuild')
+        _LIB = L
+    return _LIB
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().dm_error_string(rc).decode()
+        raise RuntimeError(f'{what} failed: {msg} (code {rc})')

@@ -1,0 +1,394 @@
+// HBM-bound kernels of the mask-head path: point sample (K4), class-gathered
+// logits (K7), x2 bilinear upsample (K11), inference boundary merge (K15),
+// Gumbel selector (K10), DetailTarget (K13), mask losses (K12).
+// All are coalesced along the innermost (x / pixel) dimension; reductions use
+// wave shuffles + one atomic per workgroup.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Block-wide sum (result valid in thread 0). blockDim.x multiple of 64, <= 1024.
+__device__ __forceinline__ float block_sum(float v, float* smem) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = wave_sum(v);
+  if (lane == 0) smem[wave] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (wave == 0) {
+    r = (lane < (int)(blockDim.x >> 6)) ? smem[lane] : 0.f;
+    r = wave_sum(r);
+  }
+  __syncthreads();
+  return r;
+}
+
+// ------------------------------------------------------------------ K4
+// grid_sample(bilinear, zeros, align_corners=False) at RoI-relative pixel
+// centres.  Thread = one sample point; its 4 taps/weights are computed once and
+// reused over the channel chunk of the workgroup.
+__global__ __launch_bounds__(256) void point_sample_kernel(const float* __restrict__ feat, int B, int C, int H, int W,
+                                                           const float* __restrict__ rois, int N, int S, float scale,
+                                                           float* __restrict__ out, int CT, int pos_blocks) {
+  const int chunks = (C + CT - 1) / CT;
+  int bid = blockIdx.x;
+  const int pb = bid % pos_blocks;
+  bid /= pos_blocks;
+  const int chunk = bid % chunks;
+  const int n = bid / chunks;
+  const int pos = pb * blockDim.x + threadIdx.x;
+  if (pos >= S * S) return;
+  const int iy = pos / S, ix = pos - iy * S;
+  const float* r = rois + (size_t)n * 5;
+  const int b = (int)r[0];
+  const float x1 = r[1], y1 = r[2], x2 = r[3], y2 = r[4];
+  const int c0 = chunk * CT, c1 = min(c0 + CT, C);
+  float* o = out + ((size_t)n * C) * S * S + pos;
+  if (b < 0 || b >= B) {
+    for (int c = c0; c < c1; ++c) o[(size_t)c * S * S] = 0.f;
+    return;
+  }
+  // affine_grid(align_corners=False) base coordinate, then (g+1)/2 -> [0,1]
+  const float gx0 = ((float)(2 * ix + 1)) / (float)S - 1.0f;
+  const float gy0 = ((float)(2 * iy + 1)) / (float)S - 1.0f;
+  float px = (gx0 + 1.0f) / 2.0f;
+  float py = (gy0 + 1.0f) / 2.0f;
+  px = px * (x2 - x1) + x1;            // absolute image point
+  py = py * (y2 - y1) + y1;
+  px = px / (float)W * scale;          // relative to the feature map
+  py = py / (float)H * scale;
+  const float gx = px * 2.0f - 1.0f;   // grid_sample coordinate
+  const float gy = py * 2.0f - 1.0f;
+  const float sx = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f;
+  const float sy = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
+  const float fx = floorf(sx), fy = floorf(sy);
+  // keep the int conversion safe for far-away points (all taps void anyway)
+  const float cfx = fminf(fmaxf(fx, -2.0f), (float)W + 1.0f);
+  const float cfy = fminf(fmaxf(fy, -2.0f), (float)H + 1.0f);
+  const bool far = (cfx != fx) || (cfy != fy);
+  const int x0 = (int)cfx, y0 = (int)cfy;
+  const int x1i = x0 + 1, y1i = y0 + 1;
+  const float lx = sx - fx, ly = sy - fy;
+  float w_nw = (1.f - lx) * (1.f - ly), w_ne = lx * (1.f - ly), w_sw = (1.f - lx) * ly, w_se = lx * ly;
+  const bool okx0 = x0 >= 0 && x0 < W, okx1 = x1i >= 0 && x1i < W;
+  const bool oky0 = y0 >= 0 && y0 < H, oky1 = y1i >= 0 && y1i < H;
+  const bool v_nw = !far && okx0 && oky0, v_ne = !far && okx1 && oky0, v_sw = !far && okx0 && oky1,
+             v_se = !far && okx1 && oky1;
+  const int o_nw = v_nw ? y0 * W + x0 : 0, o_ne = v_ne ? y0 * W + x1i : 0;
+  const int o_sw = v_sw ? y1i * W + x0 : 0, o_se = v_se ? y1i * W + x1i : 0;
+  if (!v_nw) w_nw = 0.f;
+  if (!v_ne) w_ne = 0.f;
+  if (!v_sw) w_sw = 0.f;
+  if (!v_se) w_se = 0.f;
+  const float* f = feat + ((size_t)b * C) * H * W;
+  const size_t plane = (size_t)H * W;
+  for (int c = c0; c < c1; ++c) {
+    const float* fc = f + (size_t)c * plane;
+    o[(size_t)c * S * S] = fc[o_nw] * w_nw + fc[o_ne] * w_ne + fc[o_sw] * w_sw + fc[o_se] * w_se;
+  }
+}
+
+// ------------------------------------------------------------------ K7
+// Thread = pixel of one RoI; the two weight rows W[label] are wave-uniform.
+__global__ __launch_bounds__(256) void class_logits_kernel(const float* __restrict__ x, int N, int C, int HW,
+                                                           const float* __restrict__ wi, const float* __restrict__ bi,
+                                                           const float* __restrict__ wd, const float* __restrict__ bd,
+                                                           int num_classes, const int64_t* __restrict__ labels,
+                                                           float* __restrict__ inst, float* __restrict__ det,
+                                                           float* __restrict__ sig, int sig_ct, int sig_off,
+                                                           int pix_blocks) {
+  const int n = blockIdx.x / pix_blocks;
+  const int p = (blockIdx.x - n * pix_blocks) * blockDim.x + threadIdx.x;
+  if (p >= HW) return;
+  int lab = (int)labels[n];
+  lab = min(max(lab, 0), num_classes - 1);
+  const float* wri = wi + (size_t)lab * C;
+  const float* wrd = wd + (size_t)lab * C;
+  const float* xp = x + (size_t)n * C * HW + p;
+  float ai = 0.f, ad = 0.f;
+#pragma unroll 4
+  for (int c = 0; c < C; ++c) {
+    const float v = xp[(size_t)c * HW];
+    ai += wri[c] * v;
+    ad += wrd[c] * v;
+  }
+  ai += bi[lab];
+  ad += bd[lab];
+  inst[(size_t)n * HW + p] = ai;
+  det[(size_t)n * HW + p] = ad;
+  if (sig) {
+    sig[((size_t)n * sig_ct + sig_off) * HW + p] = sigmoidf_(ai);
+    sig[((size_t)n * sig_ct + sig_off + 1) * HW + p] = sigmoidf_(ad);
+  }
+}
+
+// ------------------------------------------------------------------ K11
+__global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ in, int NC, int H, int W, int ac,
+                                                         int relu, float* __restrict__ out) {
+  const int OH = 2 * H, OW = 2 * W;
+  const size_t total = (size_t)NC * OH * OW;
+  const float rh = ac ? (OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f) : 0.5f;
+  const float rw = ac ? (OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f) : 0.5f;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(idx % OW);
+    const int oy = (int)((idx / OW) % OH);
+    const size_t nc = idx / ((size_t)OW * OH);
+    float sy, sx;
+    if (ac) {
+      sy = rh * (float)oy;
+      sx = rw * (float)ox;
+    } else {
+      sy = fmaxf(rh * ((float)oy + 0.5f) - 0.5f, 0.f);
+      sx = fmaxf(rw * ((float)ox + 0.5f) - 0.5f, 0.f);
+    }
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + ((y0 < H - 1) ? 1 : 0), x1 = x0 + ((x0 < W - 1) ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* p = in + nc * H * W;
+    float v = hy * (hx * p[y0 * W + x0] + lx * p[y0 * W + x1]) + ly * (hx * p[y1 * W + x0] + lx * p[y1 * W + x1]);
+    if (relu) v = fmaxf(v, 0.f);
+    out[idx] = v;
+  }
+}
+
+// ------------------------------------------------------------------ K15
+// One workgroup per RoI.  LDS holds the coarse logits and the non-boundary map.
+__global__ __launch_bounds__(256) void boundary_merge_kernel(const float* __restrict__ coarse, float* __restrict__ fine,
+                                                             int n, int S) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* cl = lds;            // [S*S] coarse logits
+  float* nb = lds + S * S;    // [S*S] 1 = not a boundary pixel
+  const int r = blockIdx.x;
+  const float* c = coarse + (size_t)r * S * S;
+  for (int i = threadIdx.x; i < S * S; i += blockDim.x) cl[i] = c[i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < S * S; i += blockDim.x) {
+    const int y = i / S, x = i - y * S;
+    const bool m = sigmoidf_(cl[i]) >= 0.5f;
+    // generate_block_target(boundary_width=1): 3x3 Laplacian on the zero-padded
+    // mask (pos) and on 1 - padded mask (neg: padding counts as background=1)
+    int sum_in = 0, cnt_in = 0;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int yy = y + dy, xx = x + dx;
+        if (yy >= 0 && yy < S && xx >= 0 && xx < S) {
+          cnt_in++;
+          sum_in += (sigmoidf_(cl[yy * S + xx]) >= 0.5f) ? 1 : 0;
+        }
+      }
+    // pos: m && (9*m - sum3x3(mask_padded)) >= 1  <=> m && sum_in < 9
+    // neg: !m && (9 - sum3x3(1 - mask_padded)) ... = !m && some in-bounds neighbour is foreground
+    const bool pos = m && (sum_in < 9);
+    const bool neg = (!m) && (sum_in > 0);
+    nb[i] = (pos || neg) ? 0.f : 1.f;
+    (void)cnt_in;
+  }
+  __syncthreads();
+  const int OS = 2 * S;
+  const float rs = OS > 1 ? (float)(S - 1) / (float)(OS - 1) : 0.f;
+  float* f = fine + (size_t)r * OS * OS;
+  for (int i = threadIdx.x; i < OS * OS; i += blockDim.x) {
+    const int oy = i / OS, ox = i - oy * OS;
+    const float sy = rs * (float)oy, sx = rs * (float)ox;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + ((y0 < S - 1) ? 1 : 0), x1 = x0 + ((x0 < S - 1) ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    const float nbv = hy * (hx * nb[y0 * S + x0] + lx * nb[y0 * S + x1]) + ly * (hx * nb[y1 * S + x0] + lx * nb[y1 * S + x1]);
+    if (nbv >= 0.5f) {
+      f[i] = hy * (hx * cl[y0 * S + x0] + lx * cl[y0 * S + x1]) + ly * (hx * cl[y1 * S + x0] + lx * cl[y1 * S + x1]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ K10
+__global__ void gumbel_kernel(const float* __restrict__ logits, const float* __restrict__ U, int N, int K, float T,
+                              float* __restrict__ y_soft, float* __restrict__ one_hot, int32_t* __restrict__ index) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float eps = 1e-20f;
+  float z[8];
+  float zmax = -INFINITY;
+  for (int k = 0; k < K; ++k) {
+    const float g = -logf(-logf(U[n * K + k] + eps) + eps);
+    z[k] = (logits[n * K + k] + g) / T;
+    zmax = fmaxf(zmax, z[k]);
+  }
+  float s = 0.f;
+  for (int k = 0; k < K; ++k) {
+    z[k] = expf(z[k] - zmax);
+    s += z[k];
+  }
+  int best = 0;
+  float bv = -1.f;
+  for (int k = 0; k < K; ++k) {
+    const float y = z[k] / s;
+    y_soft[n * K + k] = y;
+    if (y > bv) {  // strict: first maximum wins, as torch.max
+      bv = y;
+      best = k;
+    }
+  }
+  index[n] = best;
+  for (int k = 0; k < K; ++k) one_hot[n * K + k] = (k == best) ? 1.f : 0.f;
+}
+
+// ------------------------------------------------------------------ K13
+__global__ __launch_bounds__(256) void detail_target_kernel(const float* __restrict__ masks, int N, int S, float f0,
+                                                            float f1, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* m = lds;  // [S*S]
+  const int r = blockIdx.x;
+  const float* src = masks + (size_t)r * S * S;
+  for (int i = threadIdx.x; i < S * S; i += blockDim.x) m[i] = src[i];
+  __syncthreads();
+  auto lap = [&](int y, int x) -> float {
+    float acc = 0.f;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int yy = y + dy, xx = x + dx;
+        if (yy >= 0 && yy < S && xx >= 0 && xx < S) acc += ((dy == 0 && dx == 0) ? 8.f : -1.f) * m[yy * S + xx];
+      }
+    return fmaxf(acc, 0.f);
+  };
+  const int S2 = (S - 1) / 2 + 1;  // stride-2 conv output size (pad 1, k 3)
+  for (int i = threadIdx.x; i < S * S; i += blockDim.x) {
+    const int y = i / S, x = i - y * S;
+    const float b1 = lap(y, x) > 0.1f ? 1.f : 0.f;
+    // F.interpolate(nearest): src = floor(dst * in/out)
+    const int y2 = min((int)floorf((float)y * ((float)S2 / (float)S)), S2 - 1);
+    const int x2 = min((int)floorf((float)x * ((float)S2 / (float)S)), S2 - 1);
+    const float b2 = lap(2 * y2, 2 * x2) > 0.1f ? 1.f : 0.f;
+    const float fz = f0 * b1 + f1 * b2;
+    out[(size_t)r * S * S + i] = fz > 0.1f ? 1.f : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------ K12
+// grid = (pixel blocks, N).  sums[0] += BCE-with-logits sum, sums[1] += weighted
+// eps-BCE sum; per_roi[n] += un-weighted eps-BCE sum of RoI n.
+__global__ __launch_bounds__(256) void mask_loss_kernel(const float* __restrict__ ip, const float* __restrict__ dp,
+                                                        const float* __restrict__ it, const float* __restrict__ dt,
+                                                        const float* __restrict__ weight, int N, int HW,
+                                                        float* __restrict__ sums, float* __restrict__ per_roi,
+                                                        float* __restrict__ gi, float* __restrict__ gd) {
+  __shared__ float red[16];
+  const int n = blockIdx.y;
+  const float w = weight[n];
+  const float eps = 1e-10f;
+  float s_bce = 0.f, s_det = 0.f;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+    const size_t i = (size_t)n * HW + p;
+    const float x = ip[i], t = it[i];
+    // F.binary_cross_entropy_with_logits: (1-t)*x + max(-x,0) + log(exp(-mv) + exp(-x-mv))
+    const float mv = fmaxf(-x, 0.f);
+    s_bce += (1.f - t) * x + mv + logf(expf(-mv) + expf(-x - mv));
+    const float xd = dp[i], td = dt[i];
+    const float s = sigmoidf_(xd);
+    s_det += -(td * logf(s + eps) + (1.f - td) * logf(1.f - s + eps));
+    if (gi) gi[i] = sigmoidf_(x) - t;
+    if (gd) {
+      const float ds = s * (1.f - s);
+      gd[i] = -w * (td * ds / (s + eps) - (1.f - td) * ds / (1.f - s + eps));
+    }
+  }
+  const float b = block_sum(s_bce, red);
+  const float d = block_sum(s_det, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(&sums[0], b);
+    atomicAdd(&sums[1], w * d);
+    if (per_roi) atomicAdd(&per_roi[n], d);
+  }
+}
+
+}  // namespace
+
+extern "C" int dm_point_sample_fwd(const float* feat, int B, int C, int H, int W, const float* rois, int N, int S,
+                                   float spatial_scale, float* out, dm_stream_t stream) {
+  if (!feat || !rois || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0 || N < 0 || S <= 0) return DM_ERR_INVALID_ARG;
+  if (N == 0) return DM_OK;
+  const int CT = 16;
+  const int chunks = dm_ceil_div(C, CT);
+  const int pos_blocks = dm_ceil_div(S * S, 256);
+  hipLaunchKernelGGL(point_sample_kernel, dim3((unsigned)(N * chunks * pos_blocks)), dim3(256), 0, (hipStream_t)stream,
+                     feat, B, C, H, W, rois, N, S, spatial_scale, out, CT, pos_blocks);
+  return dm_check_launch();
+}
+
+extern "C" int dm_class_logits_fwd(const float* x, int N, int C, int HW, const float* w_inst, const float* b_inst,
+                                   const float* w_det, const float* b_det, int num_classes, const int64_t* labels,
+                                   float* inst, float* det, float* sig_out, int sig_ch_total, int sig_ch_offset,
+                                   dm_stream_t stream) {
+  if (!x || !w_inst || !b_inst || !w_det || !b_det || !labels || !inst || !det) return DM_ERR_INVALID_ARG;
+  if (N < 0 || C <= 0 || HW <= 0 || num_classes <= 0) return DM_ERR_INVALID_ARG;
+  if (sig_out && (sig_ch_offset < 0 || sig_ch_offset + 2 > sig_ch_total)) return DM_ERR_INVALID_ARG;
+  if (N == 0) return DM_OK;
+  const int pix_blocks = dm_ceil_div(HW, 256);
+  hipLaunchKernelGGL(class_logits_kernel, dim3((unsigned)(N * pix_blocks)), dim3(256), 0, (hipStream_t)stream, x, N, C,
+                     HW, w_inst, b_inst, w_det, b_det, num_classes, labels, inst, det, sig_out, sig_ch_total,
+                     sig_ch_offset, pix_blocks);
+  return dm_check_launch();
+}
+
+extern "C" int dm_upsample2x_bilinear_fwd(const float* in, int NC, int H, int W, int align_corners, int relu, float* out,
+                                          dm_stream_t stream) {
+  if (!in || !out || NC < 0 || H <= 0 || W <= 0) return DM_ERR_INVALID_ARG;
+  if (NC == 0) return DM_OK;
+  const size_t total = (size_t)NC * 4 * H * W;
+  const int blocks = (int)min((size_t)dm_ceil_div((long long)total, 256), (size_t)16384);
+  hipLaunchKernelGGL(upsample2x_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, NC, H, W, align_corners,
+                     relu, out);
+  return dm_check_launch();
+}
+
+extern "C" int dm_boundary_merge(const float* coarse, float* fine, int n, int S, dm_stream_t stream) {
+  if (!coarse || !fine || n < 0 || S <= 0) return DM_ERR_INVALID_ARG;
+  if ((size_t)2 * S * S * sizeof(float) > 64 * 1024) return DM_ERR_UNSUPPORTED;
+  if (n == 0) return DM_OK;
+  hipLaunchKernelGGL(boundary_merge_kernel, dim3(n), dim3(256), 2 * S * S * sizeof(float), (hipStream_t)stream, coarse,
+                     fine, n, S);
+  return dm_check_launch();
+}
+
+extern "C" int dm_gumbel_select_fwd(const float* logits, const float* U, int N, int K, float temperature, float* y_soft,
+                                    float* one_hot, int32_t* index, dm_stream_t stream) {
+  if (!logits || !U || !y_soft || !one_hot || !index || N < 0 || K <= 0 || K > 8 || temperature <= 0.f)
+    return DM_ERR_INVALID_ARG;
+  if (N == 0) return DM_OK;
+  hipLaunchKernelGGL(gumbel_kernel, dim3(dm_ceil_div(N, 64)), dim3(64), 0, (hipStream_t)stream, logits, U, N, K,
+                     temperature, y_soft, one_hot, index);
+  return dm_check_launch();
+}
+
+extern "C" int dm_detail_target(const float* masks, int N, int S, float fuse0, float fuse1, float* out,
+                                dm_stream_t stream) {
+  if (!masks || !out || N < 0 || S <= 0) return DM_ERR_INVALID_ARG;
+  if ((size_t)S * S * sizeof(float) > 64 * 1024) return DM_ERR_UNSUPPORTED;
+  if (N == 0) return DM_OK;
+  hipLaunchKernelGGL(detail_target_kernel, dim3(N), dim3(256), S * S * sizeof(float), (hipStream_t)stream, masks, N, S,
+                     fuse0, fuse1, out);
+  return dm_check_launch();
+}
+
+extern "C" int dm_mask_loss_fwd_bwd(const float* inst_pred, const float* det_pred, const float* inst_tgt,
+                                    const float* det_tgt, const float* weight, int N, int HW, float* sums,
+                                    float* per_roi_det, float* grad_inst, float* grad_det, dm_stream_t stream) {
+  if (!inst_pred || !det_pred || !inst_tgt || !det_tgt || !weight || !sums || N < 0 || HW <= 0)
+    return DM_ERR_INVALID_ARG;
+  if (N == 0) return DM_OK;
+  const int pb = min(dm_ceil_div(HW, 256), 8);
+  hipLaunchKernelGGL(mask_loss_kernel, dim3(pb, N), dim3(256), 0, (hipStream_t)stream, inst_pred, det_pred, inst_tgt,
+                     det_tgt, weight, N, HW, sums, per_roi_det, grad_inst, grad_det);
+  return dm_check_launch();
+}

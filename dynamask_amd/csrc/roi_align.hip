@@ -1,0 +1,276 @@
+// K1/K2/K3: multi-level RoIAlign (avg, aligned=True, adaptive sampling grid),
+// FPN level mapping fused into the kernel (one launch for all levels).
+//
+// Workgroup = one RoI x one chunk of channels.  A thread owns output bin(s)
+// (ph, pw) and computes the bin's sample rows/columns and bilinear weights ONCE
+// (they do not depend on the channel), keeps them in registers, then walks the
+// channel chunk: per channel only 4*g*g loads + FMAs, no address arithmetic.
+// Consecutive lanes own consecutive pw, so the NCHW output is written in
+// 4*P-byte coalesced rows and the loads of a wave fall in a few feature rows.
+#include "common.h"
+
+namespace {
+
+struct RoiArgs {
+  const float* feat[DM_MAX_LEVELS];
+  float* gfeat[DM_MAX_LEVELS];
+  int H[DM_MAX_LEVELS], W[DM_MAX_LEVELS];
+  float scale[DM_MAX_LEVELS];
+  int L, B, C;
+  const float* rois;
+  int N, P, sr;
+  float finest;
+  float* out;          // fwd: output; bwd: unused
+  const float* gout;   // bwd: grad of output
+  int32_t* levels;
+  int CT;              // channels per workgroup
+};
+
+// One sample coordinate along an axis -> (low index, high index, w_low, w_high).
+// mmcv bilinear_interpolate rules: c < -1 or c > size -> void sample; clamp to
+// >= 0; low >= size-1 -> low = high = size-1, c = low.
+__device__ __forceinline__ void axis_sample(float start, float bin, int g, int p, int i, int size, int& lo, int& hi,
+                                            float& wlo, float& whi) {
+  float c = start + (float)p * bin + ((float)i + 0.5f) * bin / (float)g;
+  const bool valid = !(c < -1.0f || c > (float)size);
+  c = fmaxf(c, 0.0f);
+  int l = (int)c;
+  int h;
+  if (l >= size - 1) {
+    l = h = size - 1;
+    c = (float)l;
+  } else {
+    h = l + 1;
+  }
+  float wh = c - (float)l;
+  float wl = 1.0f - wh;
+  if (!valid) {
+    wl = 0.f;
+    wh = 0.f;
+    l = 0;
+    h = 0;
+  }
+  lo = l;
+  hi = h;
+  wlo = wl;
+  whi = wh;
+}
+
+__device__ __forceinline__ int roi_level(float x1, float y1, float x2, float y2, float finest, int L) {
+  // floor(log2(sqrt(w*h)/finest + 1e-6)) clamped to [0, L-1], evaluated as
+  // threshold compares (exact wherever log2 is correctly rounded).
+  const float s = sqrtf((x2 - x1) * (y2 - y1));
+  const float t = s / finest + 1e-6f;
+  int lvl = 0;
+  float thr = 2.0f;
+  for (int k = 1; k < L; ++k) {
+    if (t >= thr) lvl = k;
+    thr *= 2.0f;
+  }
+  return lvl;
+}
+
+template <int G, bool BWD>
+__device__ __forceinline__ void roi_bin_fast(const RoiArgs& a, const float* __restrict__ f, float* __restrict__ gf,
+                                             int Hl, int Wl, float sh, float sw, float bh, float bw, int gh, int gw,
+                                             float inv_count, int ph, int pw, int k, int c0, int c1) {
+  int ylo[G], yhi[G], xlo[G], xhi[G];
+  float wyl[G], wyh[G], wxl[G], wxh[G];
+#pragma unroll
+  for (int i = 0; i < G; ++i) {
+    ylo[i] = yhi[i] = xlo[i] = xhi[i] = 0;
+    wyl[i] = wyh[i] = wxl[i] = wxh[i] = 0.f;
+    if (i < gh) {
+      axis_sample(sh, bh, gh, ph, i, Hl, ylo[i], yhi[i], wyl[i], wyh[i]);
+      ylo[i] *= Wl;
+      yhi[i] *= Wl;
+    }
+    if (i < gw) axis_sample(sw, bw, gw, pw, i, Wl, xlo[i], xhi[i], wxl[i], wxh[i]);
+  }
+  const size_t plane = (size_t)Hl * Wl;
+  const int P = a.P;
+  for (int c = c0; c < c1; ++c) {
+    const size_t oidx = (((size_t)k * a.C + c) * P + ph) * P + pw;
+    if (!BWD) {
+      const float* fc = f + (size_t)c * plane;
+      float acc = 0.f;
+#pragma unroll
+      for (int iy = 0; iy < G; ++iy) {
+        if (iy < gh) {
+#pragma unroll
+          for (int ix = 0; ix < G; ++ix) {
+            if (ix < gw) {
+              const float v1 = fc[ylo[iy] + xlo[ix]];
+              const float v2 = fc[ylo[iy] + xhi[ix]];
+              const float v3 = fc[yhi[iy] + xlo[ix]];
+              const float v4 = fc[yhi[iy] + xhi[ix]];
+              acc += wyl[iy] * wxl[ix] * v1 + wyl[iy] * wxh[ix] * v2 + wyh[iy] * wxl[ix] * v3 + wyh[iy] * wxh[ix] * v4;
+            }
+          }
+        }
+      }
+      a.out[oidx] = acc * inv_count;
+    } else {
+      float* gc = gf + (size_t)c * plane;
+      const float g = a.gout[oidx] * inv_count;
+#pragma unroll
+      for (int iy = 0; iy < G; ++iy) {
+        if (iy < gh) {
+#pragma unroll
+          for (int ix = 0; ix < G; ++ix) {
+            if (ix < gw) {
+              const float w1 = wyl[iy] * wxl[ix], w2 = wyl[iy] * wxh[ix], w3 = wyh[iy] * wxl[ix], w4 = wyh[iy] * wxh[ix];
+              if (w1 != 0.f) atomicAdd(gc + ylo[iy] + xlo[ix], g * w1);
+              if (w2 != 0.f) atomicAdd(gc + ylo[iy] + xhi[ix], g * w2);
+              if (w3 != 0.f) atomicAdd(gc + yhi[iy] + xlo[ix], g * w3);
+              if (w4 != 0.f) atomicAdd(gc + yhi[iy] + xhi[ix], g * w4);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <bool BWD>
+__device__ __forceinline__ void roi_bin_generic(const RoiArgs& a, const float* __restrict__ f, float* __restrict__ gf,
+                                                int Hl, int Wl, float sh, float sw, float bh, float bw, int gh, int gw,
+                                                float inv_count, int ph, int pw, int k, int c0, int c1) {
+  const size_t plane = (size_t)Hl * Wl;
+  const int P = a.P;
+  for (int c = c0; c < c1; ++c) {
+    const size_t oidx = (((size_t)k * a.C + c) * P + ph) * P + pw;
+    const float* fc = BWD ? nullptr : f + (size_t)c * plane;
+    float* gc = BWD ? gf + (size_t)c * plane : nullptr;
+    const float g = BWD ? a.gout[oidx] * inv_count : 0.f;
+    float acc = 0.f;
+    for (int iy = 0; iy < gh; ++iy) {
+      int yl, yh;
+      float wyl, wyh;
+      axis_sample(sh, bh, gh, ph, iy, Hl, yl, yh, wyl, wyh);
+      for (int ix = 0; ix < gw; ++ix) {
+        int xl, xh;
+        float wxl, wxh;
+        axis_sample(sw, bw, gw, pw, ix, Wl, xl, xh, wxl, wxh);
+        if (!BWD) {
+          acc += wyl * wxl * fc[yl * Wl + xl] + wyl * wxh * fc[yl * Wl + xh] + wyh * wxl * fc[yh * Wl + xl] +
+                 wyh * wxh * fc[yh * Wl + xh];
+        } else {
+          const float w1 = wyl * wxl, w2 = wyl * wxh, w3 = wyh * wxl, w4 = wyh * wxh;
+          if (w1 != 0.f) atomicAdd(gc + yl * Wl + xl, g * w1);
+          if (w2 != 0.f) atomicAdd(gc + yl * Wl + xh, g * w2);
+          if (w3 != 0.f) atomicAdd(gc + yh * Wl + xl, g * w3);
+          if (w4 != 0.f) atomicAdd(gc + yh * Wl + xh, g * w4);
+        }
+      }
+    }
+    if (!BWD) a.out[oidx] = acc * inv_count;
+  }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
+  const int chunks = (a.C + a.CT - 1) / a.CT;
+  const int k = blockIdx.x / chunks;
+  const int chunk = blockIdx.x - k * chunks;
+  const int c0 = chunk * a.CT;
+  const int c1 = min(c0 + a.CT, a.C);
+
+  const float* r = a.rois + (size_t)k * 5;
+  const int b = (int)r[0];
+  const float x1 = r[1], y1 = r[2], x2 = r[3], y2 = r[4];
+  const int lvl = (a.L > 1) ? roi_level(x1, y1, x2, y2, a.finest, a.L) : 0;
+  if (!BWD && a.levels && chunk == 0 && threadIdx.x == 0) a.levels[k] = lvl;
+  const bool bad_batch = (b < 0 || b >= a.B);   // malformed batch index -> zeros, never an OOB read
+  const int Hl = a.H[lvl], Wl = a.W[lvl];
+  const float sc = a.scale[lvl];
+  const float sw = x1 * sc - 0.5f, sh = y1 * sc - 0.5f;
+  const float ew = x2 * sc - 0.5f, eh = y2 * sc - 0.5f;
+  const float rw = ew - sw, rh = eh - sh;
+  const int P = a.P;
+  const float bh = rh / (float)P, bw = rw / (float)P;
+  const int gh = a.sr > 0 ? a.sr : (int)ceilf(rh / (float)P);
+  const int gw = a.sr > 0 ? a.sr : (int)ceilf(rw / (float)P);
+  const float inv_count = 1.0f / (float)max(gh * gw, 1);
+  const size_t img_off = bad_batch ? 0 : (size_t)b * a.C * Hl * Wl;
+  const float* f = BWD ? nullptr : a.feat[lvl] + img_off;
+  float* gf = BWD ? a.gfeat[lvl] + img_off : nullptr;
+
+  for (int pos = threadIdx.x; pos < P * P; pos += blockDim.x) {
+    const int ph = pos / P;
+    const int pw = pos - ph * P;
+    if (gh <= 0 || gw <= 0 || bad_batch) {
+      // empty sampling grid (degenerate RoI): mmcv's loops do not run -> 0
+      if (!BWD)
+        for (int c = c0; c < c1; ++c) a.out[(((size_t)k * a.C + c) * P + ph) * P + pw] = 0.f;
+    } else if (gh <= 2 && gw <= 2) {
+      roi_bin_fast<2, BWD>(a, f, gf, Hl, Wl, sh, sw, bh, bw, gh, gw, inv_count, ph, pw, k, c0, c1);
+    } else if (gh <= 4 && gw <= 4) {
+      roi_bin_fast<4, BWD>(a, f, gf, Hl, Wl, sh, sw, bh, bw, gh, gw, inv_count, ph, pw, k, c0, c1);
+    } else {
+      roi_bin_generic<BWD>(a, f, gf, Hl, Wl, sh, sw, bh, bw, gh, gw, inv_count, ph, pw, k, c0, c1);
+    }
+  }
+}
+
+int fill_args(RoiArgs& a, const int* H, const int* W, const float* spatial_scales, int num_levels, int B, int C,
+              const float* rois, int N, int P, int sampling_ratio, float finest_scale) {
+  if (!H || !W || !spatial_scales || (!rois && N > 0)) return DM_ERR_INVALID_ARG;
+  if (num_levels < 1 || num_levels > DM_MAX_LEVELS || B <= 0 || C <= 0 || N < 0 || P <= 0 || sampling_ratio < 0)
+    return DM_ERR_INVALID_ARG;
+  a.L = num_levels; a.B = B; a.C = C; a.rois = rois; a.N = N; a.P = P; a.sr = sampling_ratio;
+  a.finest = finest_scale;
+  for (int l = 0; l < DM_MAX_LEVELS; ++l) {
+    a.H[l] = l < num_levels ? H[l] : 0;
+    a.W[l] = l < num_levels ? W[l] : 0;
+    a.scale[l] = l < num_levels ? spatial_scales[l] : 0.f;
+    a.feat[l] = nullptr;
+    a.gfeat[l] = nullptr;
+    if (l < num_levels && (H[l] <= 0 || W[l] <= 0)) return DM_ERR_INVALID_ARG;
+  }
+  // channels per workgroup: enough workgroups to fill 256 CUs several times over
+  a.CT = (P * P >= 1024) ? 4 : 16;
+  a.out = nullptr; a.gout = nullptr; a.levels = nullptr;
+  return DM_OK;
+}
+
+}  // namespace
+
+extern "C" int dm_roi_align_fwd(const float* const* feats, const int* H, const int* W, const float* spatial_scales,
+                                int num_levels, int B, int C, const float* rois, int N, int P, int sampling_ratio,
+                                float finest_scale, float* out, int32_t* levels_out, dm_stream_t stream) {
+  RoiArgs a;
+  int rc = fill_args(a, H, W, spatial_scales, num_levels, B, C, rois, N, P, sampling_ratio, finest_scale);
+  if (rc != DM_OK) return rc;
+  if (N == 0) return DM_OK;
+  if (!feats || !out) return DM_ERR_INVALID_ARG;
+  for (int l = 0; l < num_levels; ++l) {
+    if (!feats[l]) return DM_ERR_INVALID_ARG;
+    a.feat[l] = feats[l];
+  }
+  if (N == 0) return DM_OK;
+  a.out = out;
+  a.levels = levels_out;
+  const int chunks = dm_ceil_div(C, a.CT);
+  hipLaunchKernelGGL(roi_align_kernel<false>, dim3(N * chunks), dim3(256), 0, (hipStream_t)stream, a);
+  return dm_check_launch();
+}
+
+extern "C" int dm_roi_align_bwd(const float* grad_out, float* const* grad_feats, const int* H, const int* W,
+                                const float* spatial_scales, int num_levels, int B, int C, const float* rois, int N,
+                                int P, int sampling_ratio, float finest_scale, dm_stream_t stream) {
+  RoiArgs a;
+  int rc = fill_args(a, H, W, spatial_scales, num_levels, B, C, rois, N, P, sampling_ratio, finest_scale);
+  if (rc != DM_OK) return rc;
+  if (N == 0) return DM_OK;
+  if (!grad_feats || !grad_out) return DM_ERR_INVALID_ARG;
+  for (int l = 0; l < num_levels; ++l) {
+    if (!grad_feats[l]) return DM_ERR_INVALID_ARG;
+    a.gfeat[l] = grad_feats[l];
+  }
+  if (N == 0) return DM_OK;
+  a.gout = grad_out;
+  const int chunks = dm_ceil_div(C, a.CT);
+  hipLaunchKernelGGL(roi_align_kernel<true>, dim3(N * chunks), dim3(256), 0, (hipStream_t)stream, a);
+  return dm_check_launch();
+}

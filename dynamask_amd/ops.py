@@ -1,0 +1,248 @@
+"""Operator bindings: torch device tensors -> raw pointers -> C ABI.
+
+PyTorch is plumbing here (device memory, streams); all arithmetic runs in
+libdynamask_hip.so.  Every function requires contiguous fp32 tensors on a HIP
+device and raises otherwise -- no eager fallback.
+"""
+import ctypes
+
+import torch
+
+from ._lib import check, lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f'{name}: expected a tensor')
+    if not t.is_cuda:
+        raise RuntimeError(f'{name}: dynamask_amd operators run on the MI355X only (got a {t.device} tensor); '
+                           'there is no CPU fallback')
+    if t.dtype != dtype:
+        raise TypeError(f'{name}: expected {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise ValueError(f'{name}: tensor must be contiguous (NCHW)')
+    return t
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def _int_array(vals):
+    return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def _float_array(vals):
+    return (ctypes.c_float * len(vals))(*[float(v) for v in vals])
+
+
+# ------------------------------------------------------------------ RoIAlign
+def roi_align(feats, rois, output_size, spatial_scales, sampling_ratio=0, finest_scale=56.0, return_levels=False):
+    feats = [_chk(f, 'feat') for f in feats]
+    _chk(rois, 'rois')
+    B, C = feats[0].shape[:2]
+    N = rois.shape[0]
+    out = torch.empty((N, C, output_size, output_size), device=rois.device, dtype=torch.float32)
+    levels = torch.zeros((N,), device=rois.device, dtype=torch.int32) if return_levels else None
+    rc = lib().dm_roi_align_fwd(_ptr_array(feats), _int_array([f.shape[2] for f in feats]),
+                                _int_array([f.shape[3] for f in feats]), _float_array(spatial_scales), len(feats),
+                                B, C, _p(rois), N, output_size, sampling_ratio, finest_scale, _p(out), _p(levels),
+                                _stream())
+    check(rc, 'dm_roi_align_fwd')
+    return (out, levels) if return_levels else out
+
+
+def roi_align_backward(grad_out, feat_shapes, rois, output_size, spatial_scales, sampling_ratio=0, finest_scale=56.0):
+    _chk(grad_out, 'grad_out')
+    _chk(rois, 'rois')
+    grads = [torch.zeros(s, device=grad_out.device, dtype=torch.float32) for s in feat_shapes]
+    B, C = feat_shapes[0][:2]
+    N = rois.shape[0]
+    rc = lib().dm_roi_align_bwd(_p(grad_out), _ptr_array(grads), _int_array([s[2] for s in feat_shapes]),
+                                _int_array([s[3] for s in feat_shapes]), _float_array(spatial_scales),
+                                len(feat_shapes), B, C, _p(rois), N, output_size, sampling_ratio, finest_scale,
+                                _stream())
+    check(rc, 'dm_roi_align_bwd')
+    return grads
+
+
+# --------------------------------------------------------------- convolutions
+def packed_cout(cout):
+    return lib().dm_conv_packed_cout(int(cout))
+
+
+def pack_conv_weight(w, transpose_flip=False):
+    """OIHW -> [k*k][Cin][CoutP] (see include/dynamask_hip.h)."""
+    _chk(w, 'weight')
+    cout, cin, kh, kw = w.shape
+    assert kh == kw and kh in (1, 3)
+    rows = cout if transpose_flip else cin
+    cols = cin if transpose_flip else cout
+    wp = torch.empty((kh * kw, rows, packed_cout(cols)), device=w.device, dtype=torch.float32)
+    check(lib().dm_conv_pack_weight(_p(w), cout, cin, kh, 1 if transpose_flip else 0, _p(wp), _stream()),
+          'dm_conv_pack_weight')
+    return wp
+
+
+def conv2d(srcs, w_packed, bias, cout, ksize, relu=False, out=None, out_ch_offset=0):
+    """Fused concat(srcs) -> conv(ksize, same) -> +bias -> ReLU."""
+    if isinstance(srcs, torch.Tensor):
+        srcs = [srcs]
+    srcs = [_chk(s, 'src') for s in srcs]
+    _chk(w_packed, 'w_packed')
+    if bias is not None:
+        _chk(bias, 'bias')
+    NB, _, H, W = srcs[0].shape
+    for s in srcs:
+        assert s.shape[0] == NB and s.shape[2] == H and s.shape[3] == W
+    cin = sum(s.shape[1] for s in srcs)
+    assert w_packed.shape == (ksize * ksize, cin, packed_cout(cout)), (tuple(w_packed.shape), ksize, cin, cout)
+    if out is None:
+        out = torch.empty((NB, cout, H, W), device=srcs[0].device, dtype=torch.float32)
+    else:
+        _chk(out, 'out')
+        assert out.shape[0] == NB and out.shape[2] == H and out.shape[3] == W
+    rc = lib().dm_conv2d_fwd(_ptr_array(srcs), _int_array([s.shape[1] for s in srcs]), len(srcs), NB, H, W,
+                             _p(w_packed), _p(bias), cout, ksize, 1 if relu else 0, _p(out), out.shape[1],
+                             out_ch_offset, _stream())
+    check(rc, 'dm_conv2d_fwd')
+    return out
+
+
+def deform_conv(x, offset, w_packed, cout, deform_groups, relu=False):
+    _chk(x, 'x')
+    _chk(offset, 'offset')
+    _chk(w_packed, 'w_packed')
+    NB, C, H, W = x.shape
+    assert offset.shape == (NB, deform_groups * 18, H, W)
+    assert w_packed.shape == (9, C, packed_cout(cout))
+    out = torch.empty((NB, cout, H, W), device=x.device, dtype=torch.float32)
+    check(lib().dm_deform_conv_fwd(_p(x), _p(offset), NB, C, H, W, _p(w_packed), cout, deform_groups,
+                                   1 if relu else 0, _p(out), _stream()), 'dm_deform_conv_fwd')
+    return out
+
+
+def pack_deconv_weight(w):
+    _chk(w, 'weight')
+    cin, cout, kh, kw = w.shape
+    assert kh == 2 and kw == 2
+    wp = torch.empty((1, cin, packed_cout(4 * cout)), device=w.device, dtype=torch.float32)
+    check(lib().dm_deconv_pack_weight(_p(w), cin, cout, _p(wp), _stream()), 'dm_deconv_pack_weight')
+    return wp
+
+
+def deconv2x2(x, w_packed, bias, cout, relu=False):
+    _chk(x, 'x')
+    _chk(w_packed, 'w_packed')
+    NB, C, H, W = x.shape
+    out = torch.empty((NB, cout, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+    check(lib().dm_deconv2x2_fwd(_p(x), NB, C, H, W, _p(w_packed), _p(bias), cout, 1 if relu else 0, _p(out),
+                                 _stream()), 'dm_deconv2x2_fwd')
+    return out
+
+
+def carafe(x, enc, up_kernel=5, group=1, scale=2):
+    _chk(x, 'x')
+    _chk(enc, 'enc')
+    NB, C, H, W = x.shape
+    assert enc.shape == (NB, up_kernel * up_kernel * group * scale * scale, H, W)
+    out = torch.empty((NB, C, H * scale, W * scale), device=x.device, dtype=torch.float32)
+    check(lib().dm_carafe_fwd(_p(x), _p(enc), NB, C, H, W, up_kernel, group, scale, _p(out), _stream()),
+          'dm_carafe_fwd')
+    return out
+
+
+# ------------------------------------------------------------ bandwidth kernels
+def point_sample(feat, rois, output_size, spatial_scale):
+    _chk(feat, 'feat')
+    _chk(rois, 'rois')
+    B, C, H, W = feat.shape
+    N = rois.shape[0]
+    out = torch.empty((N, C, output_size, output_size), device=feat.device, dtype=torch.float32)
+    check(lib().dm_point_sample_fwd(_p(feat), B, C, H, W, _p(rois), N, output_size, spatial_scale, _p(out),
+                                    _stream()), 'dm_point_sample_fwd')
+    return out
+
+
+def class_logits(x, w_inst, b_inst, w_det, b_det, labels, sig_out=None, sig_ch_offset=0):
+    _chk(x, 'x')
+    for t, n in ((w_inst, 'w_inst'), (b_inst, 'b_inst'), (w_det, 'w_det'), (b_det, 'b_det')):
+        _chk(t, n)
+    _chk(labels, 'labels', torch.int64)
+    N, C, H, W = x.shape
+    nc = w_inst.shape[0]
+    inst = torch.empty((N, 1, H, W), device=x.device, dtype=torch.float32)
+    det = torch.empty((N, 1, H, W), device=x.device, dtype=torch.float32)
+    sig_ct = 0
+    if sig_out is not None:
+        _chk(sig_out, 'sig_out')
+        assert sig_out.shape[0] == N and sig_out.shape[2:] == x.shape[2:]
+        sig_ct = sig_out.shape[1]
+    check(lib().dm_class_logits_fwd(_p(x), N, C, H * W, _p(w_inst), _p(b_inst), _p(w_det), _p(b_det), nc,
+                                    _p(labels), _p(inst), _p(det), _p(sig_out), sig_ct, sig_ch_offset, _stream()),
+          'dm_class_logits_fwd')
+    return inst, det
+
+
+def upsample2x(x, align_corners=False, relu=False):
+    _chk(x, 'x')
+    N, C, H, W = x.shape
+    out = torch.empty((N, C, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+    check(lib().dm_upsample2x_bilinear_fwd(_p(x), N * C, H, W, 1 if align_corners else 0, 1 if relu else 0,
+                                           _p(out), _stream()), 'dm_upsample2x_bilinear_fwd')
+    return out
+
+
+def boundary_merge_(coarse, fine):
+    """In place on ``fine`` (as the reference, dynamask_roi_head.py:148)."""
+    _chk(coarse, 'coarse')
+    _chk(fine, 'fine')
+    n, S = coarse.shape[0], coarse.shape[-1]
+    assert fine.shape[0] == n and fine.shape[-1] == 2 * S and fine.shape[-2] == 2 * S
+    check(lib().dm_boundary_merge(_p(coarse), _p(fine), n, S, _stream()), 'dm_boundary_merge')
+    return fine
+
+
+def gumbel_select(logits, U, temperature=0.5):
+    _chk(logits, 'logits')
+    _chk(U, 'U')
+    N, K = logits.shape
+    y = torch.empty_like(logits)
+    hot = torch.empty_like(logits)
+    idx = torch.empty((N,), device=logits.device, dtype=torch.int32)
+    check(lib().dm_gumbel_select_fwd(_p(logits), _p(U), N, K, temperature, _p(y), _p(hot), _p(idx), _stream()),
+          'dm_gumbel_select_fwd')
+    return y, hot, idx
+
+
+def detail_target(masks, fuse=(0.7, 0.3)):
+    _chk(masks, 'masks')
+    N, S = masks.shape[0], masks.shape[-1]
+    out = torch.empty((N, S, S), device=masks.device, dtype=torch.float32)
+    check(lib().dm_detail_target(_p(masks), N, S, float(fuse[0]), float(fuse[1]), _p(out), _stream()),
+          'dm_detail_target')
+    return out
+
+
+def mask_loss(inst_pred, det_pred, inst_tgt, det_tgt, weight, need_grad=True):
+    """Returns (sums[2], per_roi_det[N], grad_inst, grad_det) -- see the header."""
+    for t, n in ((inst_pred, 'inst_pred'), (det_pred, 'det_pred'), (inst_tgt, 'inst_tgt'), (det_tgt, 'det_tgt'),
+                 (weight, 'weight')):
+        _chk(t, n)
+    N = inst_pred.shape[0]
+    HW = inst_pred.numel() // max(N, 1)
+    sums = torch.zeros((2,), device=inst_pred.device, dtype=torch.float32)
+    per_roi = torch.zeros((N,), device=inst_pred.device, dtype=torch.float32)
+    gi = torch.empty_like(inst_pred) if need_grad else None
+    gd = torch.empty_like(det_pred) if need_grad else None
+    check(lib().dm_mask_loss_fwd_bwd(_p(inst_pred), _p(det_pred), _p(inst_tgt), _p(det_tgt), _p(weight), N, HW,
+                                     _p(sums), _p(per_roi), _p(gi), _p(gd), _stream()), 'dm_mask_loss_fwd_bwd')
+    return sums, per_roi, gi, gd

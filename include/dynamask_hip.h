@@ -1,0 +1,206 @@
+/*
+ * dynamask_hip.h -- C ABI of libdynamask_hip.so, the MI355X (gfx950) operator
+ * library behind the DynaMask mask-head hot path.
+ *
+ * Contract:
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer to fp32
+ *     (or int32 / int64 where stated), NCHW-contiguous, owned by the caller;
+ *   - no allocation, no global state, re-entrant; work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the null stream) and the call
+ *     returns without synchronising;
+ *   - return value: 0 = enqueued, negative = error (DM_ERR_*); the host binding
+ *     raises on any non-zero code (dm_error_string()).
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to
+ * the reference tree, lslrh/DynaMask).
+ */
+#ifndef DYNAMASK_HIP_H
+#define DYNAMASK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DM_OK 0
+#define DM_ERR_INVALID_ARG (-1)   /* bad shape / null pointer / unsupported parameter */
+#define DM_ERR_LAUNCH (-2)        /* hipLaunch / hipGetLastError reported a failure   */
+#define DM_ERR_UNSUPPORTED (-3)   /* valid request the library has no kernel for      */
+
+#define DM_MAX_LEVELS 4
+#define DM_MAX_SOURCES 4
+
+typedef void* dm_stream_t; /* hipStream_t */
+
+const char* dm_error_string(int code);
+/* ABI version: bumped whenever a signature changes. */
+int dm_abi_version(void);
+
+/* ---------------------------------------------------------------------------
+ * K1/K2  multi-level RoIAlign forward (avg pooling, aligned=True, adaptive grid)
+ * replaces: SingleRoIExtractor.forward + map_roi_levels
+ *           (mmdet/models/roi_heads/roi_extractors/single_level_roi_extractor.py:32-81)
+ *           and the per-level mmcv.ops.RoIAlign it builds
+ *           (roi_extractors/base_roi_extractor.py:49-55).
+ * feats[l]   : [B, C, H[l], W[l]]   l < num_levels (1..4)
+ * rois       : [N, 5] = (batch_idx, x1, y1, x2, y2) in image pixels
+ * out        : [N, C, P, P]
+ * levels_out : optional [N] int32, the FPN level chosen per RoI (NULL to skip)
+ * level = clamp(floor(log2(sqrt(w*h)/finest_scale + 1e-6)), 0, num_levels-1);
+ * num_levels == 1 skips the mapping (single-level extractor, base_roi_head.py:53-57).
+ * ------------------------------------------------------------------------- */
+int dm_roi_align_fwd(const float* const* feats, const int* H, const int* W, const float* spatial_scales,
+                     int num_levels, int B, int C, const float* rois, int N, int P, int sampling_ratio,
+                     float finest_scale, float* out, int32_t* levels_out, dm_stream_t stream);
+
+/* K3  RoIAlign backward: scatter-add (float atomics) of grad_out into the
+ * per-level feature gradients, which the caller has zero-filled. */
+int dm_roi_align_bwd(const float* grad_out, float* const* grad_feats, const int* H, const int* W,
+                     const float* spatial_scales, int num_levels, int B, int C, const float* rois, int N,
+                     int P, int sampling_ratio, float finest_scale, dm_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Weight packing for the implicit-GEMM convolutions: OIHW [Cout, Cin, k, k] ->
+ * [k*k][Cin][CoutP] with CoutP = dm_conv_packed_cout(Cout) (zero padded).
+ * transpose_flip != 0 packs the weights of the data-gradient convolution
+ * (in/out channels swapped, taps rotated by 180 degrees): input is still the
+ * forward OIHW tensor, the packed tensor then has "Cout" = Cin of the forward.
+ * ------------------------------------------------------------------------- */
+int dm_conv_packed_cout(int Cout);
+int dm_conv_pack_weight(const float* w_oihw, int Cout, int Cin, int ksize, int transpose_flip,
+                        float* w_packed, dm_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * K5/K6  dense convolution forward, stride 1, "same" padding, ksize in {1,3},
+ * fp32 in / fp32 accumulate on the MFMA units, fused concat + bias + ReLU.
+ * replaces: mmcv ConvModule / nn.Conv2d calls of
+ *           mask_heads/dynamask_head.py:73,83,86,104,117-121,203-213,221-222,
+ *           mask_heads/fcn_mask_head.py:59-71,119-120,102,125.
+ * srcs[s]  : [NB, src_channels[s], H, W]; the channel-concatenation of the
+ *            sources is the conv input (torch.cat at dynamask_head.py:107-116
+ *            is folded into the K loop), sum(src_channels) = Cin
+ * w_packed : dm_conv_pack_weight layout, bias: [Cout] or NULL
+ * out      : written at channels [out_ch_offset, out_ch_offset+Cout) of a
+ *            tensor [NB, out_ch_total, H, W]
+ * ------------------------------------------------------------------------- */
+int dm_conv2d_fwd(const float* const* srcs, const int* src_channels, int num_srcs, int NB, int H, int W,
+                  const float* w_packed, const float* bias, int Cout, int ksize, int relu, float* out,
+                  int out_ch_total, int out_ch_offset, dm_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * K4  SimpleRoIAlign / point_sample forward (grid_sample bilinear, zero
+ * padding, align_corners=False at RoI-relative pixel centres).
+ * replaces: mmcv.ops.SimpleRoIAlign at mask_heads/dynamask_head.py:74,105.
+ * feat [B, C, H, W], rois [N,5] -> out [N, C, S, S]
+ * ------------------------------------------------------------------------- */
+int dm_point_sample_fwd(const float* feat, int B, int C, int H, int W, const float* rois, int N, int S,
+                        float spatial_scale, float* out, dm_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * K7  per-RoI class-gathered 1x1 logits, two branches at once.
+ * replaces: instance_logits(x)[arange(N), labels][:, None] and the detail twin
+ *           (mask_heads/dynamask_head.py:110-113, 236-237).
+ * x [N, C, HW]; w_inst/w_det [num_classes, C]; b_* [num_classes];
+ * labels [N] int64 (values clamped to [0, num_classes-1] by the caller's contract)
+ * inst/det      : [N, HW] raw logits
+ * sig_out       : optional; sigmoid(inst), sigmoid(det) written to channels
+ *                 sig_ch_offset, sig_ch_offset+1 of a [N, sig_ch_total, HW] tensor
+ * ------------------------------------------------------------------------- */
+int dm_class_logits_fwd(const float* x, int N, int C, int HW, const float* w_inst, const float* b_inst,
+                        const float* w_det, const float* b_det, int num_classes, const int64_t* labels,
+                        float* inst, float* det, float* sig_out, int sig_ch_total, int sig_ch_offset,
+                        dm_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * K8  deformable convolution v1 forward, 3x3, stride 1, pad 1, dilation 1,
+ * groups 1, no bias, fused ReLU option.
+ * replaces: mmcv.ops.DeformConv2dPack (DCN) at mask_heads/dynamask_head.py:84,118-119;
+ *           arithmetic spec mmdet/ops/dcn/src/deform_conv_cuda_kernel.cu:84-115,190-243,
+ *           mmdet/ops/dcn/src/deform_conv_cuda.cpp:152-260.
+ * x [NB, C, H, W]; offset [NB, deform_groups*18, H, W] (dh,dw interleaved per tap);
+ * w_packed: dm_conv_pack_weight(ksize=3) of the [Cout, C, 3, 3] weight; out [NB, Cout, H, W]
+ * ------------------------------------------------------------------------- */
+int dm_deform_conv_fwd(const float* x, const float* offset, int NB, int C, int H, int W,
+                       const float* w_packed, int Cout, int deform_groups, int relu, float* out,
+                       dm_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * K11  x2 bilinear upsampling.
+ * replaces: nn.Upsample(scale_factor=2, mode='bilinear') + ReLU
+ *           (mask_heads/dynamask_head.py:87,123; align_corners=False) and
+ *           F.interpolate(scale_factor=2, 'bilinear', align_corners=True)
+ *           (mask_heads/dynamask_head.py:239-243).
+ * in [NC, H, W] -> out [NC, 2H, 2W]
+ * ------------------------------------------------------------------------- */
+int dm_upsample2x_bilinear_fwd(const float* in, int NC, int H, int W, int align_corners, int relu,
+                               float* out, dm_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * K15  inference boundary-aware merge of one coarse->fine stage pair.
+ * replaces: the loop body of DynaMaskRoIHead.simple_test_mask
+ *           (roi_heads/dynamask_roi_head.py:138-149) incl. generate_block_target
+ *           (losses/cross_entropy_loss.py:123-154) with boundary_width=1.
+ * coarse [n, S, S] logits, fine [n, 2S, 2S] logits (overwritten in place where
+ * the x2 align_corners=True upsampled non-boundary mask is >= 0.5).
+ * ------------------------------------------------------------------------- */
+int dm_boundary_merge(const float* coarse, float* fine, int n, int S, dm_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * K16  deconv 2x2 stride 2 (+bias, +ReLU): nn.ConvTranspose2d(C, Cout, 2, 2)
+ * replaces: FCNMaskHead.upsample 'deconv' (mask_heads/fcn_mask_head.py:77-83,121-124).
+ * x [NB, C, H, W]; w_packed = dm_deconv_pack_weight of the [C, Cout, 2, 2] weight;
+ * out [NB, Cout, 2H, 2W]
+ * ------------------------------------------------------------------------- */
+int dm_deconv_pack_weight(const float* w_iohw, int Cin, int Cout, float* w_packed, dm_stream_t stream);
+int dm_deconv2x2_fwd(const float* x, int NB, int C, int H, int W, const float* w_packed, const float* bias,
+                     int Cout, int relu, float* out, dm_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * K17  CARAFE: kernel normaliser (pixel_shuffle + softmax over k*k) fused with
+ * the reassembly.  replaces: mmcv CARAFEPack.kernel_normalizer +
+ * feature_reassemble (mask_heads/fcn_mask_head.py:84-87,121).
+ * x [NB, C, H, W]; enc [NB, k*k*group*scale*scale, H, W] (content encoder
+ * output, before pixel shuffle); out [NB, C, scale*H, scale*W]
+ * ------------------------------------------------------------------------- */
+int dm_carafe_fwd(const float* x, const float* enc, int NB, int C, int H, int W, int up_kernel, int group,
+                  int scale, float* out, dm_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * K10  resolution selector: straight-through Gumbel-softmax (hard), T = 0.5.
+ * replaces: DynaMaskRoIHead.get_mask_label / gumbel_softmax
+ *           (roi_heads/dynamask_roi_head.py:84-114); U is the explicit uniform
+ *           noise the reference draws at :90.
+ * logits, U [N, 4] -> y_soft [N,4] (softmax((logits+g)/T)), index [N] int32
+ * (first maximum, as torch.max), one_hot [N,4]
+ * ------------------------------------------------------------------------- */
+int dm_gumbel_select_fwd(const float* logits, const float* U, int N, int K, float temperature,
+                         float* y_soft, float* one_hot, int32_t* index, dm_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * K13  DetailTarget: Laplacian boundary pyramid target, bit-exact {0,1}.
+ * replaces: DetailTarget.forward (losses/cross_entropy_loss.py:363-418).
+ * masks [N, S, S] in {0,1} -> out [N, S, S]; fuse = the two fuse_kernel weights
+ * ------------------------------------------------------------------------- */
+int dm_detail_target(const float* masks, int N, int S, float fuse0, float fuse1, float* out,
+                     dm_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * K12  mask losses of one stage, forward + gradients in one pass.
+ * replaces: binary_cross_entropy (losses/cross_entropy_loss.py:56-87) and the
+ *           fork's eps-BCE mask_cross_entropy (:90-120) as used at :458-462.
+ * inst_pred, det_pred, inst_tgt, det_tgt : [N, HW]; weight [N] (mask_labels[:,idx])
+ * sums (device, 2 floats, caller zero-fills): sums[0] += sum of BCE-with-logits,
+ *   sums[1] += sum_n weight[n] * sum_p -(t log(s+eps) + (1-t) log(1-s+eps))
+ * per_roi_det [N] (optional): the un-weighted per-RoI eps-BCE sums (for d/dweight)
+ * grad_inst / grad_det (optional): d sums[0]/d inst_pred, d(eps-BCE)/d det_pred
+ *   scaled by weight[n]; the host applies the scalar normalisers.
+ * ------------------------------------------------------------------------- */
+int dm_mask_loss_fwd_bwd(const float* inst_pred, const float* det_pred, const float* inst_tgt,
+                         const float* det_tgt, const float* weight, int N, int HW, float* sums,
+                         float* per_roi_det, float* grad_inst, float* grad_det, dm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DYNAMASK_HIP_H */

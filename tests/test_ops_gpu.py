@@ -1,0 +1,277 @@
+"""Parity of every HIP operator (through the C ABI) against the CPU oracle.
+fp32 tolerance of BASELINE.json's north_star: atol = rtol = 1e-4; index /
+integer-valued outputs bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import golden_inputs as gi
+from oracle import ref_model, ref_ops
+
+pytestmark = pytest.mark.gpu
+
+TOL = dict(atol=1e-4, rtol=1e-4)
+
+
+def _g(seed):
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return g
+
+
+def _dev(t):
+    return t.cuda().contiguous()
+
+
+def _close(a, b, **kw):
+    kw = kw or TOL
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else b
+    np.testing.assert_allclose(a, b, **kw)
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from dynamask_amd import ops as o
+    return o
+
+
+def _random_rois(n, B, img_h, img_w, seed):
+    from dynamask_amd import synth
+    per = (n + B - 1) // B
+    return synth.make_rois(B, per, img_h, img_w, seed=seed)[:n] if B == 1 else synth.make_rois(B, per, img_h, img_w, seed=seed)
+
+
+def test_roi_align_multilevel_golden_rois(ops, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g4_head.npz'))
+    hi = gi.head_inputs()
+    feats = [_dev(f) for f in hi['feats'][:4]]
+    out, lv = ops.roi_align(feats, _dev(hi['rois']), 14, [1 / 4, 1 / 8, 1 / 16, 1 / 32], return_levels=True)
+    assert np.array_equal(lv.cpu().numpy(), g['levels'])          # level indices bit-exact
+    _close(out, g['ins_feats'])
+
+
+def test_roi_align_random_rois_all_levels(ops):
+    from dynamask_amd import synth
+    feats = synth.make_fpn(2, 640, 800, 32, seed=7)
+    rois = synth.make_rois(2, 40, 640, 800, seed=8, max_size=800.0)
+    ref = ref_ops.single_roi_extractor(feats[:4], rois, 14, (4, 8, 16, 32))
+    lv_ref = ref_ops.map_roi_levels(rois, 4)
+    assert len(set(lv_ref.tolist())) == 4
+    out, lv = ops.roi_align([_dev(f) for f in feats[:4]], _dev(rois), 14, [1 / 4, 1 / 8, 1 / 16, 1 / 32],
+                            return_levels=True)
+    assert np.array_equal(lv.cpu().numpy(), lv_ref.numpy())
+    _close(out, ref)
+
+
+def test_roi_align_single_level_56_and_sampling_ratio(ops):
+    from dynamask_amd import synth
+    feats = synth.make_fpn(2, 256, 320, 16, seed=9)
+    rois = torch.cat([synth.make_rois(2, 6, 256, 320, seed=10, max_size=400.0), gi.head_inputs()['rois']], 0)
+    rois = rois[torch.argsort(rois[:, 0], stable=True)]
+    ref = ref_ops.single_roi_extractor([feats[0]], rois, 56, (4,))
+    out = ops.roi_align([_dev(feats[0])], _dev(rois), 56, [1 / 4])
+    _close(out, ref)
+    ref2 = ref_ops.roi_align(feats[1], rois, 7, 1 / 8, sampling_ratio=2)
+    out2 = ops.roi_align([_dev(feats[1])], _dev(rois), 7, [1 / 8], sampling_ratio=2)
+    _close(out2, ref2)
+    # empty RoI set
+    assert ops.roi_align([_dev(feats[0])], _dev(rois[:0]), 14, [1 / 4]).shape == (0, 16, 14, 14)
+
+
+def test_roi_align_backward(ops):
+    from dynamask_amd import synth
+    feats = [f.requires_grad_(True) for f in synth.make_fpn(2, 160, 224, 8, seed=11)[:4]]
+    rois = synth.make_rois(2, 12, 160, 224, seed=12, max_size=400.0)
+    ref = ref_ops.single_roi_extractor(feats, rois, 14, (4, 8, 16, 32))
+    go = torch.randn(ref.shape, generator=_g(13))
+    ref.backward(go)
+    grads = ops.roi_align_backward(_dev(go), [tuple(f.shape) for f in feats], _dev(rois), 14,
+                                   [1 / 4, 1 / 8, 1 / 16, 1 / 32])
+    for gr, f in zip(grads, feats):
+        _close(gr, f.grad if f.grad is not None else torch.zeros_like(f), atol=2e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize('N,Cin,Cout,S,ks', [
+    (7, 256, 256, 14, 3),     # instance convs
+    (3, 64, 36, 56, 3),       # DCN offset conv, stage 2
+    (5, 128, 36, 28, 3),      # DCN offset conv, stage 1
+    (9, 48, 30, 7, 3),        # tiles spanning >2 images, ragged channels
+    (7, 256, 126, 14, 1),     # fuse_transform_out
+    (4, 64, 30, 56, 1),
+    (2, 256, 64, 33, 1),      # odd spatial size
+    (1, 40, 80, 5, 1),
+])
+def test_conv2d_single_source(ops, N, Cin, Cout, S, ks):
+    x = torch.randn(N, Cin, S, S, generator=_g(20))
+    w = torch.randn(Cout, Cin, ks, ks, generator=_g(21)) / (Cin * ks * ks) ** 0.5
+    b = torch.randn(Cout, generator=_g(22))
+    for relu in (False, True):
+        ref = F.conv2d(x, w, b, padding=ks // 2)
+        if relu:
+            ref = F.relu(ref)
+        out = ops.conv2d(_dev(x), ops.pack_conv_weight(_dev(w)), _dev(b), Cout, ks, relu=relu)
+        _close(out, ref)
+
+
+def test_conv2d_fused_concat_and_channel_slice_output(ops):
+    # fuse_conv[0]: cat[x(C), isf(C), sig(1), sig(1)] -> C ; written into a channel slice
+    N, C, S = 6, 64, 28
+    xs = [torch.randn(N, c, S, S, generator=_g(30 + i)) for i, c in enumerate((C, C, 1, 1))]
+    w = torch.randn(C, 2 * C + 2, 1, 1, generator=_g(35)) / (2 * C) ** 0.5
+    b = torch.randn(C, generator=_g(36))
+    ref = F.relu(F.conv2d(torch.cat(xs, 1), w, b))
+    out = torch.full((N, C + 2, S, S), -7.0).cuda()
+    ops.conv2d([_dev(t) for t in xs], ops.pack_conv_weight(_dev(w)), _dev(b), C, 1, relu=True, out=out, out_ch_offset=1)
+    _close(out[:, 1:C + 1], ref)
+    assert torch.all(out[:, 0] == -7.0) and torch.all(out[:, C + 1] == -7.0)
+
+
+def test_conv2d_on_fpn_map(ops):
+    x = torch.randn(2, 256, 40, 56, generator=_g(40)) * 0.5
+    w = torch.randn(128, 256, 1, 1, generator=_g(41)) / 16
+    b = torch.randn(128, generator=_g(42)) * 0.1
+    out = ops.conv2d(_dev(x), ops.pack_conv_weight(_dev(w)), _dev(b), 128, 1, relu=True)
+    _close(out, F.relu(F.conv2d(x, w, b)))
+
+
+def test_conv2d_bwd_data_weights_packing(ops):
+    # data gradient of a 3x3 conv == conv with transposed, 180-degree-rotated weights
+    N, Cin, Cout, S = 3, 24, 40, 14
+    x = torch.randn(N, Cin, S, S, generator=_g(45), requires_grad=True)
+    w = torch.randn(Cout, Cin, 3, 3, generator=_g(46)) / 15
+    y = F.conv2d(x, w, padding=1)
+    go = torch.randn(y.shape, generator=_g(47))
+    y.backward(go)
+    gx = ops.conv2d(_dev(go), ops.pack_conv_weight(_dev(w), transpose_flip=True), None, Cin, 3)
+    _close(gx, x.grad)
+
+
+def test_point_sample(ops):
+    hi = gi.head_inputs()
+    feat = hi['feats'][2][:, :48].contiguous()      # P4
+    for S, scale in ((14, 0.25), (28, 1 / 16)):
+        ref = ref_ops.simple_roi_align(feat, hi['rois'], S, scale)
+        out = ops.point_sample(_dev(feat), _dev(hi['rois']), S, scale)
+        _close(out, ref)
+
+
+def test_class_logits(ops):
+    N, C, S, nc = 7, 128, 28, 80
+    x = torch.randn(N, C, S, S, generator=_g(50))
+    wi = torch.randn(nc, C, 1, 1, generator=_g(51)) / C ** 0.5
+    wd = torch.randn(nc, C, 1, 1, generator=_g(52)) / C ** 0.5
+    bi = torch.randn(nc, generator=_g(53))
+    bd = torch.randn(nc, generator=_g(54))
+    labels = torch.randint(0, nc, (N,), generator=_g(55))
+    ar = torch.arange(N)
+    ri = F.conv2d(x, wi, bi)[ar, labels][:, None]
+    rd = F.conv2d(x, wd, bd)[ar, labels][:, None]
+    sig = torch.zeros(N, 6, S, S).cuda()
+    oi, od = ops.class_logits(_dev(x), _dev(wi.view(nc, C)), _dev(bi), _dev(wd.view(nc, C)), _dev(bd), _dev(labels),
+                              sig_out=sig, sig_ch_offset=4)
+    _close(oi, ri)
+    _close(od, rd)
+    _close(sig[:, 4:5], ri.sigmoid())
+    _close(sig[:, 5:6], rd.sigmoid())
+
+
+@pytest.mark.parametrize('N,C,S', [(7, 256, 14), (5, 128, 28), (3, 64, 56), (2, 8, 9)])
+def test_deform_conv(ops, N, C, S):
+    x = torch.randn(N, C, S, S, generator=_g(60))
+    w = torch.randn(C, C, 3, 3, generator=_g(61)) / (9 * C) ** 0.5
+    off = torch.randn(N, 36, S, S, generator=_g(62)) * 1.5
+    off[0, :, 0, 0] = 40.0          # far outside: all taps void
+    off[-1, :, -1, -1] = -3.25
+    ref = F.relu(ref_ops.deform_conv2d(x, off, w, 1, 1, 1, 2))
+    out = ops.deform_conv(_dev(x), _dev(off), ops.pack_conv_weight(_dev(w)), C, 2, relu=True)
+    _close(out, ref)
+    # known answer: zero offsets == plain conv
+    out0 = ops.deform_conv(_dev(x), torch.zeros_like(off).cuda(), ops.pack_conv_weight(_dev(w)), C, 2)
+    _close(out0, F.conv2d(x, w, padding=1))
+
+
+def test_upsample2x(ops):
+    x = torch.randn(5, 7, 14, 14, generator=_g(70))
+    _close(ops.upsample2x(_dev(x), align_corners=False, relu=True),
+           F.relu(F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)), atol=1e-5, rtol=1e-5)
+    y = torch.randn(4, 1, 56, 56, generator=_g(71))
+    _close(ops.upsample2x(_dev(y), align_corners=True),
+           F.interpolate(y, scale_factor=2, mode='bilinear', align_corners=True), atol=1e-5, rtol=1e-5)
+
+
+def test_boundary_merge_matches_reference_golden(ops, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g5_merge.npz'))
+    ips = [_dev(t.clone()) for t in gi.merge_inputs()['ips']]
+    preds = ips[1:]
+    for i in range(len(preds) - 1):
+        ops.boundary_merge_(preds[i], preds[i + 1])
+    _close(preds[-1], g['merged'], atol=1e-5, rtol=1e-5)
+
+
+def test_gumbel_selector_matches_reference_golden(ops, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g3_gumbel.npz'))
+    logits = gi.gumbel_logits()
+    torch.manual_seed(gi.GUMBEL_SEED)
+    U = torch.rand(logits.shape)
+    y, hot, idx = ops.gumbel_select(_dev(logits), _dev(U), 0.5)
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), g['index'])      # selection indices bit-exact
+    _close(hot, g['y_hard'], atol=1e-6, rtol=0)
+    y_ref, _ = ref_model.gumbel_select(logits, U, 0.5)
+    # y_hard of the reference = (one_hot - y).detach() + y  -> value == one_hot; soft part vs oracle
+    _close(y, F.softmax((logits + (-torch.log(-torch.log(U + 1e-20) + 1e-20))) / 0.5, -1), atol=1e-5, rtol=1e-4)
+    # U == 0.5 everywhere -> index = argmax(logits)   (SURVEY 8c known answer v)
+    _, _, idx2 = ops.gumbel_select(_dev(logits), torch.full_like(logits, 0.5).cuda(), 0.5)
+    assert np.array_equal(idx2.cpu().numpy(), logits.argmax(-1).numpy())
+
+
+def test_detail_target_matches_reference_golden(ops, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g1_losses.npz'))
+    li = gi.loss_inputs()
+    for i in range(4):
+        out = ops.detail_target(_dev(li['targets'][i]))
+        assert np.array_equal(out.cpu().numpy()[:, None], g[f'detail_target{i}'])   # bit-exact {0,1}
+
+
+def test_mask_loss_matches_reference_golden(ops, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g1_losses.npz'))
+    li = gi.loss_inputs()
+    ip, dp, t = li['ips'][1], li['dps'][1], li['targets'][1]
+    w = li['mask_labels'][:, 1].contiguous()
+    dt = ref_model.detail_target(t).squeeze(1)
+    n_el = ip.numel()
+    # golden eps-BCE was taken against the instance target itself
+    sums0, _, _, _ = ops.mask_loss(_dev(ip), _dev(dp), _dev(t), _dev(t), _dev(w), need_grad=False)
+    _close(sums0[0] / n_el, g['bce_stage1'], atol=1e-5, rtol=1e-4)
+    _close(sums0[1] / n_el, g['epsbce_stage1'], atol=1e-5, rtol=1e-4)
+    sums, per_roi, gi_, gd_ = ops.mask_loss(_dev(ip), _dev(dp), _dev(t), _dev(dt), _dev(w))
+    _close(sums[1] / n_el, ref_model.mask_cross_entropy(dp.squeeze(1), dt, w.view(-1, 1, 1)), atol=1e-5, rtol=1e-4)
+    _close((per_roi * _dev(w)).sum(), sums[1], atol=1e-3, rtol=1e-5)
+    ipr = ip.clone().requires_grad_(True)
+    dpr = dp.clone().requires_grad_(True)
+    (ref_model.binary_cross_entropy(ipr.squeeze(1), t) * n_el).backward()
+    (ref_model.mask_cross_entropy(dpr.squeeze(1), dt, w.view(-1, 1, 1)) * n_el).backward()
+    _close(gi_, ipr.grad, atol=1e-5, rtol=1e-4)
+    _close(gd_, dpr.grad, atol=1e-5, rtol=1e-4)
+
+
+def test_deconv_and_carafe(ops):
+    x = torch.relu(torch.randn(3, 256, 14, 14, generator=_g(80)))
+    w = torch.randn(256, 256, 2, 2, generator=_g(81)) / 16
+    b = torch.randn(256, generator=_g(82)) * 0.1
+    ref = F.relu(F.conv_transpose2d(x, w, b, stride=2))
+    out = ops.deconv2x2(_dev(x), ops.pack_deconv_weight(_dev(w)), _dev(b), 256, relu=True)
+    _close(out, ref)
+    enc = torch.randn(3, 100, 14, 14, generator=_g(83))
+    mask = F.pixel_shuffle(enc, 2)
+    mask = F.softmax(mask.view(3, 1, 25, 28, 28), dim=2).view(3, 25, 28, 28)
+    ref2 = ref_ops.carafe_reassemble(x, mask, 5, 1, 2)
+    _close(ops.carafe(_dev(x), _dev(enc), 5, 1, 2), ref2)
+
+
+def test_ops_refuse_cpu_tensors(ops):
+    with pytest.raises(RuntimeError):
+        ops.upsample2x(torch.zeros(1, 1, 4, 4))
