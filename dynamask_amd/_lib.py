@@ -18,7 +18,7 @@ SIGNATURES = {
     'dm_roi_align_bwd': ([_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _c_float, _vp], _c_int),
     'dm_conv_packed_cout': ([_c_int], _c_int),
     'dm_conv_pack_weight': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp], _c_int),
-    'dm_conv2d_fwd': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp], _c_int),
+    'dm_conv2d_fwd': ([_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp], _c_int),
     'dm_point_sample_fwd': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_float, _vp, _vp], _c_int),
     'dm_class_logits_fwd': ([_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp], _c_int),
     'dm_deform_conv_fwd': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _vp, _vp], _c_int),
@@ -28,6 +28,10 @@ SIGNATURES = {
     'dm_deconv2x2_fwd': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _vp, _vp], _c_int),
     'dm_carafe_fwd': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp], _c_int),
     'dm_gumbel_select_fwd': ([_vp, _vp, _c_int, _c_int, _c_float, _vp, _vp, _vp, _vp], _c_int),
+    'dm_gumbel_select_bwd': ([_vp, _vp, _c_int, _c_int, _c_float, _vp, _vp], _c_int),
+    'dm_class_balance_fwd_bwd': ([_vp, _c_int, _c_int, _vp, _vp, _vp], _c_int),
+    'dm_bn_stats': ([_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_float, _vp], _c_int),
+    'dm_bn_relu_maxpool_fwd': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_float, _vp, _vp], _c_int),
     'dm_detail_target': ([_vp, _c_int, _c_int, _c_float, _c_float, _vp, _vp], _c_int),
     'dm_mask_loss_fwd_bwd': ([_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp], _c_int),
 }

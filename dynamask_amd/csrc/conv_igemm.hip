@@ -29,6 +29,7 @@ namespace {
 struct ConvArgs {
   const float* src[DM_MAX_SOURCES];
   int src_c[DM_MAX_SOURCES];
+  long long src_bs[DM_MAX_SOURCES];  // batch stride of each source, in floats
   int num_srcs;
   int NB, H, W, HW, Q;
   const float* wp;
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_igemm_kernel(ConvArgs a) {
   for (int s = 0; s < a.num_srcs; ++s) {
     const float* __restrict__ sp = a.src[s];
     const int Cs = a.src_c[s];
+    const size_t bs = (size_t)a.src_bs[s];
     for (int c0 = 0; c0 < Cs; c0 += CK) {
       const int ckv = min(CK, Cs - c0);
       const int ckp = (ckv + 1) & ~1;
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_igemm_kernel(ConvArgs a) {
           const int pos = tid + k * NT;
           if (pos < plane) {
             const bool ok = st_n[k] >= 0;
-            const float* gp = sp + ((size_t)max(st_n[k], 0) * Cs + c0) * HW + st_pix[k];
+            const float* gp = sp + (size_t)max(st_n[k], 0) * bs + (size_t)c0 * HW + st_pix[k];
             for (int ci = 0; ci < ckp; ++ci) {
               float v = 0.f;
               if (ok && ci < ckv) v = gp[(size_t)ci * HW];
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_igemm_kernel(ConvArgs a) {
         q = min(q, a.Q - 1);
         const int n = q / HW;
         const int p = q - n * HW;
-        const float* gp = sp + ((size_t)n * Cs + c0) * HW + p;
+        const float* gp = sp + (size_t)n * bs + (size_t)c0 * HW + p;
         for (int ci = sub; ci < ckp; ci += SUB) {
           float v = 0.f;
           if (ok && ci < ckv) v = gp[(size_t)ci * HW];
@@ -317,7 +319,8 @@ extern "C" int dm_conv_pack_weight(const float* w_oihw, int Cout, int Cin, int k
   return dm_check_launch();
 }
 
-extern "C" int dm_conv2d_fwd(const float* const* srcs, const int* src_channels, int num_srcs, int NB, int H, int W,
+extern "C" int dm_conv2d_fwd(const float* const* srcs, const int* src_channels, const long long* src_batch_strides,
+                             int num_srcs, int NB, int H, int W,
                              const float* w_packed, const float* bias, int Cout, int ksize, int relu, float* out,
                              int out_ch_total, int out_ch_offset, dm_stream_t stream) {
   if (!srcs || !src_channels || num_srcs < 1 || num_srcs > DM_MAX_SOURCES || !w_packed || !out) return DM_ERR_INVALID_ARG;
@@ -330,9 +333,12 @@ extern "C" int dm_conv2d_fwd(const float* const* srcs, const int* src_channels, 
   for (int s = 0; s < DM_MAX_SOURCES; ++s) {
     a.src[s] = s < num_srcs ? srcs[s] : nullptr;
     a.src_c[s] = s < num_srcs ? src_channels[s] : 0;
+    a.src_bs[s] = 0;
     if (s < num_srcs) {
       if (!srcs[s] || src_channels[s] <= 0) return DM_ERR_INVALID_ARG;
       a.Cin += src_channels[s];
+      a.src_bs[s] = src_batch_strides ? src_batch_strides[s] : (long long)src_channels[s] * H * W;
+      if (a.src_bs[s] < (long long)src_channels[s] * H * W) return DM_ERR_INVALID_ARG;
     }
   }
   a.num_srcs = num_srcs;
@@ -387,8 +393,8 @@ extern "C" int dm_deconv2x2_fwd(const float* x, int NB, int C, int H, int W, con
   if ((long long)NB * H * W > 0x7fffffffLL) return DM_ERR_INVALID_ARG;
   if (NB == 0) return DM_OK;
   ConvArgs a;
-  for (int s = 0; s < DM_MAX_SOURCES; ++s) { a.src[s] = nullptr; a.src_c[s] = 0; }
-  a.src[0] = x; a.src_c[0] = C; a.num_srcs = 1; a.Cin = C;
+  for (int s = 0; s < DM_MAX_SOURCES; ++s) { a.src[s] = nullptr; a.src_c[s] = 0; a.src_bs[s] = 0; }
+  a.src[0] = x; a.src_c[0] = C; a.src_bs[0] = (long long)C * H * W; a.num_srcs = 1; a.Cin = C;
   a.NB = NB; a.H = H; a.W = W; a.HW = H * W; a.Q = NB * H * W;
   a.wp = w_packed; a.bias = bias; a.Cout = 4 * Cout; a.CoutP = dm_conv_packed_cout(4 * Cout);
   a.relu = relu; a.out = out; a.out_ch_total = 0; a.out_ch_offset = 0; a.shuffle = Cout;

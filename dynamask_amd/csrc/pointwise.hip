@@ -392,3 +392,67 @@ extern "C" int dm_mask_loss_fwd_bwd(const float* inst_pred, const float* det_pre
                      det_tgt, weight, N, HW, sums, per_roi_det, grad_inst, grad_det);
   return dm_check_launch();
 }
+
+// ------------------------------------------------------------------ K14
+// class-balance entropy  cb = sum_k p_k log(p_k + 1e-10),  p = colsum / total
+// (losses/cross_entropy_loss.py:478-481) and its gradient wrt mask_labels
+// (identical for every RoI).  One workgroup; N <= a few hundred.
+namespace {
+__global__ __launch_bounds__(256) void class_balance_kernel(const float* __restrict__ ml, int N, int K,
+                                                            float* __restrict__ loss, float* __restrict__ grad) {
+  __shared__ float red[16];
+  __shared__ float col[8];
+  __shared__ float gk[8];
+  for (int k = 0; k < K; ++k) {
+    float s = 0.f;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) s += ml[n * K + k];
+    const float t = block_sum(s, red);
+    if (threadIdx.x == 0) col[k] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float T = 0.f;
+    for (int k = 0; k < K; ++k) T += col[k];
+    float cb = 0.f, dot = 0.f;
+    float fp[8];
+    for (int k = 0; k < K; ++k) {
+      const float p = col[k] / T;
+      cb += p * logf(p + 1e-10f);
+      fp[k] = logf(p + 1e-10f) + p / (p + 1e-10f);
+      dot += fp[k] * p;
+    }
+    loss[0] = cb;
+    for (int k = 0; k < K; ++k) gk[k] = (fp[k] - dot) / T;
+  }
+  __syncthreads();
+  if (grad)
+    for (int i = threadIdx.x; i < N * K; i += blockDim.x) grad[i] = gk[i % K];
+}
+
+// K10 backward: y_hard = (one_hot - y).detach() + y  ->  d/dlogits of the
+// softmax((logits+g)/T) branch only.
+__global__ void gumbel_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gy, int N, int K, float T,
+                                  float* __restrict__ glogits) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float dot = 0.f;
+  for (int k = 0; k < K; ++k) dot += y[n * K + k] * gy[n * K + k];
+  for (int k = 0; k < K; ++k) glogits[n * K + k] = y[n * K + k] * (gy[n * K + k] - dot) / T;
+}
+}  // namespace
+
+extern "C" int dm_class_balance_fwd_bwd(const float* mask_labels, int N, int K, float* loss, float* grad,
+                                        dm_stream_t stream) {
+  if (!mask_labels || !loss || N <= 0 || K <= 0 || K > 8) return DM_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(class_balance_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mask_labels, N, K, loss, grad);
+  return dm_check_launch();
+}
+
+extern "C" int dm_gumbel_select_bwd(const float* y_soft, const float* grad_y, int N, int K, float temperature,
+                                    float* grad_logits, dm_stream_t stream) {
+  if (!y_soft || !grad_y || !grad_logits || N < 0 || K <= 0 || temperature <= 0.f) return DM_ERR_INVALID_ARG;
+  if (N == 0) return DM_OK;
+  hipLaunchKernelGGL(gumbel_bwd_kernel, dim3(dm_ceil_div(N, 64)), dim3(64), 0, (hipStream_t)stream, y_soft, grad_y, N, K,
+                     temperature, grad_logits);
+  return dm_check_launch();
+}

@@ -1,0 +1,368 @@
+"""Mask heads behind the reference's HEADS registry.
+
+``DynaMaskHead`` / ``SFMStage`` mirror
+``mmdet/models/roi_heads/mask_heads/dynamask_head.py:54-244`` and
+``FCNMaskHead`` mirrors ``mask_heads/fcn_mask_head.py:19-126``: same
+constructor kwargs, same ``forward`` signatures, same ``state_dict`` keys
+(SURVEY App. D), so reference checkpoints load.  The arithmetic is entirely in
+libdynamask_hip.so; these classes only own parameters and sequence launches:
+
+  * torch.cat never runs: concat sources are walked in the conv kernel's K loop,
+    and producers write straight into channel slices of the consumer's input;
+  * the 80-class logits conv + gather (dynamask_head.py:110-111) is a per-RoI
+    gathered dot product (1/80 of the work);
+  * bias, ReLU, sigmoid ride in the producing kernels' epilogues.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .registry import HEADS, UPSAMPLE_LAYERS, build_loss
+
+
+class _Packed:
+    """Cache of kernel-layout weights, refreshed when the parameter changes."""
+
+    def __init__(self):
+        self._c = {}
+
+    def get(self, key, param, fn):
+        ver = (param.data_ptr(), param._version, param.device)
+        e = self._c.get(key)
+        if e is None or e[0] != ver:
+            with torch.no_grad():
+                e = (ver, fn(param.detach().contiguous()))
+            self._c[key] = e
+        return e[1]
+
+
+class _Conv(nn.Module):
+    """Parameter holder named like nn.Conv2d (weight [Cout,Cin,k,k], bias)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        nn.init.kaiming_normal_(self.weight, mode='fan_out', nonlinearity='relu')
+        self._pk = _Packed()
+
+    def packed(self):
+        return self._pk.get('w', self.weight, ops.pack_conv_weight)
+
+    def run(self, srcs, relu=False, out=None, out_ch_offset=0):
+        b = self.bias.detach() if self.bias is not None else None
+        return ops.conv2d(srcs, self.packed(), b, self.out_channels, self.kernel_size, relu=relu, out=out,
+                          out_ch_offset=out_ch_offset)
+
+
+class ConvModule(nn.Module):
+    """mmcv ConvModule without norm: conv(bias) + ReLU; keys ``conv.weight/bias``."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, padding=0, dilation=1, conv_cfg=None, norm_cfg=None,
+                 act_cfg=dict(type='ReLU')):
+        super().__init__()
+        if conv_cfg is not None or norm_cfg is not None:
+            raise NotImplementedError('conv_cfg / norm_cfg are None in configs/dynamask')
+        if dilation != 1 or padding != kernel_size // 2:
+            raise NotImplementedError('only "same" stride-1 convolutions are on the path')
+        self.conv = _Conv(in_channels, out_channels, kernel_size)
+        self.with_activation = act_cfg is not None
+
+    def forward(self, x):
+        return self.conv.run(x, relu=self.with_activation)
+
+
+class DeformConv2dPack(nn.Module):
+    """DCNv1 3x3 + its zero-initialised offset conv; keys ``weight``,
+    ``conv_offset.weight/bias`` (mmdet/ops/dcn/deform_conv.py:189-275)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=(3, 3), stride=(1, 1), padding=1, deform_groups=1):
+        super().__init__()
+        ks = kernel_size if isinstance(kernel_size, int) else kernel_size[0]
+        if ks != 3:
+            raise NotImplementedError('3x3 DCN only')
+        self.in_channels, self.out_channels, self.deform_groups = in_channels, out_channels, deform_groups
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, 3, 3))
+        stdv = 1.0 / math.sqrt(in_channels * 9)
+        nn.init.uniform_(self.weight, -stdv, stdv)
+        self.conv_offset = _Conv(in_channels, deform_groups * 18, 3)
+        nn.init.zeros_(self.conv_offset.weight)
+        self._pk = _Packed()
+
+    def forward(self, x, relu=False):
+        offset = self.conv_offset.run(x)
+        wp = self._pk.get('w', self.weight, ops.pack_conv_weight)
+        return ops.deform_conv(x, offset, wp, self.out_channels, self.deform_groups, relu=relu)
+
+
+class SFMStage(nn.Module):
+    """dynamask_head.py:54-125."""
+
+    def __init__(self, semantic_in_channel=256, semantic_out_channel=256, instance_in_channel=256,
+                 instance_out_channel=256, out_size=14, num_classes=80, semantic_out_stride=4,
+                 mask_use_sigmoid=False, upsample_cfg=dict(type='bilinear', scale_factor=2)):
+        super().__init__()
+        self.semantic_out_stride = semantic_out_stride
+        self.mask_use_sigmoid = mask_use_sigmoid
+        self.num_classes = num_classes
+        self.out_size = out_size
+        self.instance_in_channel = instance_in_channel
+        self.instance_out_channel = instance_out_channel
+        if upsample_cfg.get('type') != 'bilinear' or upsample_cfg.get('scale_factor') != 2:
+            raise NotImplementedError('SFMStage upsample is bilinear x2 in configs/dynamask '
+                                      '(a carafe cfg cannot be passed unchanged: SURVEY K17)')
+        self.semantic_transform_in = _Conv(semantic_in_channel, semantic_out_channel, 1)
+        self.spatial_scale = 1.0 / semantic_out_stride
+        self.instance_logits = _Conv(instance_in_channel, num_classes, 1)
+        self.detail_logits = _Conv(instance_in_channel, num_classes, 1)
+        fuse_in_channel = instance_in_channel + semantic_out_channel + 2
+        self.fuse_conv = nn.ModuleList([
+            _Conv(fuse_in_channel, instance_in_channel, 1),
+            DeformConv2dPack(instance_in_channel, instance_in_channel, kernel_size=(3, 3), stride=(1, 1), padding=1,
+                             deform_groups=2)])
+        self.fuse_transform_out = _Conv(instance_in_channel, instance_out_channel - 2, 1)
+
+    def forward(self, instance_feats, semantic_feat, rois, roi_labels, upsample=True):
+        n, c, s = instance_feats.shape[0], self.instance_in_channel, self.out_size
+        co = self.instance_out_channel
+        # instance-wise semantic feats: relu(conv1x1) on the whole FPN map, then point sample
+        sem = self.semantic_transform_in.run(semantic_feat, relu=True)
+        ins_sem = ops.point_sample(sem, rois, s, self.spatial_scale)
+        # [fused_feats(co-2) | sigmoid(ip) | sigmoid(dp)] is assembled in place
+        tail = torch.empty((n, co, s, s), device=instance_feats.device, dtype=torch.float32)
+        nc = self.num_classes
+        ip, dp = ops.class_logits(instance_feats, self.instance_logits.weight.detach().view(nc, c),
+                                  self.instance_logits.bias.detach(), self.detail_logits.weight.detach().view(nc, c),
+                                  self.detail_logits.bias.detach(), roi_labels, sig_out=tail, sig_ch_offset=co - 2)
+        fused = self.fuse_conv[0].run([instance_feats, ins_sem, tail[:, co - 2:]], relu=True)
+        fused = self.fuse_conv[1](fused, relu=True)
+        self.fuse_transform_out.run(fused, relu=True, out=tail, out_ch_offset=0)
+        if upsample:
+            tail = ops.upsample2x(tail, align_corners=False, relu=True)
+        return ip, dp, tail
+
+
+@HEADS.register_module()
+class DynaMaskHead(nn.Module):
+    """dynamask_head.py:128-244."""
+
+    def __init__(self, num_convs_instance=2, num_convs_semantic=4, conv_in_channels_instance=256,
+                 conv_in_channels_semantic=256, conv_kernel_size_instance=3, conv_kernel_size_semantic=3,
+                 conv_out_channels_instance=256, conv_out_channels_semantic=256, conv_cfg=None, norm_cfg=None,
+                 semantic_out_stride=[16, 8, 4], mask_use_sigmoid=False, pre_upsample_last_stage=False,
+                 stage_num_classes=[80, 80, 80, 80], stage_sup_size=[14, 28, 56, 112],
+                 upsample_cfg=dict(type='bilinear', scale_factor=2),
+                 loss_cfg=dict(type='DynaCrossEntropyLoss')):
+        super().__init__()
+        self.num_convs_instance = num_convs_instance
+        self.conv_kernel_size_instance = conv_kernel_size_instance
+        self.conv_in_channels_instance = conv_in_channels_instance
+        self.conv_out_channels_instance = conv_out_channels_instance
+        self.num_convs_semantic = num_convs_semantic
+        self.conv_kernel_size_semantic = conv_kernel_size_semantic
+        self.conv_in_channels_semantic = conv_in_channels_semantic
+        self.conv_out_channels_semantic = conv_out_channels_semantic
+        self.conv_cfg, self.norm_cfg = conv_cfg, norm_cfg
+        self.semantic_out_stride = semantic_out_stride
+        self.stage_sup_size = stage_sup_size
+        self.stage_num_classes = stage_num_classes
+        self.pre_upsample_last_stage = pre_upsample_last_stage
+
+        convs = []
+        for i in range(num_convs_instance):
+            cin = conv_in_channels_instance if i == 0 else conv_out_channels_instance
+            convs.append(ConvModule(cin, conv_out_channels_instance, conv_kernel_size_instance, dilation=1, padding=1))
+        self.instance_convs = nn.ModuleList(convs)
+        self.loss_func = build_loss(loss_cfg)
+
+        assert len(self.stage_sup_size) > 1
+        self.stages = nn.ModuleList()
+        out_channel = conv_out_channels_instance
+        for idx, out_size in enumerate(self.stage_sup_size[:-1]):
+            in_channel = out_channel
+            out_channel = in_channel // 2
+            self.stages.append(SFMStage(
+                semantic_in_channel=conv_out_channels_semantic, semantic_out_channel=in_channel,
+                instance_in_channel=in_channel, instance_out_channel=out_channel, out_size=out_size,
+                num_classes=self.stage_num_classes[idx], semantic_out_stride=semantic_out_stride[-1],
+                mask_use_sigmoid=mask_use_sigmoid, upsample_cfg=upsample_cfg))
+        self.final_instance_logits = _Conv(out_channel, self.stage_num_classes[-1], 1)
+        self.final_detail_logits = _Conv(out_channel, self.stage_num_classes[-1], 1)
+
+    def init_weights(self):
+        for m in [self.final_instance_logits, self.final_detail_logits]:
+            nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            nn.init.constant_(m.bias, 0)
+
+    def forward(self, instance_feats, semantic_feats, rois, roi_labels, last_stage=None):
+        """Returns (stage_instance_preds, stage_detail_preds) as the reference.
+
+        ``last_stage`` (extension, default None = all): stop after the logits of
+        that exit (1 = the fixed 28x28 exit of BASELINE configs[1])."""
+        for conv in self.instance_convs:
+            instance_feats = conv(instance_feats)
+        stage_instance_preds, stage_detail_preds = [], []
+        roi_labels = roi_labels.long().contiguous()
+        for idx, stage in enumerate(self.stages):
+            if last_stage is not None and idx == last_stage:
+                # exit here: only the logits of this resolution are needed
+                c, nc = stage.instance_in_channel, stage.num_classes
+                ip, dp = ops.class_logits(instance_feats, stage.instance_logits.weight.detach().view(nc, c),
+                                          stage.instance_logits.bias.detach(),
+                                          stage.detail_logits.weight.detach().view(nc, c),
+                                          stage.detail_logits.bias.detach(), roi_labels)
+                stage_instance_preds.append(ip)
+                stage_detail_preds.append(dp)
+                return stage_instance_preds, stage_detail_preds
+            upsample_flag = self.pre_upsample_last_stage or idx < len(self.stages) - 1
+            ip, dp, instance_feats = stage(instance_feats, semantic_feats[-idx - 3], rois, roi_labels, upsample_flag)
+            stage_instance_preds.append(ip)
+            stage_detail_preds.append(dp)
+        if self.stage_num_classes[-1] == 1:
+            roi_labels = roi_labels.clamp(max=0)
+        nc = self.stage_num_classes[-1]
+        c = self.final_instance_logits.in_channels
+        ip, dp = ops.class_logits(instance_feats, self.final_instance_logits.weight.detach().view(nc, c),
+                                  self.final_instance_logits.bias.detach(),
+                                  self.final_detail_logits.weight.detach().view(nc, c),
+                                  self.final_detail_logits.bias.detach(), roi_labels)
+        if not self.pre_upsample_last_stage:
+            ip = ops.upsample2x(ip, align_corners=True)
+            dp = ops.upsample2x(dp, align_corners=True)
+        stage_instance_preds.append(ip)
+        stage_detail_preds.append(dp)
+        return stage_instance_preds, stage_detail_preds
+
+
+# ---------------------------------------------------------------- FCN mask head
+@UPSAMPLE_LAYERS.register_module(name='deconv')
+class _Deconv(nn.Module):
+    """nn.ConvTranspose2d(k=2, s=2) parameter holder: weight [Cin, Cout, 2, 2]."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=2, stride=2):
+        super().__init__()
+        if kernel_size != 2 or stride != 2:
+            raise NotImplementedError('deconv upsample is 2x2 stride 2 on the path')
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight = nn.Parameter(torch.empty(in_channels, out_channels, 2, 2))
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        nn.init.kaiming_normal_(self.weight, mode='fan_out', nonlinearity='relu')
+        self._pk = _Packed()
+
+    def forward(self, x, relu=False):
+        wp = self._pk.get('w', self.weight, ops.pack_deconv_weight)
+        return ops.deconv2x2(x, wp, self.bias.detach(), self.out_channels, relu=relu)
+
+
+@UPSAMPLE_LAYERS.register_module(name='carafe')
+class CARAFEPack(nn.Module):
+    """mmcv CARAFEPack: keys channel_compressor.*, content_encoder.*."""
+
+    def __init__(self, channels, scale_factor, up_kernel=5, up_group=1, encoder_kernel=3, encoder_dilation=1,
+                 compressed_channels=64):
+        super().__init__()
+        if encoder_kernel != 3 or encoder_dilation != 1:
+            raise NotImplementedError('CARAFE encoder is 3x3, dilation 1 on the path')
+        self.channels, self.scale_factor, self.up_kernel, self.up_group = channels, scale_factor, up_kernel, up_group
+        self.channel_compressor = _Conv(channels, compressed_channels, 1)
+        self.content_encoder = _Conv(compressed_channels, up_kernel * up_kernel * up_group * scale_factor ** 2, 3)
+        self.init_weights()
+
+    def init_weights(self):
+        nn.init.xavier_uniform_(self.channel_compressor.weight)
+        nn.init.zeros_(self.channel_compressor.bias)
+        nn.init.normal_(self.content_encoder.weight, std=0.001)
+        nn.init.zeros_(self.content_encoder.bias)
+
+    def forward(self, x, relu=False):
+        comp = self.channel_compressor.run(x)
+        enc = self.content_encoder.run(comp)
+        return ops.carafe(x, enc, self.up_kernel, self.up_group, self.scale_factor)
+
+
+@UPSAMPLE_LAYERS.register_module(name='bilinear')
+class _BilinearUp(nn.Module):
+    def __init__(self, scale_factor=2, mode='bilinear', align_corners=False):
+        super().__init__()
+        if scale_factor != 2:
+            raise NotImplementedError('x2 upsampling only')
+        self.align_corners = bool(align_corners)
+
+    def forward(self, x, relu=False):
+        return ops.upsample2x(x, align_corners=self.align_corners, relu=relu)
+
+
+def build_upsample_layer(cfg):
+    cfg = dict(cfg)
+    t = cfg.pop('type')
+    cls = UPSAMPLE_LAYERS.get(t)
+    if cls is None:
+        raise KeyError(f'unsupported upsample type {t!r}')
+    return cls(**cfg)
+
+
+@HEADS.register_module()
+class FCNMaskHead(nn.Module):
+    """fcn_mask_head.py:19-126 (forward only: the fork's loss path is broken,
+    SURVEY App. C Q5)."""
+
+    def __init__(self, num_convs=4, roi_feat_size=14, in_channels=256, conv_kernel_size=3, conv_out_channels=256,
+                 num_classes=80, class_agnostic=False, upsample_cfg=dict(type='deconv', scale_factor=2),
+                 conv_cfg=None, norm_cfg=None, loss_mask=None):
+        super().__init__()
+        self.upsample_cfg = dict(upsample_cfg)
+        if self.upsample_cfg['type'] not in [None, 'deconv', 'nearest', 'bilinear', 'carafe']:
+            raise ValueError(f'Invalid upsample method {self.upsample_cfg["type"]}, accepted methods are '
+                             '"deconv", "nearest", "bilinear", "carafe"')
+        self.num_convs = num_convs
+        self.in_channels = in_channels
+        self.conv_kernel_size = conv_kernel_size
+        self.conv_out_channels = conv_out_channels
+        self.upsample_method = self.upsample_cfg.get('type')
+        self.scale_factor = self.upsample_cfg.pop('scale_factor', None)
+        self.num_classes = num_classes
+        self.class_agnostic = class_agnostic
+        self.convs = nn.ModuleList()
+        for i in range(num_convs):
+            cin = in_channels if i == 0 else conv_out_channels
+            self.convs.append(ConvModule(cin, conv_out_channels, conv_kernel_size, padding=(conv_kernel_size - 1) // 2,
+                                         conv_cfg=conv_cfg, norm_cfg=norm_cfg))
+        up_in = conv_out_channels if num_convs > 0 else in_channels
+        cfg_ = dict(self.upsample_cfg)
+        if self.upsample_method is None:
+            self.upsample = None
+        elif self.upsample_method == 'deconv':
+            cfg_.update(in_channels=up_in, out_channels=conv_out_channels, kernel_size=self.scale_factor,
+                        stride=self.scale_factor)
+            self.upsample = build_upsample_layer(cfg_)
+        elif self.upsample_method == 'carafe':
+            cfg_.update(channels=up_in, scale_factor=self.scale_factor)
+            self.upsample = build_upsample_layer(cfg_)
+        elif self.upsample_method == 'bilinear':
+            cfg_.update(scale_factor=self.scale_factor, mode='bilinear', align_corners=False)
+            self.upsample = build_upsample_layer(cfg_)
+        else:
+            raise NotImplementedError('nearest upsampling is not on the measured path')
+        out_channels = 1 if class_agnostic else num_classes
+        logits_in = conv_out_channels if self.upsample_method == 'deconv' else up_in
+        self.conv_logits = _Conv(logits_in, out_channels, 1)
+
+    def init_weights(self):
+        for m in [self.upsample, self.conv_logits]:
+            if m is None:
+                continue
+            if isinstance(m, CARAFEPack):
+                m.init_weights()
+            elif hasattr(m, 'weight'):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        for conv in self.convs:
+            x = conv(x)
+        if self.upsample is not None:
+            x = self.upsample(x, relu=(self.upsample_method == 'deconv'))
+        return self.conv_logits.run(x)

@@ -28,6 +28,17 @@ def _chk(t, name, dtype=torch.float32):
     return t
 
 
+def _chk_src(t):
+    """A conv source may be a channel slice of a wider NCHW tensor: channels,
+    rows and columns dense, arbitrary batch stride."""
+    if isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 and \
+            not t.is_contiguous():
+        _, C, H, W = t.shape
+        if t.stride(3) == 1 and t.stride(2) == W and t.stride(1) == H * W and t.stride(0) >= C * H * W:
+            return t
+    return _chk(t, 'src')
+
+
 def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
@@ -96,7 +107,7 @@ def conv2d(srcs, w_packed, bias, cout, ksize, relu=False, out=None, out_ch_offse
     """Fused concat(srcs) -> conv(ksize, same) -> +bias -> ReLU."""
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
-    srcs = [_chk(s, 'src') for s in srcs]
+    srcs = [_chk_src(s) for s in srcs]
     _chk(w_packed, 'w_packed')
     if bias is not None:
         _chk(bias, 'bias')
@@ -110,7 +121,8 @@ def conv2d(srcs, w_packed, bias, cout, ksize, relu=False, out=None, out_ch_offse
     else:
         _chk(out, 'out')
         assert out.shape[0] == NB and out.shape[2] == H and out.shape[3] == W
-    rc = lib().dm_conv2d_fwd(_ptr_array(srcs), _int_array([s.shape[1] for s in srcs]), len(srcs), NB, H, W,
+    strides = (ctypes.c_longlong * len(srcs))(*[int(s.stride(0)) for s in srcs])
+    rc = lib().dm_conv2d_fwd(_ptr_array(srcs), _int_array([s.shape[1] for s in srcs]), strides, len(srcs), NB, H, W,
                              _p(w_packed), _p(bias), cout, ksize, 1 if relu else 0, _p(out), out.shape[1],
                              out_ch_offset, _stream())
     check(rc, 'dm_conv2d_fwd')
@@ -246,3 +258,44 @@ def mask_loss(inst_pred, det_pred, inst_tgt, det_tgt, weight, need_grad=True):
     check(lib().dm_mask_loss_fwd_bwd(_p(inst_pred), _p(det_pred), _p(inst_tgt), _p(det_tgt), _p(weight), N, HW,
                                      _p(sums), _p(per_roi), _p(gi), _p(gd), _stream()), 'dm_mask_loss_fwd_bwd')
     return sums, per_roi, gi, gd
+
+
+def gumbel_select_backward(y_soft, grad_y, temperature=0.5):
+    _chk(y_soft, 'y_soft')
+    _chk(grad_y, 'grad_y')
+    N, K = y_soft.shape
+    g = torch.empty_like(y_soft)
+    check(lib().dm_gumbel_select_bwd(_p(y_soft), _p(grad_y), N, K, temperature, _p(g), _stream()),
+          'dm_gumbel_select_bwd')
+    return g
+
+
+def class_balance(mask_labels):
+    """(cb loss scalar tensor, d cb / d mask_labels)."""
+    _chk(mask_labels, 'mask_labels')
+    N, K = mask_labels.shape
+    loss = torch.empty((1,), device=mask_labels.device, dtype=torch.float32)
+    grad = torch.empty_like(mask_labels)
+    check(lib().dm_class_balance_fwd_bwd(_p(mask_labels), N, K, _p(loss), _p(grad), _stream()),
+          'dm_class_balance_fwd_bwd')
+    return loss[0], grad
+
+
+def bn_stats(x, running_mean=None, running_var=None, momentum=0.1):
+    _chk(x, 'x')
+    NB, C, H, W = x.shape
+    mean = torch.empty((C,), device=x.device, dtype=torch.float32)
+    var = torch.empty((C,), device=x.device, dtype=torch.float32)
+    check(lib().dm_bn_stats(_p(x), NB, C, H * W, _p(mean), _p(var), _p(running_mean), _p(running_var), momentum,
+                            _stream()), 'dm_bn_stats')
+    return mean, var
+
+
+def bn_relu_maxpool(x, mean, var, gamma, beta, eps=1e-5):
+    for t, n in ((x, 'x'), (mean, 'mean'), (var, 'var'), (gamma, 'gamma'), (beta, 'beta')):
+        _chk(t, n)
+    NB, C, H, W = x.shape
+    out = torch.empty((NB, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), device=x.device, dtype=torch.float32)
+    check(lib().dm_bn_relu_maxpool_fwd(_p(x), NB, C, H, W, _p(mean), _p(var), _p(gamma), _p(beta), eps, _p(out),
+                                       _stream()), 'dm_bn_relu_maxpool_fwd')
+    return out

@@ -1,0 +1,182 @@
+"""DynaMaskRoIHead behind the reference's HEADS registry.
+
+Mirrors ``mmdet/models/roi_heads/dynamask_roi_head.py:10-158`` +
+``base_roi_head.py:10-58`` for the MASK path: ``_mask_forward``,
+``get_mask_label`` (MaskPre + straight-through Gumbel selector),
+``_mask_forward_train`` and ``simple_test_mask``.  The bbox branch, the
+assigner/sampler and mask-target generation are outside the hot path (SURVEY
+section 8: OOS / "next"); their config entries are accepted and kept, not built.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .mask_heads import _Conv
+from .registry import HEADS, build_head, build_roi_extractor
+
+
+def bbox2roi(bbox_list):
+    """mmdet/core/bbox/transforms.py:54-73."""
+    rois_list = []
+    for img_id, bboxes in enumerate(bbox_list):
+        if bboxes.size(0) > 0:
+            img_inds = bboxes.new_full((bboxes.size(0), 1), img_id)
+            rois = torch.cat([img_inds, bboxes[:, :4]], dim=-1)
+        else:
+            rois = bboxes.new_zeros((0, 5))
+        rois_list.append(rois)
+    return torch.cat(rois_list, 0)
+
+
+class _BN(nn.Module):
+    """BatchNorm2d parameter/buffer holder (keys as nn.BatchNorm2d)."""
+
+    def __init__(self, c, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.eps, self.momentum = eps, momentum
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer('running_mean', torch.zeros(c))
+        self.register_buffer('running_var', torch.ones(c))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+
+
+class _Linear(nn.Module):
+    """nn.Linear parameter holder; runs as a 1x1 conv on a 1x1 map (MFMA GEMM)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.in_features, self.out_features = cin, cout
+        lin = nn.Linear(cin, cout)
+        self.weight = nn.Parameter(lin.weight.detach().clone())
+        self.bias = nn.Parameter(lin.bias.detach().clone())
+        self._pk = None
+
+    def run(self, x, relu=False):
+        from .mask_heads import _Packed
+        if self._pk is None:
+            self._pk = _Packed()
+        wp = self._pk.get('w', self.weight, lambda w: ops.pack_conv_weight(w.view(self.out_features, self.in_features, 1, 1)))
+        n = x.shape[0]
+        y = ops.conv2d(x.reshape(n, self.in_features, 1, 1), wp, self.bias.detach(), self.out_features, 1, relu=relu)
+        return y.view(n, self.out_features)
+
+
+class MaskPre(nn.Module):
+    """Resolution predictor -- base_roi_head.py:10-27."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = _Conv(256, 128, 1)
+        self.bn1 = _BN(128)
+        self.conv2 = _Conv(128, 16, 3)
+        self.bn2 = _BN(16)
+        self.fc1 = _Linear(3136, 512)
+        self.fc2 = _Linear(512, 4)
+        # torch defaults of the reference (nn.Conv2d): kaiming_uniform(a=sqrt(5))
+        for m, ref in ((self.conv1, nn.Conv2d(256, 128, 1)), (self.conv2, nn.Conv2d(128, 16, 3, padding=1))):
+            with torch.no_grad():
+                m.weight.copy_(ref.weight)
+                m.bias.copy_(ref.bias)
+
+    def _bn_pool(self, x, bn):
+        if self.training:
+            mean, var = ops.bn_stats(x, bn.running_mean, bn.running_var, bn.momentum)
+            bn.num_batches_tracked += 1
+        else:
+            mean, var = bn.running_mean, bn.running_var
+        return ops.bn_relu_maxpool(x, mean, var, bn.weight.detach(), bn.bias.detach(), bn.eps)
+
+    def forward(self, x):
+        x = self._bn_pool(self.conv1.run(x), self.bn1)
+        x = self._bn_pool(self.conv2.run(x), self.bn2)
+        x = x.reshape(x.size(0), 3136)
+        x = self.fc1.run(x, relu=True)
+        return self.fc2.run(x)
+
+
+@HEADS.register_module()
+class DynaMaskRoIHead(nn.Module):
+    def __init__(self, bbox_roi_extractor=None, bbox_head=None, mask_roi_extractor=None, mask_head=None,
+                 shared_head=None, train_cfg=None, test_cfg=None):
+        super().__init__()
+        self.train_cfg = train_cfg
+        self.test_cfg = test_cfg
+        # bbox branch: out of the hot path -- configuration kept for the caller
+        self.bbox_roi_extractor_cfg = bbox_roi_extractor
+        self.bbox_head_cfg = bbox_head
+        if shared_head is not None:
+            raise NotImplementedError('shared_head is None in configs/dynamask')
+        if mask_head is not None:
+            if mask_roi_extractor is None:
+                raise NotImplementedError('configs/dynamask gives the mask branch its own RoI extractor')
+            self.mask_roi_extractor = build_roi_extractor(mask_roi_extractor)
+            self.share_roi_extractor = False
+            self.mask_head = build_head(mask_head)
+        # base_roi_head.py:53-58 (created for every RoI head: Quirk Q4)
+        self.semantic_roi_extractor = build_roi_extractor(dict(
+            type='SingleRoIExtractor', roi_layer=dict(type='RoIAlign', output_size=56, sampling_ratio=0),
+            out_channels=256, featmap_strides=[4, ]))
+        self.mask_predictor = MaskPre()
+
+    @property
+    def with_bbox(self):
+        return False
+
+    @property
+    def with_mask(self):
+        return hasattr(self, 'mask_head') and self.mask_head is not None
+
+    def init_weights(self, pretrained=None):
+        if self.with_mask:
+            self.mask_head.init_weights()
+            self.mask_roi_extractor.init_weights()
+
+    # ------------------------------------------------------------------ forward
+    def _mask_forward(self, x, rois, roi_labels, last_stage=None):
+        """dynamask_roi_head.py:75-81."""
+        ins_feats = self.mask_roi_extractor(x[:self.mask_roi_extractor.num_inputs], rois)
+        ips, dps = self.mask_head(ins_feats, x, rois, roi_labels, last_stage=last_stage)
+        return dict(stage_instance_preds=ips, stage_detail_preds=dps)
+
+    def sample_uniform(self, shape, device):
+        """The reference draws on the CPU generator and copies (dynamask_roi_head.py:90-91, Q9)."""
+        return torch.rand(shape).to(device)
+
+    def get_mask_label(self, ins_semantic_feats, noise=None, return_index=False):
+        """dynamask_roi_head.py:84-87,97-114: logits -> ST-Gumbel-softmax (hard)."""
+        logits = self.mask_predictor(ins_semantic_feats)
+        if noise is None:
+            noise = self.sample_uniform(logits.shape, logits.device)
+        y, hot, idx = ops.gumbel_select(logits, noise.contiguous(), 0.5)
+        return (hot, idx, logits, y) if return_index else hot
+
+    def _mask_forward_train(self, x, pos_rois, pos_labels, stage_mask_targets, noise=None):
+        """dynamask_roi_head.py:48-73 from ``pos_rois`` on (sampling and
+        ``mask_head.get_targets`` are the caller's: SURVEY 8f rank 1)."""
+        mask_results = self._mask_forward(x, pos_rois, pos_labels)
+        ins_semantic_feats = self.semantic_roi_extractor([x[0].detach(), ], pos_rois)
+        mask_labels, idx, logits, y = self.get_mask_label(ins_semantic_feats, noise, return_index=True)
+        loss_mask = self.mask_head.loss_func(mask_results['stage_instance_preds'], mask_results['stage_detail_preds'],
+                                             stage_mask_targets, mask_labels)
+        mask_results.update(loss_mask=loss_mask, mask_labels=mask_labels, mask_index=idx, mask_logits=logits)
+        return mask_results
+
+    def merge_stage_preds(self, stage_instance_preds):
+        """Boundary-aware coarse-to-fine merge, dynamask_roi_head.py:138-149
+        (in place on the finer logits, as the reference; the 14x14 exit is unused)."""
+        preds = stage_instance_preds[1:]
+        for idx in range(len(preds) - 1):
+            ops.boundary_merge_(preds[idx], preds[idx + 1])
+        return preds[-1]
+
+    def simple_test_mask_logits(self, x, det_bboxes, det_labels, scale_factor=1.0, rescale=False):
+        """simple_test_mask up to the merged 112x112 logits (pasting into the
+        image is the step after the path)."""
+        if det_bboxes.shape[0] == 0:
+            return det_bboxes.new_zeros((0, 1, 112, 112))
+        _bboxes = det_bboxes[:, :4] * scale_factor if rescale else det_bboxes
+        mask_rois = bbox2roi([_bboxes]).contiguous()
+        # the reference chunks by 100 RoIs "to avoid memory overflow" (:132); 288 GB of HBM do not need it
+        res = self._mask_forward(x, mask_rois, det_labels)
+        return self.merge_stage_preds(res['stage_instance_preds'])

@@ -43,7 +43,8 @@ int dm_abi_version(void);
  *           (mmdet/models/roi_heads/roi_extractors/single_level_roi_extractor.py:32-81)
  *           and the per-level mmcv.ops.RoIAlign it builds
  *           (roi_extractors/base_roi_extractor.py:49-55).
- * feats[l]   : [B, C, H[l], W[l]]   l < num_levels (1..4)
+ * feats[l]   : [B, C, H[l], W[l]]   l < num_levels (1..4); feats, H, W and
+ *              spatial_scales are HOST arrays (feats holds device pointers)
  * rois       : [N, 5] = (batch_idx, x1, y1, x2, y2) in image pixels
  * out        : [N, C, P, P]
  * levels_out : optional [N] int32, the FPN level chosen per RoI (NULL to skip)
@@ -79,12 +80,16 @@ int dm_conv_pack_weight(const float* w_oihw, int Cout, int Cin, int ksize, int t
  *           mask_heads/fcn_mask_head.py:59-71,119-120,102,125.
  * srcs[s]  : [NB, src_channels[s], H, W]; the channel-concatenation of the
  *            sources is the conv input (torch.cat at dynamask_head.py:107-116
- *            is folded into the K loop), sum(src_channels) = Cin
+ *            is folded into the K loop), sum(src_channels) = Cin.
+ *            src_batch_strides[s] (floats; NULL = dense) lets a source be a
+ *            channel slice of a wider tensor.  srcs / src_channels /
+ *            src_batch_strides are HOST arrays (of device pointers / ints).
  * w_packed : dm_conv_pack_weight layout, bias: [Cout] or NULL
  * out      : written at channels [out_ch_offset, out_ch_offset+Cout) of a
  *            tensor [NB, out_ch_total, H, W]
  * ------------------------------------------------------------------------- */
-int dm_conv2d_fwd(const float* const* srcs, const int* src_channels, int num_srcs, int NB, int H, int W,
+int dm_conv2d_fwd(const float* const* srcs, const int* src_channels, const long long* src_batch_strides,
+                  int num_srcs, int NB, int H, int W,
                   const float* w_packed, const float* bias, int Cout, int ksize, int relu, float* out,
                   int out_ch_total, int out_ch_offset, dm_stream_t stream);
 
@@ -199,6 +204,33 @@ int dm_detail_target(const float* masks, int N, int S, float fuse0, float fuse1,
 int dm_mask_loss_fwd_bwd(const float* inst_pred, const float* det_pred, const float* inst_tgt,
                          const float* det_tgt, const float* weight, int N, int HW, float* sums,
                          float* per_roi_det, float* grad_inst, float* grad_det, dm_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * K9  resolution predictor MaskPre (roi_heads/base_roi_head.py:10-27): BatchNorm
+ * batch statistics (train mode; biased variance for normalisation, running
+ * stats updated with the unbiased one when the pointers are non-NULL) and the
+ * fused BN -> ReLU -> max_pool2d(kernel 3, stride 2, pad 1).  The convs / FCs
+ * of MaskPre run through dm_conv2d_fwd.
+ * x [NB, C, H, W]; mean/var/gamma/beta [C]; out [NB, C, (H-1)/2+1, (W-1)/2+1]
+ * ------------------------------------------------------------------------- */
+int dm_bn_stats(const float* x, int NB, int C, int HW, float* mean, float* var, float* running_mean,
+                float* running_var, float momentum, dm_stream_t stream);
+int dm_bn_relu_maxpool_fwd(const float* x, int NB, int C, int H, int W, const float* mean, const float* var,
+                           const float* gamma, const float* beta, float eps, float* out, dm_stream_t stream);
+
+/* K10 backward: gradient of the soft branch of the straight-through estimator
+ * (y_hard = (one_hot - y).detach() + y, dynamask_roi_head.py:112-113). */
+int dm_gumbel_select_bwd(const float* y_soft, const float* grad_y, int N, int K, float temperature,
+                         float* grad_logits, dm_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * K14  class-balance entropy of the selector and its gradient.
+ * replaces: losses/cross_entropy_loss.py:478-481.
+ * mask_labels [N, K] -> loss[0] = sum_k p_k log(p_k + 1e-10), p = colsum/total;
+ * grad [N, K] (optional) = d loss / d mask_labels
+ * ------------------------------------------------------------------------- */
+int dm_class_balance_fwd_bwd(const float* mask_labels, int N, int K, float* loss, float* grad,
+                             dm_stream_t stream);
 
 #ifdef __cplusplus
 }

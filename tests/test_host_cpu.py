@@ -1,0 +1,106 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol the header
+declares (no compute), the registry/config boundary, state_dict compatibility,
+and that the product refuses to run without a HIP device."""
+import os
+import re
+
+import pytest
+import torch
+
+import golden_inputs as gi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build():
+    from dynamask_amd import build
+    return build.build_library(verbose=False)
+
+
+def test_library_exports_every_declared_symbol():
+    path = _build()
+    assert os.path.exists(path)
+    hdr = open(os.path.join(ROOT, 'include', 'dynamask_hip.h')).read()
+    declared = set(re.findall(r'\b(dm_[a-z0-9_]+)\s*\(', hdr))
+    declared.discard('dm_error_string')
+    declared.add('dm_error_string')
+    from dynamask_amd import _lib
+    L = _lib.lib()
+    assert set(_lib.SIGNATURES) == declared, declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.dm_abi_version() == _lib.ABI_VERSION
+    assert L.dm_conv_packed_cout(36) == 64 and L.dm_conv_packed_cout(256) == 256
+    assert L.dm_error_string(-1).decode().startswith('invalid')
+
+
+def test_argument_validation_without_gpu():
+    from dynamask_amd import _lib
+    L = _lib.lib()
+    # null pointers / bad sizes are rejected before any HIP call
+    assert L.dm_upsample2x_bilinear_fwd(None, 1, 4, 4, 0, 0, None, None) == -1
+    assert L.dm_conv_pack_weight(None, 4, 4, 3, 0, None, None) == -1
+    assert L.dm_gumbel_select_fwd(None, None, 4, 4, 0.5, None, None, None, None) == -1
+
+
+def test_ops_fail_loudly_on_cpu_tensors():
+    from dynamask_amd import ops
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        ops.upsample2x(torch.zeros(1, 1, 4, 4))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        ops.roi_align([torch.zeros(1, 1, 4, 4)], torch.zeros(1, 5), 7, [1.0])
+
+
+def _cfg():
+    from dynamask_amd import registry
+    return dict(type='DynaMaskRoIHead',
+                mask_roi_extractor=dict(type='SingleRoIExtractor', **gi.MASK_ROI_EXTRACTOR_CFG),
+                mask_head=dict(type='DynaMaskHead', **gi.MASK_HEAD_CFG),
+                train_cfg=registry.ConfigDict(flops=[0.23, 0.62, 1.01, 1.4], Lambda=0.3, mask_size=28),
+                test_cfg=registry.ConfigDict(mask_thr_binary=0.5))
+
+
+def test_registry_builds_roi_head_with_reference_state_dict_keys():
+    from dynamask_amd import registry, roi_head, losses, mask_heads, roi_extractors  # noqa: F401
+    m = registry.build_head(_cfg())
+    ref = {**gi.head_state(), **gi.mask_pre_state()}
+    assert set(m.state_dict()) == set(ref)
+    m.load_state_dict(ref, strict=True)
+    n_head = sum(v.numel() for k, v in m.state_dict().items() if k.startswith('mask_head.'))
+    n_pre = sum(p.numel() for p in m.mask_predictor.parameters())
+    assert n_head == 2502632 + 2 and n_pre == 1659828            # flat gradient buffer = 4 162 462 floats
+    for name in ('DynaMaskRoIHead', 'DynaMaskHead', 'FCNMaskHead'):
+        assert name in registry.HEADS
+    assert 'SingleRoIExtractor' in registry.ROI_EXTRACTORS and 'DynaCrossEntropyLoss' in registry.LOSSES
+    with pytest.raises(KeyError):
+        registry.build_head(dict(type='NoSuchHead'))
+
+
+@pytest.mark.skipif(not os.path.exists('/root/reference/configs/dynamask/coco/r50-dynamask-1x.py'),
+                    reason='reference tree only exists in the authoring container')
+def test_reference_config_is_consumed_unchanged():
+    from dynamask_amd import registry, roi_head, losses, mask_heads, roi_extractors  # noqa: F401
+    cfg = registry.Config.fromfile('/root/reference/configs/dynamask/coco/r50-dynamask-1x.py')
+    rh = dict(cfg.model.roi_head)
+    rh.update(train_cfg=cfg.train_cfg.rcnn, test_cfg=cfg.test_cfg.rcnn)
+    m = registry.build_head(rh)
+    assert m.train_cfg.flops == [0.23, 0.62, 1.01, 1.4] and m.test_cfg.mask_thr_binary == 0.5
+    assert m.mask_head.loss_func.start_stage == 4 and m.mask_head.loss_func.cb_loss_weight == 0.8
+    assert m.mask_roi_extractor.featmap_strides == [4, 8, 16, 32]
+    # the values restated in tests/golden/golden_inputs.py are the config's
+    assert dict(cfg.model.roi_head.mask_head.loss_cfg) == dict(type='DynaCrossEntropyLoss', **gi.LOSS_CFG)
+
+
+def test_fcn_head_state_dict_keys():
+    from dynamask_amd import registry, mask_heads  # noqa: F401
+    for up in ('deconv', 'carafe'):
+        cfg = dict(type='FCNMaskHead', num_convs=4, in_channels=256, conv_out_channels=256, num_classes=80)
+        if up == 'carafe':
+            cfg['upsample_cfg'] = dict(type='carafe', scale_factor=2, up_kernel=5, up_group=1, encoder_kernel=3,
+                                       encoder_dilation=1, compressed_channels=64)
+        h = registry.build_head(cfg)
+        ref = {k[len('mask_head.'):]: v for k, v in gi.fcn_state(up).items()}
+        assert set(h.state_dict()) == set(ref)
+        h.load_state_dict(ref, strict=True)
+    with pytest.raises(ValueError):
+        registry.build_head(dict(type='FCNMaskHead', upsample_cfg=dict(type='bogus', scale_factor=2)))

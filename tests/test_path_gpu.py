@@ -1,0 +1,166 @@
+"""End-to-end parity of the mask-head path (registry-built modules -> C ABI ->
+HIP kernels) against golden vectors produced by the reference's own modules and
+against the CPU oracle.  atol = rtol = 1e-4 fp32; selection indices bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+from oracle import ref_model, ref_ops
+
+pytestmark = pytest.mark.gpu
+TOL = dict(atol=1e-4, rtol=1e-4)
+
+
+def _close(a, b, **kw):
+    kw = kw or TOL
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else b
+    np.testing.assert_allclose(a, b, **kw)
+
+
+def _dev(t):
+    return t.cuda().contiguous()
+
+
+def _roi_head(train=False):
+    from dynamask_amd import registry, roi_head  # noqa: F401  (registers the classes)
+    from dynamask_amd import losses, mask_heads, roi_extractors  # noqa: F401
+    cfg = dict(type='DynaMaskRoIHead',
+               mask_roi_extractor=dict(type='SingleRoIExtractor', **gi.MASK_ROI_EXTRACTOR_CFG),
+               mask_head=dict(type='DynaMaskHead', **gi.MASK_HEAD_CFG),
+               train_cfg=registry.ConfigDict(flops=[0.23, 0.62, 1.01, 1.4], Lambda=0.3, mask_size=28),
+               test_cfg=registry.ConfigDict(mask_thr_binary=0.5))
+    m = registry.build_head(cfg)
+    m.load_state_dict({**gi.head_state(), **gi.mask_pre_state()}, strict=True)
+    m = m.cuda()
+    m.train(train)
+    return m
+
+
+def test_mask_forward_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g4_head.npz'))
+    hi = gi.head_inputs()
+    m = _roi_head()
+    with torch.no_grad():
+        res = m._mask_forward([_dev(f) for f in hi['feats']], _dev(hi['rois']), _dev(hi['labels']))
+    for i in range(4):
+        _close(res['stage_instance_preds'][i], g[f'ip{i}'])
+        _close(res['stage_detail_preds'][i], g[f'dp{i}'])
+
+
+def test_fixed_28_exit_matches_full_forward(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g4_head.npz'))
+    hi = gi.head_inputs()
+    m = _roi_head()
+    with torch.no_grad():
+        res = m._mask_forward([_dev(f) for f in hi['feats']], _dev(hi['rois']), _dev(hi['labels']), last_stage=1)
+    assert len(res['stage_instance_preds']) == 2
+    _close(res['stage_instance_preds'][1], g['ip1'])
+    _close(res['stage_detail_preds'][1], g['dp1'])
+
+
+def test_inference_merge_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g5_merge.npz'))
+    m = _roi_head()
+    merged = m.merge_stage_preds([_dev(t.clone()) for t in gi.merge_inputs()['ips']])
+    _close(merged, g['merged'], atol=1e-5, rtol=1e-5)
+
+
+def test_simple_test_mask_logits_vs_oracle():
+    hi = gi.head_inputs()
+    m = _roi_head()
+    sel = hi['rois'][:, 0] == 0
+    boxes = hi['rois'][sel][:, 1:]
+    labels = hi['labels'][sel]
+    with torch.no_grad():
+        out = m.simple_test_mask_logits([_dev(f) for f in hi['feats']], _dev(boxes), _dev(labels))
+        sd = gi.head_state()
+        rois = torch.cat([torch.zeros(len(boxes), 1), boxes], 1)
+        ips, _ = ref_model.mask_forward(sd, hi['feats'], rois, labels)
+        ref = ref_model.boundary_merge(ips)
+    # the merge thresholds sigmoid >= 0.5 on logits that differ by ~1e-6 between CPU and GPU:
+    # allow a handful of pixels to flip side, everything else must agree to 1e-4
+    diff = (out.cpu() - ref).abs()
+    bad = (diff > 1e-4 + 1e-4 * ref.abs()).float().mean().item()
+    assert bad < 1e-3, bad
+
+
+def test_fcn_mask_head_matches_reference_golden(golden_dir):
+    from dynamask_amd import registry
+    g = np.load(os.path.join(golden_dir, 'g6_fcn.npz'))
+    x = _dev(gi.fcn_input())
+    for up in ('deconv', 'carafe', 'bilinear'):
+        cfg = dict(type='FCNMaskHead', **gi.FCN_HEAD_CFG)
+        if up == 'carafe':
+            cfg['upsample_cfg'] = dict(type='carafe', scale_factor=2, up_kernel=5, up_group=1, encoder_kernel=3,
+                                       encoder_dilation=1, compressed_channels=64)
+        elif up == 'bilinear':
+            cfg['upsample_cfg'] = dict(type='bilinear', scale_factor=2)
+        cfg.pop('loss_mask')
+        head = registry.build_head(cfg)
+        head.load_state_dict({k[len('mask_head.'):]: v for k, v in gi.fcn_state(up).items()}, strict=True)
+        head = head.cuda()
+        with torch.no_grad():
+            _close(head(x), g[up])
+
+
+def test_mask_pre_and_selector_match_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g2_maskpre.npz'))
+    x = _dev(gi.mask_pre_input())
+    m = _roi_head(train=False)
+    with torch.no_grad():
+        _close(m.mask_predictor(x), g['logits_eval'])
+    m.train(True)
+    with torch.no_grad():
+        logits = m.mask_predictor(x)
+    _close(logits, g['logits_train'])
+    _close(m.mask_predictor.bn1.running_mean, g['bn1_running_mean'], atol=1e-6, rtol=1e-4)
+    _close(m.mask_predictor.bn1.running_var, g['bn1_running_var'], atol=1e-6, rtol=1e-4)
+    _close(m.mask_predictor.bn2.running_var, g['bn2_running_var'], atol=1e-6, rtol=1e-4)
+    assert int(m.mask_predictor.bn1.num_batches_tracked) == 1
+    # selector on the golden logits: indices bit-exact, with the top-2 margin reported
+    U = torch.rand(4, 4, generator=torch.Generator().manual_seed(5))
+    from dynamask_amd import ops
+    _, hot, idx = ops.gumbel_select(logits.contiguous(), _dev(U), 0.5)
+    _, idx_ref = ref_model.gumbel_select(torch.from_numpy(g['logits_train']), U, 0.5)
+    assert np.array_equal(idx.cpu().numpy(), idx_ref.numpy())
+
+
+def test_dyna_loss_and_grads_match_reference_golden(golden_dir):
+    from dynamask_amd import registry
+    from dynamask_amd import losses  # noqa: F401
+    g = np.load(os.path.join(golden_dir, 'g1_losses.npz'))
+    li = gi.loss_inputs()
+    loss_mod = registry.build_loss(dict(type='DynaCrossEntropyLoss', **gi.LOSS_CFG)).cuda()
+    ips = [_dev(t).requires_grad_(True) for t in li['ips']]
+    dps = [_dev(t).requires_grad_(True) for t in li['dps']]
+    ml = _dev(li['mask_labels']).requires_grad_(True)
+    out = loss_mod(ips, dps, [_dev(t) for t in li['targets']], ml)
+    loss = out['loss_masks']
+    loss.backward()
+    _close(loss, g['loss_masks'], atol=1e-5, rtol=1e-4)
+    _close(ml.grad, g['grad_mask_labels'], atol=1e-5, rtol=1e-4)
+    for i in range(4):
+        _close(dps[i].grad, g[f'grad_dp{i}'], atol=1e-6, rtol=1e-4)
+        gip = ips[i].grad if ips[i].grad is not None else torch.zeros_like(ips[i])
+        _close(gip, g[f'grad_ip{i}'], atol=1e-6, rtol=1e-4)
+
+
+def test_mask_forward_train_loss_vs_oracle():
+    hi = gi.head_inputs()
+    n = hi['rois'].shape[0]
+    m = _roi_head(train=True)
+    U = torch.rand(n, 4, generator=torch.Generator().manual_seed(9))
+    tg = gi.head_targets(n)
+    with torch.no_grad():
+        res = m._mask_forward_train([_dev(f) for f in hi['feats']], _dev(hi['rois']), _dev(hi['labels']),
+                                    [_dev(t) for t in tg], noise=_dev(U))
+        sd = {**gi.head_state(), **gi.mask_pre_state()}
+        loss_ref, ml_ref, idx_ref, logits_ref = ref_model.mask_forward_train(sd, hi['feats'], hi['rois'],
+                                                                             hi['labels'], tg, U)
+    _close(res['mask_logits'], logits_ref)
+    assert np.array_equal(res['mask_index'].cpu().numpy(), idx_ref.numpy())       # resolution selection bit-exact
+    _close(res['loss_mask']['loss_masks'], loss_ref)
