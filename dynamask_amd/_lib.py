@@ -51,6 +51,11 @@ def lib():
             raise DynaMaskLibraryError(
                 f'{LIB_PATH} not found: build it with `python -m dynamask_amd.build` '
                 '(or __graft_entry__.build()); dynamask_amd has no CPU/eager fallback')
+        # PyTorch-ROCm ships its own libamdhip64; import it FIRST so that the
+        # process has exactly one HIP runtime (the library's DT_NEEDED
+        # libamdhip64.so.7 then binds to the copy torch already loaded, and the
+        # streams / device pointers torch hands us belong to the same runtime).
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (argtypes, restype) in SIGNATURES.items():
             fn = getattr(L, name)       # AttributeError if the symbol is missing

@@ -78,9 +78,9 @@ extern "C" int dm_carafe_fwd(const float* x, const float* enc, int NB, int C, in
   const dim3 grid((unsigned)(NB * group * chunks * pix_blocks));
   hipStream_t st = (hipStream_t)stream;
   if (up_kernel == 5) {
-    hipLaunchKernelGGL(carafe_kernel<5>, grid, dim3(256), 0, st, x, enc, NB, C, H, W, group, scale, out, CT, pix_blocks);
+    DM_LAUNCH(carafe_kernel<5>, grid, dim3(256), 0, st, x, enc, NB, C, H, W, group, scale, out, CT, pix_blocks);
   } else if (up_kernel == 3) {
-    hipLaunchKernelGGL(carafe_kernel<3>, grid, dim3(256), 0, st, x, enc, NB, C, H, W, group, scale, out, CT, pix_blocks);
+    DM_LAUNCH(carafe_kernel<3>, grid, dim3(256), 0, st, x, enc, NB, C, H, W, group, scale, out, CT, pix_blocks);
   } else {
     return DM_ERR_UNSUPPORTED;
   }

@@ -9,6 +9,15 @@
 
 static inline int dm_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// hipGetLastError() is sticky per thread: a benign error left behind by another
+// library's HIP call (torch probing peer access, an event query returning
+// "not ready") would otherwise be blamed on our launch.  Clear it first.
+#define DM_LAUNCH(...)        \
+  do {                        \
+    (void)hipGetLastError();  \
+    hipLaunchKernelGGL(__VA_ARGS__); \
+  } while (0)
+
 // Post-launch check: the launch itself is asynchronous; configuration errors
 // (bad grid, too much LDS) surface here.
 static inline int dm_check_launch() {

@@ -297,7 +297,7 @@ int launch_conv(ConvArgs& a, hipStream_t st) {
   }
   const size_t lds_bytes = sizeof(float) * ((size_t)KS * KS * CK * TM + (size_t)CK * a.plane);
   if (lds_bytes > 64 * 1024) return DM_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((conv_igemm_kernel<KS, WGM, WGN, WM, WN, CK>), dim3(a.MT * NTiles), dim3(NT), lds_bytes, st, a);
+  DM_LAUNCH((conv_igemm_kernel<KS, WGM, WGN, WM, WN, CK>), dim3(a.MT * NTiles), dim3(NT), lds_bytes, st, a);
   return dm_check_launch();
 }
 
@@ -314,7 +314,7 @@ extern "C" int dm_conv_pack_weight(const float* w_oihw, int Cout, int Cin, int k
   const int colsP = dm_conv_packed_cout(cols_in);
   const int total = kk * rows_out * colsP;
   const int blocks = min(dm_ceil_div(total, 256), 2048);
-  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, Cout, Cin, kk,
+  DM_LAUNCH(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, Cout, Cin, kk,
                      transpose_flip, w_packed, rows_out, cols_in, colsP);
   return dm_check_launch();
 }
@@ -382,7 +382,7 @@ extern "C" int dm_deconv_pack_weight(const float* w_iohw, int Cin, int Cout, flo
   if (!w_iohw || !w_packed || Cin <= 0 || Cout <= 0) return DM_ERR_INVALID_ARG;
   const int colsP = dm_conv_packed_cout(4 * Cout);
   const int total = Cin * colsP;
-  hipLaunchKernelGGL(pack_deconv_kernel, dim3(min(dm_ceil_div(total, 256), 2048)), dim3(256), 0, (hipStream_t)stream,
+  DM_LAUNCH(pack_deconv_kernel, dim3(min(dm_ceil_div(total, 256), 2048)), dim3(256), 0, (hipStream_t)stream,
                      w_iohw, Cin, Cout, w_packed, colsP);
   return dm_check_launch();
 }

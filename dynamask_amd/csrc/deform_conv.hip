@@ -194,7 +194,7 @@ int launch_dcn(DcnArgs& a, hipStream_t st) {
   const int NTiles = dm_ceil_div(a.Q, TN);
   const size_t lds_bytes = sizeof(float) * ((size_t)9 * CK * TM + (size_t)CK * 9 * TN);
   if (lds_bytes > 64 * 1024) return DM_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((deform_conv_kernel<WGM, WGN, WM, WN, CK>), dim3(a.MT * NTiles), dim3(NT), lds_bytes, st, a);
+  DM_LAUNCH((deform_conv_kernel<WGM, WGN, WM, WN, CK>), dim3(a.MT * NTiles), dim3(NT), lds_bytes, st, a);
   return dm_check_launch();
 }
 

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __res
 extern "C" int dm_bn_stats(const float* x, int NB, int C, int HW, float* mean, float* var, float* running_mean,
                            float* running_var, float momentum, dm_stream_t stream) {
   if (!x || !mean || !var || NB <= 0 || C <= 0 || HW <= 0) return DM_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(C), dim3(1024), 0, (hipStream_t)stream, x, NB, C, HW, mean, var,
+  DM_LAUNCH(bn_stats_kernel, dim3(C), dim3(1024), 0, (hipStream_t)stream, x, NB, C, HW, mean, var,
                      running_mean, running_var, momentum);
   return dm_check_launch();
 }
@@ -110,7 +110,7 @@ extern "C" int dm_bn_relu_maxpool_fwd(const float* x, int NB, int C, int H, int 
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
   const size_t total = (size_t)NB * C * OH * OW;
   const int blocks = (int)min((size_t)dm_ceil_div((long long)total, 256), (size_t)16384);
-  hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, NB, C, H, W, mean, var,
+  DM_LAUNCH(bn_relu_maxpool_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, NB, C, H, W, mean, var,
                      gamma, beta, eps, out, OH, OW);
   return dm_check_launch();
 }

@@ -321,7 +321,7 @@ extern "C" int dm_point_sample_fwd(const float* feat, int B, int C, int H, int W
   const int CT = 16;
   const int chunks = dm_ceil_div(C, CT);
   const int pos_blocks = dm_ceil_div(S * S, 256);
-  hipLaunchKernelGGL(point_sample_kernel, dim3((unsigned)(N * chunks * pos_blocks)), dim3(256), 0, (hipStream_t)stream,
+  DM_LAUNCH(point_sample_kernel, dim3((unsigned)(N * chunks * pos_blocks)), dim3(256), 0, (hipStream_t)stream,
                      feat, B, C, H, W, rois, N, S, spatial_scale, out, CT, pos_blocks);
   return dm_check_launch();
 }
@@ -335,7 +335,7 @@ extern "C" int dm_class_logits_fwd(const float* x, int N, int C, int HW, const f
   if (sig_out && (sig_ch_offset < 0 || sig_ch_offset + 2 > sig_ch_total)) return DM_ERR_INVALID_ARG;
   if (N == 0) return DM_OK;
   const int pix_blocks = dm_ceil_div(HW, 256);
-  hipLaunchKernelGGL(class_logits_kernel, dim3((unsigned)(N * pix_blocks)), dim3(256), 0, (hipStream_t)stream, x, N, C,
+  DM_LAUNCH(class_logits_kernel, dim3((unsigned)(N * pix_blocks)), dim3(256), 0, (hipStream_t)stream, x, N, C,
                      HW, w_inst, b_inst, w_det, b_det, num_classes, labels, inst, det, sig_out, sig_ch_total,
                      sig_ch_offset, pix_blocks);
   return dm_check_launch();
@@ -347,7 +347,7 @@ extern "C" int dm_upsample2x_bilinear_fwd(const float* in, int NC, int H, int W,
   if (NC == 0) return DM_OK;
   const size_t total = (size_t)NC * 4 * H * W;
   const int blocks = (int)min((size_t)dm_ceil_div((long long)total, 256), (size_t)16384);
-  hipLaunchKernelGGL(upsample2x_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, NC, H, W, align_corners,
+  DM_LAUNCH(upsample2x_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, NC, H, W, align_corners,
                      relu, out);
   return dm_check_launch();
 }
@@ -356,7 +356,7 @@ extern "C" int dm_boundary_merge(const float* coarse, float* fine, int n, int S,
   if (!coarse || !fine || n < 0 || S <= 0) return DM_ERR_INVALID_ARG;
   if ((size_t)2 * S * S * sizeof(float) > 64 * 1024) return DM_ERR_UNSUPPORTED;
   if (n == 0) return DM_OK;
-  hipLaunchKernelGGL(boundary_merge_kernel, dim3(n), dim3(256), 2 * S * S * sizeof(float), (hipStream_t)stream, coarse,
+  DM_LAUNCH(boundary_merge_kernel, dim3(n), dim3(256), 2 * S * S * sizeof(float), (hipStream_t)stream, coarse,
                      fine, n, S);
   return dm_check_launch();
 }
@@ -366,7 +366,7 @@ extern "C" int dm_gumbel_select_fwd(const float* logits, const float* U, int N, 
   if (!logits || !U || !y_soft || !one_hot || !index || N < 0 || K <= 0 || K > 8 || temperature <= 0.f)
     return DM_ERR_INVALID_ARG;
   if (N == 0) return DM_OK;
-  hipLaunchKernelGGL(gumbel_kernel, dim3(dm_ceil_div(N, 64)), dim3(64), 0, (hipStream_t)stream, logits, U, N, K,
+  DM_LAUNCH(gumbel_kernel, dim3(dm_ceil_div(N, 64)), dim3(64), 0, (hipStream_t)stream, logits, U, N, K,
                      temperature, y_soft, one_hot, index);
   return dm_check_launch();
 }
@@ -376,7 +376,7 @@ extern "C" int dm_detail_target(const float* masks, int N, int S, float fuse0, f
   if (!masks || !out || N < 0 || S <= 0) return DM_ERR_INVALID_ARG;
   if ((size_t)S * S * sizeof(float) > 64 * 1024) return DM_ERR_UNSUPPORTED;
   if (N == 0) return DM_OK;
-  hipLaunchKernelGGL(detail_target_kernel, dim3(N), dim3(256), S * S * sizeof(float), (hipStream_t)stream, masks, N, S,
+  DM_LAUNCH(detail_target_kernel, dim3(N), dim3(256), S * S * sizeof(float), (hipStream_t)stream, masks, N, S,
                      fuse0, fuse1, out);
   return dm_check_launch();
 }
@@ -388,7 +388,7 @@ extern "C" int dm_mask_loss_fwd_bwd(const float* inst_pred, const float* det_pre
     return DM_ERR_INVALID_ARG;
   if (N == 0) return DM_OK;
   const int pb = min(dm_ceil_div(HW, 256), 8);
-  hipLaunchKernelGGL(mask_loss_kernel, dim3(pb, N), dim3(256), 0, (hipStream_t)stream, inst_pred, det_pred, inst_tgt,
+  DM_LAUNCH(mask_loss_kernel, dim3(pb, N), dim3(256), 0, (hipStream_t)stream, inst_pred, det_pred, inst_tgt,
                      det_tgt, weight, N, HW, sums, per_roi_det, grad_inst, grad_det);
   return dm_check_launch();
 }
@@ -444,7 +444,7 @@ __global__ void gumbel_bwd_kernel(const float* __restrict__ y, const float* __re
 extern "C" int dm_class_balance_fwd_bwd(const float* mask_labels, int N, int K, float* loss, float* grad,
                                         dm_stream_t stream) {
   if (!mask_labels || !loss || N <= 0 || K <= 0 || K > 8) return DM_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(class_balance_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mask_labels, N, K, loss, grad);
+  DM_LAUNCH(class_balance_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mask_labels, N, K, loss, grad);
   return dm_check_launch();
 }
 
@@ -452,7 +452,7 @@ extern "C" int dm_gumbel_select_bwd(const float* y_soft, const float* grad_y, in
                                     float* grad_logits, dm_stream_t stream) {
   if (!y_soft || !grad_y || !grad_logits || N < 0 || K <= 0 || temperature <= 0.f) return DM_ERR_INVALID_ARG;
   if (N == 0) return DM_OK;
-  hipLaunchKernelGGL(gumbel_bwd_kernel, dim3(dm_ceil_div(N, 64)), dim3(64), 0, (hipStream_t)stream, y_soft, grad_y, N, K,
+  DM_LAUNCH(gumbel_bwd_kernel, dim3(dm_ceil_div(N, 64)), dim3(64), 0, (hipStream_t)stream, y_soft, grad_y, N, K,
                      temperature, grad_logits);
   return dm_check_launch();
 }

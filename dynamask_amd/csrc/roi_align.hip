@@ -252,7 +252,7 @@ extern "C" int dm_roi_align_fwd(const float* const* feats, const int* H, const i
   a.out = out;
   a.levels = levels_out;
   const int chunks = dm_ceil_div(C, a.CT);
-  hipLaunchKernelGGL(roi_align_kernel<false>, dim3(N * chunks), dim3(256), 0, (hipStream_t)stream, a);
+  DM_LAUNCH(roi_align_kernel<false>, dim3(N * chunks), dim3(256), 0, (hipStream_t)stream, a);
   return dm_check_launch();
 }
 
@@ -271,6 +271,6 @@ extern "C" int dm_roi_align_bwd(const float* grad_out, float* const* grad_feats,
   if (N == 0) return DM_OK;
   a.gout = grad_out;
   const int chunks = dm_ceil_div(C, a.CT);
-  hipLaunchKernelGGL(roi_align_kernel<true>, dim3(N * chunks), dim3(256), 0, (hipStream_t)stream, a);
+  DM_LAUNCH(roi_align_kernel<true>, dim3(N * chunks), dim3(256), 0, (hipStream_t)stream, a);
   return dm_check_launch();
 }
