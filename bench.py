@@ -190,7 +190,7 @@ def main():
         # ---- roofline of the dominant kernel: conv3x3 256->256 on [512,256,14,14] ----
         x = torch.randn(ROIS_PER_IMG, 256, 14, 14, device=dev)
         conv = head.mask_head.instance_convs[0].conv
-        wp, b = conv.packed(), conv.bias.detach()
+        wp, b = conv.packed([256]), conv.bias.detach()
         ms = time_kernel(lambda: ops.conv2d(x, wp, b, 256, 3, relu=True))
         flops = 2.0 * ROIS_PER_IMG * 196 * 256 * 256 * 9
         ach = flops / (ms * 1e-3) / 1e12

@@ -4,7 +4,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdynamask_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -17,7 +17,8 @@ SIGNATURES = {
     'dm_roi_align_fwd': ([_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _c_float, _vp, _vp, _vp], _c_int),
     'dm_roi_align_bwd': ([_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _c_float, _vp], _c_int),
     'dm_conv_packed_cout': ([_c_int], _c_int),
-    'dm_conv_pack_weight': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp], _c_int),
+    'dm_conv_packed_floats': ([_c_int, _c_int, _c_int, _vp], ctypes.c_longlong),
+    'dm_conv_pack_weight': ([_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp], _c_int),
     'dm_conv2d_fwd': ([_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp], _c_int),
     'dm_point_sample_fwd': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_float, _vp, _vp], _c_int),
     'dm_class_logits_fwd': ([_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp], _c_int),

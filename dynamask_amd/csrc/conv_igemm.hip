@@ -1,27 +1,31 @@
-// K5/K6: dense stride-1 "same" convolution (1x1 / 3x3) as an implicit GEMM on the
-// fp32-input MFMA units of gfx950 (v_mfma_f32_32x32x2_f32: exact fp32 fma chain).
+// K5/K6/K16: dense stride-1 "same" convolution (1x1 / 3x3) and deconv 2x2/s2 as an
+// implicit GEMM on the fp32-input MFMA units of gfx950 (v_mfma_f32_32x32x2_f32:
+// exact fp32 fma chain, 1e-4 parity with the fp32 reference by construction).
 //
-// GEMM view (per launch):   Out[co, q] = bias[co] + sum_k  Wp[k, co] * X[k, q]
+// GEMM view (per launch):   Out[co, q] = bias[co] + sum_k  Wq[k, co] * X[k, q]
 //   rows   co : output channels (MFMA "A" operand = packed weights, M side)
 //   cols   q  : FLAT pixel index over the whole batch, q = n*H*W + y*W + x
 //               (MFMA "B" operand = the im2col of the input, N side).  Flat
-//               columns mean no padding waste for 14x14 RoI maps (196 px) and one
-//               kernel for RoI tensors and whole FPN maps alike.
-//   k         : (tap, input channel); the channel-concatenation of up to 4
+//               columns: no padding waste for 14x14 RoI maps (196 px), one kernel
+//               for RoI tensors and whole FPN maps alike.
+//   k         : (tap, input channel); the channel concatenation of up to 4
 //               source tensors is walked in the K loop (torch.cat never
 //               materialises).
-// D layout of the 32x32 MFMA puts the pixel on the lane, so every accumulator
+// The 32x32 MFMA D layout puts the pixel on the lane, so every accumulator
 // register stores 32 consecutive pixels of one output channel: 128-B coalesced
 // NCHW stores.
 //
-// LDS per workgroup: A chunk [taps][CK][TM] + B chunk [CK][plane].
-//   3x3: B holds, per input channel, the image rows the tile's pixels need (+1
-//        halo row/column of zeros each side, per image segment), so a tap is a
-//        constant LDS offset from the lane's base address.
-//   1x1: B is [CK][TN] straight.
-// fp32 MFMA issues one 32x32x2 per 64 cycles per SIMD and needs only 512 B of
-// operands for it, so LDS bandwidth is ~25 % used: the kernel is MFMA-bound by
-// construction; 2-3 workgroups per CU overlap staging with compute.
+// K ordering is ours to choose, so input channels are handled in QUADS: packed
+// weights are [tap][channel quad][cout][4] and the LDS images are
+//   A: [tap][quad][TM couts][4]      B: [quad][plane position][4]
+// so ONE ds_read_b128 per operand feeds FOUR k-steps: MFMA j of a quad pair
+// uses k = j (lanes 0-31, even quad) and k = 4+j (lanes 32-63, odd quad).
+// Consecutive lanes read consecutive 16-B slots: conflict-free.
+//
+// Pipeline per workgroup (256 threads, 4 waves, 2x2 32x32 blocks per wave at
+// the 128x128 tile): the NEXT chunk's global loads are issued into registers
+// before the MFMAs of the current chunk and written to LDS after them
+// (issue-early / write-late), so L2 latency hides under 144 MFMAs per wave.
 #include "common.h"
 
 namespace {
@@ -32,9 +36,9 @@ struct ConvArgs {
   long long src_bs[DM_MAX_SOURCES];  // batch stride of each source, in floats
   int num_srcs;
   int NB, H, W, HW, Q;
-  const float* wp;
+  const float* wq;   // [taps][KQ][CoutP][4]
   const float* bias;
-  int Cin, Cout, CoutP;
+  int KQ, Cout, CoutP;
   int relu;
   float* out;
   int out_ch_total, out_ch_offset;
@@ -43,17 +47,22 @@ struct ConvArgs {
   int shuffle;    // deconv 2x2/s2 epilogue: packed cout = phase*shuffle + co, stored at (2y+dy, 2x+dx)
 };
 
-template <int KS, int WGM, int WGN, int WM, int WN, int CK>
+// CK input channels per chunk (multiple of 8); MAXPOS = plane positions per thread (3x3)
+template <int KS, int WGM, int WGN, int WM, int WN, int CK, int MAXPOS>
 __global__ __launch_bounds__(WGM* WGN * 64) void conv_igemm_kernel(ConvArgs a) {
   constexpr int TM = WGM * WM * 32;
   constexpr int TN = WGN * WN * 32;
   constexpr int NT = WGM * WGN * 64;
   constexpr int TAPS = KS * KS;
-  constexpr int MAXPOS = 4;  // 3x3: staged plane positions per thread
+  constexpr int NQ = CK / 4;                      // channel quads per chunk
+  constexpr int A_F4 = TAPS * NQ * TM;            // float4 slots of the A chunk
+  constexpr int A_PER_T = (A_F4 + NT - 1) / NT;
+  constexpr int B1_PER_T = (NQ * TN + NT - 1) / NT;   // 1x1: float4 slots per thread
+  constexpr int BREG = (KS == 3) ? MAXPOS * NQ : B1_PER_T;
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* ldsA = lds;                       // [TAPS][CK][TM]
-  float* ldsB = lds + TAPS * CK * TM;      // [CK][plane]
+  dm_f32x4* ldsA = reinterpret_cast<dm_f32x4*>(lds);                 // [TAPS][NQ][TM]
+  dm_f32x4* ldsB = reinterpret_cast<dm_f32x4*>(lds) + A_F4;          // [NQ][plane]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -80,7 +89,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_igemm_kernel(ConvArgs a) {
   const int Wp = a.Wp;
 
   // ---- per-lane column bookkeeping ----------------------------------------
-  int lane_base[WN];   // LDS float offset of tap (0,0) of this lane's pixel
+  int lane_base[WN];   // LDS float4 index of tap (0,0) of this lane's pixel (+ odd-quad offset)
   int col_n[WN], col_p[WN];
   bool col_ok[WN];
 #pragma unroll
@@ -104,8 +113,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_igemm_kernel(ConvArgs a) {
     }
   }
 
-  // ---- 3x3: which plane positions this thread stages (fixed for the tile) --
-  int st_pix[MAXPOS], st_n[MAXPOS];
+  // ---- B staging assignment (fixed for the tile) ---------------------------
+  //  3x3: thread -> up to MAXPOS plane positions (all CK channels of each)
+  //  1x1: thread -> column j = tid % TN, quads (tid / TN) + i * (NT / TN)
+  int st_pix[(KS == 3) ? MAXPOS : 1], st_n[(KS == 3) ? MAXPOS : 1];
   if (KS == 3) {
     const int Rused = (n1 == n0) ? (rows0 + 2) : (rows0 + 2) + (n1 - n0 - 1) * (H + 2) + (y1l + 3);
 #pragma unroll
@@ -132,6 +143,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_igemm_kernel(ConvArgs a) {
         }
       }
     }
+  } else {
+    int q = q0 + (tid % TN);
+    const bool ok = q < a.Q;
+    q = min(q, a.Q - 1);
+    const int n = q / HW;
+    st_pix[0] = q - n * HW;
+    st_n[0] = ok ? n : -1;
   }
 
   dm_f32x16 acc[WM][WN];
@@ -142,82 +160,133 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  int cbase = 0;
-  for (int s = 0; s < a.num_srcs; ++s) {
-    const float* __restrict__ sp = a.src[s];
-    const int Cs = a.src_c[s];
-    const size_t bs = (size_t)a.src_bs[s];
-    for (int c0 = 0; c0 < Cs; c0 += CK) {
-      const int ckv = min(CK, Cs - c0);
-      const int ckp = (ckv + 1) & ~1;
-
-      // ---- stage A: packed weights rows (tap, ci) x TM couts ---------------
-      for (int idx = tid; idx < TAPS * CK * (TM / 4); idx += NT) {
-        const int row = idx / (TM / 4);
-        const int c4 = idx - row * (TM / 4);
-        const int tap = row / CK;
-        const int ci = row - tap * CK;
-        const int co = m0 + c4 * 4;
-        dm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ci < ckv && co < a.CoutP) {
-          v = *reinterpret_cast<const dm_f32x4*>(a.wp + ((size_t)(tap * a.Cin + cbase + c0 + ci)) * a.CoutP + co);
-        }
-        *reinterpret_cast<dm_f32x4*>(ldsA + row * TM + c4 * 4) = v;
-      }
-      // ---- stage B ---------------------------------------------------------
-      if (KS == 3) {
-#pragma unroll
-        for (int k = 0; k < MAXPOS; ++k) {
-          const int pos = tid + k * NT;
-          if (pos < plane) {
-            const bool ok = st_n[k] >= 0;
-            const float* gp = sp + (size_t)max(st_n[k], 0) * bs + (size_t)c0 * HW + st_pix[k];
-            for (int ci = 0; ci < ckp; ++ci) {
-              float v = 0.f;
-              if (ok && ci < ckv) v = gp[(size_t)ci * HW];
-              ldsB[ci * plane + pos] = v;
-            }
-          }
-        }
-      } else {
-        constexpr int SUB = NT / TN > 0 ? NT / TN : 1;
-        const int j = tid % TN;
-        const int sub = tid / TN;
-        int q = q0 + j;
-        const bool ok = q < a.Q;
-        q = min(q, a.Q - 1);
-        const int n = q / HW;
-        const int p = q - n * HW;
-        const float* gp = sp + (size_t)n * bs + (size_t)c0 * HW + p;
-        for (int ci = sub; ci < ckp; ci += SUB) {
-          float v = 0.f;
-          if (ok && ci < ckv) v = gp[(size_t)ci * HW];
-          ldsB[ci * plane + j] = v;
-        }
-      }
-      __syncthreads();
-
-      // ---- MFMA over this chunk ---------------------------------------------
-#pragma unroll
-      for (int tap = 0; tap < TAPS; ++tap) {
-        const int tapoff = (KS == 3) ? ((tap / 3) * Wp + (tap % 3)) : 0;
-        const float* pa = ldsA + (tap * CK + hi) * TM + wave_m * (WM * 32) + l31;
-        for (int kk = 0; kk < ckp; kk += 2) {
-          float av[WM], bv[WN];
-#pragma unroll
-          for (int i = 0; i < WM; ++i) av[i] = pa[kk * TM + i * 32];
-#pragma unroll
-          for (int j = 0; j < WN; ++j) bv[j] = ldsB[kk * plane + lane_base[j] + tapoff];
-#pragma unroll
-          for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int j = 0; j < WN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-        }
-      }
-      __syncthreads();
+  // ---- chunk iterator over (source, channel offset) ------------------------
+  int cs = 0, cc0 = 0, ckq = 0;   // current source, channel offset in it, global quad index of the chunk
+  auto chunk_valid = [&]() { return cs < a.num_srcs; };
+  auto chunk_advance = [&]() {
+    const int Cs = a.src_c[cs];
+    const int ckv = min(CK, Cs - cc0);
+    ckq += ((ckv + 7) / 8) * 2;
+    cc0 += CK;
+    if (cc0 >= Cs) {
+      cs++;
+      cc0 = 0;
     }
-    cbase += Cs;
+  };
+
+  dm_f32x4 ra[A_PER_T];
+  dm_f32x4 rb[BREG];
+
+  // issue the global loads of the chunk at (cs, cc0, ckq) into registers
+  auto prefetch = [&]() {
+    const int Cs = a.src_c[cs];
+    const int ckv = min(CK, Cs - cc0);
+    const int nq = ((ckv + 7) / 8) * 2;    // quads of this chunk present in the packed weights
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      const int idx = tid + i * NT;
+      dm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < A_F4) {
+        const int m = idx % TM;
+        const int tq = idx / TM;
+        const int qd = tq % NQ;
+        const int tap = tq / NQ;
+        if (qd < nq && m0 + m < a.CoutP)
+          v = *reinterpret_cast<const dm_f32x4*>(a.wq + (((size_t)tap * a.KQ + ckq + qd) * a.CoutP + m0 + m) * 4);
+      }
+      ra[i] = v;
+    }
+    const float* sp = a.src[cs];
+    const size_t bs = (size_t)a.src_bs[cs];
+    if (KS == 3) {
+#pragma unroll
+      for (int k = 0; k < MAXPOS; ++k) {
+        const bool ok = st_n[k] >= 0;
+        const float* gp = sp + (size_t)max(st_n[k], 0) * bs + (size_t)cc0 * HW + st_pix[k];
+#pragma unroll
+        for (int qd = 0; qd < NQ; ++qd) {
+          dm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int ci = qd * 4 + e;
+            if (ok && ci < ckv) v[e] = gp[(size_t)ci * HW];
+          }
+          rb[k * NQ + qd] = v;
+        }
+      }
+    } else {
+      const bool ok = st_n[0] >= 0;
+      const float* gp = sp + (size_t)max(st_n[0], 0) * bs + (size_t)cc0 * HW + st_pix[0];
+#pragma unroll
+      for (int i = 0; i < B1_PER_T; ++i) {
+        const int qd = tid / TN + i * (NT / TN);
+        dm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int ci = qd * 4 + e;
+          if (ok && qd < NQ && ci < ckv) v[e] = gp[(size_t)ci * HW];
+        }
+        rb[i] = v;
+      }
+    }
+  };
+
+  auto commit = [&]() {   // registers -> LDS
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      const int idx = tid + i * NT;
+      if (idx < A_F4) ldsA[idx] = ra[i];
+    }
+    if (KS == 3) {
+#pragma unroll
+      for (int k = 0; k < MAXPOS; ++k) {
+        const int pos = tid + k * NT;
+        if (pos < plane) {
+#pragma unroll
+          for (int qd = 0; qd < NQ; ++qd) ldsB[qd * plane + pos] = rb[k * NQ + qd];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < B1_PER_T; ++i) {
+        const int qd = tid / TN + i * (NT / TN);
+        if (qd < NQ) ldsB[qd * plane + (tid % TN)] = rb[i];
+      }
+    }
+  };
+
+  if (chunk_valid()) prefetch();
+  while (chunk_valid()) {
+    const int ckv_cur = min(CK, a.src_c[cs] - cc0);
+    const int ngroups = (ckv_cur + 7) / 8;   // quad pairs holding live channels
+    commit();
+    __syncthreads();
+    chunk_advance();
+    if (chunk_valid()) prefetch();
+
+    // ---- MFMA over the committed chunk ---------------------------------------
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int tapoff = (KS == 3) ? ((tap / 3) * Wp + (tap % 3)) : 0;
+#pragma unroll
+      for (int g = 0; g < NQ / 2; ++g) {
+        if (g < ngroups) {
+          dm_f32x4 av[WM], bv[WN];
+#pragma unroll
+          for (int i = 0; i < WM; ++i) av[i] = ldsA[(tap * NQ + 2 * g + hi) * TM + (wave_m * WM + i) * 32 + l31];
+#pragma unroll
+          for (int j = 0; j < WN; ++j) bv[j] = ldsB[(2 * g) * plane + lane_base[j] + tapoff];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+              for (int j = 0; j < WN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
   }
 
   // ---- epilogue: bias + ReLU, 32 consecutive pixels per register ------------
@@ -257,25 +326,69 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_igemm_kernel(ConvArgs a) {
   }
 }
 
-__global__ void pack_weight_kernel(const float* __restrict__ w, int Cout, int Cin, int kk, int flip,
-                                   float* __restrict__ wp, int rows_out, int cols_in, int colsP) {
-  // forward:  wp[(tap*Cin + ci)*CoutP + co] = w[co][ci][tap]
-  // flipped:  wp[(tap*Cout + co)*CinP + ci] = w[co][ci][kk-1-tap]
-  const int total = kk * rows_out * colsP;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    const int col = idx % colsP;
-    const int row = (idx / colsP) % rows_out;
-    const int tap = idx / (colsP * rows_out);
+// Packed weight layout [tap][KQ][CoutP][4]: KQ quads = sum over sources of
+// roundup(Cs, 8)/4, channels of a source padded with zero rows to a multiple of 8.
+struct PackArgs {
+  const float* w;
+  float* wq;
+  int Cout, Cin, kk, flip;   // dims of the OIHW tensor
+  int rows, cols, colsP;     // rows = reduction channels, cols = produced channels
+  int nsrc;
+  int src_c[DM_MAX_SOURCES];
+  int KQ;
+  int deconv;                // w is [Cin][Cout][2][2]; packed col = phase*Cout + co
+};
+
+__global__ void pack_weight_kernel(PackArgs p) {
+  const long long total = (long long)p.kk * p.KQ * p.colsP * 4;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int e = (int)(idx & 3);
+    const int col = (int)((idx >> 2) % p.colsP);
+    const int kq = (int)((idx >> 2) / p.colsP % p.KQ);
+    const int tap = (int)((idx >> 2) / ((long long)p.colsP * p.KQ));
+    // padded channel index -> (source, local channel) -> dense reduction row
+    int pc = kq * 4 + e, row = -1, base = 0;
+    for (int s = 0; s < p.nsrc; ++s) {
+      const int padded = (p.src_c[s] + 7) / 8 * 8;
+      if (pc < padded) {
+        if (pc < p.src_c[s]) row = base + pc;
+        break;
+      }
+      pc -= padded;
+      base += p.src_c[s];
+    }
     float v = 0.f;
-    if (col < cols_in) {
-      if (!flip) {
-        v = w[((size_t)col * Cin + row) * kk + tap];           // col = co, row = ci
+    if (row >= 0 && col < p.cols) {
+      if (p.deconv) {
+        const int phase = col / p.Cout, co = col - phase * p.Cout;
+        v = p.w[((size_t)row * p.Cout + co) * 4 + phase];
+      } else if (!p.flip) {
+        v = p.w[((size_t)col * p.Cin + row) * p.kk + tap];               // col = co, row = ci
       } else {
-        v = w[((size_t)row * Cin + col) * kk + (kk - 1 - tap)];  // row = co, col = ci
+        v = p.w[((size_t)row * p.Cin + col) * p.kk + (p.kk - 1 - tap)];    // row = co, col = ci
       }
     }
-    wp[idx] = v;
+    p.wq[idx] = v;
   }
+}
+
+int packed_quads(int nsrc, const int* src_c) {
+  int kq = 0;
+  for (int s = 0; s < nsrc; ++s) kq += (src_c[s] + 7) / 8 * 2;
+  return kq;
+}
+
+template <int KS, int WGM, int WGN, int WM, int WN, int CK, int MAXPOS>
+int launch_conv_mp(ConvArgs& a, hipStream_t st) {
+  constexpr int TM = WGM * WM * 32;
+  constexpr int TN = WGN * WN * 32;
+  constexpr int NT = WGM * WGN * 64;
+  const int NTiles = dm_ceil_div(a.Q, TN);
+  const size_t lds_bytes = 16 * ((size_t)KS * KS * (CK / 4) * TM + (size_t)(CK / 4) * a.plane);
+  if (lds_bytes > 64 * 1024) return DM_ERR_UNSUPPORTED;
+  DM_LAUNCH((conv_igemm_kernel<KS, WGM, WGN, WM, WN, CK, MAXPOS>), dim3(a.MT * NTiles), dim3(NT), lds_bytes, st, a);
+  return dm_check_launch();
 }
 
 template <int KS, int WGM, int WGN, int WM, int WN, int CK>
@@ -284,20 +397,25 @@ int launch_conv(ConvArgs& a, hipStream_t st) {
   constexpr int TN = WGN * WN * 32;
   constexpr int NT = WGM * WGN * 64;
   a.MT = dm_ceil_div(a.CoutP, TM);
-  const int NTiles = dm_ceil_div(a.Q, TN);
   if (KS == 3) {
     a.Wp = a.W + 2;
     const int nsegmax = dm_ceil_div(TN - 1, a.HW) + 1;
     const int rmax = dm_ceil_div(TN - 1, a.W) + 1 + 2 * nsegmax;
     a.plane = rmax * a.Wp;
-    if (a.plane > NT * 4) return DM_ERR_UNSUPPORTED;  // MAXPOS positions per thread
-  } else {
-    a.Wp = 0;
-    a.plane = TN;
+    if (a.plane <= NT) return launch_conv_mp<KS, WGM, WGN, WM, WN, CK, 1>(a, st);
+    if (a.plane <= 2 * NT) return launch_conv_mp<KS, WGM, WGN, WM, WN, CK, 2>(a, st);
+    if (a.plane <= 4 * NT) return launch_conv_mp<KS, WGM, WGN, WM, WN, CK, 4>(a, st);
+    return DM_ERR_UNSUPPORTED;
   }
-  const size_t lds_bytes = sizeof(float) * ((size_t)KS * KS * CK * TM + (size_t)CK * a.plane);
-  if (lds_bytes > 64 * 1024) return DM_ERR_UNSUPPORTED;
-  DM_LAUNCH((conv_igemm_kernel<KS, WGM, WGN, WM, WN, CK>), dim3(a.MT * NTiles), dim3(NT), lds_bytes, st, a);
+  a.Wp = 0;
+  a.plane = TN;
+  return launch_conv_mp<KS, WGM, WGN, WM, WN, CK, 1>(a, st);
+}
+
+int run_pack(PackArgs& p, hipStream_t st) {
+  const long long total = (long long)p.kk * p.KQ * p.colsP * 4;
+  const int blocks = (int)min((long long)dm_ceil_div(total, 256), 4096LL);
+  DM_LAUNCH(pack_weight_kernel, dim3(blocks), dim3(256), 0, st, p);
   return dm_check_launch();
 }
 
@@ -305,18 +423,31 @@ int launch_conv(ConvArgs& a, hipStream_t st) {
 
 extern "C" int dm_conv_packed_cout(int Cout) { return (Cout + 31) / 32 * 32; }
 
+extern "C" long long dm_conv_packed_floats(int Cout, int ksize, int num_srcs, const int* src_channels) {
+  if (Cout <= 0 || ksize <= 0 || num_srcs < 1 || num_srcs > DM_MAX_SOURCES || !src_channels) return -1;
+  return (long long)ksize * ksize * packed_quads(num_srcs, src_channels) * dm_conv_packed_cout(Cout) * 4;
+}
+
 extern "C" int dm_conv_pack_weight(const float* w_oihw, int Cout, int Cin, int ksize, int transpose_flip,
-                                   float* w_packed, dm_stream_t stream) {
+                                   int num_srcs, const int* src_channels, float* w_packed, dm_stream_t stream) {
   if (!w_oihw || !w_packed || Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3)) return DM_ERR_INVALID_ARG;
-  const int kk = ksize * ksize;
-  const int rows_out = transpose_flip ? Cout : Cin;
-  const int cols_in = transpose_flip ? Cin : Cout;
-  const int colsP = dm_conv_packed_cout(cols_in);
-  const int total = kk * rows_out * colsP;
-  const int blocks = min(dm_ceil_div(total, 256), 2048);
-  DM_LAUNCH(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, Cout, Cin, kk,
-                     transpose_flip, w_packed, rows_out, cols_in, colsP);
-  return dm_check_launch();
+  if (num_srcs < 1 || num_srcs > DM_MAX_SOURCES || !src_channels) return DM_ERR_INVALID_ARG;
+  PackArgs p;
+  p.w = w_oihw; p.wq = w_packed; p.Cout = Cout; p.Cin = Cin; p.kk = ksize * ksize; p.flip = transpose_flip ? 1 : 0;
+  p.rows = transpose_flip ? Cout : Cin;
+  p.cols = transpose_flip ? Cin : Cout;
+  p.colsP = dm_conv_packed_cout(p.cols);
+  p.nsrc = num_srcs;
+  int sum = 0;
+  for (int s = 0; s < DM_MAX_SOURCES; ++s) {
+    p.src_c[s] = s < num_srcs ? src_channels[s] : 0;
+    if (s < num_srcs && src_channels[s] <= 0) return DM_ERR_INVALID_ARG;
+    sum += p.src_c[s];
+  }
+  if (sum != p.rows) return DM_ERR_INVALID_ARG;
+  p.KQ = packed_quads(num_srcs, src_channels);
+  p.deconv = 0;
+  return run_pack(p, (hipStream_t)stream);
 }
 
 extern "C" int dm_conv2d_fwd(const float* const* srcs, const int* src_channels, const long long* src_batch_strides,
@@ -329,21 +460,20 @@ extern "C" int dm_conv2d_fwd(const float* const* srcs, const int* src_channels, 
   if ((long long)NB * H * W > 0x7fffffffLL) return DM_ERR_INVALID_ARG;
   if (NB == 0) return DM_OK;
   ConvArgs a;
-  a.Cin = 0;
   for (int s = 0; s < DM_MAX_SOURCES; ++s) {
     a.src[s] = s < num_srcs ? srcs[s] : nullptr;
     a.src_c[s] = s < num_srcs ? src_channels[s] : 0;
     a.src_bs[s] = 0;
     if (s < num_srcs) {
       if (!srcs[s] || src_channels[s] <= 0) return DM_ERR_INVALID_ARG;
-      a.Cin += src_channels[s];
       a.src_bs[s] = src_batch_strides ? src_batch_strides[s] : (long long)src_channels[s] * H * W;
       if (a.src_bs[s] < (long long)src_channels[s] * H * W) return DM_ERR_INVALID_ARG;
     }
   }
   a.num_srcs = num_srcs;
+  a.KQ = packed_quads(num_srcs, src_channels);
   a.NB = NB; a.H = H; a.W = W; a.HW = H * W; a.Q = NB * H * W;
-  a.wp = w_packed; a.bias = bias; a.Cout = Cout; a.CoutP = dm_conv_packed_cout(Cout);
+  a.wq = w_packed; a.bias = bias; a.Cout = Cout; a.CoutP = dm_conv_packed_cout(Cout);
   a.relu = relu; a.out = out; a.out_ch_total = out_ch_total; a.out_ch_offset = out_ch_offset;
   a.shuffle = 0;
   hipStream_t st = (hipStream_t)stream;
@@ -361,30 +491,17 @@ extern "C" int dm_conv2d_fwd(const float* const* srcs, const int* src_channels, 
 // K16: ConvTranspose2d(k=2, s=2) = four independent 1x1 GEMMs (one per output
 // phase).  Run as ONE 1x1 implicit GEMM with 4*Cout packed output channels and
 // a pixel-shuffling epilogue.
-namespace {
-__global__ void pack_deconv_kernel(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ wp, int colsP) {
-  // wp[ci][phase*Cout + co] = w[ci][co][dy][dx], phase = dy*2+dx
-  const int total = Cin * colsP;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    const int col = idx % colsP;
-    const int ci = idx / colsP;
-    float v = 0.f;
-    if (col < 4 * Cout) {
-      const int phase = col / Cout, co = col - phase * Cout;
-      v = w[((size_t)ci * Cout + co) * 4 + phase];
-    }
-    wp[idx] = v;
-  }
-}
-}  // namespace
-
 extern "C" int dm_deconv_pack_weight(const float* w_iohw, int Cin, int Cout, float* w_packed, dm_stream_t stream) {
   if (!w_iohw || !w_packed || Cin <= 0 || Cout <= 0) return DM_ERR_INVALID_ARG;
-  const int colsP = dm_conv_packed_cout(4 * Cout);
-  const int total = Cin * colsP;
-  DM_LAUNCH(pack_deconv_kernel, dim3(min(dm_ceil_div(total, 256), 2048)), dim3(256), 0, (hipStream_t)stream,
-                     w_iohw, Cin, Cout, w_packed, colsP);
-  return dm_check_launch();
+  PackArgs p;
+  p.w = w_iohw; p.wq = w_packed; p.Cout = Cout; p.Cin = Cin; p.kk = 1; p.flip = 0;
+  p.rows = Cin; p.cols = 4 * Cout; p.colsP = dm_conv_packed_cout(4 * Cout);
+  p.nsrc = 1;
+  for (int s = 0; s < DM_MAX_SOURCES; ++s) p.src_c[s] = 0;
+  p.src_c[0] = Cin;
+  p.KQ = packed_quads(1, p.src_c);
+  p.deconv = 1;
+  return run_pack(p, (hipStream_t)stream);
 }
 
 extern "C" int dm_deconv2x2_fwd(const float* x, int NB, int C, int H, int W, const float* w_packed, const float* bias,
@@ -394,9 +511,10 @@ extern "C" int dm_deconv2x2_fwd(const float* x, int NB, int C, int H, int W, con
   if (NB == 0) return DM_OK;
   ConvArgs a;
   for (int s = 0; s < DM_MAX_SOURCES; ++s) { a.src[s] = nullptr; a.src_c[s] = 0; a.src_bs[s] = 0; }
-  a.src[0] = x; a.src_c[0] = C; a.src_bs[0] = (long long)C * H * W; a.num_srcs = 1; a.Cin = C;
+  a.src[0] = x; a.src_c[0] = C; a.src_bs[0] = (long long)C * H * W; a.num_srcs = 1;
+  a.KQ = packed_quads(1, a.src_c);
   a.NB = NB; a.H = H; a.W = W; a.HW = H * W; a.Q = NB * H * W;
-  a.wp = w_packed; a.bias = bias; a.Cout = 4 * Cout; a.CoutP = dm_conv_packed_cout(4 * Cout);
+  a.wq = w_packed; a.bias = bias; a.Cout = 4 * Cout; a.CoutP = dm_conv_packed_cout(4 * Cout);
   a.relu = relu; a.out = out; a.out_ch_total = 0; a.out_ch_offset = 0; a.shuffle = Cout;
   return launch_conv<1, 2, 2, 2, 2, 32>(a, (hipStream_t)stream);
 }

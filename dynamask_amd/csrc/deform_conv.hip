@@ -3,11 +3,15 @@
 // :84-115 (bilinear) and :190-243 (im2col) of the reference tree; the reference
 // materialises the [C*9, N*H*W] column matrix in HBM and calls a library GEMM
 // (deform_conv_cuda.cpp:198-237).  Here the deformable im2col is the PRODUCER
-// of the MFMA B operand: a workgroup owns TN flat pixels x ALL output channels,
-// gathers the bilinear-sampled columns of CK input channels into LDS and feeds
-// them straight to v_mfma_f32_32x32x2_f32.  The column matrix never exists in
-// HBM, and because one workgroup covers every output channel each sample is
-// gathered exactly once.
+// of the MFMA B operand: a workgroup owns TN flat pixels x (up to 256) output
+// channels, gathers the bilinear-sampled columns of 8 input channels and feeds
+// them to v_mfma_f32_32x32x2_f32 through LDS.  The column matrix never exists
+// in HBM, and since one workgroup covers every output channel (C <= 256) each
+// sample is gathered exactly once.
+//
+// Same software pipeline and quad K-ordering as conv_igemm.hip: the gather of
+// chunk c+1 (4 loads per sample, issued into registers) overlaps the 144 MFMAs
+// per wave of chunk c; LDS images  A: [tap][quad][TM][4]  B: [quad][tap][TN][4].
 //
 // The 4 tap offsets + 4 bilinear weights of a (kernel tap, pixel) pair depend
 // only on the deformable group, so each thread keeps them in registers for its
@@ -20,24 +24,27 @@ struct DcnArgs {
   const float* x;
   const float* offset;
   int NB, C, H, W, HW, Q;
-  const float* wp;  // [9][C][CoutP]
-  int Cout, CoutP, dg, relu;
+  const float* wp;  // [9][KQ][CoutP][4]
+  int Cout, CoutP, KQ, dg, relu;
   float* out;
   int MT;
 };
 
-template <int WGM, int WGN, int WM, int WN, int CK>
+template <int WGM, int WGN, int WM, int WN>
 __global__ __launch_bounds__(WGM* WGN * 64) void deform_conv_kernel(DcnArgs a) {
+  constexpr int CK = 8;
   constexpr int TM = WGM * WM * 32;
   constexpr int TN = WGN * WN * 32;
   constexpr int NT = WGM * WGN * 64;
   constexpr int TG = NT / TN;                 // thread groups sharing a pixel column
   constexpr int MAXT = (9 + TG - 1) / TG;     // taps owned per thread
+  constexpr int A_F4 = 9 * 2 * TM;
+  constexpr int A_PER_T = (A_F4 + NT - 1) / NT;
   static_assert(NT % TN == 0, "threads must tile the pixel columns");
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* ldsA = lds;                    // [9][CK][TM]
-  float* ldsB = lds + 9 * CK * TM;      // [CK][9][TN]
+  dm_f32x4* ldsA = reinterpret_cast<dm_f32x4*>(lds);           // [9][2][TM]
+  dm_f32x4* ldsB = reinterpret_cast<dm_f32x4*>(lds) + A_F4;    // [2][9][TN]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -71,10 +78,46 @@ __global__ __launch_bounds__(WGM* WGN * 64) void deform_conv_kernel(DcnArgs a) {
   const int gp = gq - gn * HW;
   const int gy = gp / W, gx = gp - gy * W;
 
-  int o1[MAXT], o2[MAXT], o3[MAXT], o4[MAXT];
-  float w1[MAXT], w2[MAXT], w3[MAXT], w4[MAXT];
+  // Per owned (tap, pixel): the 2x2 bilinear footprint as two 8-byte row pairs.
+  // pair base column cb = clamp(w_low, 0, W-2); a tap that falls outside the
+  // image keeps weight 0 (spec: deform_conv_cuda_kernel.cu:84-115), so the pair
+  // loads stay in bounds and the products equal the reference's w1..w4 * v1..v4.
+  int ot[MAXT], ob[MAXT];
+  float wt0[MAXT], wt1[MAXT], wb0[MAXT], wb1[MAXT];
   int cur_group = -1;
   const int cpg = a.C / a.dg;
+
+  auto load_params = [&](int group) {
+    const float* offp = a.offset + ((size_t)gn * a.dg + group) * 18 * HW + gp;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int tap = tg + t * TG;
+      ot[t] = ob[t] = 0;
+      wt0[t] = wt1[t] = wb0[t] = wb1[t] = 0.f;
+      if (tap < 9 && g_ok) {
+        const int ki = tap / 3, kj = tap - ki * 3;
+        const float off_h = offp[(size_t)(2 * tap) * HW];
+        const float off_w = offp[(size_t)(2 * tap + 1) * HW];
+        const float h_im = (float)(gy - 1 + ki) + off_h;
+        const float w_im = (float)(gx - 1 + kj) + off_w;
+        if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+          const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+          const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+          const float hh = 1.f - lh, hw = 1.f - lw;
+          const float wr_t = (h_low >= 0) ? hh : 0.f;
+          const float wr_b = (h_low + 1 <= H - 1) ? lh : 0.f;
+          const int rt = min(max(h_low, 0), H - 1), rbm = min(max(h_low + 1, 0), H - 1);
+          const int cb = min(max(w_low, 0), W - 2);
+          const float wc0 = (cb == w_low ? hw : 0.f) + (cb == w_low + 1 ? lw : 0.f);
+          const float wc1 = (cb + 1 == w_low ? hw : 0.f) + (cb + 1 == w_low + 1 ? lw : 0.f);
+          ot[t] = rt * W + cb;
+          ob[t] = rbm * W + cb;
+          wt0[t] = wr_t * wc0; wt1[t] = wr_t * wc1;
+          wb0[t] = wr_b * wc0; wb1[t] = wr_b * wc1;
+        }
+      }
+    }
+  };
 
   dm_f32x16 acc[WM][WN];
 #pragma unroll
@@ -84,85 +127,116 @@ __global__ __launch_bounds__(WGM* WGN * 64) void deform_conv_kernel(DcnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  for (int c0 = 0; c0 < a.C; c0 += CK) {
-    const int ckv = min(CK, a.C - c0);
-    const int ckp = (ckv + 1) & ~1;
-    const int group = c0 / cpg;   // CK divides cpg (checked on the host)
-    if (group != cur_group) {
-      cur_group = group;
-      const float* offp = a.offset + ((size_t)gn * a.dg + group) * 18 * HW + gp;
-#pragma unroll
-      for (int t = 0; t < MAXT; ++t) {
-        const int tap = tg + t * TG;
-        o1[t] = o2[t] = o3[t] = o4[t] = 0;
-        w1[t] = w2[t] = w3[t] = w4[t] = 0.f;
-        if (tap < 9 && g_ok) {
-          const int ki = tap / 3, kj = tap - ki * 3;
-          const float off_h = offp[(size_t)(2 * tap) * HW];
-          const float off_w = offp[(size_t)(2 * tap + 1) * HW];
-          const float h_im = (float)(gy - 1 + ki) + off_h;
-          const float w_im = (float)(gx - 1 + kj) + off_w;
-          if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
-            const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-            const int h_high = h_low + 1, w_high = w_low + 1;
-            const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
-            const float hh = 1.f - lh, hw = 1.f - lw;
-            if (h_low >= 0 && w_low >= 0) { o1[t] = h_low * W + w_low; w1[t] = hh * hw; }
-            if (h_low >= 0 && w_high <= W - 1) { o2[t] = h_low * W + w_high; w2[t] = hh * lw; }
-            if (h_high <= H - 1 && w_low >= 0) { o3[t] = h_high * W + w_low; w3[t] = lh * hw; }
-            if (h_high <= H - 1 && w_high <= W - 1) { o4[t] = h_high * W + w_high; w4[t] = lh * lw; }
-          }
-        }
-      }
-    }
+  struct __attribute__((packed, aligned(4))) F2 { float a, b; };
+  dm_f32x4 ra[A_PER_T];       // next chunk's weights
+  dm_f32x4 raw[MAXT * 4];     // raw row pairs of ONE channel quad of the next chunk (in flight)
+  dm_f32x4 rb0[MAXT];         // combined quad 0 of the next chunk
 
-    // ---- stage A (weights) --------------------------------------------------
-    for (int idx = tid; idx < 9 * CK * (TM / 4); idx += NT) {
-      const int row = idx / (TM / 4);
-      const int c4 = idx - row * (TM / 4);
-      const int tap = row / CK;
-      const int ci = row - tap * CK;
-      const int co = m0 + c4 * 4;
+  auto prefetch_a = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      const int idx = tid + i * NT;
       dm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ci < ckv && co < a.CoutP) v = *reinterpret_cast<const dm_f32x4*>(a.wp + ((size_t)(tap * a.C + c0 + ci)) * a.CoutP + co);
-      *reinterpret_cast<dm_f32x4*>(ldsA + row * TM + c4 * 4) = v;
+      if (idx < A_F4) {
+        const int m = idx % TM;
+        const int tq = idx / TM;
+        const int qd = tq & 1;
+        const int tap = tq >> 1;
+        if (m0 + m < a.CoutP)
+          v = *reinterpret_cast<const dm_f32x4*>(a.wp + (((size_t)tap * a.KQ + (c0 >> 2) + qd) * a.CoutP + m0 + m) * 4);
+      }
+      ra[i] = v;
     }
-    // ---- stage B: deformable im2col of CK channels --------------------------
-    {
-      const float* xp = a.x + ((size_t)gn * a.C + c0) * HW;
-      for (int ci = 0; ci < ckp; ++ci) {
-        const float* xc = xp + (size_t)ci * HW;
-        const bool live = ci < ckv;
+  };
+  auto issue_quad = [&](int c0, int qd) {   // 2 x 8-byte loads per sample, nothing waits on them here
+    const float* xp = a.x + ((size_t)gn * a.C + c0 + qd * 4) * HW;
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t) {
-          const int tap = tg + t * TG;
-          if (tap < 9) {
-            float v = 0.f;
-            if (live) v = w1[t] * xc[o1[t]] + w2[t] * xc[o2[t]] + w3[t] * xc[o3[t]] + w4[t] * xc[o4[t]];
-            ldsB[(ci * 9 + tap) * TN + gj] = v;
-          }
-        }
+    for (int t = 0; t < MAXT; ++t) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* xc = xp + (size_t)e * HW;
+        const F2 top = *reinterpret_cast<const F2*>(xc + ot[t]);
+        const F2 bot = *reinterpret_cast<const F2*>(xc + ob[t]);
+        dm_f32x4 v = {top.a, top.b, bot.a, bot.b};
+        raw[t * 4 + e] = v;
       }
     }
-    __syncthreads();
-
-    // ---- MFMA ------------------------------------------------------------------
+  };
+  auto combine = [&](int t) {
+    dm_f32x4 v;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const float* pa = ldsA + (tap * CK + hi) * TM + wave_m * (WM * 32) + l31;
-      const float* pb = ldsB + (hi * 9 + tap) * TN + wave_n * (WN * 32) + l31;
-      for (int kk = 0; kk < ckp; kk += 2) {
-        float av[WM], bv[WN];
+    for (int e = 0; e < 4; ++e) {
+      const dm_f32x4 l = raw[t * 4 + e];
+      v[e] = wt0[t] * l[0] + wt1[t] * l[1] + wb0[t] * l[2] + wb1[t] * l[3];
+    }
+    return v;
+  };
+  auto commit = [&]() {   // A registers + both B quads -> LDS (quad 1 is combined here)
 #pragma unroll
-        for (int i = 0; i < WM; ++i) av[i] = pa[kk * TM + i * 32];
+    for (int i = 0; i < A_PER_T; ++i) {
+      const int idx = tid + i * NT;
+      if (idx < A_F4) ldsA[idx] = ra[i];
+    }
 #pragma unroll
-        for (int j = 0; j < WN; ++j) bv[j] = pb[kk * 9 * TN + j * 32];
+    for (int t = 0; t < MAXT; ++t) {
+      const int tap = tg + t * TG;
+      if (tap < 9) {
+        ldsB[(0 * 9 + tap) * TN + gj] = rb0[t];
+        ldsB[(1 * 9 + tap) * TN + gj] = combine(t);
+      }
+    }
+  };
+  auto mfma_taps = [&](int t0, int t1) {
+#pragma unroll
+    for (int tap = t0; tap < t1; ++tap) {
+      dm_f32x4 av[WM], bv[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) av[i] = ldsA[(tap * 2 + hi) * TM + (wave_m * WM + i) * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) bv[j] = ldsB[(hi * 9 + tap) * TN + (wave_n * WN + j) * 32 + l31];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
-          for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-      }
+          for (int j = 0; j < WN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
     }
+  };
+
+  // prologue: chunk 0 entirely in registers
+  cur_group = 0;
+  load_params(0);
+  prefetch_a(0);
+  issue_quad(0, 0);
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) rb0[t] = combine(t);
+  issue_quad(0, 1);
+
+  for (int c0 = 0; c0 < a.C; c0 += CK) {
+    commit();
+    __syncthreads();
+    const int cn = c0 + CK;
+    const bool more = cn < a.C;
+    if (more) {
+      const int group = cn / cpg;    // CK divides cpg (checked on the host)
+      if (group != cur_group) {
+        cur_group = group;
+        load_params(group);
+      }
+      prefetch_a(cn);
+      issue_quad(cn, 0);             // in flight under taps 0..3
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_taps(0, 4);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) {
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t) rb0[t] = combine(t);
+      issue_quad(cn, 1);             // in flight under taps 4..8, combined at commit()
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_taps(4, 9);
     __syncthreads();
   }
 
@@ -185,16 +259,22 @@ __global__ __launch_bounds__(WGM* WGN * 64) void deform_conv_kernel(DcnArgs a) {
   }
 }
 
-template <int WGM, int WGN, int WM, int WN, int CK>
+template <int WGM, int WGN, int WM, int WN>
 int launch_dcn(DcnArgs& a, hipStream_t st) {
   constexpr int TM = WGM * WM * 32;
   constexpr int TN = WGN * WN * 32;
   constexpr int NT = WGM * WGN * 64;
   a.MT = dm_ceil_div(a.CoutP, TM);
   const int NTiles = dm_ceil_div(a.Q, TN);
-  const size_t lds_bytes = sizeof(float) * ((size_t)9 * CK * TM + (size_t)CK * 9 * TN);
-  if (lds_bytes > 64 * 1024) return DM_ERR_UNSUPPORTED;
-  DM_LAUNCH((deform_conv_kernel<WGM, WGN, WM, WN, CK>), dim3(a.MT * NTiles), dim3(NT), lds_bytes, st, a);
+  const size_t lds_bytes = 16 * ((size_t)9 * 2 * TM + (size_t)2 * 9 * TN);
+  static bool attr_set = false;
+  if (lds_bytes > 64 * 1024 && !attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&deform_conv_kernel<WGM, WGN, WM, WN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return DM_ERR_LAUNCH;
+    attr_set = true;
+  }
+  DM_LAUNCH((deform_conv_kernel<WGM, WGN, WM, WN>), dim3(a.MT * NTiles), dim3(NT), lds_bytes, st, a);
   return dm_check_launch();
 }
 
@@ -207,14 +287,17 @@ extern "C" int dm_deform_conv_fwd(const float* x, const float* offset, int NB, i
   if (NB < 0 || C <= 0 || H <= 0 || W <= 0 || Cout <= 0 || deform_groups <= 0 || C % deform_groups != 0)
     return DM_ERR_INVALID_ARG;
   if ((long long)NB * H * W > 0x7fffffffLL) return DM_ERR_INVALID_ARG;
-  if ((C / deform_groups) % 4 != 0) return DM_ERR_UNSUPPORTED;  // channel chunk must not straddle a deformable group
+  if ((C / deform_groups) % 8 != 0) return DM_ERR_UNSUPPORTED;  // channel chunk must not straddle a deformable group
+  if (W < 2) return DM_ERR_UNSUPPORTED;                         // the gather loads row pairs
   if (NB == 0) return DM_OK;
   DcnArgs a;
   a.x = x; a.offset = offset; a.NB = NB; a.C = C; a.H = H; a.W = W; a.HW = H * W; a.Q = NB * H * W;
-  a.wp = w_packed; a.Cout = Cout; a.CoutP = dm_conv_packed_cout(Cout); a.dg = deform_groups; a.relu = relu; a.out = out;
+  a.wp = w_packed; a.Cout = Cout; a.CoutP = dm_conv_packed_cout(Cout); a.KQ = (C + 7) / 8 * 2; a.dg = deform_groups;
+  a.relu = relu; a.out = out;
   hipStream_t st = (hipStream_t)stream;
-  if (Cout > 128) return launch_dcn<4, 2, 2, 2, 4>(a, st);   // 256 couts x 128 px, 8 waves
-  if (Cout > 64) return launch_dcn<2, 2, 2, 2, 4>(a, st);    // 128 x 128, 4 waves
-  if (Cout > 32) return launch_dcn<1, 4, 2, 1, 4>(a, st);    // 64 x 128
-  return launch_dcn<1, 4, 1, 1, 4>(a, st);                   // 32 x 128
+  // 8-wave workgroups: 4 threads share a pixel column, so a thread owns <= 3 taps
+  // (a 256-cout tile would gather each sample once but needs > 256 VGPRs: it spills)
+  if (Cout > 64) return launch_dcn<2, 4, 2, 1>(a, st);    // 128 couts x 128 px
+  if (Cout > 32) return launch_dcn<2, 4, 1, 1>(a, st);    // 64 x 128
+  return launch_dcn<1, 4, 1, 1>(a, st);                   // 32 x 128 (4 waves)
 }

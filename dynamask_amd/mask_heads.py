@@ -49,12 +49,16 @@ class _Conv(nn.Module):
         nn.init.kaiming_normal_(self.weight, mode='fan_out', nonlinearity='relu')
         self._pk = _Packed()
 
-    def packed(self):
-        return self._pk.get('w', self.weight, ops.pack_conv_weight)
+    def packed(self, src_channels=None):
+        key = tuple(src_channels) if src_channels is not None else (self.in_channels,)
+        return self._pk.get(key, self.weight, lambda w: ops.pack_conv_weight(w, src_channels=list(key)))
 
     def run(self, srcs, relu=False, out=None, out_ch_offset=0):
         b = self.bias.detach() if self.bias is not None else None
-        return ops.conv2d(srcs, self.packed(), b, self.out_channels, self.kernel_size, relu=relu, out=out,
+        if isinstance(srcs, torch.Tensor):
+            srcs = [srcs]
+        wq = self.packed([s.shape[1] for s in srcs])
+        return ops.conv2d(srcs, wq, b, self.out_channels, self.kernel_size, relu=relu, out=out,
                           out_ch_offset=out_ch_offset)
 
 

@@ -90,16 +90,27 @@ def packed_cout(cout):
     return lib().dm_conv_packed_cout(int(cout))
 
 
-def pack_conv_weight(w, transpose_flip=False):
-    """OIHW -> [k*k][Cin][CoutP] (see include/dynamask_hip.h)."""
+def packed_floats(cout, ksize, src_channels):
+    n = lib().dm_conv_packed_floats(int(cout), int(ksize), len(src_channels), _int_array(src_channels))
+    if n < 0:
+        raise ValueError('bad conv packing request')
+    return int(n)
+
+
+def pack_conv_weight(w, transpose_flip=False, src_channels=None):
+    """OIHW -> [k*k][KQ][CoutP][4] (see include/dynamask_hip.h).  ``src_channels``:
+    how the input channels split over the concat sources (default: one source)."""
     _chk(w, 'weight')
     cout, cin, kh, kw = w.shape
     assert kh == kw and kh in (1, 3)
     rows = cout if transpose_flip else cin
     cols = cin if transpose_flip else cout
-    wp = torch.empty((kh * kw, rows, packed_cout(cols)), device=w.device, dtype=torch.float32)
-    check(lib().dm_conv_pack_weight(_p(w), cout, cin, kh, 1 if transpose_flip else 0, _p(wp), _stream()),
-          'dm_conv_pack_weight')
+    if src_channels is None:
+        src_channels = [rows]
+    assert sum(src_channels) == rows
+    wp = torch.empty((packed_floats(cols, kh, src_channels),), device=w.device, dtype=torch.float32)
+    check(lib().dm_conv_pack_weight(_p(w), cout, cin, kh, 1 if transpose_flip else 0, len(src_channels),
+                                    _int_array(src_channels), _p(wp), _stream()), 'dm_conv_pack_weight')
     return wp
 
 
@@ -115,7 +126,7 @@ def conv2d(srcs, w_packed, bias, cout, ksize, relu=False, out=None, out_ch_offse
     for s in srcs:
         assert s.shape[0] == NB and s.shape[2] == H and s.shape[3] == W
     cin = sum(s.shape[1] for s in srcs)
-    assert w_packed.shape == (ksize * ksize, cin, packed_cout(cout)), (tuple(w_packed.shape), ksize, cin, cout)
+    assert w_packed.numel() == packed_floats(cout, ksize, [s.shape[1] for s in srcs]), 'weights packed for other sources'
     if out is None:
         out = torch.empty((NB, cout, H, W), device=srcs[0].device, dtype=torch.float32)
     else:
@@ -135,7 +146,7 @@ def deform_conv(x, offset, w_packed, cout, deform_groups, relu=False):
     _chk(w_packed, 'w_packed')
     NB, C, H, W = x.shape
     assert offset.shape == (NB, deform_groups * 18, H, W)
-    assert w_packed.shape == (9, C, packed_cout(cout))
+    assert w_packed.numel() == packed_floats(cout, 3, [C])
     out = torch.empty((NB, cout, H, W), device=x.device, dtype=torch.float32)
     check(lib().dm_deform_conv_fwd(_p(x), _p(offset), NB, C, H, W, _p(w_packed), cout, deform_groups,
                                    1 if relu else 0, _p(out), _stream()), 'dm_deform_conv_fwd')
@@ -146,7 +157,7 @@ def pack_deconv_weight(w):
     _chk(w, 'weight')
     cin, cout, kh, kw = w.shape
     assert kh == 2 and kw == 2
-    wp = torch.empty((1, cin, packed_cout(4 * cout)), device=w.device, dtype=torch.float32)
+    wp = torch.empty((packed_floats(4 * cout, 1, [cin]),), device=w.device, dtype=torch.float32)
     check(lib().dm_deconv_pack_weight(_p(w), cin, cout, _p(wp), _stream()), 'dm_deconv_pack_weight')
     return wp
 

@@ -63,14 +63,20 @@ int dm_roi_align_bwd(const float* grad_out, float* const* grad_feats, const int*
 
 /* ---------------------------------------------------------------------------
  * Weight packing for the implicit-GEMM convolutions: OIHW [Cout, Cin, k, k] ->
- * [k*k][Cin][CoutP] with CoutP = dm_conv_packed_cout(Cout) (zero padded).
+ * [k*k][KQ][CoutP][4]: input channels in quads, CoutP = dm_conv_packed_cout(Cout)
+ * (zero padded).  The input channels are the concatenation of `num_srcs`
+ * sources (src_channels[], HOST array, sum = Cin); each source is padded with
+ * zero rows to a multiple of 8 channels, KQ = sum(roundup(Cs, 8)) / 4, total
+ * size dm_conv_packed_floats() floats.
  * transpose_flip != 0 packs the weights of the data-gradient convolution
  * (in/out channels swapped, taps rotated by 180 degrees): input is still the
- * forward OIHW tensor, the packed tensor then has "Cout" = Cin of the forward.
+ * forward OIHW tensor, the packed tensor then has "Cout" = Cin of the forward
+ * and src_channels must sum to the forward's Cout.
  * ------------------------------------------------------------------------- */
 int dm_conv_packed_cout(int Cout);
+long long dm_conv_packed_floats(int Cout, int ksize, int num_srcs, const int* src_channels);
 int dm_conv_pack_weight(const float* w_oihw, int Cout, int Cin, int ksize, int transpose_flip,
-                        float* w_packed, dm_stream_t stream);
+                        int num_srcs, const int* src_channels, float* w_packed, dm_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * K5/K6  dense convolution forward, stride 1, "same" padding, ksize in {1,3},
@@ -124,7 +130,7 @@ int dm_class_logits_fwd(const float* x, int N, int C, int HW, const float* w_ins
  *           arithmetic spec mmdet/ops/dcn/src/deform_conv_cuda_kernel.cu:84-115,190-243,
  *           mmdet/ops/dcn/src/deform_conv_cuda.cpp:152-260.
  * x [NB, C, H, W]; offset [NB, deform_groups*18, H, W] (dh,dw interleaved per tap);
- * w_packed: dm_conv_pack_weight(ksize=3) of the [Cout, C, 3, 3] weight; out [NB, Cout, H, W]
+ * w_packed: dm_conv_pack_weight(ksize=3, one source) of the [Cout, C, 3, 3] weight; out [NB, Cout, H, W]
  * ------------------------------------------------------------------------- */
 int dm_deform_conv_fwd(const float* x, const float* offset, int NB, int C, int H, int W,
                        const float* w_packed, int Cout, int deform_groups, int relu, float* out,

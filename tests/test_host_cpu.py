@@ -39,7 +39,7 @@ def test_argument_validation_without_gpu():
     L = _lib.lib()
     # null pointers / bad sizes are rejected before any HIP call
     assert L.dm_upsample2x_bilinear_fwd(None, 1, 4, 4, 0, 0, None, None) == -1
-    assert L.dm_conv_pack_weight(None, 4, 4, 3, 0, None, None) == -1
+    assert L.dm_conv_pack_weight(None, 4, 4, 3, 0, 1, None, None, None) == -1
     assert L.dm_gumbel_select_fwd(None, None, 4, 4, 0.5, None, None, None, None) == -1
 
 

@@ -125,7 +125,8 @@ def test_conv2d_fused_concat_and_channel_slice_output(ops):
     b = torch.randn(C, generator=_g(36))
     ref = F.relu(F.conv2d(torch.cat(xs, 1), w, b))
     out = torch.full((N, C + 2, S, S), -7.0).cuda()
-    ops.conv2d([_dev(t) for t in xs], ops.pack_conv_weight(_dev(w)), _dev(b), C, 1, relu=True, out=out, out_ch_offset=1)
+    ops.conv2d([_dev(t) for t in xs], ops.pack_conv_weight(_dev(w), src_channels=[C, C, 1, 1]), _dev(b), C, 1, relu=True,
+               out=out, out_ch_offset=1)
     _close(out[:, 1:C + 1], ref)
     assert torch.all(out[:, 0] == -7.0) and torch.all(out[:, C + 1] == -7.0)
 
@@ -179,7 +180,7 @@ def test_class_logits(ops):
     _close(sig[:, 5:6], rd.sigmoid())
 
 
-@pytest.mark.parametrize('N,C,S', [(7, 256, 14), (5, 128, 28), (3, 64, 56), (2, 8, 9)])
+@pytest.mark.parametrize('N,C,S', [(7, 256, 14), (5, 128, 28), (3, 64, 56), (2, 16, 9)])
 def test_deform_conv(ops, N, C, S):
     x = torch.randn(N, C, S, S, generator=_g(60))
     w = torch.randn(C, C, 3, 3, generator=_g(61)) / (9 * C) ** 0.5
