@@ -4,7 +4,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdynamask_hip.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -33,6 +33,16 @@ SIGNATURES = {
     'dm_class_balance_fwd_bwd': ([_vp, _c_int, _c_int, _vp, _vp, _vp], _c_int),
     'dm_bn_stats': ([_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_float, _vp], _c_int),
     'dm_bn_relu_maxpool_fwd': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_float, _vp, _vp], _c_int),
+    'dm_relu_bwd': ([_vp, _vp, ctypes.c_longlong, _vp], _c_int),
+    'dm_sigmoid_bwd': ([_vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _c_int, _c_int, _vp, _c_int, _vp], _c_int),
+    'dm_channel_sum': ([_vp, ctypes.c_longlong, _c_int, _c_int, _c_int, _vp, _c_int, _vp], _c_int),
+    'dm_conv2d_wgrad': ([_vp, ctypes.c_longlong, _c_int, _vp, ctypes.c_longlong, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp], _c_int),
+    'dm_upsample2x_bilinear_bwd': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp], _c_int),
+    'dm_point_sample_bwd': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_float, _vp, _vp], _c_int),
+    'dm_class_logits_bwd': ([_vp, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _vp], _c_int),
+    'dm_deform_im2col': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp], _c_int),
+    'dm_deform_col2im_coord': ([_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp], _c_int),
+    'dm_dcn_weight_permute': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp], _c_int),
     'dm_detail_target': ([_vp, _c_int, _c_int, _c_float, _c_float, _vp, _vp], _c_int),
     'dm_mask_loss_fwd_bwd': ([_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp], _c_int),
 }

@@ -11,4 +11,4 @@ extern "C" const char* dm_error_string(int code) {
   }
 }
 
-extern "C" int dm_abi_version(void) { return 2; }
+extern "C" int dm_abi_version(void) { return 3; }

@@ -1,0 +1,550 @@
+// Backward kernels of the mask-head path (training step, BASELINE configs[2..3]).
+//
+//   conv weight gradient  : MFMA GEMM  dW[co][j] += sum_q dY[co,q] * Xcol[j,q], j=(ci,tap),
+//                           split over the pixel dimension, fp32 atomics into dW
+//   conv data gradient    : the forward implicit GEMM with transposed/rotated
+//                           weights (dm_conv_pack_weight(transpose_flip=1)) -- no kernel here
+//   bias gradient         : per-channel reduction
+//   ReLU / sigmoid masks  : elementwise on the gradient
+//   upsample, point sample, class logits: adjoint scatter / gathered dot products
+//   DCNv1                 : deformable im2col (column matrix materialised for the
+//                           backward only) + col2im / coordinate gradient, spec
+//                           mmdet/ops/dcn/src/deform_conv_cuda_kernel.cu:117-188,279-436;
+//                           the two GEMMs of deform_conv_cuda.cpp:262-486 run on the
+//                           implicit-GEMM conv kernels (1x1 over the column matrix).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// ----------------------------------------------------------------- elementwise
+__global__ __launch_bounds__(256) void relu_bwd_kernel(float* __restrict__ g, const float* __restrict__ y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    if (!(y[i] > 0.f)) g[i] = 0.f;
+}
+
+// g_logit[n,p] (+)= (ga[n,p] + gb[n,p]) * s * (1 - s),  s = sig[n, ch, p] taken from a
+// channel of a wider tensor; ga / gb are channel slices too (gb optional).
+__global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restrict__ sig, long long sig_bs,
+                                                          const float* __restrict__ ga, long long ga_bs,
+                                                          const float* __restrict__ gb, long long gb_bs, int N, int HW,
+                                                          float* __restrict__ g_logit, int accumulate) {
+  const size_t total = (size_t)N * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = i / HW;
+    const size_t p = i - n * HW;
+    const float s = sig[n * sig_bs + p];
+    float g = ga[n * ga_bs + p];
+    if (gb) g += gb[n * gb_bs + p];
+    const float v = g * s * (1.f - s);
+    g_logit[i] = accumulate ? g_logit[i] + v : v;
+  }
+}
+
+// per-channel sum over batch and pixels (bias gradient); one workgroup per channel
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ g, long long bs, int NB, int C, int HW,
+                                                          float* __restrict__ out, int accumulate) {
+  __shared__ float red[4];
+  const int c = blockIdx.x;
+  float s = 0.f;
+  const long long total = (long long)NB * HW;
+  for (long long i = threadIdx.x; i < total; i += blockDim.x) {
+    const long long n = i / HW;
+    const long long p = i - n * HW;
+    s += g[n * bs + (long long)c * HW + p];
+  }
+  s = wsum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t = red[0] + red[1] + red[2] + red[3];
+    out[c] = accumulate ? out[c] + t : t;
+  }
+}
+
+// ----------------------------------------------------------------- conv weight gradient
+struct WgradArgs {
+  const float* dy;
+  long long dy_bs;
+  const float* x;
+  long long x_bs;
+  int Cout, Cs, NB, H, W, HW, Q;
+  float* dw;
+  int ldw, coloff;
+  int JT, MT, chunks_per_split, nsplit;
+};
+
+template <int KS>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  constexpr int TM = 128, TN = 128, KT = 32, LD = KT + 1, TAPS = KS * KS;
+  __shared__ float ldsA[TM * LD];
+  __shared__ float ldsB[TN * LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_m = wave >> 1, wave_n = wave & 1;
+  const int hi = lane >> 5, l31 = lane & 31;
+  int bid = blockIdx.x;
+  const int m_tile = bid % a.MT;
+  bid /= a.MT;
+  const int j_tile = bid % a.JT;
+  const int split = bid / a.JT;
+  const int m0 = m_tile * TM, j0 = j_tile * TN;
+  const int HW = a.HW, W = a.W, H = a.H;
+  const int Jtot = a.Cs * TAPS;
+
+  dm_f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int kq = tid & 31;        // this thread's pixel column inside a chunk
+  const int r0 = tid >> 5;        // rows r0 + 8*i
+  // decode the B rows this thread stages once: j -> (ci, tap)
+  int b_ci[16], b_dy[16], b_dx[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int jg = j0 + r0 + 8 * i;
+    const int ci = jg / TAPS, tap = jg - ci * TAPS;
+    b_ci[i] = (jg < Jtot) ? ci : -1;
+    b_dy[i] = (KS == 3) ? tap / 3 - 1 : 0;
+    b_dx[i] = (KS == 3) ? tap % 3 - 1 : 0;
+  }
+  const int c_begin = split * a.chunks_per_split;
+  const int c_end = min(c_begin + a.chunks_per_split, (a.Q + KT - 1) / KT);
+  for (int ch = c_begin; ch < c_end; ++ch) {
+    const int q = ch * KT + kq;
+    const bool qok = q < a.Q;
+    const int qq = min(q, a.Q - 1);
+    const int n = qq / HW;
+    const int p = qq - n * HW;
+    const int y = p / W, x = p - y * W;
+    const float* dyp = a.dy + (size_t)n * a.dy_bs + p;
+    const float* xp = a.x + (size_t)n * a.x_bs;
+    float va[16], vb[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int co = m0 + r0 + 8 * i;
+      va[i] = (qok && co < a.Cout) ? dyp[(size_t)co * HW] : 0.f;
+      const int yy = y + b_dy[i], xx = x + b_dx[i];
+      const bool ok = qok && b_ci[i] >= 0 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      vb[i] = ok ? xp[(size_t)b_ci[i] * HW + yy * W + xx] : 0.f;
+    }
+    __syncthreads();   // previous chunk's MFMA reads are done
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      ldsA[(r0 + 8 * i) * LD + kq] = va[i];
+      ldsB[(r0 + 8 * i) * LD + kq] = vb[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < KT; kk += 2) {
+      float av[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) av[i] = ldsA[((wave_m * 2 + i) * 32 + l31) * LD + kk + hi];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bv[j] = ldsB[((wave_n * 2 + j) * 32 + l31) * LD + kk + hi];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = m0 + (wave_m * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (co < a.Cout) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int jg = j0 + (wave_n * 2 + j) * 32 + l31;
+          if (jg < Jtot) atomicAdd(a.dw + (size_t)co * a.ldw + a.coloff + jg, acc[i][j][r]);
+        }
+      }
+    }
+}
+
+// ----------------------------------------------------------------- K11 backward
+// adjoint of the x2 bilinear upsample (output-driven scatter, 4 atomics per element);
+// optional ReLU mask from the forward output.
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ yout,
+                                                             int NC, int H, int W, int ac, float* __restrict__ gin) {
+  const int OH = 2 * H, OW = 2 * W;
+  const size_t total = (size_t)NC * OH * OW;
+  const float rh = ac ? (OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f) : 0.5f;
+  const float rw = ac ? (OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f) : 0.5f;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    float g = gout[idx];
+    if (yout && !(yout[idx] > 0.f)) g = 0.f;
+    if (g == 0.f) continue;
+    const int ox = (int)(idx % OW);
+    const int oy = (int)((idx / OW) % OH);
+    const size_t nc = idx / ((size_t)OW * OH);
+    float sy, sx;
+    if (ac) {
+      sy = rh * (float)oy;
+      sx = rw * (float)ox;
+    } else {
+      sy = fmaxf(rh * ((float)oy + 0.5f) - 0.5f, 0.f);
+      sx = fmaxf(rw * ((float)ox + 0.5f) - 0.5f, 0.f);
+    }
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + ((y0 < H - 1) ? 1 : 0), x1 = x0 + ((x0 < W - 1) ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    float* p = gin + nc * H * W;
+    atomicAdd(p + y0 * W + x0, g * hy * hx);
+    atomicAdd(p + y0 * W + x1, g * hy * lx);
+    atomicAdd(p + y1 * W + x0, g * ly * hx);
+    atomicAdd(p + y1 * W + x1, g * ly * lx);
+  }
+}
+
+// ----------------------------------------------------------------- K4 backward
+__global__ __launch_bounds__(256) void point_sample_bwd_kernel(const float* __restrict__ gout, int B, int C, int H, int W,
+                                                               const float* __restrict__ rois, int N, int S, float scale,
+                                                               float* __restrict__ gfeat, int CT, int pos_blocks) {
+  const int chunks = (C + CT - 1) / CT;
+  int bid = blockIdx.x;
+  const int pb = bid % pos_blocks;
+  bid /= pos_blocks;
+  const int chunk = bid % chunks;
+  const int n = bid / chunks;
+  const int pos = pb * blockDim.x + threadIdx.x;
+  if (pos >= S * S) return;
+  const int iy = pos / S, ix = pos - iy * S;
+  const float* r = rois + (size_t)n * 5;
+  const int b = (int)r[0];
+  if (b < 0 || b >= B) return;
+  const float x1 = r[1], y1 = r[2], x2 = r[3], y2 = r[4];
+  const float gx0 = ((float)(2 * ix + 1)) / (float)S - 1.0f;
+  const float gy0 = ((float)(2 * iy + 1)) / (float)S - 1.0f;
+  float px = (gx0 + 1.0f) / 2.0f, py = (gy0 + 1.0f) / 2.0f;
+  px = px * (x2 - x1) + x1;
+  py = py * (y2 - y1) + y1;
+  px = px / (float)W * scale;
+  py = py / (float)H * scale;
+  const float gx = px * 2.0f - 1.0f, gy = py * 2.0f - 1.0f;
+  const float sx = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f;
+  const float sy = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
+  const float fx = floorf(sx), fy = floorf(sy);
+  if (fx < -1.f || fx > (float)W || fy < -1.f || fy > (float)H) return;   // all four taps void
+  const int x0 = (int)fx, y0 = (int)fy, x1i = x0 + 1, y1i = y0 + 1;
+  const float lx = sx - fx, ly = sy - fy;
+  const float w_nw = (1.f - lx) * (1.f - ly), w_ne = lx * (1.f - ly), w_sw = (1.f - lx) * ly, w_se = lx * ly;
+  const bool okx0 = x0 >= 0 && x0 < W, okx1 = x1i >= 0 && x1i < W, oky0 = y0 >= 0 && y0 < H, oky1 = y1i >= 0 && y1i < H;
+  const int c0 = chunk * CT, c1 = min(c0 + CT, C);
+  const size_t plane = (size_t)H * W;
+  float* gf = gfeat + (size_t)b * C * plane;
+  const float* go = gout + ((size_t)n * C) * S * S + pos;
+  for (int c = c0; c < c1; ++c) {
+    const float g = go[(size_t)c * S * S];
+    float* gc = gf + (size_t)c * plane;
+    if (okx0 && oky0) atomicAdd(gc + y0 * W + x0, g * w_nw);
+    if (okx1 && oky0) atomicAdd(gc + y0 * W + x1i, g * w_ne);
+    if (okx0 && oky1) atomicAdd(gc + y1i * W + x0, g * w_sw);
+    if (okx1 && oky1) atomicAdd(gc + y1i * W + x1i, g * w_se);
+  }
+}
+
+// ----------------------------------------------------------------- K7 backward
+// gx[n,c,p] (+)= wi[lab][c]*gi[n,p] + wd[lab][c]*gd[n,p];
+// gWi[lab][c] += sum_p gi*x ; gbi[lab] += sum_p gi  (same for the detail branch).
+// grid = (C, N): one workgroup per (RoI, channel).
+__global__ __launch_bounds__(256) void class_logits_bwd_kernel(const float* __restrict__ x, int N, int C, int HW,
+                                                               const float* __restrict__ wi, const float* __restrict__ wd,
+                                                               int num_classes, const int64_t* __restrict__ labels,
+                                                               const float* __restrict__ gi, const float* __restrict__ gd,
+                                                               float* __restrict__ gx, int accumulate,
+                                                               float* __restrict__ gwi, float* __restrict__ gbi,
+                                                               float* __restrict__ gwd, float* __restrict__ gbd) {
+  __shared__ float red[8];
+  const int c = blockIdx.x, n = blockIdx.y;
+  int lab = (int)labels[n];
+  lab = min(max(lab, 0), num_classes - 1);
+  const float a = wi[(size_t)lab * C + c], b = wd[(size_t)lab * C + c];
+  const float* xp = x + ((size_t)n * C + c) * HW;
+  float* gxp = gx + ((size_t)n * C + c) * HW;
+  const float* gip = gi + (size_t)n * HW;
+  const float* gdp = gd + (size_t)n * HW;
+  float si = 0.f, sd = 0.f, ti = 0.f, td = 0.f;
+  for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+    const float g1 = gip[p], g2 = gdp[p], xv = xp[p];
+    const float v = a * g1 + b * g2;
+    gxp[p] = accumulate ? gxp[p] + v : v;
+    si += g1 * xv;
+    sd += g2 * xv;
+    ti += g1;
+    td += g2;
+  }
+  si = wsum(si);
+  sd = wsum(sd);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[w] = si;
+    red[4 + w] = sd;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(gwi + (size_t)lab * C + c, red[0] + red[1] + red[2] + red[3]);
+    atomicAdd(gwd + (size_t)lab * C + c, red[4] + red[5] + red[6] + red[7]);
+  }
+  if (c == 0) {   // bias gradient once per RoI
+    __syncthreads();
+    ti = wsum(ti);
+    td = wsum(td);
+    if ((threadIdx.x & 63) == 0) {
+      red[w] = ti;
+      red[4 + w] = td;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      atomicAdd(gbi + lab, red[0] + red[1] + red[2] + red[3]);
+      atomicAdd(gbd + lab, red[4] + red[5] + red[6] + red[7]);
+    }
+  }
+}
+
+// ----------------------------------------------------------------- DCN backward pieces
+struct DcnSample {
+  bool valid;
+  int h_low, w_low;
+  float h_im, w_im;
+};
+
+__device__ __forceinline__ DcnSample dcn_sample(const float* offp, int tap, int HW, int y, int x, int H, int W) {
+  DcnSample s;
+  const int ki = tap / 3, kj = tap - ki * 3;
+  s.h_im = (float)(y - 1 + ki) + offp[(size_t)(2 * tap) * HW];
+  s.w_im = (float)(x - 1 + kj) + offp[(size_t)(2 * tap + 1) * HW];
+  s.valid = s.h_im > -1.f && s.w_im > -1.f && s.h_im < (float)H && s.w_im < (float)W;
+  s.h_low = (int)floorf(s.h_im);
+  s.w_low = (int)floorf(s.w_im);
+  return s;
+}
+
+// col[n][(tap*C + ci)][p] = bilinear sample (deformable im2col, tap-major rows)
+__global__ __launch_bounds__(256) void deform_im2col_kernel(const float* __restrict__ x, const float* __restrict__ offset,
+                                                            int NB, int C, int H, int W, int dg, float* __restrict__ col,
+                                                            int CT) {
+  const int HW = H * W;
+  const int pblocks = (HW + 255) / 256;
+  const int chunks = (C / dg + CT - 1) / CT;
+  int bid = blockIdx.x;
+  const int pb = bid % pblocks; bid /= pblocks;
+  const int chunk = bid % chunks; bid /= chunks;
+  const int tap = bid % 9; bid /= 9;
+  const int g = bid % dg;
+  const int n = bid / dg;
+  const int p = pb * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const int y = p / W, xx = p - y * W;
+  const float* offp = offset + ((size_t)n * dg + g) * 18 * HW + p;
+  const DcnSample s = dcn_sample(offp, tap, HW, y, xx, H, W);
+  const int cpg = C / dg;
+  const int c0 = g * cpg + chunk * CT, c1 = min(c0 + CT, (g + 1) * cpg);
+  float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
+  int o1 = 0, o2 = 0, o3 = 0, o4 = 0;
+  if (s.valid) {
+    const int h_high = s.h_low + 1, w_high = s.w_low + 1;
+    const float lh = s.h_im - (float)s.h_low, lw = s.w_im - (float)s.w_low, hh = 1.f - lh, hw = 1.f - lw;
+    if (s.h_low >= 0 && s.w_low >= 0) { o1 = s.h_low * W + s.w_low; w1 = hh * hw; }
+    if (s.h_low >= 0 && w_high <= W - 1) { o2 = s.h_low * W + w_high; w2 = hh * lw; }
+    if (h_high <= H - 1 && s.w_low >= 0) { o3 = h_high * W + s.w_low; w3 = lh * hw; }
+    if (h_high <= H - 1 && w_high <= W - 1) { o4 = h_high * W + w_high; w4 = lh * lw; }
+  }
+  for (int c = c0; c < c1; ++c) {
+    const float* xc = x + ((size_t)n * C + c) * HW;
+    col[((size_t)n * 9 * C + (size_t)tap * C + c) * HW + p] = w1 * xc[o1] + w2 * xc[o2] + w3 * xc[o3] + w4 * xc[o4];
+  }
+}
+
+// colgrad[n][(tap*C + ci)][p] -> gx (atomics, deformable col2im) and goffset
+// (coordinate gradient, summed over the channels of the deformable group by the
+// owning thread: no atomics).  Thread = (n, group, tap, pixel).
+__global__ __launch_bounds__(256) void dcn_col2im_coord_kernel(const float* __restrict__ colgrad, const float* __restrict__ x,
+                                                               const float* __restrict__ offset, int NB, int C, int H, int W,
+                                                               int dg, float* __restrict__ gx, float* __restrict__ goffset) {
+  const int HW = H * W;
+  const int pblocks = (HW + 255) / 256;
+  int bid = blockIdx.x;
+  const int pb = bid % pblocks; bid /= pblocks;
+  const int tap = bid % 9; bid /= 9;
+  const int g = bid % dg;
+  const int n = bid / dg;
+  const int p = pb * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const int y = p / W, xx = p - y * W;
+  const float* offp = offset + ((size_t)n * dg + g) * 18 * HW + p;
+  const DcnSample s = dcn_sample(offp, tap, HW, y, xx, H, W);
+  float* goff = goffset + ((size_t)n * dg + g) * 18 * HW + p;
+  if (!s.valid) {
+    goff[(size_t)(2 * tap) * HW] = 0.f;
+    goff[(size_t)(2 * tap + 1) * HW] = 0.f;
+    return;
+  }
+  const int h_low = s.h_low, w_low = s.w_low, h_high = h_low + 1, w_high = w_low + 1;
+  const float lh = s.h_im - (float)h_low, lw = s.w_im - (float)w_low, hh = 1.f - lh, hw = 1.f - lw;
+  const bool v1 = h_low >= 0 && w_low >= 0, v2 = h_low >= 0 && w_high <= W - 1;
+  const bool v3 = h_high <= H - 1 && w_low >= 0, v4 = h_high <= H - 1 && w_high <= W - 1;
+  const int o1 = v1 ? h_low * W + w_low : 0, o2 = v2 ? h_low * W + w_high : 0;
+  const int o3 = v3 ? h_high * W + w_low : 0, o4 = v4 ? h_high * W + w_high : 0;
+  const int cpg = C / dg;
+  float acc_h = 0.f, acc_w = 0.f;
+  for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+    const float cg = colgrad[((size_t)n * 9 * C + (size_t)tap * C + c) * HW + p];
+    const float* xc = x + ((size_t)n * C + c) * HW;
+    float* gc = gx + ((size_t)n * C + c) * HW;
+    const float x1 = v1 ? xc[o1] : 0.f, x2 = v2 ? xc[o2] : 0.f, x3 = v3 ? xc[o3] : 0.f, x4 = v4 ? xc[o4] : 0.f;
+    // d val / d h_im and d val / d w_im  (get_coordinate_weight, :145-188)
+    acc_h += cg * (-hw * x1 - lw * x2 + hw * x3 + lw * x4);
+    acc_w += cg * (-hh * x1 + hh * x2 - lh * x3 + lh * x4);
+    if (v1) atomicAdd(gc + o1, cg * hh * hw);
+    if (v2) atomicAdd(gc + o2, cg * hh * lw);
+    if (v3) atomicAdd(gc + o3, cg * lh * hw);
+    if (v4) atomicAdd(gc + o4, cg * lh * lw);
+  }
+  goff[(size_t)(2 * tap) * HW] = acc_h;
+  goff[(size_t)(2 * tap + 1) * HW] = acc_w;
+}
+
+// W[co][ci][tap]  <->  Wt[(tap*C + ci)][co]  (the two DCN GEMMs run as 1x1 convs over
+// the tap-major column matrix)
+__global__ void dcn_weight_permute_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int C,
+                                          int to_colmajor, int accumulate) {
+  const int total = Cout * C * 9;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    if (to_colmajor) {        // dst[(tap*C+ci)*Cout + co] = src[(co*C+ci)*9 + tap]
+      const int co = idx % Cout;
+      const int j = idx / Cout;
+      const int tap = j / C, ci = j - tap * C;
+      dst[idx] = src[((size_t)co * C + ci) * 9 + tap];
+    } else {                  // dst[(co*C+ci)*9 + tap] (+)= src[co*(9C) + tap*C + ci]
+      const int tap = idx % 9;
+      const int ci = (idx / 9) % C;
+      const int co = idx / (9 * C);
+      const float v = src[(size_t)co * 9 * C + tap * C + ci];
+      dst[idx] = accumulate ? dst[idx] + v : v;
+    }
+  }
+}
+
+int grid_for(size_t n) { return (int)min((size_t)dm_ceil_div((long long)n, 256), (size_t)16384); }
+
+}  // namespace
+
+extern "C" int dm_relu_bwd(float* grad, const float* out, long long count, dm_stream_t stream) {
+  if (!grad || !out || count < 0) return DM_ERR_INVALID_ARG;
+  if (count == 0) return DM_OK;
+  DM_LAUNCH(relu_bwd_kernel, dim3(grid_for((size_t)count)), dim3(256), 0, (hipStream_t)stream, grad, out, (size_t)count);
+  return dm_check_launch();
+}
+
+extern "C" int dm_sigmoid_bwd(const float* sig, long long sig_bs, const float* ga, long long ga_bs, const float* gb,
+                              long long gb_bs, int N, int HW, float* g_logit, int accumulate, dm_stream_t stream) {
+  if (!sig || !ga || !g_logit || N < 0 || HW <= 0) return DM_ERR_INVALID_ARG;
+  if (N == 0) return DM_OK;
+  DM_LAUNCH(sigmoid_bwd_kernel, dim3(grid_for((size_t)N * HW)), dim3(256), 0, (hipStream_t)stream, sig, sig_bs, ga, ga_bs,
+            gb, gb_bs, N, HW, g_logit, accumulate);
+  return dm_check_launch();
+}
+
+extern "C" int dm_channel_sum(const float* g, long long batch_stride, int NB, int C, int HW, float* out, int accumulate,
+                              dm_stream_t stream) {
+  if (!g || !out || NB <= 0 || C <= 0 || HW <= 0) return DM_ERR_INVALID_ARG;
+  DM_LAUNCH(channel_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, g, batch_stride, NB, C, HW, out, accumulate);
+  return dm_check_launch();
+}
+
+extern "C" int dm_conv2d_wgrad(const float* dy, long long dy_batch_stride, int Cout, const float* x,
+                               long long x_batch_stride, int Cs, int NB, int H, int W, int ksize, float* dw, int ldw,
+                               int col_offset, dm_stream_t stream) {
+  if (!dy || !x || !dw || Cout <= 0 || Cs <= 0 || NB <= 0 || H <= 0 || W <= 0 || (ksize != 1 && ksize != 3))
+    return DM_ERR_INVALID_ARG;
+  if ((long long)NB * H * W > 0x7fffffffLL) return DM_ERR_INVALID_ARG;
+  WgradArgs a;
+  a.dy = dy; a.dy_bs = dy_batch_stride; a.x = x; a.x_bs = x_batch_stride; a.Cout = Cout; a.Cs = Cs;
+  a.NB = NB; a.H = H; a.W = W; a.HW = H * W; a.Q = NB * H * W; a.dw = dw; a.ldw = ldw; a.coloff = col_offset;
+  a.MT = dm_ceil_div(Cout, 128);
+  a.JT = dm_ceil_div(Cs * ksize * ksize, 128);
+  const int chunks = dm_ceil_div(a.Q, 32);
+  int nsplit = max(1, min(chunks, 2048 / max(1, a.MT * a.JT)));
+  a.chunks_per_split = dm_ceil_div(chunks, nsplit);
+  a.nsplit = dm_ceil_div(chunks, a.chunks_per_split);
+  const dim3 grid((unsigned)(a.MT * a.JT * a.nsplit));
+  if (ksize == 3) DM_LAUNCH(conv_wgrad_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else DM_LAUNCH(conv_wgrad_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  return dm_check_launch();
+}
+
+extern "C" int dm_upsample2x_bilinear_bwd(const float* grad_out, const float* fwd_out_for_relu, int NC, int H, int W,
+                                          int align_corners, float* grad_in, dm_stream_t stream) {
+  if (!grad_out || !grad_in || NC < 0 || H <= 0 || W <= 0) return DM_ERR_INVALID_ARG;
+  if (NC == 0) return DM_OK;
+  DM_LAUNCH(upsample2x_bwd_kernel, dim3(grid_for((size_t)NC * 4 * H * W)), dim3(256), 0, (hipStream_t)stream, grad_out,
+            fwd_out_for_relu, NC, H, W, align_corners, grad_in);
+  return dm_check_launch();
+}
+
+extern "C" int dm_point_sample_bwd(const float* grad_out, int B, int C, int H, int W, const float* rois, int N, int S,
+                                   float spatial_scale, float* grad_feat, dm_stream_t stream) {
+  if (!grad_out || !rois || !grad_feat || B <= 0 || C <= 0 || H <= 0 || W <= 0 || N < 0 || S <= 0) return DM_ERR_INVALID_ARG;
+  if (N == 0) return DM_OK;
+  const int CT = 16;
+  const int chunks = dm_ceil_div(C, CT), pos_blocks = dm_ceil_div(S * S, 256);
+  DM_LAUNCH(point_sample_bwd_kernel, dim3((unsigned)(N * chunks * pos_blocks)), dim3(256), 0, (hipStream_t)stream, grad_out,
+            B, C, H, W, rois, N, S, spatial_scale, grad_feat, CT, pos_blocks);
+  return dm_check_launch();
+}
+
+extern "C" int dm_class_logits_bwd(const float* x, int N, int C, int HW, const float* w_inst, const float* w_det,
+                                   int num_classes, const int64_t* labels, const float* grad_inst, const float* grad_det,
+                                   float* grad_x, int accumulate_x, float* grad_w_inst, float* grad_b_inst,
+                                   float* grad_w_det, float* grad_b_det, dm_stream_t stream) {
+  if (!x || !w_inst || !w_det || !labels || !grad_inst || !grad_det || !grad_x || !grad_w_inst || !grad_b_inst ||
+      !grad_w_det || !grad_b_det)
+    return DM_ERR_INVALID_ARG;
+  if (N < 0 || C <= 0 || HW <= 0 || num_classes <= 0) return DM_ERR_INVALID_ARG;
+  if (N == 0) return DM_OK;
+  DM_LAUNCH(class_logits_bwd_kernel, dim3(C, N), dim3(256), 0, (hipStream_t)stream, x, N, C, HW, w_inst, w_det, num_classes,
+            labels, grad_inst, grad_det, grad_x, accumulate_x, grad_w_inst, grad_b_inst, grad_w_det, grad_b_det);
+  return dm_check_launch();
+}
+
+extern "C" int dm_deform_im2col(const float* x, const float* offset, int NB, int C, int H, int W, int deform_groups,
+                                float* col, dm_stream_t stream) {
+  if (!x || !offset || !col || NB < 0 || C <= 0 || H <= 0 || W <= 0 || deform_groups <= 0 || C % deform_groups)
+    return DM_ERR_INVALID_ARG;
+  if (NB == 0) return DM_OK;
+  const int CT = 32;
+  const int pblocks = dm_ceil_div(H * W, 256), chunks = dm_ceil_div(C / deform_groups, CT);
+  DM_LAUNCH(deform_im2col_kernel, dim3((unsigned)(NB * deform_groups * 9 * chunks * pblocks)), dim3(256), 0,
+            (hipStream_t)stream, x, offset, NB, C, H, W, deform_groups, col, CT);
+  return dm_check_launch();
+}
+
+extern "C" int dm_deform_col2im_coord(const float* colgrad, const float* x, const float* offset, int NB, int C, int H,
+                                      int W, int deform_groups, float* grad_x, float* grad_offset, dm_stream_t stream) {
+  if (!colgrad || !x || !offset || !grad_x || !grad_offset || NB < 0 || C <= 0 || H <= 0 || W <= 0 || deform_groups <= 0 ||
+      C % deform_groups)
+    return DM_ERR_INVALID_ARG;
+  if (NB == 0) return DM_OK;
+  const int pblocks = dm_ceil_div(H * W, 256);
+  DM_LAUNCH(dcn_col2im_coord_kernel, dim3((unsigned)(NB * deform_groups * 9 * pblocks)), dim3(256), 0, (hipStream_t)stream,
+            colgrad, x, offset, NB, C, H, W, deform_groups, grad_x, grad_offset);
+  return dm_check_launch();
+}
+
+extern "C" int dm_dcn_weight_permute(const float* src, float* dst, int Cout, int C, int to_colmajor, int accumulate,
+                                     dm_stream_t stream) {
+  if (!src || !dst || Cout <= 0 || C <= 0) return DM_ERR_INVALID_ARG;
+  DM_LAUNCH(dcn_weight_permute_kernel, dim3(grid_for((size_t)Cout * C * 9)), dim3(256), 0, (hipStream_t)stream, src, dst,
+            Cout, C, to_colmajor, accumulate);
+  return dm_check_launch();
+}

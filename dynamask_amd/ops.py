@@ -310,3 +310,139 @@ def bn_relu_maxpool(x, mean, var, gamma, beta, eps=1e-5):
     check(lib().dm_bn_relu_maxpool_fwd(_p(x), NB, C, H, W, _p(mean), _p(var), _p(gamma), _p(beta), eps, _p(out),
                                        _stream()), 'dm_bn_relu_maxpool_fwd')
     return out
+
+
+# ------------------------------------------------------------------- backward ops
+def relu_backward_(grad, out):
+    _chk(grad, 'grad')
+    _chk(out, 'out')
+    assert grad.numel() == out.numel()
+    check(lib().dm_relu_bwd(_p(grad), _p(out), grad.numel(), _stream()), 'dm_relu_bwd')
+    return grad
+
+
+def sigmoid_backward(sig, ga, gb, g_logit=None):
+    """sig / ga / gb: [N, 1, H, W] views (possibly channel slices); returns / accumulates
+    d/dlogit = (ga + gb) * sig * (1 - sig)."""
+    N, _, H, W = sig.shape
+    for t in (sig, ga) + ((gb,) if gb is not None else ()):
+        assert t.is_cuda and t.dtype == torch.float32 and t.shape[1] == 1 and t.stride(3) == 1 and t.stride(2) == W
+    acc = g_logit is not None
+    if g_logit is None:
+        g_logit = torch.empty((N, 1, H, W), device=sig.device, dtype=torch.float32)
+    check(lib().dm_sigmoid_bwd(_p(sig), sig.stride(0), _p(ga), ga.stride(0), _p(gb), gb.stride(0) if gb is not None else 0,
+                               N, H * W, _p(g_logit), 1 if acc else 0, _stream()), 'dm_sigmoid_bwd')
+    return g_logit
+
+
+def channel_sum(g, out=None):
+    g = _chk_src(g)
+    NB, C, H, W = g.shape
+    acc = out is not None
+    if out is None:
+        out = torch.empty((C,), device=g.device, dtype=torch.float32)
+    check(lib().dm_channel_sum(_p(g), g.stride(0), NB, C, H * W, _p(out), 1 if acc else 0, _stream()), 'dm_channel_sum')
+    return out
+
+
+def conv2d_wgrad(dy, srcs, ksize, dw=None):
+    """dW [Cout, sum(Cs), k, k] of conv(cat(srcs)) given dy [NB, Cout, H, W]."""
+    dy = _chk_src(dy)
+    if isinstance(srcs, torch.Tensor):
+        srcs = [srcs]
+    srcs = [_chk_src(s) for s in srcs]
+    NB, Cout, H, W = dy.shape
+    cin = sum(s.shape[1] for s in srcs)
+    if dw is None:
+        dw = torch.zeros((Cout, cin, ksize, ksize), device=dy.device, dtype=torch.float32)
+    else:
+        _chk(dw, 'dw')
+        assert dw.shape == (Cout, cin, ksize, ksize)
+    base = 0
+    for s in srcs:
+        check(lib().dm_conv2d_wgrad(_p(dy), dy.stride(0), Cout, _p(s), s.stride(0), s.shape[1], NB, H, W, ksize, _p(dw),
+                                    cin * ksize * ksize, base * ksize * ksize, _stream()), 'dm_conv2d_wgrad')
+        base += s.shape[1]
+    return dw
+
+
+def upsample2x_backward(grad_out, fwd_out, in_shape, align_corners=False):
+    _chk(grad_out, 'grad_out')
+    if fwd_out is not None:
+        _chk(fwd_out, 'fwd_out')
+    N, C, H, W = in_shape
+    gin = torch.zeros(in_shape, device=grad_out.device, dtype=torch.float32)
+    check(lib().dm_upsample2x_bilinear_bwd(_p(grad_out), _p(fwd_out), N * C, H, W, 1 if align_corners else 0, _p(gin),
+                                           _stream()), 'dm_upsample2x_bilinear_bwd')
+    return gin
+
+
+def point_sample_backward(grad_out, feat_shape, rois, spatial_scale, grad_feat=None):
+    _chk(grad_out, 'grad_out')
+    _chk(rois, 'rois')
+    B, C, H, W = feat_shape
+    N, _, S, _ = grad_out.shape
+    if grad_feat is None:
+        grad_feat = torch.zeros(feat_shape, device=grad_out.device, dtype=torch.float32)
+    check(lib().dm_point_sample_bwd(_p(grad_out), B, C, H, W, _p(rois), N, S, spatial_scale, _p(grad_feat), _stream()),
+          'dm_point_sample_bwd')
+    return grad_feat
+
+
+def class_logits_backward(x, w_inst, w_det, labels, g_inst, g_det, grad_x, accumulate_x, gw_inst, gb_inst, gw_det, gb_det):
+    for t, n in ((x, 'x'), (w_inst, 'w_inst'), (w_det, 'w_det'), (g_inst, 'g_inst'), (g_det, 'g_det'), (grad_x, 'grad_x'),
+                 (gw_inst, 'gw_inst'), (gb_inst, 'gb_inst'), (gw_det, 'gw_det'), (gb_det, 'gb_det')):
+        _chk(t, n)
+    _chk(labels, 'labels', torch.int64)
+    N, C, H, W = x.shape
+    nc = w_inst.shape[0]
+    check(lib().dm_class_logits_bwd(_p(x), N, C, H * W, _p(w_inst), _p(w_det), nc, _p(labels), _p(g_inst), _p(g_det),
+                                    _p(grad_x), 1 if accumulate_x else 0, _p(gw_inst), _p(gb_inst), _p(gw_det), _p(gb_det),
+                                    _stream()), 'dm_class_logits_bwd')
+    return grad_x
+
+
+def deform_im2col(x, offset, deform_groups):
+    _chk(x, 'x')
+    _chk(offset, 'offset')
+    NB, C, H, W = x.shape
+    col = torch.empty((NB, 9 * C, H, W), device=x.device, dtype=torch.float32)
+    check(lib().dm_deform_im2col(_p(x), _p(offset), NB, C, H, W, deform_groups, _p(col), _stream()), 'dm_deform_im2col')
+    return col
+
+
+def deform_col2im_coord(colgrad, x, offset, deform_groups):
+    _chk(colgrad, 'colgrad')
+    _chk(x, 'x')
+    _chk(offset, 'offset')
+    NB, C, H, W = x.shape
+    gx = torch.zeros_like(x)
+    goff = torch.empty_like(offset)
+    check(lib().dm_deform_col2im_coord(_p(colgrad), _p(x), _p(offset), NB, C, H, W, deform_groups, _p(gx), _p(goff),
+                                       _stream()), 'dm_deform_col2im_coord')
+    return gx, goff
+
+
+def dcn_weight_permute(src, cout, c, to_colmajor, dst=None, accumulate=False):
+    _chk(src, 'src')
+    if dst is None:
+        shape = (9 * c, cout, 1, 1) if to_colmajor else (cout, c, 3, 3)
+        dst = torch.empty(shape, device=src.device, dtype=torch.float32)
+    check(lib().dm_dcn_weight_permute(_p(src), _p(dst), cout, c, 1 if to_colmajor else 0, 1 if accumulate else 0,
+                                      _stream()), 'dm_dcn_weight_permute')
+    return dst
+
+
+def deform_conv_backward(x, offset, weight, grad_out, deform_groups):
+    """(grad_x, grad_offset, grad_weight) of DCNv1 3x3.  The two GEMMs of the
+    reference's backward run as 1x1 convs over the tap-major column matrix."""
+    NB, C, H, W = x.shape
+    cout = weight.shape[0]
+    wt = dcn_weight_permute(weight.contiguous(), cout, C, True)                # [(tap,ci)][co]
+    colgrad = conv2d(grad_out, pack_conv_weight(wt), None, 9 * C, 1)           # W^T . dY
+    gx, goff = deform_col2im_coord(colgrad, x, offset, deform_groups)
+    del colgrad
+    col = deform_im2col(x, offset, deform_groups)
+    gw_cm = conv2d_wgrad(grad_out, col, 1)                                     # [co][(tap,ci)]
+    gw = dcn_weight_permute(gw_cm, cout, C, False)
+    return gx, goff, gw

@@ -238,6 +238,58 @@ int dm_gumbel_select_bwd(const float* y_soft, const float* grad_y, int N, int K,
 int dm_class_balance_fwd_bwd(const float* mask_labels, int N, int K, float* loss, float* grad,
                              dm_stream_t stream);
 
+/* ===========================================================================
+ * Backward (training step).  Replaces what autograd derives for the reference
+ * modules above plus mmcv's DeformConv2d backward
+ * (mmdet/ops/dcn/src/deform_conv_cuda.cpp:262-486, deform_conv_cuda_kernel.cu:117-188,279-436).
+ * The conv DATA gradient is dm_conv2d_fwd with dm_conv_pack_weight(transpose_flip=1).
+ * =========================================================================== */
+
+/* grad[i] = 0 where out[i] <= 0 (in place). */
+int dm_relu_bwd(float* grad, const float* out, long long count, dm_stream_t stream);
+
+/* g_logit[n,p] (+)= (ga[n,p] + gb[n,p]) * s(1-s), s = sig[n,p]; sig / ga / gb may be
+ * channel slices of wider tensors (batch strides in floats); gb may be NULL. */
+int dm_sigmoid_bwd(const float* sig, long long sig_bs, const float* ga, long long ga_bs, const float* gb,
+                   long long gb_bs, int N, int HW, float* g_logit, int accumulate, dm_stream_t stream);
+
+/* out[c] (+)= sum_{n,p} g[n, c, p]  (bias gradient). */
+int dm_channel_sum(const float* g, long long batch_stride, int NB, int C, int HW, float* out, int accumulate,
+                   dm_stream_t stream);
+
+/* conv weight gradient, fp32 MFMA GEMM over the pixel dimension, atomically
+ * accumulated: dw[co*ldw + col_offset + ci*k*k + tap] += sum_{n,y,x} dy[n,co,y,x] *
+ * x[n,ci,y+dy-1,x+dx-1].  One call per concat source (col_offset = channel base * k*k);
+ * the caller zero-fills dw. */
+int dm_conv2d_wgrad(const float* dy, long long dy_batch_stride, int Cout, const float* x, long long x_batch_stride,
+                    int Cs, int NB, int H, int W, int ksize, float* dw, int ldw, int col_offset, dm_stream_t stream);
+
+/* adjoint of dm_upsample2x_bilinear_fwd; fwd_out_for_relu (optional) masks the
+ * fused ReLU; grad_in is accumulated into (caller zero-fills). */
+int dm_upsample2x_bilinear_bwd(const float* grad_out, const float* fwd_out_for_relu, int NC, int H, int W,
+                               int align_corners, float* grad_in, dm_stream_t stream);
+
+/* adjoint of dm_point_sample_fwd, scatter-add into grad_feat (caller zero-fills). */
+int dm_point_sample_bwd(const float* grad_out, int B, int C, int H, int W, const float* rois, int N, int S,
+                        float spatial_scale, float* grad_feat, dm_stream_t stream);
+
+/* backward of dm_class_logits_fwd: grad_x (+)= W[label] * grad; grad_w/grad_b rows of
+ * the RoI's class accumulated atomically (caller zero-fills them). */
+int dm_class_logits_bwd(const float* x, int N, int C, int HW, const float* w_inst, const float* w_det,
+                        int num_classes, const int64_t* labels, const float* grad_inst, const float* grad_det,
+                        float* grad_x, int accumulate_x, float* grad_w_inst, float* grad_b_inst, float* grad_w_det,
+                        float* grad_b_det, dm_stream_t stream);
+
+/* DCNv1 backward pieces.  col / colgrad: [NB, 9*C, H, W] with rows tap-major
+ * (row = tap*C + ci).  dm_dcn_weight_permute converts W[co][ci][tap] <->
+ * Wt[(tap*C+ci)][co] so that both GEMMs run as 1x1 convs over the column matrix. */
+int dm_deform_im2col(const float* x, const float* offset, int NB, int C, int H, int W, int deform_groups,
+                     float* col, dm_stream_t stream);
+int dm_deform_col2im_coord(const float* colgrad, const float* x, const float* offset, int NB, int C, int H, int W,
+                           int deform_groups, float* grad_x, float* grad_offset, dm_stream_t stream);
+int dm_dcn_weight_permute(const float* src, float* dst, int Cout, int C, int to_colmajor, int accumulate,
+                          dm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

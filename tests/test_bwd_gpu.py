@@ -1,0 +1,133 @@
+"""Parity of the backward kernels (C ABI) against autograd of the CPU oracle.
+Float atomics make sums order-dependent: atol 2e-4 on gradient sums."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import golden_inputs as gi
+from oracle import ref_ops
+
+pytestmark = pytest.mark.gpu
+TOL = dict(atol=2e-4, rtol=2e-4)
+
+
+def _g(seed):
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return g
+
+
+def _dev(t):
+    return t.detach().cuda().contiguous()
+
+
+def _close(a, b, **kw):
+    kw = kw or TOL
+    np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), **kw)
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from dynamask_amd import ops as o
+    return o
+
+
+@pytest.mark.parametrize('N,Cs,Cout,S,ks', [
+    (7, [256], 256, 14, 3), (5, [48], 36, 28, 3), (3, [64, 64, 2], 64, 56, 1), (6, [128], 62, 28, 1), (9, [24], 40, 7, 3),
+])
+def test_conv_wgrad_bias_and_data_grad(ops, N, Cs, Cout, S, ks):
+    xs = [torch.randn(N, c, S, S, generator=_g(10 + i)) for i, c in enumerate(Cs)]
+    cin = sum(Cs)
+    w = (torch.randn(Cout, cin, ks, ks, generator=_g(20)) / (cin * ks * ks) ** 0.5).requires_grad_(True)
+    b = torch.randn(Cout, generator=_g(21)).requires_grad_(True)
+    xcat = torch.cat(xs, 1).requires_grad_(True)
+    y = F.relu(F.conv2d(xcat, w, b, padding=ks // 2))
+    go = torch.randn(y.shape, generator=_g(22))
+    y.backward(go)
+    gy = _dev(go)
+    ops.relu_backward_(gy, _dev(y))
+    _close(ops.conv2d_wgrad(gy, [_dev(t) for t in xs], ks), w.grad, atol=5e-4, rtol=2e-4)
+    _close(ops.channel_sum(gy), b.grad, atol=5e-4, rtol=2e-4)
+    # data gradient: forward kernel with transposed / rotated weights, sources = [dy]
+    gx = ops.conv2d(gy, ops.pack_conv_weight(_dev(w), transpose_flip=True), None, cin, ks)
+    _close(gx, xcat.grad)
+
+
+def test_upsample_backward(ops):
+    for ac, relu in ((False, True), (True, False)):
+        x = torch.randn(5, 6, 14, 14, generator=_g(30), requires_grad=True)
+        y = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=ac)
+        if relu:
+            y = F.relu(y)
+        go = torch.randn(y.shape, generator=_g(31))
+        y.backward(go)
+        gin = ops.upsample2x_backward(_dev(go), _dev(y) if relu else None, tuple(x.shape), align_corners=ac)
+        _close(gin, x.grad)
+
+
+def test_point_sample_backward(ops):
+    hi = gi.head_inputs()
+    feat = hi['feats'][2][:, :24].contiguous().requires_grad_(True)
+    out = ref_ops.simple_roi_align(feat, hi['rois'], 14, 0.25)
+    go = torch.randn(out.shape, generator=_g(40))
+    out.backward(go)
+    gf = ops.point_sample_backward(_dev(go), tuple(feat.shape), _dev(hi['rois']), 0.25)
+    _close(gf, feat.grad)
+
+
+def test_class_logits_backward(ops):
+    N, C, S, nc = 7, 64, 28, 80
+    x = torch.randn(N, C, S, S, generator=_g(50), requires_grad=True)
+    wi = (torch.randn(nc, C, 1, 1, generator=_g(51)) / 8).requires_grad_(True)
+    wd = (torch.randn(nc, C, 1, 1, generator=_g(52)) / 8).requires_grad_(True)
+    bi = torch.randn(nc, generator=_g(53)).requires_grad_(True)
+    bd = torch.randn(nc, generator=_g(54)).requires_grad_(True)
+    labels = torch.tensor([3, 3, 79, 0, 42, 3, 60])
+    ar = torch.arange(N)
+    ip = F.conv2d(x, wi, bi)[ar, labels][:, None]
+    dp = F.conv2d(x, wd, bd)[ar, labels][:, None]
+    g1 = torch.randn(ip.shape, generator=_g(55))
+    g2 = torch.randn(dp.shape, generator=_g(56))
+    (ip * g1).sum().backward(retain_graph=True)
+    (dp * g2).sum().backward()
+    gx = torch.full((N, C, S, S), 1.0).cuda()
+    gwi, gwd = torch.zeros(nc, C).cuda(), torch.zeros(nc, C).cuda()
+    gbi, gbd = torch.zeros(nc).cuda(), torch.zeros(nc).cuda()
+    ops.class_logits_backward(_dev(x), _dev(wi.view(nc, C)), _dev(wd.view(nc, C)), _dev(labels), _dev(g1), _dev(g2), gx,
+                              True, gwi, gbi, gwd, gbd)
+    _close(gx - 1.0, x.grad)
+    _close(gwi, wi.grad.view(nc, C), atol=5e-4, rtol=2e-4)
+    _close(gwd, wd.grad.view(nc, C), atol=5e-4, rtol=2e-4)
+    _close(gbi, bi.grad, atol=5e-4, rtol=2e-4)
+    _close(gbd, bd.grad, atol=5e-4, rtol=2e-4)
+
+
+def test_sigmoid_backward(ops):
+    logit = torch.randn(4, 1, 9, 9, generator=_g(60), requires_grad=True)
+    s = logit.sigmoid()
+    ga = torch.randn(s.shape, generator=_g(61))
+    gb = torch.randn(s.shape, generator=_g(62))
+    (s * (ga + gb)).sum().backward()
+    wide = torch.zeros(4, 5, 9, 9).cuda()
+    wide[:, 3:4] = _dev(s)
+    gw = torch.zeros(4, 3, 9, 9).cuda()
+    gw[:, 1:2] = _dev(ga)
+    out = ops.sigmoid_backward(wide[:, 3:4], gw[:, 1:2], _dev(gb))
+    _close(out, logit.grad, atol=1e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize('N,C,S', [(5, 64, 14), (3, 32, 28), (2, 16, 9)])
+def test_deform_conv_backward(ops, N, C, S):
+    x = torch.randn(N, C, S, S, generator=_g(70), requires_grad=True)
+    w = (torch.randn(C, C, 3, 3, generator=_g(71)) / (9 * C) ** 0.5).requires_grad_(True)
+    off = (torch.randn(N, 36, S, S, generator=_g(72)) * 1.2)
+    off[0, :, 0, 0] = 30.0
+    off = off.requires_grad_(True)
+    y = ref_ops.deform_conv2d(x, off, w, 1, 1, 1, 2)
+    go = torch.randn(y.shape, generator=_g(73))
+    y.backward(go)
+    gx, goff, gw = ops.deform_conv_backward(_dev(x), _dev(off), _dev(w), _dev(go), 2)
+    _close(gx, x.grad, atol=5e-4, rtol=2e-4)
+    _close(goff, off.grad, atol=5e-4, rtol=2e-4)
+    _close(gw, w.grad, atol=5e-4, rtol=2e-4)
