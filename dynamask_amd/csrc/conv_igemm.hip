@@ -39,7 +39,7 @@ struct ConvArgs {
   const float* wq;   // [taps][KQ][CoutP][4]
   const float* bias;
   int KQ, Cout, CoutP;
-  int relu;
+  int relu;   // flags: bit0 = ReLU, bit1 = accumulate into out
   float* out;
   int out_ch_total, out_ch_offset;
   int Wp, plane;  // 3x3: W+2, Rmax*Wp ; 1x1: unused, TN
@@ -301,9 +301,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
           for (int j = 0; j < WN; ++j) {
             if (col_ok[j]) {
+              float* op = a.out + ((size_t)col_n[j] * a.out_ch_total + a.out_ch_offset + co) * HW + col_p[j];
               float v = acc[i][j][r] + b;
-              if (a.relu) v = fmaxf(v, 0.f);
-              a.out[((size_t)col_n[j] * a.out_ch_total + a.out_ch_offset + co) * HW + col_p[j]] = v;
+              if (a.relu & 2) v += *op;          // accumulate into the destination (gradient sums)
+              if (a.relu & 1) v = fmaxf(v, 0.f);
+              *op = v;
             }
           }
         } else {
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_igemm_kernel(ConvArgs a) {
           for (int j = 0; j < WN; ++j) {
             if (col_ok[j]) {
               float v = acc[i][j][r] + b;
-              if (a.relu) v = fmaxf(v, 0.f);
+              if (a.relu & 1) v = fmaxf(v, 0.f);
               const int y = col_p[j] / W, x = col_p[j] - y * W;
               a.out[(((size_t)col_n[j] * a.shuffle + oc) * (2 * H) + 2 * y + dy) * (2 * W) + 2 * x + dx] = v;
             }

@@ -135,6 +135,12 @@ class DynaMaskRoIHead(nn.Module):
     # ------------------------------------------------------------------ forward
     def _mask_forward(self, x, rois, roi_labels, last_stage=None):
         """dynamask_roi_head.py:75-81."""
+        if torch.is_grad_enabled() and last_stage is None:
+            # training: same kernels, forward keeps what the hand-sequenced backward needs
+            from . import train_path
+            ins_feats = train_path.roi_extract_train(self.mask_roi_extractor, x, rois)
+            ips, dps = train_path.mask_head_forward_train(self.mask_head, ins_feats, x, rois, roi_labels)
+            return dict(stage_instance_preds=ips, stage_detail_preds=dps)
         ins_feats = self.mask_roi_extractor(x[:self.mask_roi_extractor.num_inputs], rois)
         ips, dps = self.mask_head(ins_feats, x, rois, roi_labels, last_stage=last_stage)
         return dict(stage_instance_preds=ips, stage_detail_preds=dps)

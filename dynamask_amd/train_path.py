@@ -1,0 +1,231 @@
+"""Training step of the mask-head path: forward that keeps what the backward
+needs, and a hand-sequenced backward over the C-ABI kernels.
+
+One ``torch.autograd.Function`` per block of the reference graph (RoI extractor,
+DynaMaskHead) so that ``loss.backward()`` of an mmdet-style training loop reaches
+the parameters, the RoI features and the FPN maps -- autograd only routes
+tensors; no arithmetic runs in PyTorch.
+
+Reference graph: ``DynaMaskHead.forward`` / ``SFMStage.forward``
+(mask_heads/dynamask_head.py:102-125,220-244), ``SingleRoIExtractor.forward``
+(roi_extractors/single_level_roi_extractor.py:53-81); gradients are what
+autograd derives for them plus mmcv's DeformConv2d / RoIAlign backward
+(mmdet/ops/dcn/src/deform_conv_cuda.cpp:262-486).
+"""
+import torch
+
+from . import ops
+
+
+class RoIExtractFn(torch.autograd.Function):
+    """Multi-level RoIAlign with its scatter-add backward (K1/K3)."""
+
+    @staticmethod
+    def forward(ctx, rois, output_size, scales, sampling_ratio, finest_scale, *feats):
+        feats = [f.contiguous() for f in feats]
+        ctx.save_for_backward(rois)
+        ctx.cfg = (output_size, list(scales), sampling_ratio, finest_scale, [tuple(f.shape) for f in feats])
+        return ops.roi_align(feats, rois, output_size, scales, sampling_ratio, finest_scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        (rois,) = ctx.saved_tensors
+        output_size, scales, sr, fs, shapes = ctx.cfg
+        grads = ops.roi_align_backward(g.contiguous(), shapes, rois, output_size, scales, sr, fs)
+        return (None, None, None, None, None, *grads)
+
+
+def _flipped(conv, key, w):
+    """Packed weights of the data-gradient convolution, cached on the module."""
+    return conv._pk.get(('flip',) + key, w, lambda t: ops.pack_conv_weight(t, transpose_flip=True))
+
+
+class MaskHeadFn(torch.autograd.Function):
+    """DynaMaskHead forward/backward.  Inputs: (head, rois, labels, ins_feats,
+    n_feats, *fpn_feats, *head.parameters())."""
+
+    @staticmethod
+    def forward(ctx, head, rois, labels, ins_feats, n_feats, *tensors):
+        feats = [t.contiguous() for t in tensors[:n_feats]]
+        labels = labels.long().contiguous()
+        rois = rois.contiguous()
+        saved = {}
+        x = ins_feats.contiguous()
+        conv_in = []
+        for conv in head.instance_convs:
+            conv_in.append(x)
+            x = conv(x)
+        saved['conv_in'] = conv_in
+        saved['stages'] = []
+        ips, dps = [], []
+        for idx, stage in enumerate(head.stages):
+            up_flag = head.pre_upsample_last_stage or idx < len(head.stages) - 1
+            st = {}
+            n, c, s, co = x.shape[0], stage.instance_in_channel, stage.out_size, stage.instance_out_channel
+            feat = feats[len(feats) - idx - 3]
+            st['feat_idx'] = len(feats) - idx - 3
+            sem = stage.semantic_transform_in.run(feat, relu=True)
+            isf = ops.point_sample(sem, rois, s, stage.spatial_scale)
+            tail = torch.empty((n, co, s, s), device=x.device, dtype=torch.float32)
+            nc = stage.num_classes
+            ip, dp = ops.class_logits(x, stage.instance_logits.weight.detach().view(nc, c),
+                                      stage.instance_logits.bias.detach(), stage.detail_logits.weight.detach().view(nc, c),
+                                      stage.detail_logits.bias.detach(), labels, sig_out=tail, sig_ch_offset=co - 2)
+            f1 = stage.fuse_conv[0].run([x, isf, tail[:, co - 2:]], relu=True)
+            dcn = stage.fuse_conv[1]
+            off = dcn.conv_offset.run(f1)
+            f2 = ops.deform_conv(f1, off, dcn._pk.get('w', dcn.weight, ops.pack_conv_weight), dcn.out_channels,
+                                 dcn.deform_groups, relu=True)
+            stage.fuse_transform_out.run(f2, relu=True, out=tail, out_ch_offset=0)
+            up = ops.upsample2x(tail, align_corners=False, relu=True) if up_flag else None
+            st.update(xin=x, sem=sem, isf=isf, tail=tail, f1=f1, off=off, f2=f2, up=up)
+            saved['stages'].append(st)
+            ips.append(ip)
+            dps.append(dp)
+            x = up if up_flag else tail
+        lab_last = labels.clamp(max=0) if head.stage_num_classes[-1] == 1 else labels
+        nc = head.stage_num_classes[-1]
+        c = head.final_instance_logits.in_channels
+        ip, dp = ops.class_logits(x, head.final_instance_logits.weight.detach().view(nc, c),
+                                  head.final_instance_logits.bias.detach(),
+                                  head.final_detail_logits.weight.detach().view(nc, c),
+                                  head.final_detail_logits.bias.detach(), lab_last)
+        saved['x_last'] = x
+        saved['lab_last'] = lab_last
+        if not head.pre_upsample_last_stage:
+            ip = ops.upsample2x(ip, align_corners=True)
+            dp = ops.upsample2x(dp, align_corners=True)
+        ips.append(ip)
+        dps.append(dp)
+        ctx.head, ctx.saved, ctx.feats, ctx.rois, ctx.labels = head, saved, feats, rois, labels
+        ctx.n_feats = n_feats
+        return (*ips, *dps)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        head, sv, feats, rois, labels = ctx.head, ctx.saved, ctx.feats, ctx.rois, ctx.labels
+        dev = rois.device
+        n_st = len(head.stages) + 1
+        g_ips = [g.contiguous() if g is not None else None for g in grads[:n_st]]
+        g_dps = [g.contiguous() if g is not None else None for g in grads[n_st:]]
+        pgrad = {}                      # parameter -> gradient tensor
+        g_feats = [None] * len(feats)
+
+        def zeros(shape):
+            return torch.zeros(shape, device=dev, dtype=torch.float32)
+
+        def zl(g, like):
+            return g if g is not None else torch.zeros_like(like)
+
+        def conv_params_bwd(conv, dy, srcs, ks):
+            pgrad[conv.weight] = ops.conv2d_wgrad(dy, srcs, ks)
+            if conv.bias is not None:
+                pgrad[conv.bias] = ops.channel_sum(dy)
+
+        def data_grad(conv, dy, lo, hi, ks, out=None, accumulate=False):
+            """d/d(input channels lo:hi) of a conv: forward kernel, transposed+rotated weights."""
+            w = conv.weight
+            wq = conv._pk.get(('flip', lo, hi), w, lambda t: ops.pack_conv_weight(t[:, lo:hi].contiguous(),
+                                                                                   transpose_flip=True))
+            return ops.conv2d(dy, wq, None, hi - lo, ks, out=out, accumulate=accumulate)
+
+        # ---------------- final logits + x2 (align_corners=True) upsample
+        x_last = sv['x_last']
+        n = x_last.shape[0]
+        S = x_last.shape[-1]
+        if head.pre_upsample_last_stage:
+            g_ip, g_dp = zl(g_ips[-1], x_last[:, :1]), zl(g_dps[-1], x_last[:, :1])
+        else:
+            full = (n, 1, 2 * S, 2 * S)
+            g_ip = ops.upsample2x_backward(g_ips[-1] if g_ips[-1] is not None else zeros(full), None, (n, 1, S, S), True)
+            g_dp = ops.upsample2x_backward(g_dps[-1] if g_dps[-1] is not None else zeros(full), None, (n, 1, S, S), True)
+        fi, fd = head.final_instance_logits, head.final_detail_logits
+        nc, c = head.stage_num_classes[-1], fi.in_channels
+        g_x = torch.empty_like(x_last)
+        gwi, gwd, gbi, gbd = zeros((nc, c)), zeros((nc, c)), zeros((nc,)), zeros((nc,))
+        ops.class_logits_backward(x_last, fi.weight.detach().view(nc, c), fd.weight.detach().view(nc, c), sv['lab_last'],
+                                  g_ip, g_dp, g_x, False, gwi, gbi, gwd, gbd)
+        pgrad[fi.weight], pgrad[fi.bias] = gwi.view_as(fi.weight), gbi
+        pgrad[fd.weight], pgrad[fd.bias] = gwd.view_as(fd.weight), gbd
+
+        # ---------------- SFM stages, last to first; g_x = grad wrt the stage's output
+        for idx in reversed(range(len(head.stages))):
+            stage, st = head.stages[idx], sv['stages'][idx]
+            xin, sem, isf, tail, f1, off, f2, up = (st[k] for k in ('xin', 'sem', 'isf', 'tail', 'f1', 'off', 'f2', 'up'))
+            c, co, s = stage.instance_in_channel, stage.instance_out_channel, stage.out_size
+            if up is not None:
+                g_tail = ops.upsample2x_backward(g_x, up, tuple(tail.shape), False)      # ReLU mask fused
+            else:
+                g_tail = g_x
+            # tail = [relu(fuse_transform_out(f2)) | sigmoid(ip) | sigmoid(dp)]; sigmoids are > 0 so
+            # masking the whole tensor by tail > 0 only touches the conv channels
+            ops.relu_backward_(g_tail, tail)
+            dy = g_tail[:, :co - 2]
+            conv_params_bwd(stage.fuse_transform_out, dy, f2, 1)
+            g_f2 = data_grad(stage.fuse_transform_out, dy, 0, c, 1)
+            ops.relu_backward_(g_f2, f2)
+            dcn = stage.fuse_conv[1]
+            g_f1, g_off, gw_dcn = ops.deform_conv_backward(f1, off, dcn.weight.detach(), g_f2, dcn.deform_groups)
+            pgrad[dcn.weight] = gw_dcn
+            conv_params_bwd(dcn.conv_offset, g_off, f1, 3)
+            data_grad(dcn.conv_offset, g_off, 0, c, 3, out=g_f1, accumulate=True)
+            ops.relu_backward_(g_f1, f1)
+            f0 = stage.fuse_conv[0]
+            conv_params_bwd(f0, g_f1, [xin, isf, tail[:, co - 2:]], 1)
+            g_xin = data_grad(f0, g_f1, 0, c, 1)
+            g_isf = data_grad(f0, g_f1, c, 2 * c, 1)
+            g_sig = data_grad(f0, g_f1, 2 * c, 2 * c + 2, 1)
+            # logits: direct loss gradient + through the two sigmoid channels (tail + fuse input)
+            g_ip = zl(g_ips[idx], g_sig[:, :1]).clone() if g_ips[idx] is not None else zeros((n, 1, s, s))
+            g_dp = zl(g_dps[idx], g_sig[:, :1]).clone() if g_dps[idx] is not None else zeros((n, 1, s, s))
+            ops.sigmoid_backward(tail[:, co - 2:co - 1], g_tail[:, co - 2:co - 1], g_sig[:, 0:1], g_logit=g_ip)
+            ops.sigmoid_backward(tail[:, co - 1:co], g_tail[:, co - 1:co], g_sig[:, 1:2], g_logit=g_dp)
+            il, dl = stage.instance_logits, stage.detail_logits
+            nc = stage.num_classes
+            gwi, gwd, gbi, gbd = zeros((nc, c)), zeros((nc, c)), zeros((nc,)), zeros((nc,))
+            ops.class_logits_backward(xin, il.weight.detach().view(nc, c), dl.weight.detach().view(nc, c), labels, g_ip, g_dp,
+                                      g_xin, True, gwi, gbi, gwd, gbd)
+            pgrad[il.weight], pgrad[il.bias] = gwi.view_as(il.weight), gbi
+            pgrad[dl.weight], pgrad[dl.bias] = gwd.view_as(dl.weight), gbd
+            # semantic branch: point sample adjoint -> relu -> 1x1 conv on the FPN map
+            g_sem = ops.point_sample_backward(g_isf, tuple(sem.shape), rois, stage.spatial_scale)
+            ops.relu_backward_(g_sem, sem)
+            fidx = st['feat_idx']
+            feat = feats[fidx]
+            conv_params_bwd(stage.semantic_transform_in, g_sem, feat, 1)
+            if g_feats[fidx] is None:
+                g_feats[fidx] = data_grad(stage.semantic_transform_in, g_sem, 0, feat.shape[1], 1)
+            else:
+                data_grad(stage.semantic_transform_in, g_sem, 0, feat.shape[1], 1, out=g_feats[fidx], accumulate=True)
+            g_x = g_xin
+
+        # ---------------- instance convs
+        for i in reversed(range(len(head.instance_convs))):
+            conv = head.instance_convs[i].conv
+            x_in = sv['conv_in'][i]
+            y = sv['conv_in'][i + 1] if i + 1 < len(sv['conv_in']) else sv['stages'][0]['xin']
+            ops.relu_backward_(g_x, y)
+            conv_params_bwd(conv, g_x, x_in, conv.kernel_size)
+            g_x = data_grad(conv, g_x, 0, conv.in_channels, conv.kernel_size)
+
+        params = list(head.parameters())
+        out_p = [pgrad.get(p) for p in params]
+        for p, g in zip(params, out_p):
+            if g is not None and g.shape != p.shape:
+                raise RuntimeError('gradient shape mismatch')
+        return (None, None, None, g_x, None, *g_feats, *out_p)
+
+
+def mask_head_forward_train(head, ins_feats, feats, rois, labels):
+    """Differentiable ``DynaMaskHead.forward`` -> (stage_instance_preds, stage_detail_preds)."""
+    feats = list(feats)
+    outs = MaskHeadFn.apply(head, rois, labels, ins_feats, len(feats), *feats, *list(head.parameters()))
+    n = len(head.stages) + 1
+    return list(outs[:n]), list(outs[n:])
+
+
+def roi_extract_train(extractor, feats, rois):
+    lay = extractor.roi_layers[0]
+    feats = list(feats)[:extractor.num_inputs]
+    scales = [l.spatial_scale for l in extractor.roi_layers]
+    return RoIExtractFn.apply(rois, lay.output_size[0], scales, lay.sampling_ratio, float(extractor.finest_scale), *feats)

@@ -91,6 +91,8 @@ int dm_conv_pack_weight(const float* w_oihw, int Cout, int Cin, int ksize, int t
  *            channel slice of a wider tensor.  srcs / src_channels /
  *            src_batch_strides are HOST arrays (of device pointers / ints).
  * w_packed : dm_conv_pack_weight layout, bias: [Cout] or NULL
+ * relu     : flags -- bit 0: fused ReLU; bit 1: accumulate (out += result; used
+ *            for gradient sums in the backward)
  * out      : written at channels [out_ch_offset, out_ch_offset+Cout) of a
  *            tensor [NB, out_ch_total, H, W]
  * ------------------------------------------------------------------------- */
