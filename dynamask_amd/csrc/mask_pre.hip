@@ -114,3 +114,111 @@ extern "C" int dm_bn_relu_maxpool_fwd(const float* x, int NB, int C, int H, int 
                      gamma, beta, eps, out, OH, OW);
   return dm_check_launch();
 }
+
+// ---------------------------------------------------------------------------
+// MaskPre backward pieces: max_pool2d(3,2,1) o ReLU o BatchNorm(train).
+namespace {
+
+// scatter the pooled gradient to the window's first maximum of z = relu(bn(x))
+// (torch's max_pool2d keeps the first maximum in scan order); g_z is zero-filled
+// by the caller.  ReLU mask folded in: a zero maximum passes no gradient.
+__global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(const float* __restrict__ x, int NB, int C, int H, int W,
+                                                               const float* __restrict__ mean, const float* __restrict__ var,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float eps, const float* __restrict__ gout,
+                                                               float* __restrict__ gz, int OH, int OW) {
+  const size_t total = (size_t)NB * C * OH * OW;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(idx % OW);
+    const int oy = (int)((idx / OW) % OH);
+    const int c = (int)((idx / ((size_t)OW * OH)) % C);
+    const size_t n = idx / ((size_t)OW * OH * C);
+    const float invstd = 1.0f / sqrtf(var[c] + eps);
+    const float g = gamma[c], b = beta[c], m = mean[c];
+    const float* p = x + (n * C + c) * (size_t)H * W;
+    float best = -INFINITY;
+    int bi = -1;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int y = 2 * oy - 1 + dy;
+      if (y < 0 || y >= H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int xx = 2 * ox - 1 + dx;
+        if (xx < 0 || xx >= W) continue;
+        const float v = fmaxf((p[y * W + xx] - m) * invstd * g + b, 0.f);
+        if (v > best) {
+          best = v;
+          bi = y * W + xx;
+        }
+      }
+    }
+    if (bi >= 0 && best > 0.f) atomicAdd(gz + (n * C + c) * (size_t)H * W + bi, gout[idx]);
+  }
+}
+
+__device__ __forceinline__ float bsum(float v, float* smem) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = wave_sum_(v);
+  if (lane == 0) smem[wave] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r += smem[w];
+  __syncthreads();
+  return r;
+}
+
+// BatchNorm (training) backward, one workgroup per channel:
+//   g_gamma = sum gz*xhat, g_beta = sum gz,
+//   g_x = gamma*invstd * (gz - g_beta/M - xhat*g_gamma/M)       (written over gz)
+__global__ __launch_bounds__(1024) void bn_bwd_kernel(const float* __restrict__ x, float* __restrict__ gz, int NB, int C,
+                                                      int HW, const float* __restrict__ mean, const float* __restrict__ var,
+                                                      const float* __restrict__ gamma, float eps,
+                                                      float* __restrict__ g_gamma, float* __restrict__ g_beta) {
+  __shared__ float red[16];
+  const int c = blockIdx.x;
+  const long long total = (long long)NB * HW;
+  const float invstd = 1.0f / sqrtf(var[c] + eps), m = mean[c];
+  float s1 = 0.f, s2 = 0.f;
+  for (long long i = threadIdx.x; i < total; i += blockDim.x) {
+    const long long n = i / HW, p = i - n * HW;
+    const size_t a = ((size_t)n * C + c) * HW + p;
+    const float g = gz[a];
+    s1 += g;
+    s2 += g * (x[a] - m) * invstd;
+  }
+  const float sb = bsum(s1, red);
+  const float sg = bsum(s2, red);
+  if (threadIdx.x == 0) {
+    g_beta[c] = sb;
+    g_gamma[c] = sg;
+  }
+  const float k = gamma[c] * invstd, invM = 1.0f / (float)total;
+  for (long long i = threadIdx.x; i < total; i += blockDim.x) {
+    const long long n = i / HW, p = i - n * HW;
+    const size_t a = ((size_t)n * C + c) * HW + p;
+    const float xh = (x[a] - m) * invstd;
+    gz[a] = k * (gz[a] - sb * invM - xh * sg * invM);
+  }
+}
+
+}  // namespace
+
+extern "C" int dm_bn_relu_maxpool_bwd(const float* x, int NB, int C, int H, int W, const float* mean, const float* var,
+                                      const float* gamma, const float* beta, float eps, const float* grad_out,
+                                      float* grad_x, float* grad_gamma, float* grad_beta, dm_stream_t stream) {
+  if (!x || !mean || !var || !gamma || !beta || !grad_out || !grad_x || !grad_gamma || !grad_beta) return DM_ERR_INVALID_ARG;
+  if (NB <= 0 || C <= 0 || H <= 0 || W <= 0) return DM_ERR_INVALID_ARG;
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  const size_t total = (size_t)NB * C * OH * OW;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(grad_x, 0, (size_t)NB * C * H * W * sizeof(float), st) != hipSuccess) return DM_ERR_LAUNCH;
+  const int blocks = (int)min((size_t)dm_ceil_div((long long)total, 256), (size_t)16384);
+  DM_LAUNCH(maxpool_relu_bwd_kernel, dim3(blocks), dim3(256), 0, st, x, NB, C, H, W, mean, var, gamma, beta, eps, grad_out,
+            grad_x, OH, OW);
+  int rc = dm_check_launch();
+  if (rc != DM_OK) return rc;
+  DM_LAUNCH(bn_bwd_kernel, dim3(C), dim3(1024), 0, st, x, grad_x, NB, C, H * W, mean, var, gamma, eps, grad_gamma,
+            grad_beta);
+  return dm_check_launch();
+}

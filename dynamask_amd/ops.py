@@ -446,3 +446,15 @@ def deform_conv_backward(x, offset, weight, grad_out, deform_groups):
     gw_cm = conv2d_wgrad(grad_out, col, 1)                                     # [co][(tap,ci)]
     gw = dcn_weight_permute(gw_cm, cout, C, False)
     return gx, goff, gw
+
+
+def bn_relu_maxpool_backward(x, mean, var, gamma, beta, grad_out, eps=1e-5):
+    for t, n in ((x, 'x'), (mean, 'mean'), (var, 'var'), (gamma, 'gamma'), (beta, 'beta'), (grad_out, 'grad_out')):
+        _chk(t, n)
+    NB, C, H, W = x.shape
+    gx = torch.empty_like(x)
+    gg = torch.empty((C,), device=x.device, dtype=torch.float32)
+    gb = torch.empty((C,), device=x.device, dtype=torch.float32)
+    check(lib().dm_bn_relu_maxpool_bwd(_p(x), NB, C, H, W, _p(mean), _p(var), _p(gamma), _p(beta), eps, _p(grad_out),
+                                       _p(gx), _p(gg), _p(gb), _stream()), 'dm_bn_relu_maxpool_bwd')
+    return gx, gg, gb

@@ -50,12 +50,10 @@ class _Linear(nn.Module):
         lin = nn.Linear(cin, cout)
         self.weight = nn.Parameter(lin.weight.detach().clone())
         self.bias = nn.Parameter(lin.bias.detach().clone())
-        self._pk = None
+        from .mask_heads import _Packed
+        self._pk = _Packed()
 
     def run(self, x, relu=False):
-        from .mask_heads import _Packed
-        if self._pk is None:
-            self._pk = _Packed()
         wp = self._pk.get('w', self.weight, lambda w: ops.pack_conv_weight(w.view(self.out_features, self.in_features, 1, 1)))
         n = x.shape[0]
         y = ops.conv2d(x.reshape(n, self.in_features, 1, 1), wp, self.bias.detach(), self.out_features, 1, relu=relu)
@@ -151,10 +149,20 @@ class DynaMaskRoIHead(nn.Module):
 
     def get_mask_label(self, ins_semantic_feats, noise=None, return_index=False):
         """dynamask_roi_head.py:84-87,97-114: logits -> ST-Gumbel-softmax (hard)."""
-        logits = self.mask_predictor(ins_semantic_feats)
+        train = torch.is_grad_enabled() and self.mask_predictor.training
+        if train:
+            from . import train_path
+            logits = train_path.MaskPreFn.apply(self.mask_predictor, ins_semantic_feats.detach(),
+                                                *list(self.mask_predictor.parameters()))
+        else:
+            logits = self.mask_predictor(ins_semantic_feats)
         if noise is None:
             noise = self.sample_uniform(logits.shape, logits.device)
-        y, hot, idx = ops.gumbel_select(logits, noise.contiguous(), 0.5)
+        if train:
+            hot, idx = train_path.GumbelSelectFn.apply(logits, noise, 0.5)
+            y = None
+        else:
+            y, hot, idx = ops.gumbel_select(logits, noise.contiguous(), 0.5)
         return (hot, idx, logits, y) if return_index else hot
 
     def _mask_forward_train(self, x, pos_rois, pos_labels, stage_mask_targets, noise=None):

@@ -229,3 +229,82 @@ def roi_extract_train(extractor, feats, rois):
     feats = list(feats)[:extractor.num_inputs]
     scales = [l.spatial_scale for l in extractor.roi_layers]
     return RoIExtractFn.apply(rois, lay.output_size[0], scales, lay.sampling_ratio, float(extractor.finest_scale), *feats)
+
+
+class MaskPreFn(torch.autograd.Function):
+    """MaskPre (base_roi_head.py:10-27) in train mode: forward + backward.
+    Inputs: (mask_pre_module, x, *mask_pre.parameters()); x is the detached 56x56
+    RoI feature (dynamask_roi_head.py:59), so no data gradient leaves the block."""
+
+    @staticmethod
+    def forward(ctx, mp, x, *params):
+        x = x.contiguous()
+        y1 = mp.conv1.run(x)
+        m1, v1 = ops.bn_stats(y1, mp.bn1.running_mean, mp.bn1.running_var, mp.bn1.momentum)
+        p1 = ops.bn_relu_maxpool(y1, m1, v1, mp.bn1.weight.detach(), mp.bn1.bias.detach(), mp.bn1.eps)
+        y2 = mp.conv2.run(p1)
+        m2, v2 = ops.bn_stats(y2, mp.bn2.running_mean, mp.bn2.running_var, mp.bn2.momentum)
+        p2 = ops.bn_relu_maxpool(y2, m2, v2, mp.bn2.weight.detach(), mp.bn2.bias.detach(), mp.bn2.eps)
+        mp.bn1.num_batches_tracked += 1
+        mp.bn2.num_batches_tracked += 1
+        flat = p2.reshape(p2.size(0), 3136)
+        h = mp.fc1.run(flat, relu=True)
+        logits = mp.fc2.run(h)
+        ctx.mp = mp
+        ctx.sv = (x, y1, m1, v1, p1, y2, m2, v2, p2, h)
+        return logits
+
+    @staticmethod
+    def backward(ctx, g):
+        mp = ctx.mp
+        x, y1, m1, v1, p1, y2, m2, v2, p2, h = ctx.sv
+        n = x.shape[0]
+        pg = {}
+
+        def fc_bwd(fc, gy, xin, need_data=True):
+            gy4 = gy.contiguous().view(n, fc.out_features, 1, 1)
+            x4 = xin.contiguous().view(n, fc.in_features, 1, 1)
+            pg[fc.weight] = ops.conv2d_wgrad(gy4, x4, 1).view(fc.out_features, fc.in_features)
+            pg[fc.bias] = ops.channel_sum(gy4)
+            if not need_data:
+                return None
+            wq = fc._pk.get('flip', fc.weight, lambda t: ops.pack_conv_weight(
+                t.view(fc.out_features, fc.in_features, 1, 1), transpose_flip=True))
+            return ops.conv2d(gy4, wq, None, fc.in_features, 1).view(n, fc.in_features)
+
+        def conv_bwd(conv, gy, xin, need_data=True):
+            pg[conv.weight] = ops.conv2d_wgrad(gy, xin, conv.kernel_size)
+            pg[conv.bias] = ops.channel_sum(gy)
+            if not need_data:
+                return None
+            wq = conv._pk.get(('flip', 0, conv.in_channels), conv.weight,
+                              lambda t: ops.pack_conv_weight(t, transpose_flip=True))
+            return ops.conv2d(gy, wq, None, conv.in_channels, conv.kernel_size)
+
+        g_h = fc_bwd(mp.fc2, g, h)
+        ops.relu_backward_(g_h, h)
+        g_p2 = fc_bwd(mp.fc1, g_h, p2.reshape(n, 3136)).view_as(p2).contiguous()
+        g_y2, gg2, gb2 = ops.bn_relu_maxpool_backward(y2, m2, v2, mp.bn2.weight.detach(), mp.bn2.bias.detach(), g_p2, mp.bn2.eps)
+        pg[mp.bn2.weight], pg[mp.bn2.bias] = gg2, gb2
+        g_p1 = conv_bwd(mp.conv2, g_y2, p1)
+        g_y1, gg1, gb1 = ops.bn_relu_maxpool_backward(y1, m1, v1, mp.bn1.weight.detach(), mp.bn1.bias.detach(), g_p1, mp.bn1.eps)
+        pg[mp.bn1.weight], pg[mp.bn1.bias] = gg1, gb1
+        conv_bwd(mp.conv1, g_y1, x, need_data=False)
+        return (None, None, *[pg.get(p) for p in mp.parameters()])
+
+
+class GumbelSelectFn(torch.autograd.Function):
+    """Straight-through Gumbel-softmax (hard), dynamask_roi_head.py:97-114."""
+
+    @staticmethod
+    def forward(ctx, logits, noise, temperature):
+        y, hot, idx = ops.gumbel_select(logits.contiguous(), noise.contiguous(), temperature)
+        ctx.save_for_backward(y)
+        ctx.t = temperature
+        ctx.mark_non_differentiable(idx)
+        return hot, idx
+
+    @staticmethod
+    def backward(ctx, g_hot, _g_idx):
+        (y,) = ctx.saved_tensors
+        return ops.gumbel_select_backward(y, g_hot.contiguous(), ctx.t), None, None

@@ -226,6 +226,12 @@ int dm_bn_stats(const float* x, int NB, int C, int HW, float* mean, float* var, 
 int dm_bn_relu_maxpool_fwd(const float* x, int NB, int C, int H, int W, const float* mean, const float* var,
                            const float* gamma, const float* beta, float eps, float* out, dm_stream_t stream);
 
+/* backward of dm_bn_relu_maxpool_fwd with train-mode statistics (mean/var as
+ * returned by dm_bn_stats): grad_x [NB,C,H,W] (overwritten), grad_gamma/grad_beta [C]. */
+int dm_bn_relu_maxpool_bwd(const float* x, int NB, int C, int H, int W, const float* mean, const float* var,
+                           const float* gamma, const float* beta, float eps, const float* grad_out, float* grad_x,
+                           float* grad_gamma, float* grad_beta, dm_stream_t stream);
+
 /* K10 backward: gradient of the soft branch of the straight-through estimator
  * (y_hard = (one_hot - y).detach() + y, dynamask_roi_head.py:112-113). */
 int dm_gumbel_select_bwd(const float* y_soft, const float* grad_y, int N, int K, float temperature,

@@ -188,3 +188,42 @@ def test_training_slice_grads_match_reference_golden(golden_dir):
     for i in range(4):
         assert feats[i].grad is not None, i
         _close(gi.feat_grad_slice(feats[i].grad), g[f'grad_feat{i}'], atol=3e-5, rtol=2e-3)
+
+
+def test_mask_pre_and_selector_backward_match_reference_golden(golden_dir):
+    g2 = np.load(os.path.join(golden_dir, 'g2_maskpre.npz'))
+    g3 = np.load(os.path.join(golden_dir, 'g3_gumbel.npz'))
+    from dynamask_amd import train_path
+    m = _roi_head(train=True)
+    mp = m.mask_predictor
+    x = _dev(gi.mask_pre_input())
+    logits = train_path.MaskPreFn.apply(mp, x, *list(mp.parameters()))
+    _close(logits, g2['logits_train'])
+    logits.square().sum().backward()
+    _close(mp.fc2.weight.grad, g2['grad_fc2_w'], atol=1e-4, rtol=1e-3)
+    _close(mp.conv1.bias.grad, g2['grad_conv1_b'], atol=1e-4, rtol=1e-3)
+    _close(mp.bn1.weight.grad, g2['grad_bn1_w'], atol=1e-4, rtol=1e-3)
+    _close(mp.conv2.weight.grad, g2['grad_conv2_w'], atol=1e-4, rtol=1e-3)
+    # straight-through selector gradient
+    lg = _dev(gi.gumbel_logits()).requires_grad_(True)
+    torch.manual_seed(gi.GUMBEL_SEED)
+    U = torch.rand(lg.shape)
+    hot, idx = train_path.GumbelSelectFn.apply(lg, _dev(U), 0.5)
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), g3['index'])
+    (hot * torch.arange(1, 5, dtype=torch.float32, device='cuda')).sum().backward()
+    _close(lg.grad, g3['grad_logits'], atol=1e-5, rtol=1e-3)
+
+
+def test_full_training_step_runs_and_updates_every_parameter():
+    hi = gi.head_inputs()
+    n = hi['rois'].shape[0]
+    m = _roi_head(train=True)
+    feats = [_dev(f).requires_grad_(True) for f in hi['feats']]
+    U = torch.rand(n, 4, generator=torch.Generator().manual_seed(9))
+    res = m._mask_forward_train(feats, _dev(hi['rois']), _dev(hi['labels']), [_dev(t) for t in gi.head_targets(n)],
+                                noise=_dev(U))
+    res['loss_mask']['loss_masks'].backward()
+    missing = [k for k, p in m.named_parameters() if p.grad is None and 'fuse_kernel' not in k]
+    assert not missing, missing
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+    assert feats[0].grad is not None and feats[4].grad is None       # P6 is never read by the path
