@@ -122,6 +122,54 @@ def cpu_baseline(sd, feats, rois, labels, sample):
     return dt, n_threads, out
 
 
+def train_step_bench(head, dev, rank, world, steps=5, warmup=2):
+    """BASELINE configs[2]/[3]: training step of the mask path, 2 images/GPU x 128
+    positive RoIs, dynamic 14/28/56/112 selection + BCE backward + RCCL all-reduce of
+    the flat mask-head gradient + fused SGD.  Returns ms per step (max over ranks)."""
+    from dynamask_amd import synth
+    from dynamask_amd.dist import FlatParamGroup, mask_path_parameters
+    B, per = 2, 128
+    feats = [f.to(dev) for f in synth.make_fpn(B, IMG_H, IMG_W, 256, seed=10 + 1000 * rank)]
+    rois = synth.make_rois(B, per, IMG_H, IMG_W, seed=11 + 1000 * rank).to(dev)
+    labels = synth.make_labels(B * per, seed=12 + 1000 * rank).to(dev)
+    targets = [t.to(dev) for t in synth.make_targets(B * per, seed=13 + 1000 * rank)]
+    noise = synth.make_gumbel_noise(B * per, seed=14 + 1000 * rank).to(dev)
+    head.train()
+    grp = FlatParamGroup(mask_path_parameters(head))
+
+    def step():
+        grp.zero_grad()
+        res = head._mask_forward_train(feats, rois, labels, targets, noise=noise)
+        res['loss_mask']['loss_masks'].backward()
+        grp.all_reduce_async()
+        grp.sgd_step(lr=0.02, momentum=0.9, weight_decay=1e-4)
+        return res
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    head.eval()
+    return dt / steps * 1e3, float(res['loss_mask']['loss_masks'].detach()), grp.numel, B
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -217,7 +265,8 @@ def main():
                 pass
         # ---- other exits, for context (not the headline) ----
         extra = {}
-        extra['full_head_112_ms'] = time_kernel(lambda: head._mask_forward(feats, rois, labels), iters=5, warmup=1)
+        with torch.no_grad():
+            extra['full_head_112_ms'] = time_kernel(lambda: head._mask_forward(feats, rois, labels), iters=5, warmup=1)
         result['extra'] = extra
         # ---- CPU baseline: the oracle on this box's host cores ----
         if args.cpu_sample > 0:
@@ -229,6 +278,18 @@ def main():
                                       'sample': f'first {args.cpu_sample} of the 512 RoIs of the same image through the same '
                                                 f'28x28 exit (PyTorch-CPU oracle, {cores} threads), {dt_cpu:.2f} s per pass; '
                                                 f'scaled to 512 RoIs/img', 'max_abs_err_vs_gpu': err}
+
+    # training step (configs[2]/[3]) on every rank, last (it updates the weights):
+    # reported in `extra`, not the headline
+    train_ms, train_loss, n_flat, train_b = train_step_bench(head, dev, rank, world)
+
+    if rank == 0:
+        extra = result['extra']
+        extra['train_step'] = {'ms_per_step': train_ms, 'img_per_s': world * train_b / (train_ms * 1e-3),
+                               'imgs_per_gpu': train_b, 'pos_rois_per_img': 128, 'loss': train_loss,
+                               'allreduce_floats': n_flat,
+                               'what': 'fwd + loss + bwd (head, MaskPre, RoIAlign) + RCCL all-reduce of the flat '
+                                       'mask-path gradient + fused SGD; BASELINE configs[2] (N=1) / configs[3] (N=8)'}
         print(json.dumps(result), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -46,14 +46,15 @@ __global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restric
   }
 }
 
-// per-channel sum over batch and pixels (bias gradient); one workgroup per channel
+// per-channel sum over batch and pixels (bias gradient): grid = (C, splits), one
+// atomic per workgroup into out (zero-filled by the launcher unless accumulating)
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ g, long long bs, int NB, int C, int HW,
-                                                          float* __restrict__ out, int accumulate) {
+                                                          float* __restrict__ out) {
   __shared__ float red[4];
   const int c = blockIdx.x;
   float s = 0.f;
   const long long total = (long long)NB * HW;
-  for (long long i = threadIdx.x; i < total; i += blockDim.x) {
+  for (long long i = (long long)blockIdx.y * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.y * blockDim.x) {
     const long long n = i / HW;
     const long long p = i - n * HW;
     s += g[n * bs + (long long)c * HW + p];
@@ -61,10 +62,7 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
   s = wsum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const float t = red[0] + red[1] + red[2] + red[3];
-    out[c] = accumulate ? out[c] + t : t;
-  }
+  if (threadIdx.x == 0) atomicAdd(out + c, red[0] + red[1] + red[2] + red[3]);
 }
 
 // ----------------------------------------------------------------- conv weight gradient
@@ -365,12 +363,11 @@ __global__ __launch_bounds__(256) void deform_im2col_kernel(const float* __restr
   }
 }
 
-// colgrad[n][(tap*C + ci)][p] -> gx (atomics, deformable col2im) and goffset
-// (coordinate gradient, summed over the channels of the deformable group by the
-// owning thread: no atomics).  Thread = (n, group, tap, pixel).
-__global__ __launch_bounds__(256) void dcn_col2im_coord_kernel(const float* __restrict__ colgrad, const float* __restrict__ x,
-                                                               const float* __restrict__ offset, int NB, int C, int H, int W,
-                                                               int dg, float* __restrict__ gx, float* __restrict__ goffset) {
+// colgrad[n][(tap*C + ci)][p] -> goffset (coordinate gradient, summed over the channels
+// of the deformable group by the owning thread: no atomics).  Thread = (n, group, tap, pixel).
+__global__ __launch_bounds__(256) void dcn_coord_grad_kernel(const float* __restrict__ colgrad, const float* __restrict__ x,
+                                                             const float* __restrict__ offset, int NB, int C, int H, int W,
+                                                             int dg, float* __restrict__ goffset) {
   const int HW = H * W;
   const int pblocks = (HW + 255) / 256;
   int bid = blockIdx.x;
@@ -400,18 +397,59 @@ __global__ __launch_bounds__(256) void dcn_col2im_coord_kernel(const float* __re
   for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
     const float cg = colgrad[((size_t)n * 9 * C + (size_t)tap * C + c) * HW + p];
     const float* xc = x + ((size_t)n * C + c) * HW;
-    float* gc = gx + ((size_t)n * C + c) * HW;
     const float x1 = v1 ? xc[o1] : 0.f, x2 = v2 ? xc[o2] : 0.f, x3 = v3 ? xc[o3] : 0.f, x4 = v4 ? xc[o4] : 0.f;
     // d val / d h_im and d val / d w_im  (get_coordinate_weight, :145-188)
     acc_h += cg * (-hw * x1 - lw * x2 + hw * x3 + lw * x4);
     acc_w += cg * (-hh * x1 + hh * x2 - lh * x3 + lh * x4);
-    if (v1) atomicAdd(gc + o1, cg * hh * hw);
-    if (v2) atomicAdd(gc + o2, cg * hh * lw);
-    if (v3) atomicAdd(gc + o3, cg * lh * hw);
-    if (v4) atomicAdd(gc + o4, cg * lh * lw);
   }
   goff[(size_t)(2 * tap) * HW] = acc_h;
   goff[(size_t)(2 * tap + 1) * HW] = acc_w;
+}
+
+// Deformable col2im (data gradient).  Every contribution to gx[n, c] comes from the
+// colgrad rows (tap, c) of the same image, so a workgroup owns (n, CT channels),
+// accumulates the 9 x HW x 4 scatter-adds in an LDS copy of the planes (ds_add_f32)
+// and writes each plane once: no global atomics (the reference's col2im kernel,
+// deform_conv_cuda_kernel.cu:279-335, uses atomicAdd to HBM).
+template <int CT>
+__global__ __launch_bounds__(256) void dcn_col2im_lds_kernel(const float* __restrict__ colgrad,
+                                                             const float* __restrict__ offset, int NB, int C, int H, int W,
+                                                             int dg, float* __restrict__ gx) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [CT][HW]
+  const int HW = H * W;
+  const int chunks = C / CT;
+  const int n = blockIdx.x / chunks;
+  const int c0 = (blockIdx.x - n * chunks) * CT;
+  const int g = c0 / (C / dg);
+  for (int i = threadIdx.x; i < CT * HW; i += blockDim.x) lds[i] = 0.f;
+  __syncthreads();
+  const float* offb = offset + ((size_t)n * dg + g) * 18 * HW;
+  for (int it = threadIdx.x; it < 9 * HW; it += blockDim.x) {
+    const int tap = it / HW;
+    const int p = it - tap * HW;
+    const int y = p / W, xx = p - y * W;
+    const DcnSample s = dcn_sample(offb + p, tap, HW, y, xx, H, W);
+    if (!s.valid) continue;
+    const int h_low = s.h_low, w_low = s.w_low, h_high = h_low + 1, w_high = w_low + 1;
+    const float lh = s.h_im - (float)h_low, lw = s.w_im - (float)w_low, hh = 1.f - lh, hw = 1.f - lw;
+    const bool v1 = h_low >= 0 && w_low >= 0, v2 = h_low >= 0 && w_high <= W - 1;
+    const bool v3 = h_high <= H - 1 && w_low >= 0, v4 = h_high <= H - 1 && w_high <= W - 1;
+    const int o1 = h_low * W + w_low, o2 = h_low * W + w_high, o3 = h_high * W + w_low, o4 = h_high * W + w_high;
+    const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+    const float* cgp = colgrad + ((size_t)n * 9 * C + (size_t)tap * C + c0) * HW + p;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      const float cg = cgp[(size_t)c * HW];
+      float* pl = lds + c * HW;
+      if (v1) atomicAdd(pl + o1, cg * w1);
+      if (v2) atomicAdd(pl + o2, cg * w2);
+      if (v3) atomicAdd(pl + o3, cg * w3);
+      if (v4) atomicAdd(pl + o4, cg * w4);
+    }
+  }
+  __syncthreads();
+  float* dst = gx + ((size_t)n * C + c0) * HW;
+  for (int i = threadIdx.x; i < CT * HW; i += blockDim.x) dst[i] = lds[i];
 }
 
 // W[co][ci][tap]  <->  Wt[(tap*C + ci)][co]  (the two DCN GEMMs run as 1x1 convs over
@@ -458,7 +496,12 @@ extern "C" int dm_sigmoid_bwd(const float* sig, long long sig_bs, const float* g
 extern "C" int dm_channel_sum(const float* g, long long batch_stride, int NB, int C, int HW, float* out, int accumulate,
                               dm_stream_t stream) {
   if (!g || !out || NB <= 0 || C <= 0 || HW <= 0) return DM_ERR_INVALID_ARG;
-  DM_LAUNCH(channel_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, g, batch_stride, NB, C, HW, out, accumulate);
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate && hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st) != hipSuccess) return DM_ERR_LAUNCH;
+  const long long total = (long long)NB * HW;
+  int splits = (int)min((long long)max(1, 2048 / C), (total + 1023) / 1024);
+  splits = max(splits, 1);
+  DM_LAUNCH(channel_sum_kernel, dim3(C, splits), dim3(256), 0, st, g, batch_stride, NB, C, HW, out);
   return dm_check_launch();
 }
 
@@ -535,9 +578,27 @@ extern "C" int dm_deform_col2im_coord(const float* colgrad, const float* x, cons
       C % deform_groups)
     return DM_ERR_INVALID_ARG;
   if (NB == 0) return DM_OK;
-  const int pblocks = dm_ceil_div(H * W, 256);
-  DM_LAUNCH(dcn_col2im_coord_kernel, dim3((unsigned)(NB * deform_groups * 9 * pblocks)), dim3(256), 0, (hipStream_t)stream,
-            colgrad, x, offset, NB, C, H, W, deform_groups, grad_x, grad_offset);
+  hipStream_t st = (hipStream_t)stream;
+  const int HW = H * W;
+  const int pblocks = dm_ceil_div(HW, 256);
+  DM_LAUNCH(dcn_coord_grad_kernel, dim3((unsigned)(NB * deform_groups * 9 * pblocks)), dim3(256), 0, st, colgrad, x, offset,
+            NB, C, H, W, deform_groups, grad_offset);
+  int rc = dm_check_launch();
+  if (rc != DM_OK) return rc;
+  // channels per workgroup: LDS planes of CT x HW floats, CT | C/deform_groups
+  const int cpg = C / deform_groups;
+  if (cpg % 8 == 0 && (size_t)8 * HW * sizeof(float) <= 48 * 1024) {
+    DM_LAUNCH(dcn_col2im_lds_kernel<8>, dim3((unsigned)(NB * (C / 8))), dim3(256), (size_t)8 * HW * sizeof(float), st, colgrad,
+              offset, NB, C, H, W, deform_groups, grad_x);
+  } else if (cpg % 2 == 0 && (size_t)2 * HW * sizeof(float) <= 48 * 1024) {
+    DM_LAUNCH(dcn_col2im_lds_kernel<2>, dim3((unsigned)(NB * (C / 2))), dim3(256), (size_t)2 * HW * sizeof(float), st, colgrad,
+              offset, NB, C, H, W, deform_groups, grad_x);
+  } else if ((size_t)HW * sizeof(float) <= 48 * 1024) {
+    DM_LAUNCH(dcn_col2im_lds_kernel<1>, dim3((unsigned)(NB * C)), dim3(256), (size_t)HW * sizeof(float), st, colgrad, offset,
+              NB, C, H, W, deform_groups, grad_x);
+  } else {
+    return DM_ERR_UNSUPPORTED;
+  }
   return dm_check_launch();
 }
 

@@ -6,7 +6,15 @@
 // (they do not depend on the channel), keeps them in registers, then walks the
 // channel chunk: per channel only 4*g*g loads + FMAs, no address arithmetic.
 // Consecutive lanes own consecutive pw, so the NCHW output is written in
-// 4*P-byte coalesced rows and the loads of a wave fall in a few feature rows.
+// 4*P-byte coalesced rows.
+//
+// Forward fast path: the RoI's footprint (the feature rows/columns its samples
+// touch) is first staged into LDS with coalesced row reads -- every feature
+// element is fetched from L2/HBM exactly once per workgroup -- and the 4*g*g
+// taps per output are then LDS reads (32 lanes/clk) instead of scattered global
+// loads (the v1 kernel was load-issue bound at 9 % of the HBM roofline).
+// Footprints that do not fit the LDS budget (56x56 extraction of large RoIs) and
+// the backward keep the direct global path.
 #include "common.h"
 
 namespace {
@@ -24,6 +32,7 @@ struct RoiArgs {
   const float* gout;   // bwd: grad of output
   int32_t* levels;
   int CT;              // channels per workgroup
+  int lds_floats;      // forward: LDS budget of the footprint tile (0 = direct global path)
 };
 
 // One sample coordinate along an axis -> (low index, high index, w_low, w_high).
@@ -70,10 +79,18 @@ __device__ __forceinline__ int roi_level(float x1, float y1, float x2, float y2,
   return lvl;
 }
 
+// Source window: the samples are read from a [FH][pitch] tile whose origin is
+// feature pixel (fy0, fx0) -- the whole map for the global path (fy0 = fx0 = 0,
+// FH = Hl, pitch = Wl), the staged footprint for the LDS path.  `csrc0` = channel
+// held at f + 0 (0 for the global map, the first staged channel for LDS).
+struct SrcWin {
+  int fy0, fx0, FH, FW, pitch, plane, csrc0;
+};
+
 template <int G, bool BWD>
 __device__ __forceinline__ void roi_bin_fast(const RoiArgs& a, const float* __restrict__ f, float* __restrict__ gf,
                                              int Hl, int Wl, float sh, float sw, float bh, float bw, int gh, int gw,
-                                             float inv_count, int ph, int pw, int k, int c0, int c1) {
+                                             float inv_count, int ph, int pw, int k, int c0, int c1, const SrcWin win) {
   int ylo[G], yhi[G], xlo[G], xhi[G];
   float wyl[G], wyh[G], wxl[G], wxh[G];
 #pragma unroll
@@ -82,17 +99,22 @@ __device__ __forceinline__ void roi_bin_fast(const RoiArgs& a, const float* __re
     wyl[i] = wyh[i] = wxl[i] = wxh[i] = 0.f;
     if (i < gh) {
       axis_sample(sh, bh, gh, ph, i, Hl, ylo[i], yhi[i], wyl[i], wyh[i]);
-      ylo[i] *= Wl;
-      yhi[i] *= Wl;
+      // void samples carry weight 0; the clamp only keeps their (unused) address in the tile
+      ylo[i] = min(max(ylo[i] - win.fy0, 0), win.FH - 1) * win.pitch;
+      yhi[i] = min(max(yhi[i] - win.fy0, 0), win.FH - 1) * win.pitch;
     }
-    if (i < gw) axis_sample(sw, bw, gw, pw, i, Wl, xlo[i], xhi[i], wxl[i], wxh[i]);
+    if (i < gw) {
+      axis_sample(sw, bw, gw, pw, i, Wl, xlo[i], xhi[i], wxl[i], wxh[i]);
+      xlo[i] = min(max(xlo[i] - win.fx0, 0), win.FW - 1);
+      xhi[i] = min(max(xhi[i] - win.fx0, 0), win.FW - 1);
+    }
   }
-  const size_t plane = (size_t)Hl * Wl;
+  const size_t plane = (size_t)win.plane;
   const int P = a.P;
   for (int c = c0; c < c1; ++c) {
     const size_t oidx = (((size_t)k * a.C + c) * P + ph) * P + pw;
     if (!BWD) {
-      const float* fc = f + (size_t)c * plane;
+      const float* fc = f + (size_t)(c - win.csrc0) * plane;
       float acc = 0.f;
 #pragma unroll
       for (int iy = 0; iy < G; ++iy) {
@@ -111,7 +133,7 @@ __device__ __forceinline__ void roi_bin_fast(const RoiArgs& a, const float* __re
       }
       a.out[oidx] = acc * inv_count;
     } else {
-      float* gc = gf + (size_t)c * plane;
+      float* gc = gf + (size_t)(c - win.csrc0) * plane;
       const float g = a.gout[oidx] * inv_count;
 #pragma unroll
       for (int iy = 0; iy < G; ++iy) {
@@ -168,7 +190,10 @@ __device__ __forceinline__ void roi_bin_generic(const RoiArgs& a, const float* _
   }
 }
 
-template <bool BWD>
+// GCLS (forward): 0 = every RoI; 1 = only RoIs with sampling grid <= 2x2 (lean
+// registers -> high occupancy, which the latency-bound footprint staging needs);
+// 2 = only the remaining RoIs.  The two forward launches partition the RoIs.
+template <bool BWD, int GCLS>
 __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
   const int chunks = (a.C + a.CT - 1) / a.CT;
   const int k = blockIdx.x / chunks;
@@ -195,19 +220,109 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
   const size_t img_off = bad_batch ? 0 : (size_t)b * a.C * Hl * Wl;
   const float* f = BWD ? nullptr : a.feat[lvl] + img_off;
   float* gf = BWD ? a.gfeat[lvl] + img_off : nullptr;
+  const bool empty = gh <= 0 || gw <= 0 || bad_batch;
+  const bool small_grid = empty || (gh <= 2 && gw <= 2);
+  if (GCLS == 1 && !small_grid) return;
+  if (GCLS == 2 && small_grid) return;
+  const SrcWin gwin = {0, 0, Hl, Wl, Wl, Hl * Wl, 0};
+
+  // ---- forward fast path: footprint staged in LDS ---------------------------
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  bool use_lds = false;
+  SrcWin lwin = gwin;
+  int csub = 0;
+  if (!BWD && !empty && gh <= 4 && gw <= 4 && a.lds_floats > 0) {
+    // first / last sample coordinate per axis (same expression as axis_sample)
+    const float yf = sh + 0.5f * bh / (float)gh;
+    const float yl = sh + (float)(P - 1) * bh + ((float)(gh - 1) + 0.5f) * bh / (float)gh;
+    const float xf = sw + 0.5f * bw / (float)gw;
+    const float xl = sw + (float)(P - 1) * bw + ((float)(gw - 1) + 0.5f) * bw / (float)gw;
+    if (!(yl < -1.0f || yf > (float)Hl || xl < -1.0f || xf > (float)Wl)) {
+      const int fy0 = min((int)fmaxf(yf, 0.f), Hl - 1);
+      const int fy1 = min((int)fminf(fmaxf(yl, 0.f), (float)Hl) + 2, Hl - 1);   // +1 for the high tap, +1 margin
+      const int fx0 = min((int)fmaxf(xf, 0.f), Wl - 1);
+      const int fx1 = min((int)fminf(fmaxf(xl, 0.f), (float)Wl) + 2, Wl - 1);
+      const int FH = fy1 - fy0 + 1, FW = fx1 - fx0 + 1;
+      const int pitch = FW | 1;                      // odd pitch: rows start on different banks
+      if (FH * pitch <= a.lds_floats) {
+        use_lds = true;
+        csub = min(c1 - c0, a.lds_floats / (FH * pitch));
+        lwin = {fy0, fx0, FH, FW, pitch, FH * pitch, 0};
+      }
+    }
+  }
+
+  if (use_lds) {
+    for (int cb = c0; cb < c1; cb += csub) {
+      const int nc = min(csub, c1 - cb);
+      // stage the footprint of nc channels: flat index over (channel, row, 4-column group),
+      // 8 x 16-byte loads in flight per thread before the LDS stores (the staging is
+      // latency x concurrency bound; rows are only 4-byte aligned -> packed float4)
+      {
+        struct __attribute__((packed, aligned(4))) F4 { float v[4]; };
+        const int FWq = (lwin.FW + 3) >> 2;
+        const int total = nc * lwin.FH * FWq;
+        const float* fcb = f + (size_t)cb * Hl * Wl + (size_t)lwin.fy0 * Wl + lwin.fx0;
+        for (int base = threadIdx.x; base < total; base += 8 * 256) {
+          F4 v[8];
+          int dsti[8], cnt[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * 256;
+            dsti[u] = -1;
+            cnt[u] = 0;
+            if (idx < total) {
+              const int rowi = idx / FWq;
+              const int x = (idx - rowi * FWq) * 4;
+              const int c = rowi / lwin.FH;
+              const int r = rowi - c * lwin.FH;
+              const float* src = fcb + (size_t)c * Hl * Wl + (size_t)r * Wl + x;
+              dsti[u] = c * lwin.plane + r * lwin.pitch + x;
+              cnt[u] = min(4, lwin.FW - x);
+              if (cnt[u] == 4) {
+                v[u] = *reinterpret_cast<const F4*>(src);
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[u].v[e] = (e < cnt[u]) ? src[e] : 0.f;
+              }
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (e < cnt[u]) lds[dsti[u] + e] = v[u].v[e];
+          }
+        }
+      }
+      __syncthreads();
+      SrcWin w = lwin;
+      w.csrc0 = cb;
+      for (int pos = threadIdx.x; pos < P * P; pos += blockDim.x) {
+        const int ph = pos / P;
+        const int pw = pos - ph * P;
+        if (GCLS == 1 || (GCLS == 0 && gh <= 2 && gw <= 2))
+          roi_bin_fast<2, false>(a, lds, nullptr, Hl, Wl, sh, sw, bh, bw, gh, gw, inv_count, ph, pw, k, cb, cb + nc, w);
+        else
+          roi_bin_fast<4, false>(a, lds, nullptr, Hl, Wl, sh, sw, bh, bw, gh, gw, inv_count, ph, pw, k, cb, cb + nc, w);
+      }
+      __syncthreads();
+    }
+    return;
+  }
 
   for (int pos = threadIdx.x; pos < P * P; pos += blockDim.x) {
     const int ph = pos / P;
     const int pw = pos - ph * P;
-    if (gh <= 0 || gw <= 0 || bad_batch) {
+    if (empty) {
       // empty sampling grid (degenerate RoI): mmcv's loops do not run -> 0
       if (!BWD)
         for (int c = c0; c < c1; ++c) a.out[(((size_t)k * a.C + c) * P + ph) * P + pw] = 0.f;
-    } else if (gh <= 2 && gw <= 2) {
-      roi_bin_fast<2, BWD>(a, f, gf, Hl, Wl, sh, sw, bh, bw, gh, gw, inv_count, ph, pw, k, c0, c1);
-    } else if (gh <= 4 && gw <= 4) {
-      roi_bin_fast<4, BWD>(a, f, gf, Hl, Wl, sh, sw, bh, bw, gh, gw, inv_count, ph, pw, k, c0, c1);
-    } else {
+    } else if (GCLS != 2 && gh <= 2 && gw <= 2) {
+      roi_bin_fast<2, BWD>(a, f, gf, Hl, Wl, sh, sw, bh, bw, gh, gw, inv_count, ph, pw, k, c0, c1, gwin);
+    } else if (GCLS != 1 && gh <= 4 && gw <= 4) {
+      roi_bin_fast<4, BWD>(a, f, gf, Hl, Wl, sh, sw, bh, bw, gh, gw, inv_count, ph, pw, k, c0, c1, gwin);
+    } else if (GCLS != 1) {
       roi_bin_generic<BWD>(a, f, gf, Hl, Wl, sh, sw, bh, bw, gh, gw, inv_count, ph, pw, k, c0, c1);
     }
   }
@@ -230,6 +345,7 @@ int fill_args(RoiArgs& a, const int* H, const int* W, const float* spatial_scale
   }
   // channels per workgroup: enough workgroups to fill 256 CUs several times over
   a.CT = (P * P >= 1024) ? 4 : 16;
+  a.lds_floats = 0;
   a.out = nullptr; a.gout = nullptr; a.levels = nullptr;
   return DM_OK;
 }
@@ -251,8 +367,13 @@ extern "C" int dm_roi_align_fwd(const float* const* feats, const int* H, const i
   if (N == 0) return DM_OK;
   a.out = out;
   a.levels = levels_out;
+  a.CT = (P * P >= 1024) ? 8 : 32;
+  a.lds_floats = 12 * 1024;                 // 48 KB footprint tile -> 3 workgroups per CU
   const int chunks = dm_ceil_div(C, a.CT);
-  DM_LAUNCH(roi_align_kernel<false>, dim3(N * chunks), dim3(256), 0, (hipStream_t)stream, a);
+  DM_LAUNCH((roi_align_kernel<false, 1>), dim3(N * chunks), dim3(256), a.lds_floats * sizeof(float), (hipStream_t)stream, a);
+  int rc1 = dm_check_launch();
+  if (rc1 != DM_OK) return rc1;
+  DM_LAUNCH((roi_align_kernel<false, 2>), dim3(N * chunks), dim3(256), a.lds_floats * sizeof(float), (hipStream_t)stream, a);
   return dm_check_launch();
 }
 
@@ -271,6 +392,6 @@ extern "C" int dm_roi_align_bwd(const float* grad_out, float* const* grad_feats,
   if (N == 0) return DM_OK;
   a.gout = grad_out;
   const int chunks = dm_ceil_div(C, a.CT);
-  DM_LAUNCH(roi_align_kernel<true>, dim3(N * chunks), dim3(256), 0, (hipStream_t)stream, a);
+  DM_LAUNCH((roi_align_kernel<true, 0>), dim3(N * chunks), dim3(256), 0, (hipStream_t)stream, a);
   return dm_check_launch();
 }

@@ -29,7 +29,7 @@ class _Packed:
         self._c = {}
 
     def get(self, key, param, fn):
-        ver = (param.data_ptr(), param._version, param.device)
+        ver = (param.data_ptr(), param._version, param.device, ops.WEIGHT_EPOCH[0])
         e = self._c.get(key)
         if e is None or e[0] != ver:
             with torch.no_grad():

@@ -11,6 +11,11 @@ import torch
 from ._lib import check, lib
 
 
+# bumped whenever a kernel rewrites parameter memory behind torch's back (the fused
+# SGD step), so that packed-weight caches refresh
+WEIGHT_EPOCH = [0]
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -458,3 +463,12 @@ def bn_relu_maxpool_backward(x, mean, var, gamma, beta, grad_out, eps=1e-5):
     check(lib().dm_bn_relu_maxpool_bwd(_p(x), NB, C, H, W, _p(mean), _p(var), _p(gamma), _p(beta), eps, _p(grad_out),
                                        _p(gx), _p(gg), _p(gb), _stream()), 'dm_bn_relu_maxpool_bwd')
     return gx, gg, gb
+
+
+def sgd_momentum_step_(params_flat, grads_flat, momentum_flat, lr, momentum=0.9, weight_decay=1e-4, grad_scale=1.0,
+                       first_step=False):
+    for t, n in ((params_flat, 'params'), (grads_flat, 'grads'), (momentum_flat, 'momentum')):
+        _chk(t, n)
+    check(lib().dm_sgd_momentum_step(_p(params_flat), _p(grads_flat), _p(momentum_flat), params_flat.numel(), lr, momentum,
+                                     weight_decay, grad_scale, 1 if first_step else 0, _stream()), 'dm_sgd_momentum_step')
+    WEIGHT_EPOCH[0] += 1

@@ -290,13 +290,20 @@ int dm_class_logits_bwd(const float* x, int N, int C, int HW, const float* w_ins
 
 /* DCNv1 backward pieces.  col / colgrad: [NB, 9*C, H, W] with rows tap-major
  * (row = tap*C + ci).  dm_dcn_weight_permute converts W[co][ci][tap] <->
- * Wt[(tap*C+ci)][co] so that both GEMMs run as 1x1 convs over the column matrix. */
+ * Wt[(tap*C+ci)][co] so that both GEMMs run as 1x1 convs over the column matrix.
+ * dm_deform_col2im_coord overwrites grad_x and grad_offset (no zero-fill needed):
+ * the scatter-adds of one (image, channel) plane are accumulated in LDS. */
 int dm_deform_im2col(const float* x, const float* offset, int NB, int C, int H, int W, int deform_groups,
                      float* col, dm_stream_t stream);
 int dm_deform_col2im_coord(const float* colgrad, const float* x, const float* offset, int NB, int C, int H, int W,
                            int deform_groups, float* grad_x, float* grad_offset, dm_stream_t stream);
 int dm_dcn_weight_permute(const float* src, float* dst, int Cout, int C, int to_colmajor, int accumulate,
                           dm_stream_t stream);
+
+/* SGD(momentum, weight decay) step on a flat fp32 buffer; grad_scale folds the
+ * 1/world_size of the gradient all-reduce (apis/train.py:75-79 DDP averaging). */
+int dm_sgd_momentum_step(float* params, const float* grads, float* momentum_buf, long long count, float lr,
+                         float momentum, float weight_decay, float grad_scale, int first_step, dm_stream_t stream);
 
 #ifdef __cplusplus
 }
