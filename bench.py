@@ -175,17 +175,25 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of a HIP graph replay')
     ap.add_argument('--cpu-sample', type=int, default=32, help='RoIs of the batch timed on the host cores (0 = skip)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # rehearsal on a 1-GPU box: DM_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo
+    rehearsal = os.environ.get('DM_BENCH_REHEARSAL', '0') == '1'
+    if rehearsal:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if rehearsal:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
 
@@ -205,6 +213,29 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    torch.cuda.synchronize()
+    # The step is ~25 dependent launches; replay it as one HIP graph (no tracing
+    # compiler involved: the graph holds exactly the C-ABI launches of step()).
+    graph = None
+    if not args.no_graph:
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                graph_out = step()
+            g.replay()
+            torch.cuda.synchronize()
+            ref_out = step()
+            if not torch.equal(graph_out['stage_instance_preds'][1], ref_out['stage_instance_preds'][1]):
+                raise RuntimeError('graph replay differs from eager')
+            graph = g
+            eager_step = step
+
+            def step():          # noqa: F811
+                graph.replay()
+                return graph_out
+        except Exception as e:      # capture not available: stay eager (recorded in the JSON)
+            print(f'[bench] HIP graph capture failed, timing eager launches: {e}', file=sys.stderr)
+            graph = None
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -230,7 +261,8 @@ def main():
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[1]: DynaMask R-50-FPN mask head inference, 1333x800 FPN shapes, '
                                '512 RoIs/img, fixed 28x28 exit (RoIAlign14 + 2 conv3x3 + SFM stage 0 + stage-1 logits)',
-                   'rois_per_img': ROIS_PER_IMG, 'imgs_per_gpu': 1, 'parallelism': f'images sharded x{world}, no collective'},
+                   'rois_per_img': ROIS_PER_IMG, 'imgs_per_gpu': 1, 'parallelism': f'images sharded x{world}, no collective',
+                   'launch': 'hip graph replay' if graph is not None else 'eager'},
     }
 
     if rank == 0:
