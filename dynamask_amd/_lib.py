@@ -45,6 +45,9 @@ SIGNATURES = {
     'dm_dcn_weight_permute': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp], _c_int),
     'dm_bn_relu_maxpool_bwd': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_float, _vp, _vp, _vp, _vp, _vp], _c_int),
     'dm_sgd_momentum_step': ([_vp, _vp, _vp, ctypes.c_longlong, _c_float, _c_float, _c_float, _c_float, _c_int, _vp], _c_int),
+    'dm_mask_target_rois': ([_vp, _vp, _c_int, _c_float, _c_float, _vp, _vp], _c_int),
+    'dm_threshold_ge': ([_vp, ctypes.c_longlong, _c_float, _vp, _vp], _c_int),
+    'dm_paste_masks': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _vp, _vp], _c_int),
     'dm_detail_target': ([_vp, _c_int, _c_int, _c_float, _c_float, _vp, _vp], _c_int),
     'dm_mask_loss_fwd_bwd': ([_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp], _c_int),
 }

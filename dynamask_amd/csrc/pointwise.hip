@@ -456,3 +456,95 @@ extern "C" int dm_gumbel_select_bwd(const float* y_soft, const float* grad_y, in
                      temperature, grad_logits);
   return dm_check_launch();
 }
+
+// ---------------------------------------------------------------------------
+// Callers either side of the path.
+namespace {
+
+// rois[n] = (gt_index, clip(x1,0,maxw), clip(y1,0,maxh), clip(x2,0,maxw), clip(y2,0,maxh))
+// (DynaMaskHead.get_targets, dynamask_head.py:248-261, + BitmapMasks.crop_and_resize
+// rois assembly, core/mask/structures.py:270-276)
+__global__ void mask_target_rois_kernel(const float* __restrict__ boxes, const int64_t* __restrict__ inds, int N, float maxw,
+                                        float maxh, float* __restrict__ rois) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  rois[n * 5 + 0] = (float)inds[n];
+  rois[n * 5 + 1] = fminf(fmaxf(boxes[n * 4 + 0], 0.f), maxw);
+  rois[n * 5 + 2] = fminf(fmaxf(boxes[n * 4 + 1], 0.f), maxh);
+  rois[n * 5 + 3] = fminf(fmaxf(boxes[n * 4 + 2], 0.f), maxw);
+  rois[n * 5 + 4] = fminf(fmaxf(boxes[n * 4 + 3], 0.f), maxh);
+}
+
+__global__ __launch_bounds__(256) void threshold_kernel(const float* __restrict__ x, size_t n, float thr, float* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = x[i] >= thr ? 1.f : 0.f;
+}
+
+// K18 paste: grid_sample(bilinear, zeros, align_corners=False) of each mask at the
+// image pixel centres mapped into its box, thresholded.  grid = (row blocks, N).
+// (_do_paste_mask, fcn_mask_head.py:240-308 with skip_empty=False, + the >= thr of
+// get_seg_masks, dynamask_head.py:333-334)
+__global__ __launch_bounds__(256) void paste_masks_kernel(const float* __restrict__ masks, const float* __restrict__ boxes,
+                                                          int N, int mh, int mw, int img_h, int img_w, float thr,
+                                                          int apply_sigmoid, uint8_t* __restrict__ out) {
+  const int n = blockIdx.y;
+  const float x0 = boxes[n * 4 + 0], y0 = boxes[n * 4 + 1], x1 = boxes[n * 4 + 2], y1 = boxes[n * 4 + 3];
+  const float* m = masks + (size_t)n * mh * mw;
+  uint8_t* o = out + (size_t)n * img_h * img_w;
+  const size_t total = (size_t)img_h * img_w;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int py = (int)(i / img_w), px = (int)(i - (size_t)py * img_w);
+    float gx = ((float)px + 0.5f - x0) / (x1 - x0) * 2.f - 1.f;
+    float gy = ((float)py + 0.5f - y0) / (y1 - y0) * 2.f - 1.f;
+    if (isinf(gx)) gx = 0.f;      // degenerate boxes (reference zeroes inf coordinates, :283-288)
+    if (isinf(gy)) gy = 0.f;
+    const float sx = ((gx + 1.f) * (float)mw - 1.f) / 2.f;
+    const float sy = ((gy + 1.f) * (float)mh - 1.f) / 2.f;
+    float v = 0.f;
+    if (sx > -1.f && sx < (float)mw && sy > -1.f && sy < (float)mh) {
+      const float fx = floorf(sx), fy = floorf(sy);
+      const int ix = (int)fx, iy = (int)fy;
+      const float lx = sx - fx, ly = sy - fy;
+      auto at = [&](int yy, int xx) -> float {
+        if (yy < 0 || yy >= mh || xx < 0 || xx >= mw) return 0.f;
+        const float t = m[yy * mw + xx];
+        return apply_sigmoid ? 1.f / (1.f + expf(-t)) : t;
+      };
+      v = at(iy, ix) * (1.f - lx) * (1.f - ly) + at(iy, ix + 1) * lx * (1.f - ly) + at(iy + 1, ix) * (1.f - lx) * ly +
+          at(iy + 1, ix + 1) * lx * ly;
+    }
+    o[i] = v >= thr ? 1 : 0;
+  }
+}
+
+}  // namespace
+
+extern "C" int dm_mask_target_rois(const float* boxes, const int64_t* gt_inds, int N, float max_w, float max_h, float* rois,
+                                   dm_stream_t stream) {
+  if (N < 0) return DM_ERR_INVALID_ARG;
+  if (N == 0) return DM_OK;
+  if (!boxes || !gt_inds || !rois) return DM_ERR_INVALID_ARG;
+  DM_LAUNCH(mask_target_rois_kernel, dim3(dm_ceil_div(N, 64)), dim3(64), 0, (hipStream_t)stream, boxes, gt_inds, N, max_w,
+            max_h, rois);
+  return dm_check_launch();
+}
+
+extern "C" int dm_threshold_ge(const float* x, long long count, float thr, float* out, dm_stream_t stream) {
+  if (count < 0) return DM_ERR_INVALID_ARG;
+  if (count == 0) return DM_OK;
+  if (!x || !out) return DM_ERR_INVALID_ARG;
+  const int blocks = (int)min((long long)dm_ceil_div(count, 256), 16384LL);
+  DM_LAUNCH(threshold_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (size_t)count, thr, out);
+  return dm_check_launch();
+}
+
+extern "C" int dm_paste_masks(const float* masks, const float* boxes, int N, int mask_h, int mask_w, int img_h, int img_w,
+                              float threshold, int apply_sigmoid, uint8_t* out, dm_stream_t stream) {
+  if (N < 0 || mask_h <= 0 || mask_w <= 0 || img_h <= 0 || img_w <= 0) return DM_ERR_INVALID_ARG;
+  if (N == 0) return DM_OK;
+  if (!masks || !boxes || !out) return DM_ERR_INVALID_ARG;
+  const int bx = min(dm_ceil_div((long long)img_h * img_w, 256 * 4), 1024);
+  DM_LAUNCH(paste_masks_kernel, dim3(bx, N), dim3(256), 0, (hipStream_t)stream, masks, boxes, N, mask_h, mask_w, img_h, img_w,
+            threshold, apply_sigmoid, out);
+  return dm_check_launch();
+}

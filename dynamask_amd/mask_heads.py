@@ -241,6 +241,48 @@ class DynaMaskHead(nn.Module):
         return stage_instance_preds, stage_detail_preds
 
 
+    # ------------------------------------------------ callers either side of the path
+    def get_targets(self, pos_bboxes_list, pos_assigned_gt_inds_list, gt_masks_list):
+        """dynamask_head.py:246-271 with the GT bitmaps already on the device
+        ([G, H, W] tensors per image): clip + RoIAlign(scale 1, adaptive grid) on the
+        bitmaps + (>= 0.5), for every supervision size -- no device->host->device trip
+        (the reference goes through numpy per image and size)."""
+        per_stage = [[] for _ in self.stage_sup_size]
+        for boxes, inds, masks in zip(pos_bboxes_list, pos_assigned_gt_inds_list, gt_masks_list):
+            if hasattr(masks, 'masks'):           # a BitmapMasks-like holder of a numpy array
+                masks = torch.from_numpy(masks.masks).to(boxes.device)
+            m = masks.to(torch.float32).contiguous()[:, None]
+            maxh, maxw = m.shape[-2:]
+            rois = ops.mask_target_rois(boxes[:, :4].contiguous().float(), inds.long().contiguous(), maxw, maxh)
+            for i, size in enumerate(self.stage_sup_size):
+                t = ops.roi_align([m], rois, size, [1.0], 0)
+                per_stage[i].append(ops.threshold_ge(t, 0.5).squeeze(1))
+        return [torch.cat(t) for t in per_stage]
+
+    def get_seg_masks(self, mask_pred, det_bboxes, det_labels, rcnn_test_cfg, ori_shape, scale_factor, rescale):
+        """dynamask_head.py:279-342: sigmoid -> paste into the image -> threshold ->
+        list of (h, w) bool numpy arrays (one paste kernel for all detections)."""
+        import numpy as np
+        bboxes = det_bboxes[:, :4]
+        if rescale:
+            img_h, img_w = ori_shape[:2]
+        else:
+            img_h = int(np.round(ori_shape[0] * scale_factor).astype(np.int32))
+            img_w = int(np.round(ori_shape[1] * scale_factor).astype(np.int32))
+            scale_factor = 1.0
+        if not isinstance(scale_factor, (float, torch.Tensor)):
+            scale_factor = bboxes.new_tensor(scale_factor)
+        bboxes = (bboxes / scale_factor).contiguous()
+        threshold = rcnn_test_cfg.mask_thr_binary
+        if threshold < 0:
+            raise NotImplementedError('visualisation mode (mask_thr_binary < 0) is not on the path')
+        if mask_pred.shape[1] > 1:
+            mask_pred = mask_pred[range(len(mask_pred)), det_labels][:, None]
+        im_mask = ops.paste_masks(mask_pred.contiguous(), bboxes, img_h, img_w, threshold, apply_sigmoid=True)
+        im = im_mask.cpu().numpy()
+        return [im[i] for i in range(len(im))]
+
+
 # ---------------------------------------------------------------- FCN mask head
 @UPSAMPLE_LAYERS.register_module(name='deconv')
 class _Deconv(nn.Module):

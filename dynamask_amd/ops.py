@@ -472,3 +472,33 @@ def sgd_momentum_step_(params_flat, grads_flat, momentum_flat, lr, momentum=0.9,
     check(lib().dm_sgd_momentum_step(_p(params_flat), _p(grads_flat), _p(momentum_flat), params_flat.numel(), lr, momentum,
                                      weight_decay, grad_scale, 1 if first_step else 0, _stream()), 'dm_sgd_momentum_step')
     WEIGHT_EPOCH[0] += 1
+
+
+# ------------------------------------------------------- callers either side of the path
+def mask_target_rois(boxes, gt_inds, max_w, max_h):
+    _chk(boxes, 'boxes')
+    _chk(gt_inds, 'gt_inds', torch.int64)
+    N = boxes.shape[0]
+    rois = torch.empty((N, 5), device=boxes.device, dtype=torch.float32)
+    check(lib().dm_mask_target_rois(_p(boxes), _p(gt_inds), N, float(max_w), float(max_h), _p(rois), _stream()),
+          'dm_mask_target_rois')
+    return rois
+
+
+def threshold_ge(x, thr):
+    _chk(x, 'x')
+    out = torch.empty_like(x)
+    check(lib().dm_threshold_ge(_p(x), x.numel(), float(thr), _p(out), _stream()), 'dm_threshold_ge')
+    return out
+
+
+def paste_masks(masks, boxes, img_h, img_w, threshold=0.5, apply_sigmoid=False):
+    """masks [N, 1, h, w] or [N, h, w], boxes [N, 4] -> bool [N, img_h, img_w]."""
+    _chk(masks, 'masks')
+    _chk(boxes, 'boxes')
+    N = masks.shape[0]
+    mh, mw = masks.shape[-2:]
+    out = torch.empty((N, img_h, img_w), device=masks.device, dtype=torch.uint8)
+    check(lib().dm_paste_masks(_p(masks), _p(boxes), N, mh, mw, int(img_h), int(img_w), float(threshold),
+                               1 if apply_sigmoid else 0, _p(out), _stream()), 'dm_paste_masks')
+    return out.view(torch.bool) if N > 0 else out.bool()

@@ -194,3 +194,20 @@ class DynaMaskRoIHead(nn.Module):
         # the reference chunks by 100 RoIs "to avoid memory overflow" (:132); 288 GB of HBM do not need it
         res = self._mask_forward(x, mask_rois, det_labels)
         return self.merge_stage_preds(res['stage_instance_preds'])
+
+    def simple_test_mask(self, x, img_metas, det_bboxes, det_labels, rescale=False):
+        """dynamask_roi_head.py:117-158 -> per-class lists of (h, w) bool masks."""
+        ori_shape = img_metas[0]['ori_shape']
+        scale_factor = img_metas[0]['scale_factor']
+        num_classes = self.mask_head.stage_num_classes[0]
+        segm_result = [[] for _ in range(num_classes)]
+        if det_bboxes.shape[0] == 0:
+            return segm_result
+        if rescale and not isinstance(scale_factor, float):
+            scale_factor = torch.from_numpy(scale_factor).to(det_bboxes.device)
+        _bboxes = det_bboxes[:, :4] * scale_factor if rescale else det_bboxes
+        merged = self.simple_test_mask_logits(x, _bboxes, det_labels)
+        segs = self.mask_head.get_seg_masks(merged, _bboxes, det_labels, self.test_cfg, ori_shape, scale_factor, rescale)
+        for c, segm in zip(det_labels.tolist(), segs):
+            segm_result[c].append(segm)
+        return segm_result

@@ -247,6 +247,27 @@ int dm_class_balance_fwd_bwd(const float* mask_labels, int N, int K, float* loss
                              dm_stream_t stream);
 
 /* ===========================================================================
+ * Callers either side of the path ("next" rows 1 and 2).
+ * =========================================================================== */
+
+/* Mask-target RoIs: (gt_index, box clipped to the mask canvas).
+ * replaces: the numpy clip of DynaMaskHead.get_targets (mask_heads/dynamask_head.py:248-256)
+ * and the rois assembly of BitmapMasks.crop_and_resize (core/mask/structures.py:270-276);
+ * the crop itself is dm_roi_align_fwd on the GT bitmaps (scale 1, adaptive grid),
+ * then dm_threshold_ge(0.5) (structures.py:281-284). */
+int dm_mask_target_rois(const float* boxes, const int64_t* gt_inds, int N, float max_w, float max_h, float* rois,
+                        dm_stream_t stream);
+int dm_threshold_ge(const float* x, long long count, float thr, float* out, dm_stream_t stream);
+
+/* K18  paste N masks [N, mask_h, mask_w] into their boxes on an [img_h, img_w] canvas
+ * and binarise: out[n, y, x] = (grid_sample(mask_n) >= threshold) as uint8.
+ * replaces: _do_paste_mask (mask_heads/fcn_mask_head.py:240-308, skip_empty=False) +
+ * the threshold of get_seg_masks (mask_heads/dynamask_head.py:325-339).
+ * apply_sigmoid != 0 takes logits (mask_pred.sigmoid() of dynamask_head.py:281). */
+int dm_paste_masks(const float* masks, const float* boxes, int N, int mask_h, int mask_w, int img_h, int img_w,
+                   float threshold, int apply_sigmoid, uint8_t* out, dm_stream_t stream);
+
+/* ===========================================================================
  * Backward (training step).  Replaces what autograd derives for the reference
  * modules above plus mmcv's DeformConv2d backward
  * (mmdet/ops/dcn/src/deform_conv_cuda.cpp:262-486, deform_conv_cuda_kernel.cu:117-188,279-436).

@@ -242,3 +242,83 @@ def mask_forward_train(sd, fpn_feats, rois, roi_labels, stage_targets, U, **kw):
     fk = sd.get('mask_head.loss_func.detail_target.fuse_kernel')
     loss = dyna_loss(ips, dps, stage_targets, mask_labels, fuse_kernel=fk)
     return loss, mask_labels, ind, logits
+
+
+# ---------------------------------------------------- callers either side of the path
+def crop_and_resize(gt_masks, bboxes, out_size, inds):
+    """BitmapMasks.crop_and_resize -- core/mask/structures.py:256-286.
+    gt_masks [G,H,W] {0,1}; bboxes [n,4]; inds [n] -> float {0,1} [n,S,S]."""
+    n = bboxes.shape[0]
+    if n == 0:
+        return torch.zeros((0, out_size, out_size))
+    rois = torch.cat([torch.arange(n, dtype=torch.float32)[:, None], bboxes.float()], dim=1)
+    sel = gt_masks.float().index_select(0, inds.long())
+    t = ref_ops.roi_align(sel[:, None], rois, out_size, 1.0, 0, True).squeeze(1)
+    return (t >= 0.5).float()
+
+
+def get_targets(pos_bboxes_list, pos_assigned_gt_inds_list, gt_masks_list, stage_sup_size=STAGE_SUP_SIZE):
+    """DynaMaskHead.get_targets -- mask_heads/dynamask_head.py:246-271."""
+    per_stage = [[] for _ in stage_sup_size]
+    for boxes, inds, masks in zip(pos_bboxes_list, pos_assigned_gt_inds_list, gt_masks_list):
+        maxh, maxw = masks.shape[-2:]
+        b = boxes.clone().float()
+        b[:, [0, 2]] = b[:, [0, 2]].clamp(0, maxw)
+        b[:, [1, 3]] = b[:, [1, 3]].clamp(0, maxh)
+        for i, s in enumerate(stage_sup_size):
+            per_stage[i].append(crop_and_resize(masks, b, s, inds))
+    return [torch.cat(t) for t in per_stage]
+
+
+def paste_masks(masks, boxes, img_h, img_w, skip_empty=False):
+    """_do_paste_mask -- mask_heads/fcn_mask_head.py:240-308.  skip_empty=True (what
+    get_seg_masks uses on CPU, one mask per chunk) only samples the tight region around
+    the boxes; skip_empty=False (the reference's GPU path) samples the whole canvas.
+    The two differ only for degenerate boxes (inf coordinates zeroed, :283-288).
+    Returns (pasted, (y_slice, x_slice))."""
+    N = masks.shape[0]
+    if skip_empty:
+        x0_int, y0_int = torch.clamp(boxes.min(dim=0).values.floor()[:2] - 1, min=0).to(dtype=torch.int32)
+        x1_int = torch.clamp(boxes[:, 2].max().ceil() + 1, max=img_w).to(dtype=torch.int32)
+        y1_int = torch.clamp(boxes[:, 3].max().ceil() + 1, max=img_h).to(dtype=torch.int32)
+        x0_int, y0_int, x1_int, y1_int = int(x0_int), int(y0_int), int(x1_int), int(y1_int)
+    else:
+        x0_int, y0_int, x1_int, y1_int = 0, 0, img_w, img_h
+    x0, y0, x1, y1 = torch.split(boxes, 1, dim=1)
+    img_y = torch.arange(y0_int, y1_int, dtype=torch.float32) + 0.5
+    img_x = torch.arange(x0_int, x1_int, dtype=torch.float32) + 0.5
+    img_y = (img_y - y0) / (y1 - y0) * 2 - 1
+    img_x = (img_x - x0) / (x1 - x0) * 2 - 1
+    img_x = torch.where(torch.isinf(img_x), torch.zeros_like(img_x), img_x)
+    img_y = torch.where(torch.isinf(img_y), torch.zeros_like(img_y), img_y)
+    gx = img_x[:, None, :].expand(N, img_y.size(1), img_x.size(1))
+    gy = img_y[:, :, None].expand(N, img_y.size(1), img_x.size(1))
+    grid = torch.stack([gx, gy], dim=3)
+    out = F.grid_sample(masks.float(), grid, align_corners=False)[:, 0]
+    return out, (slice(y0_int, y1_int), slice(x0_int, x1_int))
+
+
+def get_seg_masks(mask_logits, det_bboxes, ori_shape, scale_factor, rescale, thr=0.5, device_type='cuda'):
+    """DynaMaskHead.get_seg_masks -- mask_heads/dynamask_head.py:279-342 -> bool [N,h,w].
+    device_type='cpu' reproduces the reference's CPU chunking (one mask per chunk,
+    skip_empty=True, :301-305); 'cuda' its GPU path (whole canvas)."""
+    import numpy as np
+    mask_pred = mask_logits.sigmoid()
+    bboxes = det_bboxes[:, :4]
+    if rescale:
+        img_h, img_w = ori_shape[:2]
+    else:
+        img_h = int(np.round(ori_shape[0] * scale_factor).astype(np.int32))
+        img_w = int(np.round(ori_shape[1] * scale_factor).astype(np.int32))
+        scale_factor = 1.0
+    bboxes = bboxes / scale_factor
+    N = len(mask_pred)
+    im_mask = torch.zeros(N, img_h, img_w, dtype=torch.bool)
+    if device_type == 'cpu':
+        for i in range(N):
+            chunk, (ys, xs) = paste_masks(mask_pred[i:i + 1], bboxes[i:i + 1], img_h, img_w, skip_empty=True)
+            im_mask[i:i + 1, ys, xs] = chunk >= thr
+    else:
+        chunk, _ = paste_masks(mask_pred, bboxes, img_h, img_w, skip_empty=False)
+        im_mask[:] = chunk >= thr
+    return im_mask

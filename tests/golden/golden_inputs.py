@@ -132,3 +132,36 @@ def grad_slice(g):
 def feat_grad_slice(g):
     """...and channels 0, 100 and 255 of the FPN-map grads."""
     return g[:, [0, 100, 255]]
+
+
+def paste_inputs():
+    g = _g(112)
+    n = 5
+    t = synth.make_targets(n, sizes=(28, 112), seed=113)[1]
+    logits = ((t * 2 - 1) * 3.0 + torch.randn(t.shape, generator=g)).unsqueeze(1)      # [5,1,112,112]
+    boxes = torch.tensor([[10.2, 20.4, 90.7, 140.1], [0.0, 0.0, 299.0, 199.0], [150.5, 30.0, 290.0, 60.5],
+                          [-20.0, 100.0, 60.0, 230.0], [120.0, 80.0, 120.0, 160.0]])            # last: zero width
+    det = torch.cat([boxes, torch.full((n, 1), 0.9)], 1)
+    return dict(logits=logits, det_bboxes=det, ori_shape=(200, 300, 3))
+
+
+def target_inputs():
+    """Two images: GT bitmaps [G,H,W] (uint8), positive boxes, assigned GT indices."""
+    g = _g(114)
+    out = []
+    for (G, n) in ((3, 6), (2, 5)):
+        H, W = 96, 128
+        m = torch.zeros(G, H, W, dtype=torch.uint8)
+        for k in range(G):
+            y0, x0 = int(torch.randint(0, 40, (1,), generator=g)), int(torch.randint(0, 60, (1,), generator=g))
+            h, w = int(torch.randint(20, 50, (1,), generator=g)), int(torch.randint(20, 60, (1,), generator=g))
+            m[k, y0:y0 + h, x0:x0 + w] = 1
+            m[k, y0 + h // 3:y0 + h // 2, x0:x0 + w // 3] = 0         # a notch, so masks are not plain boxes
+        cx = torch.rand(n, generator=g) * W
+        cy = torch.rand(n, generator=g) * H
+        bw = torch.rand(n, generator=g) * 70 + 6
+        bh = torch.rand(n, generator=g) * 60 + 6
+        boxes = torch.stack([cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2], 1)      # some stick out: clipped by get_targets
+        inds = torch.randint(0, G, (n,), generator=g)
+        out.append(dict(masks=m, boxes=boxes, inds=inds))
+    return out

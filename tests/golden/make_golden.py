@@ -197,7 +197,12 @@ def install_standins():
     ops.DeformConv2dPack = DeformConv2dPack
     ops.Conv2d = nn.Conv2d
     ra = _pkg('mmcv.ops.roi_align')
-    ra.roi_align = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError('placeholder'))
+    ra.roi_align = lambda inp, rois, out_shape, scale=1.0, sr=0, mode='avg', aligned=True: ref_ops.roi_align(
+        inp, rois, out_shape if isinstance(out_shape, int) else out_shape[0], scale, sr, aligned)
+    pc = _pkg('pycocotools')
+    pcm = _pkg('pycocotools.mask')
+    pc.mask = pcm
+    mmcv.imresize = mmcv.imflip = mmcv.impad = mmcv.imrescale = mmcv.imrotate = mmcv.imshear = mmcv.imtranslate = None
     car = _pkg('mmcv.ops.carafe')
     car.CARAFEPack = CARAFEPack
     mmcv.ops = ops
@@ -392,6 +397,27 @@ def main():
         g7[f'grad_feat{i}'] = _np(gi.feat_grad_slice(fe[i].grad)) if fe[i].grad is not None else np.zeros(1, np.float32)
     np.savez_compressed(os.path.join(HERE, 'g7_head_train.npz'), **g7)
     print('g7 loss', float(ltrain))
+
+
+    # ------------------------------------------ G8 paste (pure-torch reference code)
+    pi = gi.paste_inputs()
+    g8 = {}
+    for rescale, sf in ((False, 1.0), (True, 1.0), (True, 1.25)):
+        cfgt = types.SimpleNamespace(mask_thr_binary=0.5)
+        segs = head.get_seg_masks(pi['logits'].clone(), pi['det_bboxes'].clone(), torch.zeros(5, dtype=torch.long), cfgt,
+                                  pi['ori_shape'], sf, rescale)
+        g8[f'seg_rescale{int(rescale)}_sf{sf}'] = np.stack(segs).astype(np.uint8)
+    np.savez_compressed(os.path.join(HERE, 'g8_paste.npz'), **g8)
+    print('g8', {k: int(v.sum()) for k, v in g8.items()})
+
+    # ---------------- G9 mask targets: reference BitmapMasks + DynaMaskHead.get_targets
+    stm = _load('mmdet.core.mask.structures', 'mmdet/core/mask/structures.py')
+    ti = gi.target_inputs()
+    gtm = [stm.BitmapMasks(t['masks'].numpy(), t['masks'].shape[1], t['masks'].shape[2]) for t in ti]
+    tg = head.get_targets([t['boxes'] for t in ti], [t['inds'] for t in ti], gtm)
+    g9 = {f't{i}': _np(t).astype(np.uint8) for i, t in enumerate(tg)}
+    np.savez_compressed(os.path.join(HERE, 'g9_targets.npz'), **g9)
+    print('g9', {k: (v.shape, int(v.sum())) for k, v in g9.items()})
 
 
 if __name__ == '__main__':

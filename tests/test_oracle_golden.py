@@ -112,3 +112,20 @@ def test_head_train_slice_matches_reference(golden_dir):
         _close(gi.grad_slice(sd['mask_head.' + k].grad), g['grad.' + k], atol=2e-6, rtol=1e-3)
     for i in range(4):
         _close(gi.feat_grad_slice(feats[i].grad), g[f'grad_feat{i}'], atol=2e-6, rtol=1e-3)
+
+
+def test_paste_and_targets_match_reference(golden_dir):
+    g8 = _load(golden_dir, 'g8_paste.npz')
+    pi = gi.paste_inputs()
+    for rescale, sf in ((False, 1.0), (True, 1.0), (True, 1.25)):
+        # the goldens ran on CPU: the reference then pastes one mask per chunk with skip_empty=True
+        out = ref_model.get_seg_masks(pi['logits'], pi['det_bboxes'], pi['ori_shape'], sf, rescale, device_type='cpu')
+        assert np.array_equal(out.numpy().astype(np.uint8), g8[f'seg_rescale{int(rescale)}_sf{sf}'])
+        # whole-canvas (GPU) path: identical except for the degenerate zero-width box (index 4)
+        out2 = ref_model.get_seg_masks(pi['logits'], pi['det_bboxes'], pi['ori_shape'], sf, rescale, device_type='cuda')
+        assert np.array_equal(out2.numpy()[:4], out.numpy()[:4])
+    g9 = _load(golden_dir, 'g9_targets.npz')
+    ti = gi.target_inputs()
+    tg = ref_model.get_targets([t['boxes'] for t in ti], [t['inds'] for t in ti], [t['masks'] for t in ti])
+    for i in range(4):
+        assert np.array_equal(tg[i].numpy().astype(np.uint8), g9[f't{i}'])
