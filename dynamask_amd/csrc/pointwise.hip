@@ -130,32 +130,48 @@ __global__ __launch_bounds__(256) void class_logits_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------ K11
+// One thread = 4 consecutive output pixels of a row (one 16-B store); 32-bit index
+// math; the two source rows are re-used across the 4 outputs.
 __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ in, int NC, int H, int W, int ac,
                                                          int relu, float* __restrict__ out) {
-  const int OH = 2 * H, OW = 2 * W;
-  const size_t total = (size_t)NC * OH * OW;
+  const int OH = 2 * H, OW = 2 * W;          // OW is a multiple of 2; vector path needs OW % 4 == 0
+  const int OWq = (OW + 3) >> 2;
+  const long long total = (long long)NC * OH * OWq;
   const float rh = ac ? (OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f) : 0.5f;
   const float rw = ac ? (OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f) : 0.5f;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int ox = (int)(idx % OW);
-    const int oy = (int)((idx / OW) % OH);
-    const size_t nc = idx / ((size_t)OW * OH);
-    float sy, sx;
-    if (ac) {
-      sy = rh * (float)oy;
-      sx = rw * (float)ox;
-    } else {
-      sy = fmaxf(rh * ((float)oy + 0.5f) - 0.5f, 0.f);
-      sx = fmaxf(rw * ((float)ox + 0.5f) - 0.5f, 0.f);
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int xq = (int)(idx % OWq);
+    const long long t = idx / OWq;
+    const int oy = (int)(t % OH);
+    const long long nc = t / OH;
+    const float sy = ac ? rh * (float)oy : fmaxf(rh * ((float)oy + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int)sy;
+    const int y1 = y0 + ((y0 < H - 1) ? 1 : 0);
+    const float ly = sy - (float)y0, hy = 1.f - ly;
+    const float* r0 = in + nc * H * W + (long long)y0 * W;
+    const float* r1 = in + nc * H * W + (long long)y1 * W;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ox = xq * 4 + e;
+      const float sx = ac ? rw * (float)ox : fmaxf(rw * ((float)ox + 0.5f) - 0.5f, 0.f);
+      int x0 = (int)sx;
+      x0 = min(x0, W - 1);
+      const int x1 = x0 + ((x0 < W - 1) ? 1 : 0);
+      const float lx = sx - (float)x0, hx = 1.f - lx;
+      float r = hy * (hx * r0[x0] + lx * r0[x1]) + ly * (hx * r1[x0] + lx * r1[x1]);
+      if (relu) r = fmaxf(r, 0.f);
+      v[e] = r;
     }
-    const int y0 = (int)sy, x0 = (int)sx;
-    const int y1 = y0 + ((y0 < H - 1) ? 1 : 0), x1 = x0 + ((x0 < W - 1) ? 1 : 0);
-    const float ly = sy - (float)y0, lx = sx - (float)x0;
-    const float hy = 1.f - ly, hx = 1.f - lx;
-    const float* p = in + nc * H * W;
-    float v = hy * (hx * p[y0 * W + x0] + lx * p[y0 * W + x1]) + ly * (hx * p[y1 * W + x0] + lx * p[y1 * W + x1]);
-    if (relu) v = fmaxf(v, 0.f);
-    out[idx] = v;
+    float* o = out + (nc * OH + oy) * (long long)OW + xq * 4;
+    if ((OW & 3) == 0) {
+      *reinterpret_cast<dm_f32x4*>(o) = dm_f32x4{v[0], v[1], v[2], v[3]};
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (xq * 4 + e < OW) o[e] = v[e];
+    }
   }
 }
 
@@ -345,8 +361,8 @@ extern "C" int dm_upsample2x_bilinear_fwd(const float* in, int NC, int H, int W,
                                           dm_stream_t stream) {
   if (!in || !out || NC < 0 || H <= 0 || W <= 0) return DM_ERR_INVALID_ARG;
   if (NC == 0) return DM_OK;
-  const size_t total = (size_t)NC * 4 * H * W;
-  const int blocks = (int)min((size_t)dm_ceil_div((long long)total, 256), (size_t)16384);
+  const size_t total = (size_t)NC * 2 * H * ((2 * W + 3) / 4);
+  const int blocks = (int)min((size_t)dm_ceil_div((long long)total, 256), (size_t)32768);
   DM_LAUNCH(upsample2x_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, NC, H, W, align_corners,
                      relu, out);
   return dm_check_launch();
