@@ -590,6 +590,9 @@ extern "C" int dm_deform_col2im_coord(const float* colgrad, const float* x, cons
   if (cpg % 8 == 0 && (size_t)8 * HW * sizeof(float) <= 48 * 1024) {
     DM_LAUNCH(dcn_col2im_lds_kernel<8>, dim3((unsigned)(NB * (C / 8))), dim3(256), (size_t)8 * HW * sizeof(float), st, colgrad,
               offset, NB, C, H, W, deform_groups, grad_x);
+  } else if (cpg % 4 == 0 && (size_t)4 * HW * sizeof(float) <= 64 * 1024) {
+    DM_LAUNCH(dcn_col2im_lds_kernel<4>, dim3((unsigned)(NB * (C / 4))), dim3(256), (size_t)4 * HW * sizeof(float), st, colgrad,
+              offset, NB, C, H, W, deform_groups, grad_x);
   } else if (cpg % 2 == 0 && (size_t)2 * HW * sizeof(float) <= 48 * 1024) {
     DM_LAUNCH(dcn_col2im_lds_kernel<2>, dim3((unsigned)(NB * (C / 2))), dim3(256), (size_t)2 * HW * sizeof(float), st, colgrad,
               offset, NB, C, H, W, deform_groups, grad_x);
