@@ -265,24 +265,36 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_igemm_kernel(ConvArgs a) {
     if (chunk_valid()) prefetch();
 
     // ---- MFMA over the committed chunk ---------------------------------------
+    // Operand fragments are double-buffered in registers: the ds_reads of step s+1 are
+    // issued before the 4 x WM x WN MFMAs of step s, so LDS latency never stalls the
+    // matrix pipe (the compiler alone re-uses one register set and issues them late).
+    {
+      constexpr int NG = NQ / 2;
+      constexpr int STEPS = TAPS * NG;
+      auto load_frag = [&](int st, dm_f32x4* av, dm_f32x4* bv) {
+        const int tap = st / NG, g = st - tap * NG;
+        const int tapoff = (KS == 3) ? ((tap / 3) * Wp + (tap % 3)) : 0;
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-      const int tapoff = (KS == 3) ? ((tap / 3) * Wp + (tap % 3)) : 0;
+        for (int i = 0; i < WM; ++i) av[i] = ldsA[(tap * NQ + 2 * g + hi) * TM + (wave_m * WM + i) * 32 + l31];
 #pragma unroll
-      for (int g = 0; g < NQ / 2; ++g) {
-        if (g < ngroups) {
-          dm_f32x4 av[WM], bv[WN];
+        for (int j = 0; j < WN; ++j) bv[j] = ldsB[(2 * g) * plane + lane_base[j] + tapoff];
+      };
+      dm_f32x4 av[2][WM], bv[2][WN];
+      load_frag(0, av[0], bv[0]);
 #pragma unroll
-          for (int i = 0; i < WM; ++i) av[i] = ldsA[(tap * NQ + 2 * g + hi) * TM + (wave_m * WM + i) * 32 + l31];
-#pragma unroll
-          for (int j = 0; j < WN; ++j) bv[j] = ldsB[(2 * g) * plane + lane_base[j] + tapoff];
+      for (int st = 0; st < STEPS; ++st) {
+        const int cur = st & 1;
+        // quad pairs beyond the chunk's live channels hold zeros (1x1, ragged sources): skip them
+        const bool live = (NG == 1) || ((st % NG) < ngroups);
+        if (st + 1 < STEPS) load_frag(st + 1, av[cur ^ 1], bv[cur ^ 1]);
+        if (live) {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
               for (int j = 0; j < WN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i][e], bv[cur][j][e], acc[i][j], 0, 0, 0);
         }
       }
     }

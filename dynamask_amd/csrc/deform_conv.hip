@@ -186,21 +186,27 @@ __global__ __launch_bounds__(WGM* WGN * 64) void deform_conv_kernel(DcnArgs a) {
       }
     }
   };
+  // operand fragments double-buffered in registers (see conv_igemm.hip)
+  auto load_frag = [&](int tap, dm_f32x4* av, dm_f32x4* bv) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i) av[i] = ldsA[(tap * 2 + hi) * TM + (wave_m * WM + i) * 32 + l31];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) bv[j] = ldsB[(hi * 9 + tap) * TN + (wave_n * WN + j) * 32 + l31];
+  };
   auto mfma_taps = [&](int t0, int t1) {
+    dm_f32x4 av[2][WM], bv[2][WN];
+    load_frag(t0, av[0], bv[0]);
 #pragma unroll
     for (int tap = t0; tap < t1; ++tap) {
-      dm_f32x4 av[WM], bv[WN];
-#pragma unroll
-      for (int i = 0; i < WM; ++i) av[i] = ldsA[(tap * 2 + hi) * TM + (wave_m * WM + i) * 32 + l31];
-#pragma unroll
-      for (int j = 0; j < WN; ++j) bv[j] = ldsB[(hi * 9 + tap) * TN + (wave_n * WN + j) * 32 + l31];
+      const int cur = (tap - t0) & 1;
+      if (tap + 1 < t1) load_frag(tap + 1, av[cur ^ 1], bv[cur ^ 1]);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
           for (int j = 0; j < WN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i][e], bv[cur][j][e], acc[i][j], 0, 0, 0);
     }
   };
 

@@ -129,11 +129,17 @@ class SFMStage(nn.Module):
                              deform_groups=2)])
         self.fuse_transform_out = _Conv(instance_in_channel, instance_out_channel - 2, 1)
 
-    def forward(self, instance_feats, semantic_feat, rois, roi_labels, upsample=True):
+    def semantic_map(self, semantic_feat):
+        """relu(semantic_transform_in(P_l)) on the whole FPN map (dynamask_head.py:104); it does
+        not depend on the RoIs, so RoI chunks running on different streams share it."""
+        return self.semantic_transform_in.run(semantic_feat, relu=True)
+
+    def forward(self, instance_feats, semantic_feat, rois, roi_labels, upsample=True, sem=None):
         n, c, s = instance_feats.shape[0], self.instance_in_channel, self.out_size
         co = self.instance_out_channel
         # instance-wise semantic feats: relu(conv1x1) on the whole FPN map, then point sample
-        sem = self.semantic_transform_in.run(semantic_feat, relu=True)
+        if sem is None:
+            sem = self.semantic_map(semantic_feat)
         ins_sem = ops.point_sample(sem, rois, s, self.spatial_scale)
         # [fused_feats(co-2) | sigmoid(ip) | sigmoid(dp)] is assembled in place
         tail = torch.empty((n, co, s, s), device=instance_feats.device, dtype=torch.float32)
@@ -201,11 +207,17 @@ class DynaMaskHead(nn.Module):
             nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
             nn.init.constant_(m.bias, 0)
 
-    def forward(self, instance_feats, semantic_feats, rois, roi_labels, last_stage=None):
+    def semantic_maps(self, semantic_feats, last_stage=None):
+        """Per-stage relu(semantic_transform_in(.)) maps (shared by all RoIs)."""
+        n = len(self.stages) if last_stage is None else min(last_stage, len(self.stages))
+        return [self.stages[i].semantic_map(semantic_feats[-i - 3]) for i in range(n)]
+
+    def forward(self, instance_feats, semantic_feats, rois, roi_labels, last_stage=None, sems=None):
         """Returns (stage_instance_preds, stage_detail_preds) as the reference.
 
         ``last_stage`` (extension, default None = all): stop after the logits of
-        that exit (1 = the fixed 28x28 exit of BASELINE configs[1])."""
+        that exit (1 = the fixed 28x28 exit of BASELINE configs[1]).
+        ``sems`` (extension): precomputed ``semantic_maps`` (multi-stream inference)."""
         for conv in self.instance_convs:
             instance_feats = conv(instance_feats)
         stage_instance_preds, stage_detail_preds = [], []
@@ -222,7 +234,8 @@ class DynaMaskHead(nn.Module):
                 stage_detail_preds.append(dp)
                 return stage_instance_preds, stage_detail_preds
             upsample_flag = self.pre_upsample_last_stage or idx < len(self.stages) - 1
-            ip, dp, instance_feats = stage(instance_feats, semantic_feats[-idx - 3], rois, roi_labels, upsample_flag)
+            ip, dp, instance_feats = stage(instance_feats, semantic_feats[-idx - 3], rois, roi_labels, upsample_flag,
+                                           sem=None if sems is None else sems[idx])
             stage_instance_preds.append(ip)
             stage_detail_preds.append(dp)
         if self.stage_num_classes[-1] == 1:

@@ -116,6 +116,9 @@ class DynaMaskRoIHead(nn.Module):
             type='SingleRoIExtractor', roi_layer=dict(type='RoIAlign', output_size=56, sampling_ratio=0),
             out_channels=256, featmap_strides=[4, ]))
         self.mask_predictor = MaskPre()
+        # inference: RoI chunks on separate HIP streams (see _mask_forward)
+        self.num_streams = 2
+        self.stream_split_min = 128
 
     @property
     def with_bbox(self):
@@ -139,9 +142,41 @@ class DynaMaskRoIHead(nn.Module):
             ins_feats = train_path.roi_extract_train(self.mask_roi_extractor, x, rois)
             ips, dps = train_path.mask_head_forward_train(self.mask_head, ins_feats, x, rois, roi_labels)
             return dict(stage_instance_preds=ips, stage_detail_preds=dps)
-        ins_feats = self.mask_roi_extractor(x[:self.mask_roi_extractor.num_inputs], rois)
-        ips, dps = self.mask_head(ins_feats, x, rois, roi_labels, last_stage=last_stage)
+        n = rois.shape[0]
+        n_streams = self.num_streams if n >= self.stream_split_min else 1
+        if n_streams <= 1:
+            ins_feats = self.mask_roi_extractor(x[:self.mask_roi_extractor.num_inputs], rois)
+            ips, dps = self.mask_head(ins_feats, x, rois, roi_labels, last_stage=last_stage)
+            return dict(stage_instance_preds=ips, stage_detail_preds=dps)
+        # RoIs are independent: split them over HIP streams so that the tail of every kernel
+        # (its last, partially filled round of workgroups over the 256 CUs) overlaps the other
+        # chunk's work.  The FPN-wide semantic maps are computed once and shared.
+        cur = torch.cuda.current_stream()
+        streams = self._side_streams(n_streams, rois.device)
+        sems = self.mask_head.semantic_maps(x, last_stage)
+        bounds = [round(i * n / n_streams) for i in range(n_streams + 1)]
+        parts = []
+        for st, lo, hi in zip(streams, bounds[:-1], bounds[1:]):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                r, l = rois[lo:hi], roi_labels[lo:hi]
+                ins = self.mask_roi_extractor(x[:self.mask_roi_extractor.num_inputs], r)
+                parts.append(self.mask_head(ins, x, r, l, last_stage=last_stage, sems=sems))
+        for st in streams:
+            cur.wait_stream(st)
+        n_out = len(parts[0][0])
+        ips = [torch.cat([p[0][i] for p in parts]) for i in range(n_out)]
+        dps = [torch.cat([p[1][i] for p in parts]) for i in range(n_out)]
+        for p in parts:
+            for t in p[0] + p[1]:
+                t.record_stream(cur)
         return dict(stage_instance_preds=ips, stage_detail_preds=dps)
+
+    def _side_streams(self, k, device):
+        if getattr(self, '_streams', None) is None or len(self._streams) < k or self._streams_dev != device:
+            self._streams = [torch.cuda.Stream(device=device) for _ in range(k)]
+            self._streams_dev = device
+        return self._streams[:k]
 
     def sample_uniform(self, shape, device):
         """The reference draws on the CPU generator and copies (dynamask_roi_head.py:90-91, Q9)."""
