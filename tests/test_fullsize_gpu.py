@@ -1,0 +1,100 @@
+"""Parity at BASELINE.json's full sizes (512 RoIs, 1333x800 FPN) through
+size-independent properties, plus edge cases (empty / single / ragged RoI sets)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import golden_inputs as gi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from dynamask_amd import ops as o
+    return o
+
+
+@pytest.fixture(scope='module')
+def full():
+    from dynamask_amd import synth
+    dev = torch.device('cuda')
+    feats = [f.to(dev) for f in synth.make_fpn(1, 800, 1333, 256, seed=0)]
+    rois = synth.make_rois(1, 512, 800, 1333, seed=1).to(dev)
+    labels = synth.make_labels(512, seed=2).to(dev)
+    return feats, rois, labels
+
+
+def _head():
+    from dynamask_amd import registry, roi_head, losses, mask_heads, roi_extractors, synth  # noqa: F401
+    cfg = dict(type='DynaMaskRoIHead',
+               mask_roi_extractor=dict(type='SingleRoIExtractor', **gi.MASK_ROI_EXTRACTOR_CFG),
+               mask_head=dict(type='DynaMaskHead', **gi.MASK_HEAD_CFG))
+    m = registry.build_head(cfg)
+    m.load_state_dict({**synth.init_dynamask_head_state(seed=5, test_mode=True), **synth.init_mask_pre_state(seed=6)})
+    return m.cuda().eval()
+
+
+def test_roialign_constant_and_level_partition_full_size(ops, full):
+    feats, rois, _ = full
+    const = [torch.full_like(f, 3.25) for f in feats[:4]]
+    out, lv = ops.roi_align(const, rois, 14, [1 / 4, 1 / 8, 1 / 16, 1 / 32], return_levels=True)
+    assert torch.allclose(out, torch.full_like(out, 3.25), atol=1e-5)        # average of a constant map
+    assert set(lv.cpu().tolist()) == {0, 1, 2, 3}
+    # linearity in the features
+    a = ops.roi_align(feats[:4], rois, 14, [1 / 4, 1 / 8, 1 / 16, 1 / 32])
+    b = ops.roi_align([2.0 * f for f in feats[:4]], rois, 14, [1 / 4, 1 / 8, 1 / 16, 1 / 32])
+    assert torch.allclose(b, 2.0 * a, atol=1e-5, rtol=1e-5)
+
+
+def test_zero_offset_dcn_equals_conv_kernel_full_size(ops):
+    g = torch.Generator(device='cuda').manual_seed(3)
+    x = torch.randn(512, 256, 14, 14, device='cuda', generator=g)
+    w = torch.randn(256, 256, 3, 3, device='cuda', generator=g) / 48
+    wq = ops.pack_conv_weight(w)
+    y_conv = ops.conv2d(x, wq, None, 256, 3)
+    y_dcn = ops.deform_conv(x, torch.zeros(512, 36, 14, 14, device='cuda'), wq, 256, 2)
+    # two different kernels, same fp32 fma order per output (K walked tap-major, channel quads)
+    assert torch.allclose(y_conv, y_dcn, atol=1e-5, rtol=1e-5)
+    # and both agree with MIOpen's conv on a slice (independent implementation)
+    ref = F.conv2d(x[:16], w, padding=1)
+    assert torch.allclose(y_conv[:16], ref, atol=1e-4, rtol=1e-4)
+
+
+def test_head_is_roi_permutation_equivariant_and_stream_invariant(full):
+    feats, rois, labels = full
+    m = _head()
+    with torch.no_grad():
+        m.num_streams = 1
+        one = m._mask_forward(feats, rois, labels)
+        m.num_streams = 2
+        two = m._mask_forward(feats, rois, labels)
+        perm = torch.randperm(512, device='cuda', generator=torch.Generator(device='cuda').manual_seed(4))
+        m.num_streams = 1
+        shuf = m._mask_forward(feats, rois[perm].contiguous(), labels[perm].contiguous())
+    for k in ('stage_instance_preds', 'stage_detail_preds'):
+        for i in range(4):
+            assert torch.equal(one[k][i], two[k][i])                          # chunking over streams changes nothing
+            assert torch.allclose(one[k][i][perm], shuf[k][i], atol=1e-5, rtol=1e-5)
+    assert one['stage_instance_preds'][3].shape == (512, 1, 112, 112)
+    assert all(torch.isfinite(t).all() for t in one['stage_instance_preds'])
+
+
+def test_edge_cases_empty_single_and_ragged_rois():
+    hi = gi.head_inputs()
+    m = _head()
+    feats = [f.cuda() for f in hi['feats']]
+    with torch.no_grad():
+        # no detections: the reference guards this in simple_test_mask (dynamask_roi_head.py:122-123)
+        res = m.simple_test_mask(feats, [dict(ori_shape=(256, 320, 3), scale_factor=1.0)],
+                                 torch.zeros(0, 5).cuda(), torch.zeros(0, dtype=torch.long).cuda())
+        assert len(res) == 80 and all(len(r) == 0 for r in res)
+        assert m.mask_roi_extractor(feats[:4], torch.zeros(0, 5).cuda()).shape == (0, 256, 14, 14)
+        # a single RoI, and RoIs that only live in the second image of the batch
+        r1 = m._mask_forward(feats, hi['rois'][:1].cuda(), hi['labels'][:1].cuda())
+        sel = hi['rois'][:, 0] == 1
+        r2 = m._mask_forward(feats, hi['rois'][sel].cuda().contiguous(), hi['labels'][sel].cuda().contiguous())
+        full_ = m._mask_forward(feats, hi['rois'].cuda(), hi['labels'].cuda())
+    assert torch.allclose(r1['stage_instance_preds'][3], full_['stage_instance_preds'][3][:1], atol=1e-5)
+    assert torch.allclose(r2['stage_detail_preds'][2], full_['stage_detail_preds'][2][sel.cuda()], atol=1e-5)

@@ -11,21 +11,9 @@ def t(fn, it=20):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(it): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / it * 1e3
-def one(last):
+for ns in (1, 2, 3, 4, 6):
+    head.num_streams = ns
     with torch.no_grad():
-        return head._mask_forward(feats, rois, labels, last_stage=last)
-streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-halves = [(rois[:256].contiguous(), labels[:256].contiguous()), (rois[256:].contiguous(), labels[256:].contiguous())]
-def two(last):
-    cur = torch.cuda.current_stream()
-    outs = []
-    with torch.no_grad():
-        for s, (r, l) in zip(streams, halves):
-            s.wait_stream(cur)
-            with torch.cuda.stream(s):
-                outs.append(head._mask_forward(feats, r, l, last_stage=last))
-        for s in streams:
-            cur.wait_stream(s)
-    return outs
-for last in (1, None):
-    print('last_stage', last, 'one stream %.3f ms' % t(lambda: one(last)), 'two streams %.3f ms' % t(lambda: two(last)))
+        a = t(lambda: head._mask_forward(feats, rois, labels, last_stage=1))
+        b = t(lambda: head._mask_forward(feats, rois, labels), it=8)
+    print(f'streams {ns}: exit28 {a:.3f} ms   full {b:.3f} ms')
