@@ -204,6 +204,52 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __rest
   }
 }
 
+// align_corners=False, scale 2: closed-form adjoint as a GATHER (no atomics).  Output row
+// oy = 2k samples src = k - 0.25 (rows k-1: 0.25, k: 0.75; k = 0 clamps: row 0 gets 1),
+// oy = 2k+1 samples src = k + 0.25 (rows k: 0.75, k+1: 0.25; at the last row both taps
+// fold into row k).  So input row y gathers from output rows 2y-1, 2y, 2y+1, 2y+2.
+__device__ __forceinline__ void up2_adjoint_weights(int y, int H, float w[4]) {
+  w[0] = (y >= 1) ? 0.25f : 0.f;                 // oy = 2y-1
+  w[1] = (y == 0) ? 1.0f : 0.75f;                // oy = 2y
+  w[2] = (y == H - 1) ? 1.0f : 0.75f;            // oy = 2y+1
+  w[3] = (y <= H - 2) ? 0.25f : 0.f;             // oy = 2y+2
+}
+
+__global__ __launch_bounds__(256) void upsample2x_bwd_gather_kernel(const float* __restrict__ gout,
+                                                                    const float* __restrict__ yout, int NC, int H, int W,
+                                                                    float* __restrict__ gin) {
+  const int OH = 2 * H, OW = 2 * W;
+  const long long total = (long long)NC * H * W;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % W);
+    const int y = (int)((idx / W) % H);
+    const long long nc = idx / ((long long)W * H);
+    float wy[4], wx[4];
+    up2_adjoint_weights(y, H, wy);
+    up2_adjoint_weights(x, W, wx);
+    const float* g = gout + nc * OH * OW;
+    const float* m = yout ? yout + nc * OH * OW : nullptr;
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int oy = 2 * y - 1 + a;
+      if (wy[a] == 0.f) continue;
+      float row = 0.f;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int ox = 2 * x - 1 + b;
+        if (wx[b] == 0.f) continue;
+        float v = g[oy * OW + ox];
+        if (m && !(m[oy * OW + ox] > 0.f)) v = 0.f;
+        row += wx[b] * v;
+      }
+      acc += wy[a] * row;
+    }
+    gin[idx] = acc;
+  }
+}
+
 // ----------------------------------------------------------------- K4 backward
 __global__ __launch_bounds__(256) void point_sample_bwd_kernel(const float* __restrict__ gout, int B, int C, int H, int W,
                                                                const float* __restrict__ rois, int N, int S, float scale,
@@ -241,13 +287,20 @@ __global__ __launch_bounds__(256) void point_sample_bwd_kernel(const float* __re
   const size_t plane = (size_t)H * W;
   float* gf = gfeat + (size_t)b * C * plane;
   const float* go = gout + ((size_t)n * C) * S * S + pos;
-  for (int c = c0; c < c1; ++c) {
-    const float g = go[(size_t)c * S * S];
-    float* gc = gf + (size_t)c * plane;
-    if (okx0 && oky0) atomicAdd(gc + y0 * W + x0, g * w_nw);
-    if (okx1 && oky0) atomicAdd(gc + y0 * W + x1i, g * w_ne);
-    if (okx0 && oky1) atomicAdd(gc + y1i * W + x0, g * w_sw);
-    if (okx1 && oky1) atomicAdd(gc + y1i * W + x1i, g * w_se);
+  for (int cb = c0; cb < c1; cb += 8) {
+    float gv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) gv[u] = (cb + u < c1) ? go[(size_t)(cb + u) * S * S] : 0.f;   // 8 loads in flight
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (cb + u >= c1) break;
+      float* gc = gf + (size_t)(cb + u) * plane;
+      const float g = gv[u];
+      if (okx0 && oky0) atomicAdd(gc + y0 * W + x0, g * w_nw);
+      if (okx1 && oky0) atomicAdd(gc + y0 * W + x1i, g * w_ne);
+      if (okx0 && oky1) atomicAdd(gc + y1i * W + x0, g * w_sw);
+      if (okx1 && oky1) atomicAdd(gc + y1i * W + x1i, g * w_se);
+    }
   }
 }
 
@@ -424,27 +477,51 @@ __global__ __launch_bounds__(256) void dcn_col2im_lds_kernel(const float* __rest
   for (int i = threadIdx.x; i < CT * HW; i += blockDim.x) lds[i] = 0.f;
   __syncthreads();
   const float* offb = offset + ((size_t)n * dg + g) * 18 * HW;
-  for (int it = threadIdx.x; it < 9 * HW; it += blockDim.x) {
-    const int tap = it / HW;
-    const int p = it - tap * HW;
-    const int y = p / W, xx = p - y * W;
-    const DcnSample s = dcn_sample(offb + p, tap, HW, y, xx, H, W);
-    if (!s.valid) continue;
-    const int h_low = s.h_low, w_low = s.w_low, h_high = h_low + 1, w_high = w_low + 1;
-    const float lh = s.h_im - (float)h_low, lw = s.w_im - (float)w_low, hh = 1.f - lh, hw = 1.f - lw;
-    const bool v1 = h_low >= 0 && w_low >= 0, v2 = h_low >= 0 && w_high <= W - 1;
-    const bool v3 = h_high <= H - 1 && w_low >= 0, v4 = h_high <= H - 1 && w_high <= W - 1;
-    const int o1 = h_low * W + w_low, o2 = h_low * W + w_high, o3 = h_high * W + w_low, o4 = h_high * W + w_high;
-    const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-    const float* cgp = colgrad + ((size_t)n * 9 * C + (size_t)tap * C + c0) * HW + p;
+  // The loop is latency-bound (colgrad streams from HBM once): U items per thread per
+  // trip, their 2*U offset loads and CT*U column-gradient loads all in flight before
+  // the first LDS atomic.
+  constexpr int U = 4;
+  for (int it0 = threadIdx.x; it0 < 9 * HW; it0 += U * blockDim.x) {
+    float oh[U], ow[U];
+    int tapv[U], pv[U];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) {
-      const float cg = cgp[(size_t)c * HW];
-      float* pl = lds + c * HW;
-      if (v1) atomicAdd(pl + o1, cg * w1);
-      if (v2) atomicAdd(pl + o2, cg * w2);
-      if (v3) atomicAdd(pl + o3, cg * w3);
-      if (v4) atomicAdd(pl + o4, cg * w4);
+    for (int u = 0; u < U; ++u) {
+      const int it = min(it0 + u * (int)blockDim.x, 9 * HW - 1);
+      tapv[u] = it / HW;
+      pv[u] = it - tapv[u] * HW;
+      oh[u] = offb[(size_t)(2 * tapv[u]) * HW + pv[u]];
+      ow[u] = offb[(size_t)(2 * tapv[u] + 1) * HW + pv[u]];
+    }
+    float cg[U][CT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float* cgp = colgrad + ((size_t)n * 9 * C + (size_t)tapv[u] * C + c0) * HW + pv[u];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) cg[u][c] = cgp[(size_t)c * HW];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (it0 + u * (int)blockDim.x >= 9 * HW) continue;
+      const int tap = tapv[u], p = pv[u];
+      const int y = p / W, xx = p - y * W;
+      const int ki = tap / 3, kj = tap - ki * 3;
+      const float h_im = (float)(y - 1 + ki) + oh[u];
+      const float w_im = (float)(xx - 1 + kj) + ow[u];
+      if (!(h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W)) continue;
+      const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im), h_high = h_low + 1, w_high = w_low + 1;
+      const float lh = h_im - (float)h_low, lw = w_im - (float)w_low, hh = 1.f - lh, hw = 1.f - lw;
+      const bool v1 = h_low >= 0 && w_low >= 0, v2 = h_low >= 0 && w_high <= W - 1;
+      const bool v3 = h_high <= H - 1 && w_low >= 0, v4 = h_high <= H - 1 && w_high <= W - 1;
+      const int o1 = h_low * W + w_low, o2 = h_low * W + w_high, o3 = h_high * W + w_low, o4 = h_high * W + w_high;
+      const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        float* pl = lds + c * HW;
+        if (v1) atomicAdd(pl + o1, cg[u][c] * w1);
+        if (v2) atomicAdd(pl + o2, cg[u][c] * w2);
+        if (v3) atomicAdd(pl + o3, cg[u][c] * w3);
+        if (v4) atomicAdd(pl + o4, cg[u][c] * w4);
+      }
     }
   }
   __syncthreads();
@@ -530,6 +607,12 @@ extern "C" int dm_upsample2x_bilinear_bwd(const float* grad_out, const float* fw
                                           int align_corners, float* grad_in, dm_stream_t stream) {
   if (!grad_out || !grad_in || NC < 0 || H <= 0 || W <= 0) return DM_ERR_INVALID_ARG;
   if (NC == 0) return DM_OK;
+  if (!align_corners && H >= 2 && W >= 2) {
+    // gather form overwrites grad_in (no zero-fill needed, no atomics)
+    DM_LAUNCH(upsample2x_bwd_gather_kernel, dim3(grid_for((size_t)NC * H * W)), dim3(256), 0, (hipStream_t)stream, grad_out,
+              fwd_out_for_relu, NC, H, W, grad_in);
+    return dm_check_launch();
+  }
   DM_LAUNCH(upsample2x_bwd_kernel, dim3(grid_for((size_t)NC * 4 * H * W)), dim3(256), 0, (hipStream_t)stream, grad_out,
             fwd_out_for_relu, NC, H, W, align_corners, grad_in);
   return dm_check_launch();
