@@ -176,6 +176,7 @@ def main():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of a HIP graph replay')
+    ap.add_argument('--end-to-end', action='store_true', help='also time a stock MIOpen ResNet-50-FPN + the mask path (context)')
     ap.add_argument('--cpu-sample', type=int, default=32, help='RoIs of the batch timed on the host cores (0 = skip)')
     args = ap.parse_args()
 
@@ -310,6 +311,40 @@ def main():
                                       'sample': f'first {args.cpu_sample} of the 512 RoIs of the same image through the same '
                                                 f'28x28 exit (PyTorch-CPU oracle, {cores} threads), {dt_cpu:.2f} s per pass; '
                                                 f'scaled to 512 RoIs/img', 'max_abs_err_vs_gpu': err}
+
+        if args.end_to_end:
+            # Context only: the (out-of-scope) stock MIOpen backbone next to the mask path at
+            # the reference's inference shape: <=100 detections, all exits to 112x112, boundary
+            # merge, paste.  RPN / bbox branch / NMS are not part of this repo and not timed.
+            sys.path.insert(0, os.path.join(ROOT, 'tools'))
+            from stock_backbone import ResNet50FPN
+            from dynamask_amd.registry import ConfigDict
+            bb = ResNet50FPN().to(dev).eval()
+            img = torch.randn(1, 3, 800, 1344, device=dev)
+            head.test_cfg = ConfigDict(mask_thr_binary=0.5)
+            det = torch.cat([rois[:100, 1:], torch.ones(100, 1, device=dev)], 1)
+            dl = labels[:100]
+            meta = [dict(ori_shape=(800, 1333, 3), scale_factor=1.0)]
+            with torch.no_grad():
+                t_bb = time_kernel(lambda: bb(img), iters=10, warmup=3)
+
+                def e2e():
+                    f = bb(img)
+                    return head.simple_test_mask([t.contiguous() for t in f], meta, det, dl)
+                for _ in range(2):
+                    e2e()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    e2e()            # includes the device->host copy of the pasted masks, as the reference
+                torch.cuda.synchronize()
+                t_e2e = (time.perf_counter() - t0) / 5 * 1e3
+                t_mask = time_kernel(lambda: head.simple_test_mask_logits(feats, det, dl), iters=10, warmup=2)
+            result['extra']['end_to_end'] = {
+                'backbone_fpn_ms': t_bb, 'mask_path_100dets_ms': t_mask, 'backbone_plus_mask_path_ms': t_e2e,
+                'img_per_s': 1e3 / t_e2e,
+                'what': 'stock PyTorch-ROCm/MIOpen ResNet-50+FPN fp32 (random weights, out of scope) + this repo\'s mask path '
+                        'for 100 detections incl. merge, paste and D2H of the bool masks; RPN / bbox head / NMS not included'}
 
     # training step (configs[2]/[3]) on every rank, last (it updates the weights):
     # reported in `extra`, not the headline
