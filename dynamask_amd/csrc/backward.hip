@@ -461,20 +461,25 @@ __global__ __launch_bounds__(256) void dcn_coord_grad_kernel(const float* __rest
 
 // Deformable col2im (data gradient).  Every contribution to gx[n, c] comes from the
 // colgrad rows (tap, c) of the same image, so a workgroup owns (n, CT channels),
-// accumulates the 9 x HW x 4 scatter-adds in an LDS copy of the planes (ds_add_f32)
-// and writes each plane once: no global atomics (the reference's col2im kernel,
+// accumulates the 9 x HW x 4 scatter-adds in an LDS copy of the planes and writes each
+// plane once: no global atomics (the reference's col2im kernel,
 // deform_conv_cuda_kernel.cu:279-335, uses atomicAdd to HBM).
+// The LDS accumulators are 64-bit FIXED POINT (2^-36 resolution, |sum| < 1.3e8):
+// measured on gfx950 (tools/micro/lds_atomics.hip) ds_add_f32 runs at 0.38 lane-atomics
+// per clock per CU, ds_add_u64 at 6.4 (17x) -- and integer sums are order-independent,
+// so this gradient is bitwise reproducible run to run.
+#define DM_FIX_SCALE 68719476736.0      /* 2^36 */
 template <int CT>
 __global__ __launch_bounds__(256) void dcn_col2im_lds_kernel(const float* __restrict__ colgrad,
                                                              const float* __restrict__ offset, int NB, int C, int H, int W,
                                                              int dg, float* __restrict__ gx) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // [CT][HW]
+  extern __shared__ __attribute__((aligned(16))) unsigned long long lds[];   // [CT][HW] fixed point
   const int HW = H * W;
   const int chunks = C / CT;
   const int n = blockIdx.x / chunks;
   const int c0 = (blockIdx.x - n * chunks) * CT;
   const int g = c0 / (C / dg);
-  for (int i = threadIdx.x; i < CT * HW; i += blockDim.x) lds[i] = 0.f;
+  for (int i = threadIdx.x; i < CT * HW; i += blockDim.x) lds[i] = 0ull;
   __syncthreads();
   const float* offb = offset + ((size_t)n * dg + g) * 18 * HW;
   // The loop is latency-bound (colgrad streams from HBM once): U items per thread per
@@ -516,17 +521,19 @@ __global__ __launch_bounds__(256) void dcn_col2im_lds_kernel(const float* __rest
       const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
-        float* pl = lds + c * HW;
-        if (v1) atomicAdd(pl + o1, cg[u][c] * w1);
-        if (v2) atomicAdd(pl + o2, cg[u][c] * w2);
-        if (v3) atomicAdd(pl + o3, cg[u][c] * w3);
-        if (v4) atomicAdd(pl + o4, cg[u][c] * w4);
+        unsigned long long* pl = lds + c * HW;
+        const double cgd = (double)cg[u][c] * DM_FIX_SCALE;
+        if (v1) atomicAdd(pl + o1, (unsigned long long)__double2ll_rn(cgd * (double)w1));
+        if (v2) atomicAdd(pl + o2, (unsigned long long)__double2ll_rn(cgd * (double)w2));
+        if (v3) atomicAdd(pl + o3, (unsigned long long)__double2ll_rn(cgd * (double)w3));
+        if (v4) atomicAdd(pl + o4, (unsigned long long)__double2ll_rn(cgd * (double)w4));
       }
     }
   }
   __syncthreads();
   float* dst = gx + ((size_t)n * C + c0) * HW;
-  for (int i = threadIdx.x; i < CT * HW; i += blockDim.x) dst[i] = lds[i];
+  for (int i = threadIdx.x; i < CT * HW; i += blockDim.x)
+    dst[i] = (float)((double)(long long)lds[i] * (1.0 / DM_FIX_SCALE));
 }
 
 // W[co][ci][tap]  <->  Wt[(tap*C + ci)][co]  (the two DCN GEMMs run as 1x1 convs over
@@ -668,20 +675,21 @@ extern "C" int dm_deform_col2im_coord(const float* colgrad, const float* x, cons
             NB, C, H, W, deform_groups, grad_offset);
   int rc = dm_check_launch();
   if (rc != DM_OK) return rc;
-  // channels per workgroup: LDS planes of CT x HW floats, CT | C/deform_groups
+  // channels per workgroup: LDS planes of CT x HW 64-bit accumulators, CT | C/deform_groups
   const int cpg = C / deform_groups;
-  if (cpg % 8 == 0 && (size_t)8 * HW * sizeof(float) <= 48 * 1024) {
-    DM_LAUNCH(dcn_col2im_lds_kernel<8>, dim3((unsigned)(NB * (C / 8))), dim3(256), (size_t)8 * HW * sizeof(float), st, colgrad,
-              offset, NB, C, H, W, deform_groups, grad_x);
-  } else if (cpg % 4 == 0 && (size_t)4 * HW * sizeof(float) <= 64 * 1024) {
-    DM_LAUNCH(dcn_col2im_lds_kernel<4>, dim3((unsigned)(NB * (C / 4))), dim3(256), (size_t)4 * HW * sizeof(float), st, colgrad,
-              offset, NB, C, H, W, deform_groups, grad_x);
-  } else if (cpg % 2 == 0 && (size_t)2 * HW * sizeof(float) <= 48 * 1024) {
-    DM_LAUNCH(dcn_col2im_lds_kernel<2>, dim3((unsigned)(NB * (C / 2))), dim3(256), (size_t)2 * HW * sizeof(float), st, colgrad,
-              offset, NB, C, H, W, deform_groups, grad_x);
-  } else if ((size_t)HW * sizeof(float) <= 48 * 1024) {
-    DM_LAUNCH(dcn_col2im_lds_kernel<1>, dim3((unsigned)(NB * C)), dim3(256), (size_t)HW * sizeof(float), st, colgrad, offset,
-              NB, C, H, W, deform_groups, grad_x);
+  const size_t plane_b = (size_t)HW * sizeof(unsigned long long);
+  if (cpg % 8 == 0 && 8 * plane_b <= 64 * 1024) {
+    DM_LAUNCH(dcn_col2im_lds_kernel<8>, dim3((unsigned)(NB * (C / 8))), dim3(256), 8 * plane_b, st, colgrad, offset, NB, C, H,
+              W, deform_groups, grad_x);
+  } else if (cpg % 4 == 0 && 4 * plane_b <= 64 * 1024) {
+    DM_LAUNCH(dcn_col2im_lds_kernel<4>, dim3((unsigned)(NB * (C / 4))), dim3(256), 4 * plane_b, st, colgrad, offset, NB, C, H,
+              W, deform_groups, grad_x);
+  } else if (cpg % 2 == 0 && 2 * plane_b <= 64 * 1024) {
+    DM_LAUNCH(dcn_col2im_lds_kernel<2>, dim3((unsigned)(NB * (C / 2))), dim3(256), 2 * plane_b, st, colgrad, offset, NB, C, H,
+              W, deform_groups, grad_x);
+  } else if (plane_b <= 64 * 1024) {
+    DM_LAUNCH(dcn_col2im_lds_kernel<1>, dim3((unsigned)(NB * C)), dim3(256), plane_b, st, colgrad, offset, NB, C, H, W,
+              deform_groups, grad_x);
   } else {
     return DM_ERR_UNSUPPORTED;
   }
