@@ -14,6 +14,8 @@
 //                           implicit-GEMM conv kernels (1x1 over the column matrix).
 #include "common.h"
 
+#define DM_FIX_SCALE 68719476736.0 /* 2^36: 64-bit fixed-point LDS accumulators */
+
 namespace {
 
 __device__ __forceinline__ float wsum(float v) {
@@ -251,55 +253,100 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_gather_kernel(const float*
 }
 
 // ----------------------------------------------------------------- K4 backward
+// Adjoint of the point sample.  A small RoI maps its S x S lattice onto a handful of
+// feature pixels, so thousands of samples of one workgroup hit the same addresses:
+// when the RoI's footprint fits an LDS tile the scatter-adds are first reduced there
+// (64-bit fixed-point ds atomics, see dcn_col2im_lds_kernel) and flushed with ONE global
+// atomic per touched pixel; large RoIs (sparse lattice, little contention) go straight
+// to global atomics.  grid = (channel chunks of CT, N).
+__device__ __forceinline__ void ps_coord(float lo, float hi, int i, int S, int size, float scale, float& s) {
+  const float g0 = ((float)(2 * i + 1)) / (float)S - 1.0f;
+  float p = (g0 + 1.0f) / 2.0f;
+  p = p * (hi - lo) + lo;
+  p = p / (float)size * scale;
+  const float g = p * 2.0f - 1.0f;
+  s = ((g + 1.0f) * (float)size - 1.0f) / 2.0f;
+}
+
+template <int CT>
 __global__ __launch_bounds__(256) void point_sample_bwd_kernel(const float* __restrict__ gout, int B, int C, int H, int W,
                                                                const float* __restrict__ rois, int N, int S, float scale,
-                                                               float* __restrict__ gfeat, int CT, int pos_blocks) {
-  const int chunks = (C + CT - 1) / CT;
-  int bid = blockIdx.x;
-  const int pb = bid % pos_blocks;
-  bid /= pos_blocks;
-  const int chunk = bid % chunks;
-  const int n = bid / chunks;
-  const int pos = pb * blockDim.x + threadIdx.x;
-  if (pos >= S * S) return;
-  const int iy = pos / S, ix = pos - iy * S;
+                                                               float* __restrict__ gfeat, int lds_elems) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long tile[];   // [CT][TH][TW] fixed point
+  const int n = blockIdx.y;
+  const int c0 = blockIdx.x * CT;
   const float* r = rois + (size_t)n * 5;
   const int b = (int)r[0];
   if (b < 0 || b >= B) return;
   const float x1 = r[1], y1 = r[2], x2 = r[3], y2 = r[4];
-  const float gx0 = ((float)(2 * ix + 1)) / (float)S - 1.0f;
-  const float gy0 = ((float)(2 * iy + 1)) / (float)S - 1.0f;
-  float px = (gx0 + 1.0f) / 2.0f, py = (gy0 + 1.0f) / 2.0f;
-  px = px * (x2 - x1) + x1;
-  py = py * (y2 - y1) + y1;
-  px = px / (float)W * scale;
-  py = py / (float)H * scale;
-  const float gx = px * 2.0f - 1.0f, gy = py * 2.0f - 1.0f;
-  const float sx = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f;
-  const float sy = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
-  const float fx = floorf(sx), fy = floorf(sy);
-  if (fx < -1.f || fx > (float)W || fy < -1.f || fy > (float)H) return;   // all four taps void
-  const int x0 = (int)fx, y0 = (int)fy, x1i = x0 + 1, y1i = y0 + 1;
-  const float lx = sx - fx, ly = sy - fy;
-  const float w_nw = (1.f - lx) * (1.f - ly), w_ne = lx * (1.f - ly), w_sw = (1.f - lx) * ly, w_se = lx * ly;
-  const bool okx0 = x0 >= 0 && x0 < W, okx1 = x1i >= 0 && x1i < W, oky0 = y0 >= 0 && y0 < H, oky1 = y1i >= 0 && y1i < H;
-  const int c0 = chunk * CT, c1 = min(c0 + CT, C);
+  // footprint of the lattice on the feature map (coordinates are monotonic in the lattice index)
+  float sxa, sxb, sya, syb;
+  ps_coord(x1, x2, 0, S, W, scale, sxa);
+  ps_coord(x1, x2, S - 1, S, W, scale, sxb);
+  ps_coord(y1, y2, 0, S, H, scale, sya);
+  ps_coord(y1, y2, S - 1, S, H, scale, syb);
+  const float sxmin = fminf(sxa, sxb), sxmax = fmaxf(sxa, sxb), symin = fminf(sya, syb), symax = fmaxf(sya, syb);
+  if (sxmax < -1.f || sxmin > (float)W || symax < -1.f || symin > (float)H) return;   // every tap void
+  const int fx0 = max((int)floorf(fmaxf(sxmin, -1.f)), 0), fx1 = min((int)floorf(fminf(sxmax, (float)W)) + 1, W - 1);
+  const int fy0 = max((int)floorf(fmaxf(symin, -1.f)), 0), fy1 = min((int)floorf(fminf(symax, (float)H)) + 1, H - 1);
+  const int TW = fx1 - fx0 + 1, TH = fy1 - fy0 + 1;
+  const bool use_lds = TW > 0 && TH > 0 && TW * TH * CT <= lds_elems;
+  if (use_lds) {
+    for (int i = threadIdx.x; i < CT * TH * TW; i += blockDim.x) tile[i] = 0ull;
+    __syncthreads();
+  }
   const size_t plane = (size_t)H * W;
-  float* gf = gfeat + (size_t)b * C * plane;
-  const float* go = gout + ((size_t)n * C) * S * S + pos;
-  for (int cb = c0; cb < c1; cb += 8) {
-    float gv[8];
+  float* gf = gfeat + ((size_t)b * C + c0) * plane;
+  const int nch = min(CT, C - c0);
+  for (int pos = threadIdx.x; pos < S * S; pos += blockDim.x) {
+    const int iy = pos / S, ix = pos - iy * S;
+    float sx, sy;
+    ps_coord(x1, x2, ix, S, W, scale, sx);
+    ps_coord(y1, y2, iy, S, H, scale, sy);
+    const float fx = floorf(sx), fy = floorf(sy);
+    if (fx < -1.f || fx > (float)W || fy < -1.f || fy > (float)H) continue;
+    const int x0 = (int)fx, y0 = (int)fy, x1i = x0 + 1, y1i = y0 + 1;
+    const float lx = sx - fx, ly = sy - fy;
+    const float w_nw = (1.f - lx) * (1.f - ly), w_ne = lx * (1.f - ly), w_sw = (1.f - lx) * ly, w_se = lx * ly;
+    const bool okx0 = x0 >= 0 && x0 < W, okx1 = x1i >= 0 && x1i < W, oky0 = y0 >= 0 && y0 < H, oky1 = y1i >= 0 && y1i < H;
+    const float* go = gout + ((size_t)n * C + c0) * S * S + pos;
+    float gv[CT];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) gv[u] = (cb + u < c1) ? go[(size_t)(cb + u) * S * S] : 0.f;   // 8 loads in flight
+    for (int c = 0; c < CT; ++c) gv[c] = (c < nch) ? go[(size_t)c * S * S] : 0.f;
+    if (use_lds) {
+      const int tx0 = x0 - fx0, ty0 = y0 - fy0;     // in range by construction of the footprint
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (cb + u >= c1) break;
-      float* gc = gf + (size_t)(cb + u) * plane;
-      const float g = gv[u];
-      if (okx0 && oky0) atomicAdd(gc + y0 * W + x0, g * w_nw);
-      if (okx1 && oky0) atomicAdd(gc + y0 * W + x1i, g * w_ne);
-      if (okx0 && oky1) atomicAdd(gc + y1i * W + x0, g * w_sw);
-      if (okx1 && oky1) atomicAdd(gc + y1i * W + x1i, g * w_se);
+      for (int c = 0; c < CT; ++c) {
+        if (c >= nch) break;
+        unsigned long long* t = tile + (size_t)c * TH * TW;
+        const double g = (double)gv[c] * DM_FIX_SCALE;
+        if (okx0 && oky0) atomicAdd(t + ty0 * TW + tx0, (unsigned long long)__double2ll_rn(g * (double)w_nw));
+        if (okx1 && oky0) atomicAdd(t + ty0 * TW + tx0 + 1, (unsigned long long)__double2ll_rn(g * (double)w_ne));
+        if (okx0 && oky1) atomicAdd(t + (ty0 + 1) * TW + tx0, (unsigned long long)__double2ll_rn(g * (double)w_sw));
+        if (okx1 && oky1) atomicAdd(t + (ty0 + 1) * TW + tx0 + 1, (unsigned long long)__double2ll_rn(g * (double)w_se));
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        if (c >= nch) break;
+        float* gc = gf + (size_t)c * plane;
+        if (okx0 && oky0) atomicAdd(gc + y0 * W + x0, gv[c] * w_nw);
+        if (okx1 && oky0) atomicAdd(gc + y0 * W + x1i, gv[c] * w_ne);
+        if (okx0 && oky1) atomicAdd(gc + y1i * W + x0, gv[c] * w_sw);
+        if (okx1 && oky1) atomicAdd(gc + y1i * W + x1i, gv[c] * w_se);
+      }
+    }
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < nch * TH * TW; i += blockDim.x) {
+      const long long q = (long long)tile[i];
+      if (q != 0) {
+        const int c = i / (TH * TW);
+        const int rem = i - c * TH * TW;
+        const int ty = rem / TW, tx = rem - ty * TW;
+        atomicAdd(gf + (size_t)c * plane + (size_t)(fy0 + ty) * W + fx0 + tx, (float)((double)q * (1.0 / DM_FIX_SCALE)));
+      }
     }
   }
 }
@@ -468,7 +515,6 @@ __global__ __launch_bounds__(256) void dcn_coord_grad_kernel(const float* __rest
 // measured on gfx950 (tools/micro/lds_atomics.hip) ds_add_f32 runs at 0.38 lane-atomics
 // per clock per CU, ds_add_u64 at 6.4 (17x) -- and integer sums are order-independent,
 // so this gradient is bitwise reproducible run to run.
-#define DM_FIX_SCALE 68719476736.0      /* 2^36 */
 template <int CT>
 __global__ __launch_bounds__(256) void dcn_col2im_lds_kernel(const float* __restrict__ colgrad,
                                                              const float* __restrict__ offset, int NB, int C, int H, int W,
@@ -629,10 +675,11 @@ extern "C" int dm_point_sample_bwd(const float* grad_out, int B, int C, int H, i
                                    float spatial_scale, float* grad_feat, dm_stream_t stream) {
   if (!grad_out || !rois || !grad_feat || B <= 0 || C <= 0 || H <= 0 || W <= 0 || N < 0 || S <= 0) return DM_ERR_INVALID_ARG;
   if (N == 0) return DM_OK;
-  const int CT = 16;
-  const int chunks = dm_ceil_div(C, CT), pos_blocks = dm_ceil_div(S * S, 256);
-  DM_LAUNCH(point_sample_bwd_kernel, dim3((unsigned)(N * chunks * pos_blocks)), dim3(256), 0, (hipStream_t)stream, grad_out,
-            B, C, H, W, rois, N, S, spatial_scale, grad_feat, CT, pos_blocks);
+  constexpr int CT = 4;
+  const int lds_elems = 6144;                    // 48 KB of 64-bit accumulators
+  DM_LAUNCH(point_sample_bwd_kernel<CT>, dim3((unsigned)dm_ceil_div(C, CT), (unsigned)N), dim3(256),
+            (size_t)lds_elems * sizeof(unsigned long long), (hipStream_t)stream, grad_out, B, C, H, W, rois, N, S,
+            spatial_scale, grad_feat, lds_elems);
   return dm_check_launch();
 }
 
