@@ -13,6 +13,7 @@
 //                           the two GEMMs of deform_conv_cuda.cpp:262-486 run on the
 //                           implicit-GEMM conv kernels (1x1 over the column matrix).
 #include "common.h"
+#include <climits>
 
 #define DM_FIX_SCALE 68719476736.0 /* 2^36: 64-bit fixed-point LDS accumulators */
 
@@ -79,13 +80,21 @@ struct WgradArgs {
   int JT, MT, chunks_per_split, nsplit;
 };
 
-template <int KS>
+// dW[co][j] = sum_q dy[co][q] * xshift[j][q]  (j = (ci, tap), q = flat pixel): a GEMM
+// whose K dimension is the pixel axis.  Four waves, each owning a 64 x 64 accumulator
+// (2 x 2 MFMA tiles); WGM x WGN x WGK arranges them over the output tile and -- for the
+// small-output layers (64 couts x 64 columns) -- over the K chunk, so narrow weight
+// matrices do not pad to 128 x 128.  Split-K over workgroups; partial sums land with
+// float atomics.  The next chunk's global loads are issued before the MFMA loop.
+template <int KS, int WGM, int WGN, int WGK>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
-  constexpr int TM = 128, TN = 128, KT = 32, LD = KT + 1, TAPS = KS * KS;
+  static_assert(WGM * WGN * WGK == 4, "four waves");
+  constexpr int TM = 64 * WGM, TN = 64 * WGN, KT = 32, LD = KT + 1, TAPS = KS * KS;
+  constexpr int RA = TM / 8, RB = TN / 8, KW = KT / WGK;
   __shared__ float ldsA[TM * LD];
   __shared__ float ldsB[TN * LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wave_m = wave >> 1, wave_n = wave & 1;
+  const int wave_k = wave % WGK, wave_n = (wave / WGK) % WGN, wave_m = wave / (WGK * WGN);
   const int hi = lane >> 5, l31 = lane & 31;
   int bid = blockIdx.x;
   const int m_tile = bid % a.MT;
@@ -106,19 +115,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 
   const int kq = tid & 31;        // this thread's pixel column inside a chunk
   const int r0 = tid >> 5;        // rows r0 + 8*i
-  // decode the B rows this thread stages once: j -> (ci, tap)
-  int b_ci[16], b_dy[16], b_dx[16];
+  // decode the B rows this thread stages once: j -> (ci, tap), kept as plane offset + shift
+  int b_off[RB];                  // ci*HW + dy*W + dx, or INT_MIN past the last column
+  unsigned b_sh[RB];              // (dy+1) | (dx+1) << 2
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < RB; ++i) {
     const int jg = j0 + r0 + 8 * i;
     const int ci = jg / TAPS, tap = jg - ci * TAPS;
-    b_ci[i] = (jg < Jtot) ? ci : -1;
-    b_dy[i] = (KS == 3) ? tap / 3 - 1 : 0;
-    b_dx[i] = (KS == 3) ? tap % 3 - 1 : 0;
+    const int dy = (KS == 3) ? tap / 3 - 1 : 0, dx = (KS == 3) ? tap % 3 - 1 : 0;
+    b_off[i] = (jg < Jtot) ? ci * HW + dy * W + dx : INT_MIN;
+    b_sh[i] = (unsigned)(dy + 1) | ((unsigned)(dx + 1) << 2);
   }
   const int c_begin = split * a.chunks_per_split;
   const int c_end = min(c_begin + a.chunks_per_split, (a.Q + KT - 1) / KT);
-  for (int ch = c_begin; ch < c_end; ++ch) {
+  float va[RA], vb[RB];
+  auto fetch = [&](int ch) {
     const int q = ch * KT + kq;
     const bool qok = q < a.Q;
     const int qq = min(q, a.Q - 1);
@@ -126,25 +137,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int p = qq - n * HW;
     const int y = p / W, x = p - y * W;
     const float* dyp = a.dy + (size_t)n * a.dy_bs + p;
-    const float* xp = a.x + (size_t)n * a.x_bs;
-    float va[16], vb[16];
+    const float* xp = a.x + (size_t)n * a.x_bs + p;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < RA; ++i) {
       const int co = m0 + r0 + 8 * i;
       va[i] = (qok && co < a.Cout) ? dyp[(size_t)co * HW] : 0.f;
-      const int yy = y + b_dy[i], xx = x + b_dx[i];
-      const bool ok = qok && b_ci[i] >= 0 && yy >= 0 && yy < H && xx >= 0 && xx < W;
-      vb[i] = ok ? xp[(size_t)b_ci[i] * HW + yy * W + xx] : 0.f;
     }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      bool ok = qok && b_off[i] != INT_MIN;
+      if (KS == 3) {
+        const int yy = y + (int)(b_sh[i] & 3u) - 1, xx = x + (int)(b_sh[i] >> 2) - 1;
+        ok = ok && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      }
+      vb[i] = ok ? xp[b_off[i]] : 0.f;
+    }
+  };
+  if (c_begin < c_end) fetch(c_begin);
+  for (int ch = c_begin; ch < c_end; ++ch) {
     __syncthreads();   // previous chunk's MFMA reads are done
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      ldsA[(r0 + 8 * i) * LD + kq] = va[i];
-      ldsB[(r0 + 8 * i) * LD + kq] = vb[i];
-    }
-    __syncthreads();
+    for (int i = 0; i < RA; ++i) ldsA[(r0 + 8 * i) * LD + kq] = va[i];
 #pragma unroll
-    for (int kk = 0; kk < KT; kk += 2) {
+    for (int i = 0; i < RB; ++i) ldsB[(r0 + 8 * i) * LD + kq] = vb[i];
+    __syncthreads();
+    if (ch + 1 < c_end) fetch(ch + 1);
+#pragma unroll
+    for (int k2 = 0; k2 < KW; k2 += 2) {
+      const int kk = wave_k * KW + k2;
       float av[2], bv[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) av[i] = ldsA[((wave_m * 2 + i) * 32 + l31) * LD + kk + hi];
@@ -169,6 +189,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         }
       }
     }
+}
+
+template <int KS>
+void launch_wgrad(WgradArgs a, hipStream_t st) {
+  const int J = a.Cs * KS * KS;
+  const int TM = a.Cout <= 64 ? 64 : 128;
+  // candidate column-tile widths; cost = padded columns x (1 + 32/TN) (A re-load share)
+  const int cands[3] = {256, 128, 64};
+  int TN = 64;
+  double best = 1e30;
+  for (int c = 0; c < 3; ++c) {
+    const int tn = cands[c];
+    if (TM == 128 && tn == 256) continue;
+    const double cost = (double)dm_ceil_div(J, tn) * tn * (1.0 + 32.0 / tn);
+    if (cost < best) { best = cost; TN = tn; }
+  }
+  a.MT = dm_ceil_div(a.Cout, TM);
+  a.JT = dm_ceil_div(J, TN);
+  const int chunks = dm_ceil_div(a.Q, 32);
+  int nsplit = max(1, min(chunks, 2048 / max(1, a.MT * a.JT)));
+  a.chunks_per_split = dm_ceil_div(chunks, nsplit);
+  a.nsplit = dm_ceil_div(chunks, a.chunks_per_split);
+  const dim3 grid((unsigned)(a.MT * a.JT * a.nsplit));
+  if (TM == 128 && TN == 128) DM_LAUNCH((conv_wgrad_kernel<KS, 2, 2, 1>), grid, dim3(256), 0, st, a);
+  else if (TM == 128) DM_LAUNCH((conv_wgrad_kernel<KS, 2, 1, 2>), grid, dim3(256), 0, st, a);
+  else if (TN == 256) DM_LAUNCH((conv_wgrad_kernel<KS, 1, 4, 1>), grid, dim3(256), 0, st, a);
+  else if (TN == 128) DM_LAUNCH((conv_wgrad_kernel<KS, 1, 2, 2>), grid, dim3(256), 0, st, a);
+  else DM_LAUNCH((conv_wgrad_kernel<KS, 1, 1, 4>), grid, dim3(256), 0, st, a);
 }
 
 // ----------------------------------------------------------------- K11 backward
@@ -644,15 +692,8 @@ extern "C" int dm_conv2d_wgrad(const float* dy, long long dy_batch_stride, int C
   WgradArgs a;
   a.dy = dy; a.dy_bs = dy_batch_stride; a.x = x; a.x_bs = x_batch_stride; a.Cout = Cout; a.Cs = Cs;
   a.NB = NB; a.H = H; a.W = W; a.HW = H * W; a.Q = NB * H * W; a.dw = dw; a.ldw = ldw; a.coloff = col_offset;
-  a.MT = dm_ceil_div(Cout, 128);
-  a.JT = dm_ceil_div(Cs * ksize * ksize, 128);
-  const int chunks = dm_ceil_div(a.Q, 32);
-  int nsplit = max(1, min(chunks, 2048 / max(1, a.MT * a.JT)));
-  a.chunks_per_split = dm_ceil_div(chunks, nsplit);
-  a.nsplit = dm_ceil_div(chunks, a.chunks_per_split);
-  const dim3 grid((unsigned)(a.MT * a.JT * a.nsplit));
-  if (ksize == 3) DM_LAUNCH(conv_wgrad_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, a);
-  else DM_LAUNCH(conv_wgrad_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  if (ksize == 3) launch_wgrad<3>(a, (hipStream_t)stream);
+  else launch_wgrad<1>(a, (hipStream_t)stream);
   return dm_check_launch();
 }
 

@@ -90,6 +90,24 @@ def main():
         x = torch.randn(N, C, S, S, device=dev)
         ms = t(lambda: ops.upsample2x(x, relu=True))
         rows.append((f'upsample {C} @{S}', ms, (N * C * S * S * 4 * 5) / ms / 1e6, 'GB/s(in+out)'))
+    if os.environ.get('KB_WGRAD', '1') == '1':
+        NT = 256          # training RoI batch (2 images x 128 positives)
+        def wgrad(name, cin, cout, S, ks):
+            x = torch.randn(NT, cin, S, S, device=dev)
+            dy = torch.randn(NT, cout, S, S, device=dev)
+            dw = torch.zeros(cout, cin, ks, ks, device=dev)
+            ms = t(lambda: ops.conv2d_wgrad(dy, x, ks, dw=dw))
+            rows.append((name, ms, 2.0 * NT * S * S * cin * cout * ks * ks / ms / 1e9, 'TF/s'))
+        wgrad('wgrad3x3 256->256 @14', 256, 256, 14, 3)
+        wgrad('wgrad3x3 256->36 @14', 256, 36, 14, 3)
+        wgrad('wgrad3x3 64->36 @56', 64, 36, 56, 3)
+        wgrad('wgrad1x1 2304->256 @14 (dcn)', 2304, 256, 14, 1)
+        wgrad('wgrad1x1 1152->128 @28 (dcn)', 1152, 128, 28, 1)
+        wgrad('wgrad1x1 576->64 @56 (dcn)', 576, 64, 56, 1)
+        wgrad('wgrad1x1 256->256 @14', 256, 256, 14, 1)
+        wgrad('wgrad1x1 128->128 @28', 128, 128, 28, 1)
+        wgrad('wgrad1x1 64->64 @56', 64, 64, 56, 1)
+        wgrad('wgrad1x1 64->30 @56', 64, 30, 56, 1)
     print(f'{"kernel":32s} {"ms":>9s} {"rate":>10s}')
     for name, ms, rate, unit in rows:
         print(f'{name:32s} {ms:9.3f} {rate:10.1f} {unit}')
