@@ -18,7 +18,7 @@ b = torch.randn(256, device=dev)
 wq = ops.pack_conv_weight(w)
 feats = [f.to(dev) for f in synth.make_fpn(1, 800, 1333, 256, seed=0)]
 rois = synth.make_rois(1, N, 800, 1333, seed=1).to(dev)
-for _ in range(4):
+for _ in range(int(os.environ.get("PROBE_ITERS", 4))):
     ops.conv2d(x, wq, b, 256, 3, relu=True)
     ops.roi_align(feats[:4], rois, 14, [1 / 4, 1 / 8, 1 / 16, 1 / 32])
 torch.cuda.synchronize()

@@ -1,8 +1,36 @@
-import os, sys, torch
+"""Training-step timing probe: per-step wall time (host) and event time (device) for a
+few consecutive steps, to separate launch-side stalls from kernel time."""
+import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
 import bench
+from dynamask_amd import synth
+from dynamask_amd.dist import FlatParamGroup, mask_path_parameters
 dev = torch.device('cuda')
 head, sd = bench.build_head(dev)
-ms, loss, n, b = bench.train_step_bench(head, dev, 0, 1, steps=2, warmup=1)
-print('train ms', ms)
+B, per = 2, 128
+feats = [f.to(dev) for f in synth.make_fpn(B, bench.IMG_H, bench.IMG_W, 256, seed=10)]
+rois = synth.make_rois(B, per, bench.IMG_H, bench.IMG_W, seed=11).to(dev)
+labels = synth.make_labels(B * per, seed=12).to(dev)
+targets = [t.to(dev) for t in synth.make_targets(B * per, seed=13)]
+noise = synth.make_gumbel_noise(B * per, seed=14).to(dev)
+head.train()
+grp = FlatParamGroup(mask_path_parameters(head))
+for i in range(int(os.environ.get('TP_STEPS', 12))):
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    grp.zero_grad()
+    res = head._mask_forward_train(feats, rois, labels, targets, noise=noise)
+    t1 = time.perf_counter()
+    res['loss_mask']['loss_masks'].backward()
+    t2 = time.perf_counter()
+    grp.all_reduce_async()
+    grp.sgd_step(lr=0.02, momentum=0.9, weight_decay=1e-4)
+    e1.record()
+    t3 = time.perf_counter()
+    torch.cuda.synchronize()
+    t4 = time.perf_counter()
+    print(f'step {i}: wall {1e3*(t4-t0):7.2f} ms  device {e0.elapsed_time(e1):7.2f} ms  host fwd {1e3*(t1-t0):6.2f} bwd {1e3*(t2-t1):6.2f} opt {1e3*(t3-t2):5.2f}  '
+          f'mem {torch.cuda.memory_allocated()/2**30:.2f}/{torch.cuda.memory_reserved()/2**30:.2f} GiB', flush=True)
