@@ -90,7 +90,22 @@ def roialign_algorithmic_bytes(rois, feats, C=256, P=14):
     return write + min(read, touched)
 
 
-def cpu_baseline(sd, feats, rois, labels, sample):
+def host_core_share():
+    """Cores this process may actually use: min(affinity, cgroup CPU quota).  Running the
+    oracle with more threads than that is slower, not faster (measured: 128 threads on a
+    16-core quota = 10x slower than 16 threads)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            quota, period = f.read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(sd, feats, rois, labels, sample, reps=2):
     from oracle import ref_model
     n_threads = torch.get_num_threads()
     r, l = rois[:sample].contiguous(), labels[:sample].contiguous()
@@ -115,7 +130,6 @@ def cpu_baseline(sd, feats, rois, labels, sample):
     with torch.no_grad():
         run()
         t0 = time.perf_counter()
-        reps = 2
         for _ in range(reps):
             out = run()
         dt = (time.perf_counter() - t0) / reps
@@ -181,7 +195,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of a HIP graph replay')
     ap.add_argument('--end-to-end', action='store_true', help='also time a stock MIOpen ResNet-50-FPN + the mask path (context)')
-    ap.add_argument('--cpu-sample', type=int, default=128, help='RoIs of the batch timed on the host cores (0 = skip)')
+    ap.add_argument('--cpu-sample', type=int, default=512, help='RoIs of the batch timed on the host cores (0 = skip)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -309,16 +323,55 @@ def main():
         extra = {}
         with torch.no_grad():
             extra['full_head_112_ms'] = time_kernel(lambda: head._mask_forward(feats, rois, labels), iters=5, warmup=1)
+        # ---- SURVEY 8d reading (i) of cfg-2 and cfg-5: the fixed-28x28 FCN producers ----
+        from dynamask_amd import registry, synth
+        import golden_inputs as gi
+
+        def fcn_ms(up, fpn_feats, fpn_rois):
+            cfg = dict(type='FCNMaskHead', **gi.FCN_HEAD_CFG)
+            cfg.pop('loss_mask')
+            if up == 'carafe':
+                cfg['upsample_cfg'] = dict(type='carafe', scale_factor=2, up_kernel=5, up_group=1, encoder_kernel=3,
+                                           encoder_dilation=1, compressed_channels=64)
+            fcn = registry.build_head(cfg)
+            fsd = synth.init_fcn_head_state(seed=7, upsample=up, test_mode=True)
+            fcn.load_state_dict({k[len('mask_head.'):]: v for k, v in fsd.items()}, strict=True)
+            fcn = fcn.to(dev).eval()
+            ext = head.mask_roi_extractor
+            with torch.no_grad():
+                return time_kernel(lambda: fcn(ext(fpn_feats[:4], fpn_rois)), iters=5, warmup=2)
+        extra['fcn_deconv_28_ms'] = fcn_ms('deconv', feats, rois)
+        f5 = [f.to(dev) for f in synth.make_fpn(1, 1024, 2048, 256, seed=20)]
+        r5 = synth.make_rois(1, ROIS_PER_IMG, 1024, 2048, seed=21).to(dev)
+        extra['fcn_carafe_cfg5_2048x1024_ms'] = fcn_ms('carafe', f5, r5)
+        del f5, r5
+        # ---- measured device-to-device copy rate (second denominator for the HBM-bound kernels) ----
+        a_ = torch.empty(1 << 28, device=dev, dtype=torch.float32)
+        b_ = torch.empty_like(a_)
+        ms_c = time_kernel(lambda: b_.copy_(a_), iters=10, warmup=2)
+        copy_gbs = 2 * a_.numel() * 4 / (ms_c * 1e-3) / 1e9
+        del a_, b_
+        extra['hbm_copy_GBps_read_plus_write'] = copy_gbs
+        result['roofline_roialign']['frac_of_measured_copy'] = result['roofline_roialign']['achieved'] / copy_gbs
         result['extra'] = extra
         # ---- CPU baseline: the oracle on this box's host cores ----
         if args.cpu_sample > 0 and world == 1:
-            dt_cpu, cores, out_cpu = cpu_baseline(sd, feats_c, rois_c, labels_c, args.cpu_sample)
+            default_threads = torch.get_num_threads()
+            torch.set_num_threads(min(default_threads, host_core_share()))
+            dt_cpu, cores, out_cpu = cpu_baseline(sd, feats_c, rois_c, labels_c, args.cpu_sample, reps=6)
             gpu = eager_step()      # not the graph: its packed-weight buffers predate the training leg
             err = float((gpu['stage_instance_preds'][1][:args.cpu_sample, 0].cpu() - out_cpu[0]).abs().max())
+            torch.set_num_threads(1)
+            n1 = min(8, args.cpu_sample)
+            dt1, _, _ = cpu_baseline(sd, feats_c, rois_c, labels_c, n1)
+            torch.set_num_threads(default_threads)
+            extra['cpu_baseline_1thread'] = {'value': (n1 / ROIS_PER_IMG) / dt1, 'unit': 'img/s', 'cores': 1,
+                                             'sample': f'first {n1} RoIs, {dt1:.2f} s per pass'}
             result['cpu_baseline'] = {'value': (args.cpu_sample / ROIS_PER_IMG) / dt_cpu, 'unit': 'img/s', 'cores': cores,
                                       'kind': 'port',
                                       'sample': f'first {args.cpu_sample} of the 512 RoIs of the same image through the same '
-                                                f'28x28 exit (PyTorch-CPU oracle, {cores} threads), {dt_cpu:.2f} s per pass; '
+                                                f'28x28 exit (PyTorch-CPU oracle, {cores} threads = this process\'s CPU quota), '
+                                                f'{dt_cpu:.2f} s per pass x 7 passes; '
                                                 f'scaled to 512 RoIs/img', 'max_abs_err_vs_gpu': err}
 
         if args.end_to_end:
