@@ -323,6 +323,19 @@ def main():
         extra = {}
         with torch.no_grad():
             extra['full_head_112_ms'] = time_kernel(lambda: head._mask_forward(feats, rois, labels), iters=5, warmup=1)
+        # ---- per-RoI early exit: same 512 RoIs, exits uniform over 14/28/56/112 ----
+        ex = torch.arange(ROIS_PER_IMG, device=dev) % 4
+        det_boxes = rois[:, 1:].contiguous()
+        extra['dynamic_inference'] = {
+            'uniform_exits_ms': time_kernel(lambda: head.dynamic_mask_logits(feats, det_boxes, labels, exits=ex),
+                                            iters=5, warmup=2),
+            'all_exit_112_ms': time_kernel(lambda: head.dynamic_mask_logits(feats, det_boxes, labels,
+                                                                            exits=torch.full_like(ex, 3)), iters=5, warmup=2),
+            'with_selector_ms': time_kernel(lambda: head.dynamic_mask_logits(feats, det_boxes, labels), iters=5, warmup=2),
+            'selector_exit_histogram': torch.bincount(head.dynamic_mask_logits(feats, det_boxes, labels)['exits'],
+                                                      minlength=4).tolist(),
+            'what': 'RoIAlign14 + DynaMaskHead with each RoI leaving at its own exit (+ boundary merge up to it); '
+                    'with_selector adds RoIAlign56(P2) + MaskPre + argmax (random-init selector: histogram is arbitrary)'}
         # ---- SURVEY 8d reading (i) of cfg-2 and cfg-5: the fixed-28x28 FCN producers ----
         from dynamask_amd import registry, synth
         import golden_inputs as gi

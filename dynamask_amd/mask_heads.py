@@ -254,6 +254,61 @@ class DynaMaskHead(nn.Module):
         return stage_instance_preds, stage_detail_preds
 
 
+    def forward_dynamic(self, instance_feats, semantic_feats, rois, roi_labels, n_ge, sems=None):
+        """Per-RoI early exit (the reference's intent, present there only
+        as commented-out code, dynamask_roi_head.py:160-204).  RoIs must be ordered by exit,
+        deepest first; ``n_ge[k]`` = number of RoIs whose exit is >= k (``n_ge[0] == N``), so
+        the RoIs still alive at stage k are the prefix ``[:n_ge[k]]`` and no gather is needed.
+        Stage k's full body runs only on the RoIs that continue; the ones that exit at k get
+        just the two class-gathered logits.  Returns a list over k of instance logits
+        ``[n_ge[k], 1, S_k, S_k]`` -- row j equals the fixed path's exit-k prediction of RoI j
+        bit for bit (RoIs never interact inside the head)."""
+        n_ge = list(n_ge) + [0]
+        assert n_ge[0] == instance_feats.shape[0] and all(a >= b for a, b in zip(n_ge[:-1], n_ge[1:]))
+        for conv in self.instance_convs:
+            instance_feats = conv(instance_feats)
+        roi_labels = roi_labels.long().contiguous()
+        preds = []
+        for idx, stage in enumerate(self.stages):
+            n_here, n_cont = n_ge[idx], n_ge[idx + 1]
+            if n_here == 0:
+                preds.append(instance_feats.new_zeros((0, 1, stage.out_size, stage.out_size)))
+                continue
+            parts = []
+            feats_here = instance_feats
+            if n_cont > 0:
+                upsample_flag = self.pre_upsample_last_stage or idx < len(self.stages) - 1
+                ip, _, instance_feats = stage(feats_here[:n_cont], semantic_feats[-idx - 3], rois[:n_cont],
+                                              roi_labels[:n_cont], upsample_flag,
+                                              sem=None if sems is None else sems[idx])
+                parts.append(ip)
+            if n_cont < n_here:
+                c, nc = stage.instance_in_channel, stage.num_classes
+                ip, _ = ops.class_logits(feats_here[n_cont:n_here], stage.instance_logits.weight.detach().view(nc, c),
+                                         stage.instance_logits.bias.detach(),
+                                         stage.detail_logits.weight.detach().view(nc, c),
+                                         stage.detail_logits.bias.detach(), roi_labels[n_cont:n_here])
+                parts.append(ip)
+            preds.append(parts[0] if len(parts) == 1 else torch.cat(parts))
+        n_last = n_ge[len(self.stages)]
+        s_last = self.stage_sup_size[-1]
+        if n_last == 0:
+            preds.append(instance_feats.new_zeros((0, 1, s_last, s_last)))
+            return preds
+        lab = roi_labels[:n_last]
+        if self.stage_num_classes[-1] == 1:
+            lab = lab.clamp(max=0)
+        nc = self.stage_num_classes[-1]
+        c = self.final_instance_logits.in_channels
+        ip, _ = ops.class_logits(instance_feats, self.final_instance_logits.weight.detach().view(nc, c),
+                                 self.final_instance_logits.bias.detach(),
+                                 self.final_detail_logits.weight.detach().view(nc, c),
+                                 self.final_detail_logits.bias.detach(), lab)
+        if not self.pre_upsample_last_stage:
+            ip = ops.upsample2x(ip, align_corners=True)
+        preds.append(ip)
+        return preds
+
     # ------------------------------------------------ callers either side of the path
     def get_targets(self, pos_bboxes_list, pos_assigned_gt_inds_list, gt_masks_list):
         """dynamask_head.py:246-271 with the GT bitmaps already on the device

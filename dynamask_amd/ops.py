@@ -492,13 +492,19 @@ def threshold_ge(x, thr):
     return out
 
 
-def paste_masks(masks, boxes, img_h, img_w, threshold=0.5, apply_sigmoid=False):
-    """masks [N, 1, h, w] or [N, h, w], boxes [N, 4] -> bool [N, img_h, img_w]."""
+def paste_masks(masks, boxes, img_h, img_w, threshold=0.5, apply_sigmoid=False, out=None):
+    """masks [N, 1, h, w] or [N, h, w], boxes [N, 4] -> bool [N, img_h, img_w].
+    ``out``: optional contiguous uint8 [N, img_h, img_w] slab to paste into (a slice of a
+    larger canvas when detections are pasted bucket by bucket)."""
     _chk(masks, 'masks')
     _chk(boxes, 'boxes')
     N = masks.shape[0]
     mh, mw = masks.shape[-2:]
-    out = torch.empty((N, img_h, img_w), device=masks.device, dtype=torch.uint8)
+    if out is None:
+        out = torch.empty((N, img_h, img_w), device=masks.device, dtype=torch.uint8)
+    else:
+        _chk(out, 'out', torch.uint8)
+        assert tuple(out.shape) == (N, img_h, img_w)
     check(lib().dm_paste_masks(_p(masks), _p(boxes), N, mh, mw, int(img_h), int(img_w), float(threshold),
                                1 if apply_sigmoid else 0, _p(out), _stream()), 'dm_paste_masks')
     return out.view(torch.bool) if N > 0 else out.bool()

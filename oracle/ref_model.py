@@ -231,6 +231,23 @@ def boundary_merge(stage_instance_preds):
     return preds[-1]
 
 
+def dynamic_exit_logits(stage_instance_preds, exits, merge=True):
+    """Per-RoI early exit (the reference keeps it as commented-out
+    code, roi_heads/dynamask_roi_head.py:160-204: every exit is computed for every RoI and
+    RoI j takes the prediction of exit ``mask_labels[j]``).  RoIs are independent, so the
+    dynamic path must reproduce, for RoI j with exit e, the fixed path's exit-e logits;
+    with ``merge`` the boundary-aware merge of the live simple_test_mask (:138-149) is
+    applied up to that exit (28 -> ... -> S_e; the 14x14 exit stays raw, Quirk Q8).
+    Returns a list of [1, S_e, S_e] tensors in RoI order."""
+    out = []
+    for j, e in enumerate(int(v) for v in exits):
+        if e == 0 or not merge:
+            out.append(stage_instance_preds[e][j].clone())
+        else:
+            out.append(boundary_merge([None] + [p[j:j + 1] for p in stage_instance_preds[1:e + 1]])[0])
+    return out
+
+
 def mask_forward_train(sd, fpn_feats, rois, roi_labels, stage_targets, U, **kw):
     """DynaMaskRoIHead._mask_forward_train minus target generation --
     roi_heads/dynamask_roi_head.py:48-73.  Returns (loss_masks, mask_labels,

@@ -87,3 +87,23 @@ def test_carafe_uniform_kernel_is_box_filter():
     box = F.avg_pool2d(F.pad(x, (2, 2, 2, 2)), 5, stride=1)
     exp = box.repeat_interleave(2, 2).repeat_interleave(2, 3)
     assert torch.allclose(out, exp, atol=1e-6)
+
+
+def test_dynamic_exit_selection_restates_the_commented_reference_path():
+    """dynamask_roi_head.py:160-204 (commented out there): RoI j takes exit mask_labels[j];
+    with merge, exit 3 must coincide with the live boundary-merge path."""
+    import torch
+    from oracle import ref_model
+    g = torch.Generator().manual_seed(0)
+    ips = [torch.randn(5, 1, s, s, generator=g) for s in (14, 28, 56, 112)]
+    exits = torch.tensor([3, 0, 2, 1, 3])
+    raw = ref_model.dynamic_exit_logits(ips, exits, merge=False)
+    for j, e in enumerate(exits.tolist()):
+        assert torch.equal(raw[j], ips[e][j])
+    merged = ref_model.dynamic_exit_logits(ips, exits, merge=True)
+    full = ref_model.boundary_merge(ips)
+    assert torch.equal(merged[0], full[0]) and torch.equal(merged[4], full[4])
+    assert torch.equal(merged[1], ips[0][1]) and torch.equal(merged[3], ips[1][3])
+    assert merged[2].shape == (1, 56, 56)
+    two = ref_model.boundary_merge([None, ips[1][2:3], ips[2][2:3]])
+    assert torch.equal(merged[2], two[0])
