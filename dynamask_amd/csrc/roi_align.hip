@@ -328,6 +328,333 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Forward kernel for small output grids (P*P <= 256: the 14x14 mask and 7x7 bbox
+// extractions).  Workgroup = one RoI x CT channels, thread = one output bin.
+//
+//  * The RoI's footprint is staged in LDS **channel-quad interleaved**:
+//    tile[quad][row][col] is a float4 holding 4 consecutive channels of one feature
+//    pixel, so ONE ds_read_b128 fetches a tap for 4 channels and adjacent lanes read
+//    adjacent 16-byte words.  The quad plane has a compile-time size (PLANE_PX pixels):
+//    channel offsets and the column offsets of a stencil row are instruction immediates.
+//  * **Merged stencil.**  A bin's g x g bilinear samples are at most one pixel apart, so
+//    they touch at most (g+1) x (g+1) feature pixels; their 4*g*g tap weights are summed
+//    per pixel ONCE per thread (separable: Wy[r] * Wx[c], already divided by g*g) and the
+//    channel loop reads (g+1)^2 taps instead of 4*g*g (9 vs 16 at g = 2, 25 vs 64 at
+//    g = 4) -- the kernel is LDS-read bound, so this is the lever.  Grids above 4 (clipped
+//    slivers: 200 feature rows x 4 columns) use a run-time loop over samples.
+//  * The tile keeps G extra rows/columns past the last low tap (clamped duplicates at the
+//    map border): stencil cells whose weight is 0 must still read finite values.
+//  * Staging is branch-free (clamped addresses, all 16-byte row loads of a batch in
+//    flight at once) and double buffered: the next channel batch is fetched before the
+//    current one is sampled and committed to the other LDS buffer after it -- one barrier
+//    per batch.
+// Footprints above 2048 pixels (only possible without the FPN level map) take the
+// direct global path inside the same launch.
+constexpr int kTileFloats4 = 4096;   // float4 words of LDS per workgroup (64 KB): 2 buffers x NQ x PLANE_PX
+
+struct TileGeom {
+  int fy0, fx0, FH, FWq, pitch;
+};
+
+// One axis of the merged stencil: low index L of the first valid sample and the summed
+// weights of pixels L .. L+G.  axis_sample zeroes both weights of a void sample.
+template <int G>
+__device__ __forceinline__ void axis_stencil(float start, float bin, int g, int p, int size, int& L, float (&Wt)[G + 1]) {
+  int lo[G];
+  float wl[G], wh[G];
+  L = 0x7fffffff;
+#pragma unroll
+  for (int i = 0; i < G; ++i) {
+    int hi;
+    lo[i] = 0;
+    wl[i] = wh[i] = 0.f;
+    if (i < g) axis_sample(start, bin, g, p, i, size, lo[i], hi, wl[i], wh[i]);
+    const bool valid = (wl[i] != 0.f) || (wh[i] != 0.f);
+    if (valid) L = min(L, lo[i]);
+  }
+  if (L == 0x7fffffff) L = 0;
+#pragma unroll
+  for (int r = 0; r <= G; ++r) Wt[r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < G; ++i) {
+    const int d = lo[i] - L;          // 0 .. G-1 for valid samples (samples are <= 1 pixel apart)
+#pragma unroll
+    for (int r = 0; r <= G; ++r) {
+      if (r < G) Wt[r] += (d == r) ? wl[i] : 0.f;
+      if (r > 0) Wt[r] += (d == r - 1) ? wh[i] : 0.f;
+    }
+  }
+}
+
+template <int G>
+__device__ __forceinline__ void roi_tile_fwd(const RoiArgs& a, const float* __restrict__ fimg, int Hl, int Wl, float sh,
+                                             float sw, float bh, float bw, int gh, int gw, float inv_count, int k,
+                                             int c0, int c1, const TileGeom tg, float4* __restrict__ lds) {
+  constexpr int kBufPx = kTileFloats4 / 2;            // pixel-quads (float4 words) per LDS buffer
+  constexpr int S = G + 1;                            // merged stencil is S x S (G == 0: run-time grid)
+  const int tid = threadIdx.x;
+  const int P = a.P, PP = P * P;
+  const bool active = tid < PP;
+  const int ph = active ? tid / P : 0;
+  const int pw = active ? tid - ph * P : 0;
+  const int plane_px = tg.FH * tg.pitch;              // <= kBufPx (checked by the caller)
+  // as many channel quads per batch as the buffer holds: the staging is bound by bytes in
+  // flight, so every fetch should fill the 2 x 4 x 16-byte loads each thread can issue
+  const int NQ = min(kBufPx / plane_px, (c1 - c0) >> 2);      // the caller guarantees C % 4 == 0
+  const int NCB = NQ * 4;
+
+  // ---- stencils (channel independent).  Only 2*P of them are distinct (one per output
+  // row and per output column): 2*P threads build them into a table in the -- still
+  // unused -- second LDS buffer, every thread then picks its row and column entry.
+  int base = 0;
+  float W[G > 0 ? S * S : 1];
+  if (G > 0) {
+    constexpr int GG = G > 0 ? G : 1;
+    float* tab = reinterpret_cast<float*>(lds + kBufPx);     // [2][P][8]: {L, W0 .. WG}
+    if (tid < 2 * P) {
+      const bool xa = tid >= P;
+      const int p = xa ? tid - P : tid;
+      int L;
+      float Wt[GG + 1];
+      axis_stencil<GG>(xa ? sw : sh, xa ? bw : bh, xa ? gw : gh, p, xa ? Wl : Hl, L, Wt);
+      float* e = tab + tid * 8;
+      e[0] = __int_as_float(L);
+#pragma unroll
+      for (int r = 0; r <= GG; ++r) e[1 + r] = xa ? Wt[r] : Wt[r] * inv_count;
+    }
+    __syncthreads();
+    const float* ey = tab + ph * 8;
+    const float* ex = tab + (P + pw) * 8;
+    const int Ly = __float_as_int(ey[0]), Lx = __float_as_int(ex[0]);
+    // cells past the tile's last column wrap into the next staged row: finite, weight 0
+    base = min(max(Ly - tg.fy0, 0), tg.FH - S - 1) * tg.pitch + min(max(Lx - tg.fx0, 0), tg.pitch - 1);
+#pragma unroll
+    for (int r = 0; r < S; ++r)
+#pragma unroll
+      for (int c = 0; c < S; ++c) W[G > 0 ? r * S + c : 0] = ey[1 + r] * ex[1 + c];
+    // (the second buffer is first written after the barrier that follows the first commit)
+  }
+
+  // ---- staging.  Item = one tile pixel of one channel quad: 4 dword loads (the 4 channel
+  // planes; consecutive lanes read consecutive pixels -> coalesced) and ONE 16-byte LDS
+  // store, already channel-interleaved -- no register transposition.  The tile layout
+  // [quad][row][col] makes the LDS slot of item `idx` simply `idx`; which pixel it is does
+  // not depend on the batch, so its global byte offset is computed once.  Columns past the
+  // map's last one are clamped duplicates (weight 0), like rows.
+  constexpr int IPT = kBufPx / 256;              // items per thread and batch: 8
+  const size_t plane = (size_t)Hl * Wl;
+  int voff[IPT];
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) {
+    const int idx = tid + i * 256;
+    const int idc = idx < NQ * plane_px ? idx : 0;
+    const int q = idc / plane_px;
+    const int rem = idc - q * plane_px;
+    const int r = rem / tg.pitch;
+    const int x = rem - r * tg.pitch;
+    const int gy = min(tg.fy0 + r, Hl - 1);
+    const int gx = min(tg.fx0 + x, Wl - 1);
+    voff[i] = (q * 4 * (int)plane + gy * Wl + gx) * 4;       // bytes; the launcher checked they fit 31 bits
+  }
+  float pf[IPT][4];
+  auto fetch = [&](int cb) {
+    const int live = min(NQ, (c1 - cb) >> 2) * plane_px;     // items of this batch (short last batch)
+    const char* b0 = reinterpret_cast<const char*>(fimg + (size_t)cb * plane);   // uniform bases: the 4 channel
+    const char* b1 = b0 + plane * 4;                                              // planes of a quad
+    const char* b2 = b1 + plane * 4;
+    const char* b3 = b2 + plane * 4;
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+      const int vo = (tid + i * 256 < live) ? voff[i] : 0;   // surplus items re-read pixel 0 (never committed)
+      pf[i][0] = *reinterpret_cast<const float*>(b0 + vo);
+      pf[i][1] = *reinterpret_cast<const float*>(b1 + vo);
+      pf[i][2] = *reinterpret_cast<const float*>(b2 + vo);
+      pf[i][3] = *reinterpret_cast<const float*>(b3 + vo);
+    }
+  };
+  auto commit = [&](int cb, int buf) {
+    const int live = min(NQ, (c1 - cb) >> 2) * plane_px;
+    float4* dst = lds + buf * kBufPx + tid;
+#pragma unroll
+    for (int i = 0; i < IPT; ++i)
+      if (tid + i * 256 < live) dst[i * 256] = make_float4(pf[i][0], pf[i][1], pf[i][2], pf[i][3]);
+  };
+
+  auto sample = [&](int cb, int buf) {
+    if (active) {
+      const int nq = min(NQ, (c1 - cb) >> 2);
+      const float4* t = lds + buf * kBufPx;
+      float* o = a.out + ((size_t)k * a.C + cb) * PP + tid;
+      if (G == 0) {
+        // run-time grid (slivers): samples outermost, groups of 4 channel quads accumulate per sample
+        for (int q0 = 0; q0 < nq; q0 += 4) {
+          float4 acc[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int iy = 0; iy < gh; ++iy) {
+            int lo, hi;
+            float yl_w, yh_w;
+            axis_sample(sh, bh, gh, ph, iy, Hl, lo, hi, yl_w, yh_w);
+            const int yo = min(max(lo - tg.fy0, 0), tg.FH - 3) * tg.pitch;
+            yl_w *= inv_count;
+            yh_w *= inv_count;
+            for (int ix = 0; ix < gw; ++ix) {
+              float xl_w, xh_w;
+              axis_sample(sw, bw, gw, pw, ix, Wl, lo, hi, xl_w, xh_w);
+              const int xo = min(max(lo - tg.fx0, 0), tg.pitch - 1);
+              const float w0 = yl_w * xl_w, w1 = yl_w * xh_w, w2 = yh_w * xl_w, w3 = yh_w * xh_w;
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const float4* tp = t + min(q0 + u, nq - 1) * plane_px + yo + xo;
+                const float4 v1 = tp[0], v2 = tp[1], v3 = tp[tg.pitch], v4 = tp[tg.pitch + 1];
+                acc[u].x += w0 * v1.x + w1 * v2.x + w2 * v3.x + w3 * v4.x;
+                acc[u].y += w0 * v1.y + w1 * v2.y + w2 * v3.y + w3 * v4.y;
+                acc[u].z += w0 * v1.z + w1 * v2.z + w2 * v3.z + w3 * v4.z;
+                acc[u].w += w0 * v1.w + w1 * v2.w + w2 * v3.w + w3 * v4.w;
+              }
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int q = q0 + u;
+            const int cq = cb + 4 * q;
+            if (q < nq) {
+              if (cq < c1) o[(size_t)(4 * q) * PP] = acc[u].x;
+              if (cq + 1 < c1) o[(size_t)(4 * q + 1) * PP] = acc[u].y;
+              if (cq + 2 < c1) o[(size_t)(4 * q + 2) * PP] = acc[u].z;
+              if (cq + 3 < c1) o[(size_t)(4 * q + 3) * PP] = acc[u].w;
+            }
+          }
+        }
+      } else {
+        constexpr int kUnrollQ = (S >= 4) ? 1 : 2;
+#pragma unroll kUnrollQ
+        for (int q = 0; q < nq; ++q) {
+          const int cq = cb + 4 * q;
+          float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4* tq = t + q * plane_px + base;
+#pragma unroll
+          for (int r = 0; r < S; ++r) {
+            const float4* tr = tq + r * tg.pitch;
+#pragma unroll
+            for (int c = 0; c < S; ++c) {
+              const float4 v = tr[c];
+              const float wv = W[G > 0 ? r * S + c : 0];
+              acc.x += wv * v.x;
+              acc.y += wv * v.y;
+              acc.z += wv * v.z;
+              acc.w += wv * v.w;
+            }
+          }
+          o[(size_t)(4 * q) * PP] = acc.x;
+          if (cq + 1 < c1) o[(size_t)(4 * q + 1) * PP] = acc.y;
+          if (cq + 2 < c1) o[(size_t)(4 * q + 2) * PP] = acc.z;
+          if (cq + 3 < c1) o[(size_t)(4 * q + 3) * PP] = acc.w;
+        }
+      }
+    }
+  };
+
+  // Software pipeline over channel batches.  The loop body is unconditional (the last
+  // batch is peeled): a conditional prefetch would merge its registers through phi copies
+  // that the compiler places right behind the loads, i.e. it would wait for them at once.
+  fetch(c0);
+  commit(c0, 0);
+  __syncthreads();
+  int buf = 0;
+  int cb = c0;
+  if (cb + NCB < c1) {
+    do {     // bottom-tested on purpose: a top-tested loop gets rotated and the prefetch duplicated into the latch
+      fetch(cb + NCB);
+      sample(cb, buf);
+      commit(cb + NCB, buf ^ 1);
+      __syncthreads();
+      cb += NCB;
+      buf ^= 1;
+    } while (cb + NCB < c1);
+  }
+  sample(cb, buf);
+}
+
+__global__ __launch_bounds__(256, 2) void roi_align_tile_kernel(RoiArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float4 lds4[];
+  const int chunks = (a.C + a.CT - 1) / a.CT;
+  const int k = blockIdx.x / chunks;
+  const int chunk = blockIdx.x - k * chunks;
+  const int c0 = chunk * a.CT;
+  const int c1 = min(c0 + a.CT, a.C);
+  const float* r = a.rois + (size_t)k * 5;
+  const int b = (int)r[0];
+  const float x1 = r[1], y1 = r[2], x2 = r[3], y2 = r[4];
+  const int lvl = (a.L > 1) ? roi_level(x1, y1, x2, y2, a.finest, a.L) : 0;
+  if (a.levels && chunk == 0 && threadIdx.x == 0) a.levels[k] = lvl;
+  const bool bad_batch = (b < 0 || b >= a.B);
+  int Hl = a.H[0], Wl = a.W[0];
+  float sc = a.scale[0];
+  const float* flvl = a.feat[0];
+#pragma unroll
+  for (int l = 1; l < DM_MAX_LEVELS; ++l)
+    if (lvl == l) {
+      Hl = a.H[l];
+      Wl = a.W[l];
+      sc = a.scale[l];
+      flvl = a.feat[l];
+    }
+  const float sw = x1 * sc - 0.5f, sh = y1 * sc - 0.5f;
+  const float ew = x2 * sc - 0.5f, eh = y2 * sc - 0.5f;
+  const float rw = ew - sw, rh = eh - sh;
+  const int P = a.P, PP = P * P;
+  const float bh = rh / (float)P, bw = rw / (float)P;
+  const int gh = a.sr > 0 ? a.sr : (int)ceilf(rh / (float)P);
+  const int gw = a.sr > 0 ? a.sr : (int)ceilf(rw / (float)P);
+  const float inv_count = 1.0f / (float)max(gh * gw, 1);
+  const float* fimg = flvl + (bad_batch ? 0 : (size_t)b * a.C * Hl * Wl);
+  if (gh <= 0 || gw <= 0 || bad_batch) {
+    // empty sampling grid (degenerate RoI) / malformed batch index -> zeros
+    for (int i = threadIdx.x; i < (c1 - c0) * PP; i += blockDim.x) a.out[((size_t)k * a.C + c0) * PP + i] = 0.f;
+    return;
+  }
+  {
+    // first / last sample coordinate per axis (the expression of axis_sample at its extremes)
+    const float yf = sh + 0.5f * bh / (float)gh;
+    const float yl = sh + (float)(P - 1) * bh + ((float)(gh - 1) + 0.5f) * bh / (float)gh;
+    const float xf = sw + 0.5f * bw / (float)gw;
+    const float xl = sw + (float)(P - 1) * bw + ((float)(gw - 1) + 0.5f) * bw / (float)gw;
+    const int G = max(gh, gw);
+    // the merged stencil needs samples <= 1 pixel apart (always true for the adaptive grid)
+    const bool merged = G <= 4 && bh <= (float)gh && bw <= (float)gw;
+    const int pad = merged ? G : 1;          // cells past the last low tap (merged stencil: G, per-sample: 1)
+    TileGeom tg;
+    tg.fy0 = min((int)fmaxf(fminf(yf, yl), 0.f), Hl - 1);
+    tg.fx0 = min((int)fmaxf(fminf(xf, xl), 0.f), Wl - 1);
+    const int fy1 = min((int)fmaxf(fmaxf(yf, yl), 0.f), Hl - 1) + pad;
+    const int fx1 = min((int)fmaxf(fmaxf(xf, xl), 0.f), Wl - 1) + pad;
+    tg.FH = fy1 - tg.fy0 + 2;                // + one spare row: stencil cells past the row end wrap into it
+    tg.FWq = (min(fx1, Wl - 1) - tg.fx0 + 1 + 3) >> 2;
+    tg.pitch = tg.FWq * 4;
+    // keep every 16-byte staging load inside its feature row: slide the tile left at the right border
+    if (tg.fx0 + tg.pitch > Wl && tg.pitch <= Wl) tg.fx0 = Wl - tg.pitch;
+    const int px = tg.FH * tg.pitch;
+#define DM_ROI_TILE(GG) roi_tile_fwd<GG>(a, fimg, Hl, Wl, sh, sw, bh, bw, gh, gw, inv_count, k, c0, c1, tg, lds4)
+    // with the FPN level map the footprint stays below ~1700 pixels (a 200 x 4 sliver)
+    if (px <= kTileFloats4 / 2) {
+      if (!merged) DM_ROI_TILE(0);
+      else if (G == 1) DM_ROI_TILE(1);
+      else if (G == 2) DM_ROI_TILE(2);
+      else if (G == 3) DM_ROI_TILE(3);
+      else DM_ROI_TILE(4);
+      return;
+    }
+#undef DM_ROI_TILE
+  }
+  for (int pos = threadIdx.x; pos < PP; pos += blockDim.x) {
+    const int ph = pos / P;
+    const int pw = pos - ph * P;
+    roi_bin_generic<false>(a, fimg, nullptr, Hl, Wl, sh, sw, bh, bw, gh, gw, inv_count, ph, pw, k, c0, c1);
+  }
+}
+
 int fill_args(RoiArgs& a, const int* H, const int* W, const float* spatial_scales, int num_levels, int B, int C,
               const float* rois, int N, int P, int sampling_ratio, float finest_scale) {
   if (!H || !W || !spatial_scales || (!rois && N > 0)) return DM_ERR_INVALID_ARG;
@@ -367,9 +694,17 @@ extern "C" int dm_roi_align_fwd(const float* const* feats, const int* H, const i
   if (N == 0) return DM_OK;
   a.out = out;
   a.levels = levels_out;
-  // The kernel is latency-bound (stage -> barrier -> sample per channel batch), so many small
-  // workgroups beat few fat ones: swept CT in {2..256} x LDS in {4..64} KB on 512 RoIs:
-  // 16 channels / 24 KB is the optimum (0.159 ms; 32/48 KB 0.171 ms; 256/48 KB 0.57 ms).
+  bool tile_ok = P * P <= 256 && C % 4 == 0;
+  for (int l = 0; l < num_levels; ++l) tile_ok = tile_ok && (long long)H[l] * W[l] <= (1 << 23);   // 32-bit staging offsets
+  if (tile_ok) {
+    // 64 channels per workgroup: 2048 workgroups at 512 RoIs (swept 32 .. 256)
+    a.CT = 64;
+    const int chunks = dm_ceil_div(C, a.CT);
+    DM_LAUNCH(roi_align_tile_kernel, dim3(N * chunks), dim3(256), kTileFloats4 * sizeof(float4), (hipStream_t)stream, a);
+    return dm_check_launch();
+  }
+  // Large output grids (56x56 extraction): planar LDS staging where the footprint fits,
+  // direct global taps otherwise; two launches partition the RoIs by sampling-grid class.
   a.CT = (P * P >= 1024) ? 8 : 16;
   a.lds_floats = 6 * 1024;
   const int chunks = dm_ceil_div(C, a.CT);
