@@ -307,7 +307,7 @@ def main():
         ms_r = time_kernel(lambda: ext(feats[:4], rois))
         nbytes = roialign_algorithmic_bytes(rois_c, feats_c)
         ach_r = nbytes / (ms_r * 1e-3) / 1e9
-        result['roofline_roialign'] = {'kernel': 'roi_align_kernel<false,1> + <false,2> (two launches partition the RoIs by sampling grid; P2..P5 -> [512,256,14,14])', 'bound': 'hbm',
+        result['roofline_roialign'] = {'kernel': 'roi_align_tile_kernel (one launch; LDS-staged channel-quad tiles, merged stencils; P2..P5 -> [512,256,14,14])', 'bound': 'hbm',
                                        'achieved': ach_r, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                        'frac': ach_r / PEAK_HBM_GBS, 'traffic': None, 'ms_per_launch': ms_r,
                                        'bytes_per_launch': nbytes}

@@ -335,26 +335,38 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
 //  * The RoI's footprint is staged in LDS **channel-quad interleaved**:
 //    tile[quad][row][col] is a float4 holding 4 consecutive channels of one feature
 //    pixel, so ONE ds_read_b128 fetches a tap for 4 channels and adjacent lanes read
-//    adjacent 16-byte words.  The quad plane has a compile-time size (PLANE_PX pixels):
-//    channel offsets and the column offsets of a stencil row are instruction immediates.
+//    adjacent 16-byte words; the columns of a stencil row are instruction immediates.
 //  * **Merged stencil.**  A bin's g x g bilinear samples are at most one pixel apart, so
 //    they touch at most (g+1) x (g+1) feature pixels; their 4*g*g tap weights are summed
-//    per pixel ONCE per thread (separable: Wy[r] * Wx[c], already divided by g*g) and the
-//    channel loop reads (g+1)^2 taps instead of 4*g*g (9 vs 16 at g = 2, 25 vs 64 at
-//    g = 4) -- the kernel is LDS-read bound, so this is the lever.  Grids above 4 (clipped
-//    slivers: 200 feature rows x 4 columns) use a run-time loop over samples.
-//  * The tile keeps G extra rows/columns past the last low tap (clamped duplicates at the
-//    map border): stencil cells whose weight is 0 must still read finite values.
-//  * Staging is branch-free (clamped addresses, all 16-byte row loads of a batch in
-//    flight at once) and double buffered: the next channel batch is fetched before the
-//    current one is sampled and committed to the other LDS buffer after it -- one barrier
-//    per batch.
-// Footprints above 2048 pixels (only possible without the FPN level map) take the
+//    per pixel once (separable: Wy[r] * Wx[c], already divided by g*g) and the channel
+//    loop reads (g+1)^2 taps instead of 4*g*g (9 vs 16 at g = 2, 25 vs 64 at g = 4) -- the
+//    sampling is LDS-read bound, so this is the lever.  Only 2*P stencils are distinct:
+//    2*P threads build them into an LDS table, every thread multiplies its row and column
+//    entry.  Grids above 4 (clipped slivers: 200 feature rows x 4 columns) and fixed
+//    sampling ratios with samples more than a pixel apart use a run-time loop over samples.
+//  * The tile keeps G rows/columns past the last low tap: stencil cells of weight 0 must
+//    still read finite values.  Those cells, and everything past the map border, are
+//    clamped duplicates of the last weighted row/column -- same cache lines, no traffic.
+//  * Staging: one tile pixel of one channel quad per lane -- 4 coalesced dword loads (the
+//    4 channel planes) and ONE 16-byte LDS store, already interleaved (no register
+//    transposition, no bank conflicts).  The LDS slot of item idx is idx; its global
+//    offset does not depend on the batch and is computed once (multiply-high divisions).
+//  * As many channel quads per batch as a buffer holds (bytes in flight are what the
+//    staging is bound by); double buffered: the next batch is fetched into registers
+//    before the current one is sampled and committed to the other buffer after it -- one
+//    barrier per batch.  The loop is bottom-tested on purpose (see below).
+// Footprints above 1536 pixels (only possible without the FPN level map) take the
 // direct global path inside the same launch.
-constexpr int kTileFloats4 = 4096;   // float4 words of LDS per workgroup (64 KB): 2 buffers x NQ x PLANE_PX
+//
+// Measured (512 RoIs, 1333x800 FPN, P2..P5): 68 us; per-workgroup timeline (s_memtime):
+// setup 0.8 us, staging round trip ~1.8 us under load, 0.7 us of sampling per batch; PMC:
+// VALU 35 % / LDS 25 % busy, L2 hit rate of the staging reads ~32 % (174 MB leave the L2
+// per launch for 91 MB of maps: short unaligned row segments over-fetch 64-byte sectors).
+constexpr int kTileFloats4 = 3072;   // float4 words of LDS per workgroup (48 KB = 2 buffers of 1536 pixel-quads): 3 workgroups per CU
 
 struct TileGeom {
-  int fy0, fx0, FH, FWq, pitch;
+  int fy0, fx0, FH, pitch;   // tile origin (feature pixel), rows, columns
+  int ymax, xmax;            // last row / column that carries weight: cells past it are clamped duplicates
 };
 
 // One axis of the merged stencil: low index L of the first valid sample and the summed
@@ -427,8 +439,7 @@ __device__ __forceinline__ void roi_tile_fwd(const RoiArgs& a, const float* __re
     const float* ey = tab + ph * 8;
     const float* ex = tab + (P + pw) * 8;
     const int Ly = __float_as_int(ey[0]), Lx = __float_as_int(ex[0]);
-    // cells past the tile's last column wrap into the next staged row: finite, weight 0
-    base = min(max(Ly - tg.fy0, 0), tg.FH - S - 1) * tg.pitch + min(max(Lx - tg.fx0, 0), tg.pitch - 1);
+    base = min(max(Ly - tg.fy0, 0), tg.FH - S) * tg.pitch + min(max(Lx - tg.fx0, 0), tg.pitch - S);
 #pragma unroll
     for (int r = 0; r < S; ++r)
 #pragma unroll
@@ -445,16 +456,21 @@ __device__ __forceinline__ void roi_tile_fwd(const RoiArgs& a, const float* __re
   constexpr int IPT = kBufPx / 256;              // items per thread and batch: 8
   const size_t plane = (size_t)Hl * Wl;
   int voff[IPT];
+  // idx -> (quad, row, col) with multiply-high by ceil(2^32 / d): exact for idx * d < 2^32
+  // (idx < 2048, d <= 2048; d >= 4 so the constants fit 32 bits); the two real divisions are uniform
+  const unsigned m_plane = 0xFFFFFFFFu / (unsigned)plane_px + 1u;
+  const unsigned m_pitch = 0xFFFFFFFFu / (unsigned)tg.pitch + 1u;
 #pragma unroll
   for (int i = 0; i < IPT; ++i) {
     const int idx = tid + i * 256;
     const int idc = idx < NQ * plane_px ? idx : 0;
-    const int q = idc / plane_px;
+    const int q = (int)__umulhi((unsigned)idc, m_plane);
     const int rem = idc - q * plane_px;
-    const int r = rem / tg.pitch;
+    const int r = (int)__umulhi((unsigned)rem, m_pitch);
     const int x = rem - r * tg.pitch;
-    const int gy = min(tg.fy0 + r, Hl - 1);
-    const int gx = min(tg.fx0 + x, Wl - 1);
+    // cells that only pad the stencil repeat the last weighted row / column: same cache lines, no extra traffic
+    const int gy = min(tg.fy0 + r, tg.ymax);
+    const int gx = min(tg.fx0 + x, tg.xmax);
     voff[i] = (q * 4 * (int)plane + gy * Wl + gx) * 4;       // bytes; the launcher checked they fit 31 bits
   }
   float pf[IPT][4];
@@ -496,13 +512,13 @@ __device__ __forceinline__ void roi_tile_fwd(const RoiArgs& a, const float* __re
             int lo, hi;
             float yl_w, yh_w;
             axis_sample(sh, bh, gh, ph, iy, Hl, lo, hi, yl_w, yh_w);
-            const int yo = min(max(lo - tg.fy0, 0), tg.FH - 3) * tg.pitch;
+            const int yo = min(max(lo - tg.fy0, 0), tg.FH - 2) * tg.pitch;
             yl_w *= inv_count;
             yh_w *= inv_count;
             for (int ix = 0; ix < gw; ++ix) {
               float xl_w, xh_w;
               axis_sample(sw, bw, gw, pw, ix, Wl, lo, hi, xl_w, xh_w);
-              const int xo = min(max(lo - tg.fx0, 0), tg.pitch - 1);
+              const int xo = min(max(lo - tg.fx0, 0), tg.pitch - 2);
               const float w0 = yl_w * xl_w, w1 = yl_w * xh_w, w2 = yh_w * xl_w, w3 = yh_w * xh_w;
 #pragma unroll
               for (int u = 0; u < 4; ++u) {
@@ -577,7 +593,7 @@ __device__ __forceinline__ void roi_tile_fwd(const RoiArgs& a, const float* __re
   sample(cb, buf);
 }
 
-__global__ __launch_bounds__(256, 2) void roi_align_tile_kernel(RoiArgs a) {
+__global__ __launch_bounds__(256, 3) void roi_align_tile_kernel(RoiArgs a) {
   extern __shared__ __attribute__((aligned(16))) float4 lds4[];
   const int chunks = (a.C + a.CT - 1) / a.CT;
   const int k = blockIdx.x / chunks;
@@ -628,13 +644,12 @@ __global__ __launch_bounds__(256, 2) void roi_align_tile_kernel(RoiArgs a) {
     TileGeom tg;
     tg.fy0 = min((int)fmaxf(fminf(yf, yl), 0.f), Hl - 1);
     tg.fx0 = min((int)fmaxf(fminf(xf, xl), 0.f), Wl - 1);
-    const int fy1 = min((int)fmaxf(fmaxf(yf, yl), 0.f), Hl - 1) + pad;
-    const int fx1 = min((int)fmaxf(fmaxf(xf, xl), 0.f), Wl - 1) + pad;
-    tg.FH = fy1 - tg.fy0 + 2;                // + one spare row: stencil cells past the row end wrap into it
-    tg.FWq = (min(fx1, Wl - 1) - tg.fx0 + 1 + 3) >> 2;
-    tg.pitch = tg.FWq * 4;
-    // keep every 16-byte staging load inside its feature row: slide the tile left at the right border
-    if (tg.fx0 + tg.pitch > Wl && tg.pitch <= Wl) tg.fx0 = Wl - tg.pitch;
+    const int ylast = min((int)fmaxf(fmaxf(yf, yl), 0.f), Hl - 1);     // last low tap
+    const int xlast = min((int)fmaxf(fmaxf(xf, xl), 0.f), Wl - 1);
+    tg.FH = ylast + pad - tg.fy0 + 1;
+    tg.pitch = xlast + pad - tg.fx0 + 1;
+    tg.ymax = min(ylast + 1, Hl - 1);
+    tg.xmax = min(xlast + 1, Wl - 1);
     const int px = tg.FH * tg.pitch;
 #define DM_ROI_TILE(GG) roi_tile_fwd<GG>(a, fimg, Hl, Wl, sh, sw, bh, bw, gh, gw, inv_count, k, c0, c1, tg, lds4)
     // with the FPN level map the footprint stays below ~1700 pixels (a 200 x 4 sliver)
@@ -697,8 +712,9 @@ extern "C" int dm_roi_align_fwd(const float* const* feats, const int* H, const i
   bool tile_ok = P * P <= 256 && C % 4 == 0;
   for (int l = 0; l < num_levels; ++l) tile_ok = tile_ok && (long long)H[l] * W[l] <= (1 << 23);   // 32-bit staging offsets
   if (tile_ok) {
-    // 64 channels per workgroup: 2048 workgroups at 512 RoIs (swept 32 .. 256)
-    a.CT = 64;
+    // 32 channels per workgroup (swept 16 .. 256 at 128 .. 2048 RoIs): more channels amortise the
+    // per-workgroup setup, fewer shorten the chain of dependent staging batches of the large RoIs
+    a.CT = 32;
     const int chunks = dm_ceil_div(C, a.CT);
     DM_LAUNCH(roi_align_tile_kernel, dim3(N * chunks), dim3(256), kTileFloats4 * sizeof(float4), (hipStream_t)stream, a);
     return dm_check_launch();

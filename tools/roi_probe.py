@@ -6,7 +6,24 @@ from dynamask_amd import ops, synth
 dev = torch.device('cuda')
 N = int(os.environ.get('RP_N', 512))
 feats = [f.to(dev) for f in synth.make_fpn(1, 800, 1333, 256, seed=0)]
-rois = synth.make_rois(1, N, 800, 1333, seed=1).to(dev)
+rois = synth.make_rois(1, N, 800, 1333, seed=1)
+if os.environ.get('RP_SORT'):
+    import math
+    def key(r):
+        x1, y1, x2, y2 = r[1:].tolist()
+        s = math.sqrt(max((x2 - x1) * (y2 - y1), 1e-6))
+        lvl = min(3, max(0, int(math.floor(math.log2(s / 56 + 1e-6)))))
+        cx, cy = int((x1 + x2) / 2) >> 4, int((y1 + y2) / 2) >> 4
+        m = 0
+        for b in range(8):
+            m |= ((cx >> b) & 1) << (2 * b) | ((cy >> b) & 1) << (2 * b + 1)
+        return (lvl, m)
+    order = sorted(range(N), key=lambda i: key(rois[i]))
+    if os.environ.get('RP_SORT') == '8':      # deal the sorted list into 8 contiguous groups, interleaved: RoI j -> group j % 8
+        g = [order[i * (N // 8):(i + 1) * (N // 8)] for i in range(8)]
+        order = [g[j % 8][j // 8] for j in range(N)]
+    rois = rois[order].contiguous()
+rois = rois.to(dev)
 def t(fn, iters=30, warmup=5):
     for _ in range(warmup): fn()
     torch.cuda.synchronize()
