@@ -433,8 +433,21 @@ def main():
                 torch.cuda.synchronize()
                 t_e2e = (time.perf_counter() - t0) / 5 * 1e3
                 t_mask = time_kernel(lambda: head.simple_test_mask_logits(feats, det, dl), iters=10, warmup=2)
+
+                def e2e_rle():
+                    f = bb(img)
+                    return head.simple_test_mask([t.contiguous() for t in f], meta, det, dl, encode=True)
+                for _ in range(2):
+                    e2e_rle()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    e2e_rle()        # masks leave the device as COCO RLE (device encoder), not as bitmaps
+                torch.cuda.synchronize()
+                t_e2e_rle = (time.perf_counter() - t0) / 5 * 1e3
             result['extra']['end_to_end'] = {
                 'backbone_fpn_ms': t_bb, 'mask_path_100dets_ms': t_mask, 'backbone_plus_mask_path_ms': t_e2e,
+                'backbone_plus_mask_path_rle_ms': t_e2e_rle, 'img_per_s_rle': 1e3 / t_e2e_rle,
                 'img_per_s': 1e3 / t_e2e,
                 'what': 'stock PyTorch-ROCm/MIOpen ResNet-50+FPN fp32 (random weights, out of scope) + this repo\'s mask path '
                         'for 100 detections incl. merge, paste and D2H of the bool masks; RPN / bbox head / NMS not included'}

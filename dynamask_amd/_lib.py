@@ -4,7 +4,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdynamask_hip.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -44,6 +44,10 @@ SIGNATURES = {
     'dm_deform_col2im_coord': ([_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp], _c_int),
     'dm_dcn_weight_permute': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp], _c_int),
     'dm_bn_relu_maxpool_bwd': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_float, _vp, _vp, _vp, _vp, _vp], _c_int),
+    'dm_rle_scratch_ints': ([_c_int, _c_int, _c_int], ctypes.c_longlong),
+    'dm_rle_encode_canvas': ([_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp], _c_int),
+    'dm_paste_rle': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp], _c_int),
+    'dm_rle_string': ([_vp, _c_int, ctypes.c_longlong, ctypes.c_char_p, ctypes.c_longlong], ctypes.c_longlong),
     'dm_sgd_momentum_step': ([_vp, _vp, _vp, ctypes.c_longlong, _c_float, _c_float, _c_float, _c_float, _c_int, _vp], _c_int),
     'dm_mask_target_rois': ([_vp, _vp, _c_int, _c_float, _c_float, _vp, _vp], _c_int),
     'dm_threshold_ge': ([_vp, ctypes.c_longlong, _c_float, _vp, _vp], _c_int),

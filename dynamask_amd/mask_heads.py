@@ -356,6 +356,31 @@ class DynaMaskHead(nn.Module):
         return [im[i] for i in range(len(im))]
 
 
+    def get_seg_rles(self, mask_pred, det_bboxes, det_labels, rcnn_test_cfg, ori_shape, scale_factor, rescale):
+        """``get_seg_masks`` followed by ``encode_mask_results`` (dynamask_head.py:279-342 +
+        core/mask/utils.py:36-63) without the bitmaps: paste, threshold and run-length
+        encoding run on the device, only run boundaries are copied to the host.  Returns one
+        COCO RLE dict per detection -- what ``mask_util.encode(np.array(m[:, :, None],
+        order='F'))[0]`` yields for the bitmap ``get_seg_masks`` would have returned."""
+        import numpy as np
+        bboxes = det_bboxes[:, :4]
+        if rescale:
+            img_h, img_w = ori_shape[:2]
+        else:
+            img_h = int(np.round(ori_shape[0] * scale_factor).astype(np.int32))
+            img_w = int(np.round(ori_shape[1] * scale_factor).astype(np.int32))
+            scale_factor = 1.0
+        if not isinstance(scale_factor, (float, torch.Tensor)):
+            scale_factor = bboxes.new_tensor(scale_factor)
+        bboxes = (bboxes / scale_factor).contiguous()
+        threshold = rcnn_test_cfg.mask_thr_binary
+        if threshold < 0:
+            raise NotImplementedError('visualisation mode (mask_thr_binary < 0) is not on the path')
+        if mask_pred.shape[1] > 1:
+            mask_pred = mask_pred[range(len(mask_pred)), det_labels][:, None]
+        return ops.paste_rle(mask_pred.contiguous(), bboxes, img_h, img_w, threshold, apply_sigmoid=True)
+
+
 # ---------------------------------------------------------------- FCN mask head
 @UPSAMPLE_LAYERS.register_module(name='deconv')
 class _Deconv(nn.Module):

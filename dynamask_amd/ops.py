@@ -90,6 +90,87 @@ def roi_align_backward(grad_out, feat_shapes, rois, output_size, spatial_scales,
     return grads
 
 
+# --------------------------------------------------------------- RLE (after the path, 8f rank 2)
+def _rle_collect(N, img_h, img_w, runs, start, positions, launch, capacity):
+    """Shared tail of the two encoders: read the run totals, re-run once with a larger
+    buffer if the boundaries did not fit, copy exactly the used part of `positions`, build
+    the COCO dicts ({'size': [h, w], 'counts': bytes}, what pycocotools' encode returns)."""
+    import ctypes as C
+    start_h = start.cpu()                        # synchronises the stream
+    total = int(start_h[N])
+    if total > capacity:
+        positions = torch.empty((total,), device=runs.device, dtype=torch.int32)
+        launch(positions, total)
+        start_h = start.cpu()
+    pos_h = torch.empty((max(total, 1),), dtype=torch.int32, pin_memory=True)
+    if total > 0:
+        pos_h[:total].copy_(positions[:total], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+    base = pos_h.data_ptr()
+    L = lib()
+    out = []
+    cap = 64
+    buf = C.create_string_buffer(cap)
+    for n in range(N):
+        s0, s1 = int(start_h[n]), int(start_h[n + 1])
+        need = (s1 - s0 + 1) * 7             # <= 7 characters per count (31-bit values)
+        if need > cap:
+            cap = need
+            buf = C.create_string_buffer(cap)
+        ln = L.dm_rle_string(C.c_void_p(base + 4 * s0), s1 - s0, img_h * img_w, buf, cap)
+        if ln < 0:
+            raise RuntimeError('dm_rle_string: buffer too small')
+        out.append({'size': [int(img_h), int(img_w)], 'counts': buf.raw[:ln]})
+    return out
+
+
+def rle_encode(canvas):
+    """uint8/bool [N, h, w] device bitmaps -> list of COCO RLE dicts (device encoder)."""
+    if canvas.dtype == torch.bool:
+        canvas = canvas.view(torch.uint8)
+    _chk(canvas, 'canvas', torch.uint8)
+    N, h, w = canvas.shape
+    if N == 0:
+        return []
+    dev = canvas.device
+    scratch = torch.empty((lib().dm_rle_scratch_ints(N, h, w),), device=dev, dtype=torch.int32)
+    runs = torch.empty((N,), device=dev, dtype=torch.int32)
+    start = torch.empty((N + 1,), device=dev, dtype=torch.int32)
+    capacity = max(4096, N * 4 * (h + w))
+
+    def launch(positions, cap):
+        check(lib().dm_rle_encode_canvas(_p(canvas), N, h, w, _p(scratch), _p(runs), _p(start), _p(positions), cap,
+                                         _stream()), 'dm_rle_encode_canvas')
+    positions = torch.empty((capacity,), device=dev, dtype=torch.int32)
+    launch(positions, capacity)
+    return _rle_collect(N, h, w, runs, start, positions, launch, capacity)
+
+
+def paste_rle(masks, boxes, img_h, img_w, threshold=0.5, apply_sigmoid=False):
+    """Paste + threshold + RLE in one go: the [N, img_h, img_w] canvas is never written and only
+    the run boundaries cross PCIe.  Same pixel arithmetic as ``paste_masks``."""
+    _chk(masks, 'masks')
+    _chk(boxes, 'boxes')
+    N = masks.shape[0]
+    if N == 0:
+        return []
+    mh, mw = masks.shape[-2:]
+    dev = masks.device
+    img_h, img_w = int(img_h), int(img_w)
+    scratch = torch.empty((lib().dm_rle_scratch_ints(N, img_h, img_w),), device=dev, dtype=torch.int32)
+    runs = torch.empty((N,), device=dev, dtype=torch.int32)
+    start = torch.empty((N + 1,), device=dev, dtype=torch.int32)
+    capacity = max(4096, N * 4 * (img_h + img_w))
+
+    def launch(positions, cap):
+        check(lib().dm_paste_rle(_p(masks), _p(boxes), N, mh, mw, img_h, img_w, float(threshold),
+                                 1 if apply_sigmoid else 0, _p(scratch), _p(runs), _p(start), _p(positions), cap,
+                                 _stream()), 'dm_paste_rle')
+    positions = torch.empty((capacity,), device=dev, dtype=torch.int32)
+    launch(positions, capacity)
+    return _rle_collect(N, img_h, img_w, runs, start, positions, launch, capacity)
+
+
 # --------------------------------------------------------------- convolutions
 def packed_cout(cout):
     return lib().dm_conv_packed_cout(int(cout))

@@ -318,8 +318,10 @@ class DynaMaskRoIHead(nn.Module):
             segm_result[c].append(segm)
         return segm_result
 
-    def simple_test_mask(self, x, img_metas, det_bboxes, det_labels, rescale=False):
-        """dynamask_roi_head.py:117-158 -> per-class lists of (h, w) bool masks."""
+    def simple_test_mask(self, x, img_metas, det_bboxes, det_labels, rescale=False, encode=False):
+        """dynamask_roi_head.py:117-158 -> per-class lists of (h, w) bool masks.
+        ``encode=True`` (extension): per-class lists of COCO RLE dicts instead, i.e. the result
+        after the caller's ``encode_mask_results`` (apis/test.py:52-57), produced on the device."""
         ori_shape = img_metas[0]['ori_shape']
         scale_factor = img_metas[0]['scale_factor']
         num_classes = self.mask_head.stage_num_classes[0]
@@ -330,7 +332,8 @@ class DynaMaskRoIHead(nn.Module):
             scale_factor = torch.from_numpy(scale_factor).to(det_bboxes.device)
         _bboxes = det_bboxes[:, :4] * scale_factor if rescale else det_bboxes
         merged = self.simple_test_mask_logits(x, _bboxes, det_labels)
-        segs = self.mask_head.get_seg_masks(merged, _bboxes, det_labels, self.test_cfg, ori_shape, scale_factor, rescale)
+        to_segs = self.mask_head.get_seg_rles if encode else self.mask_head.get_seg_masks
+        segs = to_segs(merged, _bboxes, det_labels, self.test_cfg, ori_shape, scale_factor, rescale)
         for c, segm in zip(det_labels.tolist(), segs):
             segm_result[c].append(segm)
         return segm_result

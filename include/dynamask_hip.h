@@ -267,6 +267,25 @@ int dm_threshold_ge(const float* x, long long count, float thr, float* out, dm_s
 int dm_paste_masks(const float* masks, const float* boxes, int N, int mask_h, int mask_w, int img_h, int img_w,
                    float threshold, int apply_sigmoid, uint8_t* out, dm_stream_t stream);
 
+/* K19  COCO run-length encoding on the device.
+ * replaces: encode_mask_results (mmdet/core/mask/utils.py:36-63: pycocotools rleEncode of a
+ * column-major host copy of every bitmap) and, in the fused form, the [N, img_h, img_w]
+ * canvas of get_seg_masks (mask_heads/dynamask_head.py:325-342) together with its
+ * device->host copy.  Outputs: mask_runs[n] = number of run boundaries of mask n,
+ * mask_start[n] (N+1 entries) = offset of its boundaries in `positions` (packed, column-major
+ * pixel indices j = x*img_h + y where the value changes; the value before j = 0 is 0).
+ * Boundaries past `capacity` are counted but not stored (caller re-runs with a larger buffer).
+ * seg_scratch: dm_rle_scratch_ints(N, img_h, img_w) int32.
+ * dm_rle_string (host code, no GPU work): boundaries -> run lengths -> the printable
+ * `counts` string of the COCO RLE format; returns its length, or -(needed) if cap is short. */
+long long dm_rle_scratch_ints(int N, int img_h, int img_w);
+int dm_rle_encode_canvas(const uint8_t* canvas, int N, int img_h, int img_w, int* seg_scratch, int* mask_runs,
+                         int* mask_start, int* positions, int capacity, dm_stream_t stream);
+int dm_paste_rle(const float* masks, const float* boxes, int N, int mask_h, int mask_w, int img_h, int img_w,
+                 float threshold, int apply_sigmoid, int* seg_scratch, int* mask_runs, int* mask_start,
+                 int* positions, int capacity, dm_stream_t stream);
+long long dm_rle_string(const int* positions, int runs, long long total_pixels, char* out, long long cap);
+
 /* ===========================================================================
  * Backward (training step).  Replaces what autograd derives for the reference
  * modules above plus mmcv's DeformConv2d backward

@@ -332,3 +332,80 @@ def carafe_pack(x, comp_w, comp_b, enc_w, enc_b, scale=2, up_kernel=5, up_group=
     mch = int(mc / float(up_kernel * up_kernel))
     mask = F.softmax(mask.view(n, mch, -1, h, w), dim=2).view(n, mc, h, w).contiguous()
     return carafe_reassemble(x, mask, up_kernel, up_group, scale)
+
+
+# --------------------------------------------------------------------------- COCO RLE
+# Third-party arithmetic absent from /root/reference: pycocotools (requirements/runtime.txt,
+# call site mmdet/core/mask/utils.py:55-60 `mask_util.encode(np.array(m[:, :, None], order='F'))`).
+# Restated from the published cocoapi/common/maskApi.c (rleEncode, rleToString, rleFrString).
+# PARITY UNPINNED: the reference holds no golden RLE strings (tests only call encode on zeros).
+def rle_counts(mask):
+    """rleEncode: run lengths of a [h, w] 0/1 mask walked column-major, first run = zeros."""
+    import numpy as np
+    t = np.asarray(mask).astype(np.uint8).T.reshape(-1)          # column-major order
+    if t.size == 0:
+        return [0]
+    change = np.flatnonzero(np.concatenate([[t[0] != 0], t[1:] != t[:-1]]))
+    # a boundary at 0 (mask starts with 1) yields the leading empty run of zeros
+    edges = np.concatenate([[0], change, [t.size]])
+    return np.diff(edges).tolist()
+
+
+def rle_to_string(cnts):
+    """rleToString: 5-bit groups, bit 5 = continuation, +48; counts from the 3rd on are
+    differences to the count two positions back."""
+    out = bytearray()
+    for i, c in enumerate(cnts):
+        x = int(c)
+        if i > 2:
+            x -= int(cnts[i - 2])
+        more = True
+        while more:
+            ch = x & 0x1f
+            x >>= 5
+            more = (x != -1) if (ch & 0x10) else (x != 0)
+            if more:
+                ch |= 0x20
+            out.append(ch + 48)
+    return bytes(out)
+
+
+def rle_from_string(s):
+    """rleFrString (inverse of rle_to_string)."""
+    cnts = []
+    p = 0
+    while p < len(s):
+        x = 0
+        k = 0
+        more = True
+        while more:
+            c = s[p] - 48
+            x |= (c & 0x1f) << (5 * k)
+            more = bool(c & 0x20)
+            p += 1
+            k += 1
+            if not more and (c & 0x10):
+                x |= -1 << (5 * k)
+        if len(cnts) > 2:
+            x += cnts[-2]
+        cnts.append(x)
+    return cnts
+
+
+def rle_encode(mask):
+    """What pycocotools.mask.encode returns for one [h, w] bitmap."""
+    h, w = mask.shape
+    return {'size': [int(h), int(w)], 'counts': rle_to_string(rle_counts(mask))}
+
+
+def rle_decode(rle):
+    import numpy as np
+    h, w = rle['size']
+    cnts = rle_from_string(rle['counts'])
+    t = np.zeros(h * w, dtype=np.uint8)
+    p, v = 0, 0
+    for c in cnts:
+        t[p:p + c] = v
+        p += c
+        v ^= 1
+    return t.reshape(w, h).T

@@ -276,3 +276,45 @@ def test_deconv_and_carafe(ops):
 def test_ops_refuse_cpu_tensors(ops):
     with pytest.raises(RuntimeError):
         ops.upsample2x(torch.zeros(1, 1, 4, 4))
+
+
+# ------------------------------------------------------------------ K19 RLE (8f rank 2)
+def test_rle_encode_canvas_matches_oracle_and_round_trips(ops):
+    rng = np.random.default_rng(3)
+    cases = [np.zeros((5, 7), np.uint8), np.ones((5, 7), np.uint8), (rng.random((37, 53)) < 0.5).astype(np.uint8),
+             (rng.random((64, 64)) < 0.02).astype(np.uint8)]
+    blob = np.zeros((300, 417), np.uint8)
+    yy, xx = np.mgrid[:300, :417]
+    blob[((yy - 140) / 90.0) ** 2 + ((xx - 200) / 150.0) ** 2 < 1] = 1
+    blob[100:120, 180:260] = 0
+    cases.append(blob)
+    for m in cases:
+        got = ops.rle_encode(torch.from_numpy(m[None]).cuda())
+        ref = ref_ops.rle_encode(m)
+        assert got[0] == ref, (m.shape, got[0]['counts'][:40], ref['counts'][:40])
+        assert (ref_ops.rle_decode(got[0]) == m).all()
+    # a batch: segments > 1 per mask (4096-pixel segments), packed offsets
+    batch = np.stack([(rng.random((130, 97)) < p).astype(np.uint8) for p in (0.0, 0.3, 1.0, 0.9, 0.01)])
+    got = ops.rle_encode(torch.from_numpy(batch).cuda())
+    for g, m in zip(got, batch):
+        assert g == ref_ops.rle_encode(m)
+    assert ops.rle_encode(torch.zeros((0, 4, 4), dtype=torch.uint8, device='cuda')) == []
+
+
+def test_paste_rle_equals_rle_of_pasted_canvas(ops):
+    g = torch.Generator().manual_seed(5)
+    N, S, H, W = 9, 28, 211, 307
+    masks = torch.randn(N, 1, S, S, generator=g) * 3
+    ctr = torch.rand(N, 2, generator=g) * torch.tensor([W, H])
+    wh = torch.rand(N, 2, generator=g) * 150 + 4
+    boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], 1)
+    boxes[0] = torch.tensor([-20.0, -30.0, 80.0, 60.0])        # sticks out of the image
+    boxes[1] = torch.tensor([10.0, 10.0, 10.0, 40.0])           # zero width
+    canvas = ops.paste_masks(masks.cuda(), boxes.cuda(), H, W, 0.5, apply_sigmoid=True)
+    via_canvas = ops.rle_encode(canvas)
+    fused = ops.paste_rle(masks.cuda(), boxes.cuda(), H, W, 0.5, apply_sigmoid=True)
+    assert fused == via_canvas
+    cv = canvas.cpu().numpy()
+    for n in range(N):
+        assert (ref_ops.rle_decode(fused[n]) == cv[n]).all()
+        assert fused[n] == ref_ops.rle_encode(cv[n])

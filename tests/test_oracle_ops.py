@@ -107,3 +107,24 @@ def test_dynamic_exit_selection_restates_the_commented_reference_path():
     assert merged[2].shape == (1, 56, 56)
     two = ref_model.boundary_merge([None, ips[1][2:3], ips[2][2:3]])
     assert torch.equal(merged[2], two[0])
+
+
+def test_rle_oracle_known_answers_and_round_trip():
+    """COCO RLE restated from cocoapi's maskApi.c (pycocotools absent: parity unpinned);
+    hand-derived vectors + encode/decode round trips."""
+    import numpy as np
+    from oracle import ref_ops as R
+    assert R.rle_encode(np.ones((2, 2), np.uint8)) == {'size': [2, 2], 'counts': b'04'}
+    assert R.rle_encode(np.zeros((2, 2), np.uint8)) == {'size': [2, 2], 'counts': b'4'}
+    assert R.rle_counts(np.array([[0, 1], [1, 1]])) == [1, 3]            # column-major walk: 0,1,1,1
+    assert R.rle_counts(np.array([[1, 0], [0, 0]])) == [0, 1, 3]
+    # 40 = 0b01000 + (1 << 5): two groups, 8|0x20 -> 'X', 1 -> '1'
+    assert R.rle_to_string([40]) == b'X1'
+    # from the fourth count on the difference to the count two back is stored (5 - 3 = 2)
+    assert R.rle_to_string([7, 3, 5]) == b'735' and R.rle_to_string([7, 3, 9, 5]) == b'739' + bytes([(2 & 0x1f) + 48])
+    assert R.rle_from_string(R.rle_to_string([7, 3, 9, 1, 300, 2])) == [7, 3, 9, 1, 300, 2]
+    rng = np.random.default_rng(1)
+    for shape in ((1, 1), (3, 5), (17, 4), (40, 33)):
+        for _ in range(10):
+            m = (rng.random(shape) < rng.random()).astype(np.uint8)
+            assert (R.rle_decode(R.rle_encode(m)) == m).all()

@@ -366,3 +366,24 @@ def test_dynamic_test_mask_pastes_each_detection_from_its_own_exit():
         got = res[c][k]
         assert got.shape == (256, 320) and got.dtype == np.bool_
         assert (got != ref).mean() < 2e-4, (j, e, (got != ref).sum())
+
+
+def test_simple_test_mask_encoded_equals_encoding_of_the_bitmaps():
+    """simple_test_mask(encode=True) == encode_mask_results(simple_test_mask()) (apis/test.py:52-57)."""
+    hi = gi.head_inputs()
+    m = _roi_head()
+    from dynamask_amd.registry import ConfigDict
+    m.test_cfg = ConfigDict(mask_thr_binary=0.5)
+    sel = hi['rois'][:, 0] == 0
+    det = torch.cat([hi['rois'][sel][:, 1:], torch.ones(int(sel.sum()), 1)], 1)
+    labels = hi['labels'][sel]
+    fd = [_dev(f) for f in hi['feats']]
+    metas = [dict(ori_shape=(256, 320, 3), scale_factor=1.0)]
+    with torch.no_grad():
+        bitmaps = m.simple_test_mask(fd, metas, _dev(det), _dev(labels), rescale=False)
+        rles = m.simple_test_mask(fd, metas, _dev(det), _dev(labels), rescale=False, encode=True)
+    assert len(rles) == 80
+    for c in range(80):
+        assert len(rles[c]) == len(bitmaps[c])
+        for r, b in zip(rles[c], bitmaps[c]):
+            assert r == ref_ops.rle_encode(b.astype(np.uint8))
