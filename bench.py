@@ -199,11 +199,27 @@ def train_step_bench(head, dev, rank, world, steps=6, warmup=4):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # communication alone: the flat-gradient all-reduce (16.65 MB) timed by itself, so that
+    # the scaling curve can be read with and without it; 0 at world size 1
+    comm_ms = 0.0
+    if world > 1:
+        import torch.distributed as dist
+        for _ in range(2):
+            grp.all_reduce_async(); grp.wait()
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            grp.all_reduce_async(); grp.wait()
+        torch.cuda.synchronize()
+        comm_ms = (time.perf_counter() - t0) / 5 * 1e3
+        t = torch.tensor([comm_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        comm_ms = float(t.item())
     from dynamask_amd import ops
     grp.flat_param.copy_(saved)
     ops.WEIGHT_EPOCH[0] += 1                # packed-weight caches follow the restored parameters
     head.eval()
-    return dt / steps * 1e3, float(res['loss_mask']['loss_masks'].detach()), grp.numel, B
+    return dt / steps * 1e3, float(res['loss_mask']['loss_masks'].detach()), grp.numel, B, comm_ms
 
 
 def main():
@@ -305,7 +321,7 @@ def main():
     # training step (configs[2]/[3]) on every rank (parameters are restored afterwards);
     # reported in `extra`, not the headline.  Runs before the CPU leg: the oracle's host
     # threads keep spinning for a while and would slow the launch thread.
-    train_ms, train_loss, n_flat, train_b = train_step_bench(head, dev, rank, world)
+    train_ms, train_loss, n_flat, train_b, comm_ms = train_step_bench(head, dev, rank, world)
 
     if rank == 0:
         from dynamask_amd import ops
@@ -456,7 +472,7 @@ def main():
         extra = result['extra']
         extra['train_step'] = {'ms_per_step': train_ms, 'img_per_s': world * train_b / (train_ms * 1e-3),
                                'imgs_per_gpu': train_b, 'pos_rois_per_img': 128, 'loss': train_loss,
-                               'allreduce_floats': n_flat,
+                               'allreduce_floats': n_flat, 'allreduce_alone_ms': comm_ms,
                                'what': 'fwd + loss + bwd (head, MaskPre, RoIAlign) + RCCL all-reduce of the flat '
                                        'mask-path gradient + fused SGD; BASELINE configs[2] (N=1) / configs[3] (N=8)'}
         print(json.dumps(result), flush=True)
