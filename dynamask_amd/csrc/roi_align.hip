@@ -585,7 +585,9 @@ __device__ __forceinline__ void roi_tile_fwd(const RoiArgs& a, const float* __re
       fetch(cb + NCB);
       sample(cb, buf);
       commit(cb + NCB, buf ^ 1);
-      __syncthreads();
+      // LDS-only barrier: __syncthreads() would also drain vmcnt(0), i.e. wait for the
+      // acknowledgement of the output stores sample() has just issued -- nobody reads those
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       cb += NCB;
       buf ^= 1;
     } while (cb + NCB < c1);
