@@ -53,6 +53,11 @@ def make_inputs(rank, dev):
     return feats, rois, labels
 
 
+def bbox2roi_(boxes):
+    from dynamask_amd.roi_head import bbox2roi
+    return bbox2roi(boxes).contiguous()
+
+
 def time_kernel(fn, iters=20, warmup=3):
     """Average duration (ms) of `fn` (launches on torch's current stream)."""
     for _ in range(warmup):
@@ -461,6 +466,37 @@ def main():
                     e2e_rle()        # masks leave the device as COCO RLE (device encoder), not as bitmaps
                 torch.cuda.synchronize()
                 t_e2e_rle = (time.perf_counter() - t0) / 5 * 1e3
+            # whole RoI head at the reference's test shape: 1000 proposals -> bbox branch
+            # (RoIAlign 7x7, 2 FC + predictors, decode, NMS) -> <= 100 detections -> mask branch -> RLE
+            from dynamask_amd import bbox_heads  # noqa: F401
+            rh = registry.build_head(dict(
+                type='DynaMaskRoIHead',
+                bbox_roi_extractor=dict(type='SingleRoIExtractor', **gi.BBOX_ROI_EXTRACTOR_CFG),
+                bbox_head=dict(type='Shared2FCBBoxHead', **gi.BBOX_HEAD_CFG),
+                mask_roi_extractor=dict(type='SingleRoIExtractor', **gi.MASK_ROI_EXTRACTOR_CFG),
+                mask_head=dict(type='DynaMaskHead', **gi.MASK_HEAD_CFG), test_cfg=ConfigDict(**gi.RCNN_TEST_CFG)))
+            rh.load_state_dict({**sd, **synth.init_bbox_head_state(seed=8)}, strict=True)
+            rh = rh.to(dev).eval()
+            props = synth.make_rois(1, 1000, IMG_H, IMG_W, seed=31)[:, 1:].contiguous().to(dev)
+            meta2 = [dict(img_shape=(IMG_H, IMG_W, 3), ori_shape=(IMG_H, IMG_W, 3), scale_factor=1.0)]
+
+            def full_head():
+                return rh.simple_test(feats, [props], meta2, rescale=False, encode=True)
+            for _ in range(2):
+                full_head()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                out_fh = full_head()
+            torch.cuda.synchronize()
+            t_fh = (time.perf_counter() - t0) / 5 * 1e3
+            n_det = sum(len(b) for b in out_fh[0])
+            with torch.no_grad():
+                t_bbox = time_kernel(lambda: rh._bbox_forward(feats, bbox2roi_([props])), iters=10, warmup=2)
+            result['extra']['roi_head_simple_test'] = {
+                'ms': t_fh, 'detections': n_det, 'bbox_forward_1000_props_ms': t_bbox,
+                'what': 'DynaMaskRoIHead.simple_test on resident FPN maps: 1000 proposals -> RoIAlign7 + Shared2FC (library '
+                        'GEMMs) + softmax/decode + NMS -> masks of the kept detections -> RLE (random-init heads)'}
             result['extra']['end_to_end'] = {
                 'backbone_fpn_ms': t_bb, 'mask_path_100dets_ms': t_mask, 'backbone_plus_mask_path_ms': t_e2e,
                 'backbone_plus_mask_path_rle_ms': t_e2e_rle, 'img_per_s_rle': 1e3 / t_e2e_rle,

@@ -4,7 +4,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdynamask_hip.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -48,6 +48,9 @@ SIGNATURES = {
     'dm_rle_encode_canvas': ([_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp], _c_int),
     'dm_paste_rle': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp], _c_int),
     'dm_rle_string': ([_vp, _c_int, ctypes.c_longlong, ctypes.c_char_p, ctypes.c_longlong], ctypes.c_longlong),
+    'dm_bbox_decode': ([_vp, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _vp, _vp, _c_float, _c_float, _c_float, _c_float, _c_float, _vp, _vp, _vp], _c_int),
+    'dm_nms_mask': ([_vp, _c_int, _c_float, _c_int, _vp, _vp], _c_int),
+    'dm_nms_reduce': ([_vp, _c_int, _vp, _c_int], _c_int),
     'dm_sgd_momentum_step': ([_vp, _vp, _vp, ctypes.c_longlong, _c_float, _c_float, _c_float, _c_float, _c_int, _vp], _c_int),
     'dm_mask_target_rois': ([_vp, _vp, _c_int, _c_float, _c_float, _vp, _vp], _c_int),
     'dm_threshold_ge': ([_vp, ctypes.c_longlong, _c_float, _vp, _vp], _c_int),

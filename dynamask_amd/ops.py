@@ -171,6 +171,55 @@ def paste_rle(masks, boxes, img_h, img_w, threshold=0.5, apply_sigmoid=False):
     return _rle_collect(N, img_h, img_w, runs, start, positions, launch, capacity)
 
 
+# --------------------------------------------------------------- bbox branch (8f rank 4)
+def bbox_decode(rois, cls_score, bbox_pred, num_classes, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.),
+                wh_ratio_clip=16 / 1000, max_shape=None, scale=(1.0, 1.0), class_agnostic=False):
+    """softmax(cls_score), delta2bbox(rois, bbox_pred) clipped to ``max_shape`` (h, w) and
+    divided by ``scale`` (sx, sy).  rois [N, 5] (batch column first) or [N, 4]."""
+    _chk(rois, 'rois')
+    N = rois.shape[0]
+    dev = rois.device
+    nb = 1 if class_agnostic else num_classes
+    scores = None
+    if cls_score is not None:
+        _chk(cls_score, 'cls_score')
+        assert cls_score.shape == (N, num_classes + 1)
+        scores = torch.empty_like(cls_score)
+    if bbox_pred is not None:
+        _chk(bbox_pred, 'bbox_pred')
+        assert bbox_pred.shape == (N, 4 * nb)
+    bboxes = torch.empty((N, 4 * nb), device=dev, dtype=torch.float32)
+    ch, cw = (float(max_shape[0]), float(max_shape[1])) if max_shape is not None else (0.0, 0.0)
+    check(lib().dm_bbox_decode(_p(rois), rois.shape[1], rois.shape[1] - 4, _p(cls_score), _p(bbox_pred), N, num_classes,
+                               1 if class_agnostic else 0, _float_array(means), _float_array(stds), float(wh_ratio_clip),
+                               ch, cw, float(scale[0]), float(scale[1]), _p(scores), _p(bboxes), _stream()),
+          'dm_bbox_decode')
+    return bboxes, scores
+
+
+def nms(boxes, scores, iou_threshold, offset=0, max_num=-1):
+    """mmcv.ops.nms: (dets [k, 5] in descending score order, keep indices [k] into the input).
+    Suppression matrix on the device, greedy pass on the host."""
+    import ctypes as C
+    _chk(boxes, 'boxes')
+    _chk(scores, 'scores')
+    M = boxes.shape[0]
+    if M == 0:
+        return boxes.new_zeros((0, 5)), torch.zeros((0,), dtype=torch.long, device=boxes.device)
+    order = torch.sort(scores, descending=True, stable=True)[1]
+    sb = boxes[order].contiguous()
+    words = (M + 63) // 64
+    mask = torch.empty((M, words), device=boxes.device, dtype=torch.int64)
+    check(lib().dm_nms_mask(_p(sb), M, float(iou_threshold), int(offset), _p(mask), _stream()), 'dm_nms_mask')
+    mask_h = mask.cpu()                                   # synchronises
+    keep_h = torch.empty((M,), dtype=torch.int32)
+    n = lib().dm_nms_reduce(C.c_void_p(mask_h.data_ptr()), M, C.c_void_p(keep_h.data_ptr()), int(max_num))
+    keep_sorted = keep_h[:n].to(device=boxes.device, dtype=torch.long)
+    keep = order[keep_sorted]
+    dets = torch.cat([boxes[keep], scores[keep][:, None]], 1)
+    return dets, keep
+
+
 # --------------------------------------------------------------- convolutions
 def packed_cout(cout):
     return lib().dm_conv_packed_cout(int(cout))

@@ -100,9 +100,13 @@ class DynaMaskRoIHead(nn.Module):
         super().__init__()
         self.train_cfg = train_cfg
         self.test_cfg = test_cfg
-        # bbox branch: out of the hot path -- configuration kept for the caller
+        # bbox branch (inference only): built when configured
         self.bbox_roi_extractor_cfg = bbox_roi_extractor
         self.bbox_head_cfg = bbox_head
+        if bbox_head is not None:
+            from . import bbox_heads  # noqa: F401  (registers Shared2FCBBoxHead)
+            self.bbox_roi_extractor = build_roi_extractor(bbox_roi_extractor)
+            self.bbox_head = build_head(bbox_head)
         if shared_head is not None:
             raise NotImplementedError('shared_head is None in configs/dynamask')
         if mask_head is not None:
@@ -122,7 +126,7 @@ class DynaMaskRoIHead(nn.Module):
 
     @property
     def with_bbox(self):
-        return False
+        return hasattr(self, 'bbox_head') and self.bbox_head is not None
 
     @property
     def with_mask(self):
@@ -229,6 +233,32 @@ class DynaMaskRoIHead(nn.Module):
         # the reference chunks by 100 RoIs "to avoid memory overflow" (:132); 288 GB of HBM do not need it
         res = self._mask_forward(x, mask_rois, det_labels)
         return self.merge_stage_preds(res['stage_instance_preds'])
+
+    # ------------------------------------------------------------ bbox branch (inference)
+    def _bbox_forward(self, x, rois):
+        """standard_roi_head.py:135-146."""
+        bbox_feats = self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois)
+        cls_score, bbox_pred = self.bbox_head(bbox_feats)
+        return dict(cls_score=cls_score, bbox_pred=bbox_pred, bbox_feats=bbox_feats)
+
+    @torch.no_grad()
+    def simple_test_bboxes(self, x, img_metas, proposals, rcnn_test_cfg, rescale=False):
+        """test_mixins.py:52-71 (BBoxTestMixin.simple_test_bboxes), one image."""
+        rois = bbox2roi(proposals).contiguous()
+        res = self._bbox_forward(x, rois)
+        return self.bbox_head.get_bboxes(rois, res['cls_score'], res['bbox_pred'], img_metas[0]['img_shape'],
+                                         img_metas[0]['scale_factor'], rescale=rescale, cfg=rcnn_test_cfg)
+
+    @torch.no_grad()
+    def simple_test(self, x, proposal_list, img_metas, proposals=None, rescale=False, encode=False):
+        """standard_roi_head.py:217-236: boxes, then masks of the kept detections."""
+        from .bbox_heads import bbox2result
+        det_bboxes, det_labels = self.simple_test_bboxes(x, img_metas, proposal_list, self.test_cfg, rescale=rescale)
+        bbox_results = bbox2result(det_bboxes, det_labels, self.bbox_head.num_classes)
+        if not self.with_mask:
+            return bbox_results
+        segm_results = self.simple_test_mask(x, img_metas, det_bboxes, det_labels, rescale=rescale, encode=encode)
+        return bbox_results, segm_results
 
     # ------------------------------------------------------------ dynamic inference
     @torch.no_grad()

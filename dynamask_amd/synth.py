@@ -203,3 +203,21 @@ def init_fcn_head_state(seed=7, prefix='mask_head.', in_channels=256, num_convs=
     sd[prefix + 'conv_logits.weight'] = _kaiming_fan_out((num_classes, C, 1, 1), g)
     sd[prefix + 'conv_logits.bias'] = bias(num_classes)
     return sd
+
+
+def init_bbox_head_state(seed=8, prefix='bbox_head.', in_channels=256, roi_feat=7, fc_out=1024, num_classes=80):
+    """state_dict of Shared2FCBBoxHead (convfc_bbox_head.py:189-205).  Test-mode scales: the
+    reference's init (xavier / N(0, 0.01) / N(0, 0.001)) gives near-uniform class scores, so the
+    predictors are drawn larger to spread the softmax and the box deltas."""
+    g = _gen(seed)
+    K = in_channels * roi_feat * roi_feat
+    sd = {}
+    sd[prefix + 'shared_fcs.0.weight'] = torch.randn((fc_out, K), generator=g) * math.sqrt(2.0 / (K + fc_out))
+    sd[prefix + 'shared_fcs.0.bias'] = torch.randn(fc_out, generator=g) * 0.05
+    sd[prefix + 'shared_fcs.1.weight'] = torch.randn((fc_out, fc_out), generator=g) * math.sqrt(2.0 / (2 * fc_out))
+    sd[prefix + 'shared_fcs.1.bias'] = torch.randn(fc_out, generator=g) * 0.05
+    sd[prefix + 'fc_cls.weight'] = torch.randn((num_classes + 1, fc_out), generator=g) * 0.25
+    sd[prefix + 'fc_cls.bias'] = torch.randn(num_classes + 1, generator=g) * 0.1
+    sd[prefix + 'fc_reg.weight'] = torch.randn((4 * num_classes, fc_out), generator=g) * 0.05
+    sd[prefix + 'fc_reg.bias'] = torch.randn(4 * num_classes, generator=g) * 0.05
+    return sd

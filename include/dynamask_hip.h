@@ -286,6 +286,26 @@ int dm_paste_rle(const float* masks, const float* boxes, int N, int mask_h, int 
                  int* positions, int capacity, dm_stream_t stream);
 long long dm_rle_string(const int* positions, int runs, long long total_pixels, char* out, long long cap);
 
+/* K20  bbox branch post-processing: softmax over the class logits, DeltaXYWH decode, clip to
+ * the image, rescale.  replaces: BBoxHead.get_bboxes up to the NMS
+ * (roi_heads/bbox_heads/bbox_head.py:186-217) and delta2bbox
+ * (core/bbox/coder/delta_xywh_bbox_coder.py:165-204).  rois [N, roi_stride] with x1 at column
+ * roi_x0 (5 / 1 for the reference's [batch, x1, y1, x2, y2] rows); cls_score [N, num_classes+1]
+ * or null; bbox_pred [N, 4*num_classes] ([N, 4] if class_agnostic) or null (then the rois
+ * themselves are clipped); clip_h/clip_w <= 0: no clipping; scale_x/scale_y: divide the boxes
+ * (rescale=True), 1 otherwise.  Outputs scores [N, num_classes+1], bboxes like bbox_pred.
+ * K21  dm_nms_mask: suppression bit matrix of M score-sorted boxes [M, 4] (bit j of row i,
+ * j > i, set when IoU > iou_threshold; offset 0/1 as mmcv.ops.nms) -- replaces the device half of
+ * mmcv.ops.nms as called by multiclass_nms (core/post_processing/bbox_nms.py:5-68);
+ * dm_nms_reduce is the host half (greedy pass), returns the number of kept indices. */
+int dm_bbox_decode(const float* rois, int roi_stride, int roi_x0, const float* cls_score, const float* bbox_pred,
+                   int N, int num_classes, int class_agnostic, const float* means, const float* stds,
+                   float wh_ratio_clip, float clip_h, float clip_w, float scale_x, float scale_y, float* scores,
+                   float* bboxes, dm_stream_t stream);
+int dm_nms_mask(const float* boxes_sorted, int M, float iou_threshold, int offset, unsigned long long* mask,
+                dm_stream_t stream);
+int dm_nms_reduce(const unsigned long long* mask_host, int M, int* keep, int max_keep);
+
 /* ===========================================================================
  * Backward (training step).  Replaces what autograd derives for the reference
  * modules above plus mmcv's DeformConv2d backward

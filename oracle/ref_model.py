@@ -339,3 +339,117 @@ def get_seg_masks(mask_logits, det_bboxes, ori_shape, scale_factor, rescale, thr
         chunk, _ = paste_masks(mask_pred, bboxes, img_h, img_w, skip_empty=False)
         im_mask[:] = chunk >= thr
     return im_mask
+
+
+# --------------------------------------------------------------------------- bbox branch (8f rank 4)
+def bbox_head_forward(sd, x, pre='bbox_head.'):
+    """Shared2FCBBoxHead.forward -- roi_heads/bbox_heads/convfc_bbox_head.py:138-186 with
+    num_shared_fcs=2 and nothing else (:189-205)."""
+    x = x.flatten(1)
+    for i in range(2):
+        x = F.relu(F.linear(x, sd[f'{pre}shared_fcs.{i}.weight'], sd[f'{pre}shared_fcs.{i}.bias']))
+    cls_score = F.linear(x, sd[pre + 'fc_cls.weight'], sd[pre + 'fc_cls.bias'])
+    bbox_pred = F.linear(x, sd[pre + 'fc_reg.weight'], sd[pre + 'fc_reg.bias'])
+    return cls_score, bbox_pred
+
+
+def delta2bbox(rois, deltas, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), max_shape=None, wh_ratio_clip=16 / 1000):
+    """core/bbox/coder/delta_xywh_bbox_coder.py:118-204."""
+    import numpy as np
+    n4 = deltas.size(1) // 4
+    means = deltas.new_tensor(means).view(1, -1).repeat(1, n4)
+    stds = deltas.new_tensor(stds).view(1, -1).repeat(1, n4)
+    d = deltas * stds + means
+    dx, dy, dw, dh = d[:, 0::4], d[:, 1::4], d[:, 2::4], d[:, 3::4]
+    max_ratio = float(np.abs(np.log(wh_ratio_clip)))
+    dw = dw.clamp(min=-max_ratio, max=max_ratio)
+    dh = dh.clamp(min=-max_ratio, max=max_ratio)
+    px = ((rois[:, 0] + rois[:, 2]) * 0.5).unsqueeze(1).expand_as(dx)
+    py = ((rois[:, 1] + rois[:, 3]) * 0.5).unsqueeze(1).expand_as(dy)
+    pw = (rois[:, 2] - rois[:, 0]).unsqueeze(1).expand_as(dw)
+    ph = (rois[:, 3] - rois[:, 1]).unsqueeze(1).expand_as(dh)
+    gw, gh = pw * dw.exp(), ph * dh.exp()
+    gx, gy = px + pw * dx, py + ph * dy
+    x1, y1, x2, y2 = gx - gw * 0.5, gy - gh * 0.5, gx + gw * 0.5, gy + gh * 0.5
+    if max_shape is not None:
+        x1 = x1.clamp(min=0, max=max_shape[1])
+        y1 = y1.clamp(min=0, max=max_shape[0])
+        x2 = x2.clamp(min=0, max=max_shape[1])
+        y2 = y2.clamp(min=0, max=max_shape[0])
+    return torch.stack([x1, y1, x2, y2], dim=-1).view(deltas.size())
+
+
+def nms(boxes, scores, iou_threshold, offset=0):
+    """mmcv.ops.nms (mmcv 1.0.5; THIRD-PARTY, absent from the tree: parity unpinned) -- greedy
+    suppression in descending score order, IoU > threshold suppresses, areas with `offset`.
+    Returns (dets [k, 5], keep indices)."""
+    order = torch.sort(scores, descending=True, stable=True)[1]
+    b = boxes[order]
+    n = b.shape[0]
+    area = (b[:, 2] - b[:, 0] + offset) * (b[:, 3] - b[:, 1] + offset)
+    dead = torch.zeros(n, dtype=torch.bool)
+    keep = []
+    for i in range(n):
+        if dead[i]:
+            continue
+        keep.append(i)
+        if i + 1 < n:
+            w = (torch.minimum(b[i, 2], b[i + 1:, 2]) - torch.maximum(b[i, 0], b[i + 1:, 0]) + offset).clamp(min=0)
+            h = (torch.minimum(b[i, 3], b[i + 1:, 3]) - torch.maximum(b[i, 1], b[i + 1:, 1]) + offset).clamp(min=0)
+            inter = w * h
+            iou = inter / (area[i] + area[i + 1:] - inter)
+            dead[i + 1:] |= iou > iou_threshold
+    keep = order[torch.tensor(keep, dtype=torch.long)]
+    return torch.cat([boxes[keep], scores[keep][:, None]], 1), keep
+
+
+def batched_nms(boxes, scores, idxs, nms_cfg):
+    """mmcv.ops.nms.batched_nms (third-party, unpinned): per-class NMS by coordinate offsets."""
+    cfg = dict(nms_cfg)
+    cfg.pop('type', 'nms')
+    max_coordinate = boxes.max()
+    offsets = idxs.to(boxes) * (max_coordinate + 1)
+    dets, keep = nms(boxes + offsets[:, None], scores, cfg.get('iou_threshold', cfg.get('iou_thr', 0.5)))
+    return torch.cat([boxes[keep], dets[:, -1:]], 1), keep
+
+
+def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1):
+    """core/post_processing/bbox_nms.py:5-68."""
+    num_classes = multi_scores.size(1) - 1
+    if multi_bboxes.shape[1] > 4:
+        bboxes = multi_bboxes.view(multi_scores.size(0), -1, 4)
+    else:
+        bboxes = multi_bboxes[:, None].expand(multi_scores.size(0), num_classes, 4)
+    scores = multi_scores[:, :-1]
+    valid_mask = scores > score_thr
+    bboxes = bboxes[valid_mask]
+    scores = scores[valid_mask]
+    labels = valid_mask.nonzero(as_tuple=False)[:, 1]
+    if bboxes.numel() == 0:
+        return multi_bboxes.new_zeros((0, 5)), multi_bboxes.new_zeros((0,), dtype=torch.long)
+    dets, keep = batched_nms(bboxes, scores, labels, nms_cfg)
+    if max_num > 0:
+        dets, keep = dets[:max_num], keep[:max_num]
+    return dets, labels[keep]
+
+
+def get_bboxes(rois, cls_score, bbox_pred, img_shape, scale_factor, rescale=False, cfg=None,
+               means=(0., 0., 0., 0.), stds=(0.1, 0.1, 0.2, 0.2)):
+    """BBoxHead.get_bboxes -- roi_heads/bbox_heads/bbox_head.py:186-223."""
+    scores = F.softmax(cls_score, dim=1) if cls_score is not None else None
+    if bbox_pred is not None:
+        bboxes = delta2bbox(rois[:, 1:], bbox_pred, means, stds, max_shape=img_shape)
+    else:
+        bboxes = rois[:, 1:].clone()
+        if img_shape is not None:
+            bboxes[:, [0, 2]] = bboxes[:, [0, 2]].clamp(min=0, max=img_shape[1])
+            bboxes[:, [1, 3]] = bboxes[:, [1, 3]].clamp(min=0, max=img_shape[0])
+    if rescale:
+        if isinstance(scale_factor, float):
+            bboxes = bboxes / scale_factor
+        else:
+            sf = bboxes.new_tensor(scale_factor)
+            bboxes = (bboxes.view(bboxes.size(0), -1, 4) / sf).view(bboxes.size()[0], -1)
+    if cfg is None:
+        return bboxes, scores
+    return multiclass_nms(bboxes, scores, cfg['score_thr'], cfg['nms'], cfg['max_per_img'])

@@ -165,3 +165,35 @@ def target_inputs():
         inds = torch.randint(0, G, (n,), generator=g)
         out.append(dict(masks=m, boxes=boxes, inds=inds))
     return out
+
+
+# ------------------------------------------------------------------ bbox branch (8f rank 4)
+BBOX_HEAD_CFG = dict(in_channels=256, fc_out_channels=1024, roi_feat_size=7, num_classes=80,
+                     bbox_coder=dict(type='DeltaXYWHBBoxCoder', target_means=[0., 0., 0., 0.],
+                                     target_stds=[0.1, 0.1, 0.2, 0.2]),
+                     reg_class_agnostic=False,
+                     loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=2.0),
+                     loss_bbox=dict(type='L1Loss', loss_weight=2.0))
+BBOX_ROI_EXTRACTOR_CFG = dict(roi_layer=dict(type='RoIAlign', output_size=7, sampling_ratio=0), out_channels=256,
+                              featmap_strides=[4, 8, 16, 32])
+RCNN_TEST_CFG = dict(score_thr=0.05, nms=dict(type='nms', iou_threshold=0.5), max_per_img=100, mask_thr_binary=0.5)
+BBOX_IMG_SHAPE = (256, 320, 3)
+
+
+def bbox_head_state():
+    return synth.init_bbox_head_state(seed=201)
+
+
+def bbox_inputs(n=60):
+    """RoI features [n, 256, 7, 7] and proposals [n, 5] (one image, clustered so NMS has work to do)."""
+    g = torch.Generator().manual_seed(202)
+    x = torch.randn(n, 256, 7, 7, generator=g) * 0.5
+    ctr = torch.rand(12, 2, generator=g) * torch.tensor([260.0, 200.0]) + 30
+    which = torch.randint(0, 12, (n,), generator=g)
+    c = ctr[which] + torch.randn(n, 2, generator=g) * 6
+    wh = torch.rand(n, 2, generator=g) * 80 + 20
+    boxes = torch.cat([c - wh / 2, c + wh / 2], 1)
+    boxes[:, 0::2] = boxes[:, 0::2].clamp(0, 319)
+    boxes[:, 1::2] = boxes[:, 1::2].clamp(0, 255)
+    rois = torch.cat([torch.zeros(n, 1), boxes], 1)
+    return x, rois

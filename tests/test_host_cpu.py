@@ -87,6 +87,12 @@ def test_reference_config_is_consumed_unchanged():
     assert m.train_cfg.flops == [0.23, 0.62, 1.01, 1.4] and m.test_cfg.mask_thr_binary == 0.5
     assert m.mask_head.loss_func.start_stage == 4 and m.mask_head.loss_func.cb_loss_weight == 0.8
     assert m.mask_roi_extractor.featmap_strides == [4, 8, 16, 32]
+    # bbox branch (8f rank 4): built from the same unchanged config, reference state_dict keys
+    assert m.with_bbox and m.bbox_head.num_classes == 80 and m.bbox_head.bbox_coder.stds == (0.1, 0.1, 0.2, 0.2)
+    keys = set(m.state_dict().keys())
+    for k in ('shared_fcs.0.weight', 'shared_fcs.1.bias', 'fc_cls.weight', 'fc_reg.bias'):
+        assert 'bbox_head.' + k in keys
+    assert tuple(m.bbox_head.shared_fcs[0].weight.shape) == (1024, 12544) and tuple(m.bbox_head.fc_reg.weight.shape) == (320, 1024)
     # the values restated in tests/golden/golden_inputs.py are the config's
     assert dict(cfg.model.roi_head.mask_head.loss_cfg) == dict(type='DynaCrossEntropyLoss', **gi.LOSS_CFG)
 

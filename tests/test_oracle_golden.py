@@ -129,3 +129,33 @@ def test_paste_and_targets_match_reference(golden_dir):
     tg = ref_model.get_targets([t['boxes'] for t in ti], [t['inds'] for t in ti], [t['masks'] for t in ti])
     for i in range(4):
         assert np.array_equal(tg[i].numpy().astype(np.uint8), g9[f't{i}'])
+
+
+def test_bbox_branch_oracle_matches_reference_golden(golden_dir):
+    """g10: Shared2FCBBoxHead.forward / BBoxHead.get_bboxes / delta2bbox / multiclass_nms of the
+    reference (the NMS inside is a stand-in: mmcv is third-party, see make_golden_bbox.py)."""
+    import golden_inputs as gi
+    from oracle import ref_model
+    g = np.load(os.path.join(golden_dir, 'g10_bbox.npz'))
+    sd = gi.bbox_head_state()
+    x, rois = gi.bbox_inputs()
+    with torch.no_grad():
+        cls_score, bbox_pred = ref_model.bbox_head_forward(sd, x)
+        np.testing.assert_allclose(cls_score.numpy(), g['cls_score'], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(bbox_pred.numpy(), g['bbox_pred'], rtol=1e-4, atol=1e-4)
+        cs, bp = torch.from_numpy(g['cls_score']), torch.from_numpy(g['bbox_pred'])
+        b, s = ref_model.get_bboxes(rois, cs, bp, gi.BBOX_IMG_SHAPE, 1.0)
+        np.testing.assert_allclose(b.numpy(), g['bboxes'], rtol=1e-5, atol=1e-4)
+        np.testing.assert_allclose(s.numpy(), g['scores'], rtol=1e-5, atol=1e-7)
+        sf = np.array([1.25, 1.6, 1.25, 1.6], dtype=np.float32)
+        b1, _ = ref_model.get_bboxes(rois, cs, bp, gi.BBOX_IMG_SHAPE, sf, rescale=True)
+        np.testing.assert_allclose(b1.numpy(), g['bboxes_rescaled'], rtol=1e-5, atol=1e-4)
+        d, lab = ref_model.get_bboxes(rois, cs, bp, gi.BBOX_IMG_SHAPE, 1.0, cfg=gi.RCNN_TEST_CFG)
+        np.testing.assert_allclose(d.numpy(), g['det_bboxes'], rtol=1e-5, atol=1e-4)
+        assert (lab.numpy() == g['det_labels']).all()
+        r = torch.Tensor([[0., 0., 1., 1.], [0., 0., 1., 1.], [0., 0., 1., 1.], [5., 5., 5., 5.]])
+        dl = torch.Tensor([[0., 0., 0., 0.], [1., 1., 1., 1.], [0., 0., 2., -1.], [0.7, -1.9, -0.5, 0.3]])
+        np.testing.assert_allclose(ref_model.delta2bbox(r, dl, max_shape=(32, 32)).numpy(), g['doc_example'], atol=1e-6)
+        # the reference's own docstring values (delta_xywh_bbox_coder.py:155-160)
+        np.testing.assert_allclose(g['doc_example'], [[0, 0, 1, 1], [0.1409, 0.1409, 2.8591, 2.8591],
+                                                       [0, 0.3161, 4.1945, 0.6839], [5, 5, 5, 5]], atol=1e-4)

@@ -387,3 +387,84 @@ def test_simple_test_mask_encoded_equals_encoding_of_the_bitmaps():
         assert len(rles[c]) == len(bitmaps[c])
         for r, b in zip(rles[c], bitmaps[c]):
             assert r == ref_ops.rle_encode(b.astype(np.uint8))
+
+
+# ------------------------------------------------------------------ bbox branch (8f rank 4)
+def _bbox_roi_head():
+    from dynamask_amd import registry, bbox_heads, roi_head, mask_heads, roi_extractors, losses  # noqa: F401
+    from dynamask_amd.registry import ConfigDict
+    cfg = dict(type='DynaMaskRoIHead',
+               bbox_roi_extractor=dict(type='SingleRoIExtractor', **gi.BBOX_ROI_EXTRACTOR_CFG),
+               bbox_head=dict(type='Shared2FCBBoxHead', **gi.BBOX_HEAD_CFG),
+               mask_roi_extractor=dict(type='SingleRoIExtractor', **gi.MASK_ROI_EXTRACTOR_CFG),
+               mask_head=dict(type='DynaMaskHead', **gi.MASK_HEAD_CFG),
+               test_cfg=ConfigDict(**gi.RCNN_TEST_CFG))
+    m = registry.build_head(cfg)
+    m.load_state_dict({**gi.head_state(), **gi.mask_pre_state(), **gi.bbox_head_state()}, strict=True)
+    return m.cuda().eval()
+
+
+def test_bbox_head_and_decode_match_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g10_bbox.npz'))
+    m = _bbox_roi_head()
+    x, rois = gi.bbox_inputs()
+    with torch.no_grad():
+        cls_score, bbox_pred = m.bbox_head(_dev(x))
+    # library fp32 GEMM over K = 12544: summation order differs from the CPU reference
+    _close(cls_score, g['cls_score'], atol=2e-4, rtol=1e-4)
+    _close(bbox_pred, g['bbox_pred'], atol=2e-4, rtol=1e-4)
+    cs, bp = _dev(torch.from_numpy(g['cls_score'])), _dev(torch.from_numpy(g['bbox_pred']))
+    b, s = m.bbox_head.get_bboxes(_dev(rois), cs, bp, gi.BBOX_IMG_SHAPE, 1.0)
+    _close(b, g['bboxes'], atol=1e-4, rtol=1e-5)
+    _close(s, g['scores'], atol=1e-6, rtol=1e-5)
+    sf = np.array([1.25, 1.6, 1.25, 1.6], dtype=np.float32)
+    b1, _ = m.bbox_head.get_bboxes(_dev(rois), cs, bp, gi.BBOX_IMG_SHAPE, sf, rescale=True)
+    _close(b1, g['bboxes_rescaled'], atol=1e-4, rtol=1e-5)
+    d, lab = m.bbox_head.get_bboxes(_dev(rois), cs, bp, gi.BBOX_IMG_SHAPE, 1.0, cfg=m.test_cfg)
+    assert d.shape == (100, 5)
+    same = (lab.cpu().numpy() == g['det_labels']) & (np.abs(d.cpu().numpy() - g['det_bboxes']).max(1) < 1e-3)
+    assert same.mean() > 0.97, same.mean()      # an IoU within an ulp of 0.5 may fall on the other side
+    r = torch.Tensor([[0., 0., 1., 1.], [0., 0., 1., 1.], [0., 0., 1., 1.], [5., 5., 5., 5.]])
+    dl = torch.Tensor([[0., 0., 0., 0.], [1., 1., 1., 1.], [0., 0., 2., -1.], [0.7, -1.9, -0.5, 0.3]])
+    from dynamask_amd.bbox_heads import DeltaXYWHBBoxCoder
+    _close(DeltaXYWHBBoxCoder().decode(_dev(r), _dev(dl), max_shape=(32, 32)), g['doc_example'], atol=1e-6)
+
+
+def test_nms_matches_oracle():
+    from dynamask_amd import ops
+    g = torch.Generator().manual_seed(4)
+    for n in (1, 5, 64, 65, 300, 1500):
+        ctr = torch.rand(n, 2, generator=g) * 300
+        wh = torch.rand(n, 2, generator=g) * 90 + 5
+        boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], 1)
+        scores = torch.rand(n, generator=g)
+        for off in (0, 1):
+            dets, keep = ops.nms(boxes.cuda(), scores.cuda(), 0.5, offset=off)
+            rd, rk = ref_model.nms(boxes, scores, 0.5, offset=off)
+            assert keep.cpu().tolist() == rk.tolist(), (n, off)
+            _close(dets, rd.numpy(), atol=0, rtol=0)
+    d0, k0 = ops.nms(torch.zeros((0, 4), device='cuda'), torch.zeros((0,), device='cuda'), 0.5)
+    assert d0.shape == (0, 5) and k0.numel() == 0
+
+
+def test_simple_test_boxes_then_masks():
+    m = _bbox_roi_head()
+    hi = gi.head_inputs()
+    fd = [_dev(f) for f in hi['feats']]
+    _, rois = gi.bbox_inputs()
+    metas = [dict(img_shape=gi.BBOX_IMG_SHAPE, ori_shape=gi.BBOX_IMG_SHAPE, scale_factor=1.0)]
+    bbox_results, segm_results = m.simple_test(fd, [_dev(rois[:, 1:])], metas, rescale=False)
+    assert len(bbox_results) == 80 and len(segm_results) == 80
+    n = sum(len(b) for b in bbox_results)
+    assert 0 < n <= 100 and sum(len(s) for s in segm_results) == n
+    for b, s in zip(bbox_results, segm_results):
+        assert b.shape[1:] == (5,) and len(s) == len(b)
+        for mask in s:
+            assert mask.shape == (256, 320) and mask.dtype == np.bool_
+    # the detections themselves: oracle on the same extractor output
+    with torch.no_grad():
+        feats7 = m.bbox_roi_extractor(fd[:4], _dev(rois))
+        cs, bp = ref_model.bbox_head_forward(gi.bbox_head_state(), feats7.cpu())
+        d, lab = ref_model.get_bboxes(rois, cs, bp, gi.BBOX_IMG_SHAPE, 1.0, cfg=gi.RCNN_TEST_CFG)
+    got = np.concatenate([b for b in bbox_results if len(b)])
+    assert abs(len(got) - len(d)) <= 2
