@@ -72,8 +72,23 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_igemm_kernel(ConvArgs a) {
   const int hi = lane >> 5;
   const int l31 = lane & 31;
 
-  const int m_tile = blockIdx.x % a.MT;
-  const int n_tile = blockIdx.x / a.MT;
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own
+  // L2), so the MT cout tiles of one pixel tile -- which read the same input -- are placed
+  // 8 apart in launch order: same XCD, back to back.  The ragged tail keeps the plain order.
+  int m_tile, n_tile;
+  {
+    const int b = blockIdx.x, grp = 8 * a.MT;
+    const int full = (gridDim.x / grp) * grp;
+    if (b < full) {
+      const int g = b / grp, r = b - g * grp;
+      m_tile = r / 8;
+      n_tile = g * 8 + (r & 7);
+    } else {
+      const int r = b - full;
+      m_tile = r % a.MT;
+      n_tile = full / a.MT + r / a.MT;
+    }
+  }
   const int m0 = m_tile * TM;
   const int q0 = n_tile * TN;
   const int HW = a.HW, W = a.W, H = a.H;
