@@ -351,18 +351,17 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
 //    4 channel planes) and ONE 16-byte LDS store, already interleaved (no register
 //    transposition, no bank conflicts).  The LDS slot of item idx is idx; its global
 //    offset does not depend on the batch and is computed once (multiply-high divisions).
-//  * As many channel quads per batch as a buffer holds (bytes in flight are what the
-//    staging is bound by); double buffered: the next batch is fetched into registers
-//    before the current one is sampled and committed to the other buffer after it -- one
-//    barrier per batch.  The loop is bottom-tested on purpose (see below).
-// Footprints above 1536 pixels (only possible without the FPN level map) take the
+//  * As many channel quads per batch as the buffer holds (bytes in flight are what the
+//    staging is bound by); one buffer, 4 workgroups per CU hide each other's staging
+//    round trips (see the batch loop).
+// Footprints above 2048 pixels (only possible without the FPN level map) take the
 // direct global path inside the same launch.
 //
-// Measured (512 RoIs, 1333x800 FPN, P2..P5): 68 us; per-workgroup timeline (s_memtime):
+// Measured (512 RoIs, 1333x800 FPN, P2..P5): 68-70 us; per-workgroup timeline (s_memtime):
 // setup 0.8 us, staging round trip ~1.8 us under load, 0.7 us of sampling per batch; PMC:
 // VALU 35 % / LDS 25 % busy, L2 hit rate of the staging reads ~32 % (174 MB leave the L2
 // per launch for 91 MB of maps: short unaligned row segments over-fetch 64-byte sectors).
-constexpr int kTileFloats4 = 3072;   // float4 words of LDS per workgroup (48 KB = 2 buffers of 1536 pixel-quads): 3 workgroups per CU
+constexpr int kTileFloats4 = 2048;   // float4 words of the staging buffer (32 KB): 4 workgroups share a CU   // float4 words of LDS per workgroup (48 KB = 2 buffers of 1536 pixel-quads): 3 workgroups per CU
 
 struct TileGeom {
   int fy0, fx0, FH, pitch;   // tile origin (feature pixel), rows, columns
@@ -403,7 +402,7 @@ template <int G>
 __device__ __forceinline__ void roi_tile_fwd(const RoiArgs& a, const float* __restrict__ fimg, int Hl, int Wl, float sh,
                                              float sw, float bh, float bw, int gh, int gw, float inv_count, int k,
                                              int c0, int c1, const TileGeom tg, float4* __restrict__ lds) {
-  constexpr int kBufPx = kTileFloats4 / 2;            // pixel-quads (float4 words) per LDS buffer
+  constexpr int kBufPx = kTileFloats4;               // pixel-quads (float4 words) of the staging buffer
   constexpr int S = G + 1;                            // merged stencil is S x S (G == 0: run-time grid)
   const int tid = threadIdx.x;
   const int P = a.P, PP = P * P;
@@ -423,7 +422,7 @@ __device__ __forceinline__ void roi_tile_fwd(const RoiArgs& a, const float* __re
   float W[G > 0 ? S * S : 1];
   if (G > 0) {
     constexpr int GG = G > 0 ? G : 1;
-    float* tab = reinterpret_cast<float*>(lds + kBufPx);     // [2][P][8]: {L, W0 .. WG}
+    float* tab = reinterpret_cast<float*>(lds + kTileFloats4);     // [2][P][8]: {L, W0 .. WG}, behind the buffer
     if (tid < 2 * P) {
       const bool xa = tid >= P;
       const int p = xa ? tid - P : tid;
@@ -453,7 +452,7 @@ __device__ __forceinline__ void roi_tile_fwd(const RoiArgs& a, const float* __re
   // [quad][row][col] makes the LDS slot of item `idx` simply `idx`; which pixel it is does
   // not depend on the batch, so its global byte offset is computed once.  Columns past the
   // map's last one are clamped duplicates (weight 0), like rows.
-  constexpr int IPT = kBufPx / 256;              // items per thread and batch: 8
+  constexpr int IPT = (kBufPx + 255) / 256;      // items per thread and batch: 8
   const size_t plane = (size_t)Hl * Wl;
   int voff[IPT];
   // idx -> (quad, row, col) with multiply-high by ceil(2^32 / d): exact for idx * d < 2^32
@@ -572,30 +571,24 @@ __device__ __forceinline__ void roi_tile_fwd(const RoiArgs& a, const float* __re
     }
   };
 
-  // Software pipeline over channel batches.  The loop body is unconditional (the last
-  // batch is peeled): a conditional prefetch would merge its registers through phi copies
-  // that the compiler places right behind the loads, i.e. it would wait for them at once.
-  fetch(c0);
-  commit(c0, 0);
-  __syncthreads();
-  int buf = 0;
-  int cb = c0;
-  if (cb + NCB < c1) {
-    do {     // bottom-tested on purpose: a top-tested loop gets rotated and the prefetch duplicated into the latch
-      fetch(cb + NCB);
-      sample(cb, buf);
-      commit(cb + NCB, buf ^ 1);
-      // LDS-only barrier: __syncthreads() would also drain vmcnt(0), i.e. wait for the
-      // acknowledgement of the output stores sample() has just issued -- nobody reads those
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      cb += NCB;
-      buf ^= 1;
-    } while (cb + NCB < c1);
+  // One staging buffer: fetch -> commit -> barrier -> sample -> barrier per channel batch.
+  // The staging round trip (~1.8 us under load) is not hidden inside the workgroup but by the
+  // 4 workgroups that share a CU (32 KB of LDS and <= 128 VGPRs each).  Measured against a
+  // double-buffered pipeline (next batch prefetched into registers, 48 KB, 3 workgroups/CU):
+  // 69.6 vs 71.0 us at 512 RoIs, 23.5 vs 29.4 us at 128 -- a whole-buffer batch holds more
+  // channel quads, so there are fewer dependent round trips per workgroup.
+  for (int cb = c0; cb < c1; cb += NCB) {
+    fetch(cb);
+    commit(cb, 0);
+    __syncthreads();
+    sample(cb, 0);
+    // LDS-only barrier: __syncthreads() would also wait (vmcnt(0)) for the acknowledgement of
+    // the output stores sample() has just issued
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
-  sample(cb, buf);
 }
 
-__global__ __launch_bounds__(256, 3) void roi_align_tile_kernel(RoiArgs a) {
+__global__ __launch_bounds__(256, 4) void roi_align_tile_kernel(RoiArgs a) {
   extern __shared__ __attribute__((aligned(16))) float4 lds4[];
   const int chunks = (a.C + a.CT - 1) / a.CT;
   const int k = blockIdx.x / chunks;
@@ -655,7 +648,7 @@ __global__ __launch_bounds__(256, 3) void roi_align_tile_kernel(RoiArgs a) {
     const int px = tg.FH * tg.pitch;
 #define DM_ROI_TILE(GG) roi_tile_fwd<GG>(a, fimg, Hl, Wl, sh, sw, bh, bw, gh, gw, inv_count, k, c0, c1, tg, lds4)
     // with the FPN level map the footprint stays below ~1700 pixels (a 200 x 4 sliver)
-    if (px <= kTileFloats4 / 2) {
+    if (px <= kTileFloats4) {
       if (!merged) DM_ROI_TILE(0);
       else if (G == 1) DM_ROI_TILE(1);
       else if (G == 2) DM_ROI_TILE(2);
@@ -718,7 +711,7 @@ extern "C" int dm_roi_align_fwd(const float* const* feats, const int* H, const i
     // per-workgroup setup, fewer shorten the chain of dependent staging batches of the large RoIs
     a.CT = 32;
     const int chunks = dm_ceil_div(C, a.CT);
-    DM_LAUNCH(roi_align_tile_kernel, dim3(N * chunks), dim3(256), kTileFloats4 * sizeof(float4), (hipStream_t)stream, a);
+    DM_LAUNCH(roi_align_tile_kernel, dim3(N * chunks), dim3(256), (kTileFloats4 + 64) * sizeof(float4), (hipStream_t)stream, a);
     return dm_check_launch();
   }
   // Large output grids (56x56 extraction): planar LDS staging where the footprint fits,
