@@ -318,3 +318,47 @@ def test_paste_rle_equals_rle_of_pasted_canvas(ops):
     for n in range(N):
         assert (ref_ops.rle_decode(fused[n]) == cv[n]).all()
         assert fused[n] == ref_ops.rle_encode(cv[n])
+
+
+def test_roi_align_tile_kernel_corner_cases(ops):
+    """Every route through the LDS tile kernel (P = 14 and 7): merged stencils g = 1..4, the
+    run-time grid (clipped slivers, g up to 15), RoIs hanging over every border, one-pixel and
+    inverted RoIs, a footprint too large for the buffer (single level, whole map -> global path),
+    channel counts that leave a short last batch."""
+    from dynamask_amd import synth
+    feats = synth.make_fpn(2, 800, 1344, 24, seed=21)
+    r = [
+        [0, 10.0, 10.0, 26.0, 26.0],            # g = 1, level 0
+        [0, 100.0, 50.0, 190.0, 150.0],         # g = 2
+        [1, 300.0, 100.0, 410.0, 260.0],        # g = 3 on level 0 (tall)
+        [0, 5.0, 0.0, 20.0, 799.0],             # sliver: 800 tall, 15 wide -> level 0, g = 15
+        [1, 0.0, 700.0, 1343.0, 712.0],         # flat sliver along the bottom border
+        [0, -40.0, -30.0, 60.0, 45.0],          # hangs over the top-left corner
+        [1, 1300.0, 760.0, 1400.0, 850.0],      # hangs over the bottom-right corner
+        [0, 500.0, 300.0, 500.5, 300.5],        # sub-pixel RoI
+        [1, 600.0, 400.0, 590.0, 390.0],        # inverted (negative size) -> empty grid
+        [0, 0.0, 0.0, 1343.0, 799.0],           # whole image (level 3)
+        [1, 200.0, 100.0, 1000.0, 700.0],       # large, level 3
+        [0, 64.0, 64.0, 175.0, 175.0],          # just below the level-1 threshold
+        [1, 64.0, 64.0, 176.5, 176.5],          # just above it
+    ]
+    rois = torch.tensor(r, dtype=torch.float32)
+    fd = [_dev(f) for f in feats[:4]]
+    for P in (14, 7):
+        ref = ref_ops.single_roi_extractor(feats[:4], rois, P, (4, 8, 16, 32))
+        out = ops.roi_align(fd, _dev(rois), P, [1 / 4, 1 / 8, 1 / 16, 1 / 32])
+        _close(out, ref)
+    # single level + huge RoIs: footprint > 2048 pixels -> direct global path inside the same kernel
+    ref = ref_ops.roi_align(feats[0], rois, 14, 1 / 4, sampling_ratio=0)
+    out = ops.roi_align([fd[0]], _dev(rois), 14, [1 / 4])
+    _close(out, ref)
+    # fixed sampling ratio whose samples are more than a pixel apart -> per-sample path in LDS
+    ref = ref_ops.roi_align(feats[1], rois, 14, 1 / 8, sampling_ratio=2)
+    out = ops.roi_align([fd[1]], _dev(rois), 14, [1 / 8], sampling_ratio=2)
+    _close(out, ref)
+    # 20 channels: 5 quads -> the last batch of a workgroup is short; 6 channels: C % 4 != 0 -> old kernel
+    for C in (20, 6):
+        f2 = [f[:, :C].contiguous() for f in feats[:4]]
+        ref = ref_ops.single_roi_extractor(f2, rois, 14, (4, 8, 16, 32))
+        out = ops.roi_align([_dev(f) for f in f2], _dev(rois), 14, [1 / 4, 1 / 8, 1 / 16, 1 / 32])
+        _close(out, ref)
