@@ -15,4 +15,8 @@ Parity status (see DESIGN.md "Oracle"):
     They are restated from mmcv's published algorithm and pinned only by
     known-answer tests (constant/ramp maps, zero-offset DCN == conv2d,
     grid_sample identity, float64 brute force).
+  * likewise third-party and unpinned: mmcv.ops.nms / batched_nms (restated greedy
+    NMS) and pycocotools' RLE (cocoapi maskApi.c restated; round trips + hand vectors).
+  * bbox branch (Shared2FCBBoxHead, get_bboxes, delta2bbox): PINNED by g10
+    (tests/golden/make_golden_bbox.py).
 """
