@@ -665,6 +665,237 @@ __global__ __launch_bounds__(256, 4) void roi_align_tile_kernel(RoiArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Forward kernel for larger output grids (16 < P <= 64: the 56x56 extraction on P2 that
+// feeds MaskPre).  Same LDS tile format, merged stencils and staging as the
+// 14x14 kernel, generalised in two ways:
+//   * **bands**: the footprint of a large RoI (up to 200 x 336 feature pixels) does not fit
+//     LDS, but a band of R output rows only needs (R * bin_h + g + 2) feature rows; the
+//     workgroup walks the bands and re-stages per band (rows shared by two bands are read twice);
+//   * several output bins per thread: the stencils of all P rows and P columns sit in an LDS
+//     table, a thread rebuilds the (g+1)^2 products of each bin it owns from two table
+//     entries and reuses them for the channel quads of the batch.
+// RoIs wider than the buffer allows even for a one-row band take the direct global path.
+constexpr int kBandTabFloats4 = 2 * 64 * 8 / 4;      // stencil table for P <= 64
+
+template <int G>
+__device__ __forceinline__ void roi_band_fwd(const RoiArgs& a, const float* __restrict__ fimg, int Hl, int Wl, float sh,
+                                             float sw, float bh, float bw, int gh, int gw, float inv_count, int k,
+                                             int c0, int c1, int fx0, int pitch, int xmax, int rows_per_band,
+                                             float4* __restrict__ lds) {
+  constexpr int S = G + 1;
+  constexpr int GG = G > 0 ? G : 1;
+  constexpr int IPT = (kTileFloats4 + 255) / 256;
+  const int tid = threadIdx.x;
+  const int P = a.P, PP = P * P;
+  const size_t plane = (size_t)Hl * Wl;
+  float* tab = reinterpret_cast<float*>(lds + kTileFloats4);     // [2][P][8]: {L, W0 .. WG}
+  if (G > 0) {
+    if (tid < 2 * P) {
+      const bool xa = tid >= P;
+      const int p = xa ? tid - P : tid;
+      int L;
+      float Wt[GG + 1];
+      axis_stencil<GG>(xa ? sw : sh, xa ? bw : bh, xa ? gw : gh, p, xa ? Wl : Hl, L, Wt);
+      float* e = tab + tid * 8;
+      e[0] = __int_as_float(L);
+#pragma unroll
+      for (int r = 0; r <= GG; ++r) e[1 + r] = xa ? Wt[r] : Wt[r] * inv_count;
+    }
+    __syncthreads();
+  }
+  const int pad = G > 0 ? G : 1;
+  const unsigned m_pitch = 0xFFFFFFFFu / (unsigned)pitch + 1u;
+  for (int ph0 = 0; ph0 < P; ph0 += rows_per_band) {
+    const int R = min(rows_per_band, P - ph0);
+    // band tile rows: first / last sample of the band (the expressions of axis_sample)
+    const float yf = sh + (float)ph0 * bh + 0.5f * bh / (float)gh;
+    const float yl = sh + (float)(ph0 + R - 1) * bh + ((float)(gh - 1) + 0.5f) * bh / (float)gh;
+    const int fy0 = min((int)fmaxf(fminf(yf, yl), 0.f), Hl - 1);
+    const int ylast = min((int)fmaxf(fmaxf(yf, yl), 0.f), Hl - 1);
+    const int FH = ylast + pad - fy0 + 1;
+    const int ymax = min(ylast + 1, Hl - 1);
+    const int plane_px = FH * pitch;                       // <= kTileFloats4 by the choice of rows_per_band
+    const int NQ = min(kTileFloats4 / plane_px, (c1 - c0) >> 2);
+    const int NCB = NQ * 4;
+    const unsigned m_plane = 0xFFFFFFFFu / (unsigned)plane_px + 1u;
+    int voff[IPT];
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+      const int idx = tid + i * 256;
+      const int idc = idx < NQ * plane_px ? idx : 0;
+      const int q = (int)__umulhi((unsigned)idc, m_plane);
+      const int rem = idc - q * plane_px;
+      const int r = (int)__umulhi((unsigned)rem, m_pitch);
+      const int x = rem - r * pitch;
+      const int gy = min(fy0 + r, ymax);
+      const int gx = min(fx0 + x, xmax);
+      voff[i] = (q * 4 * (int)plane + gy * Wl + gx) * 4;
+    }
+    for (int cb = c0; cb < c1; cb += NCB) {
+      const int nq = min(NQ, (c1 - cb) >> 2);
+      const int live = nq * plane_px;
+      {
+        const char* b0 = reinterpret_cast<const char*>(fimg + (size_t)cb * plane);
+        const char* b1 = b0 + plane * 4;
+        const char* b2 = b1 + plane * 4;
+        const char* b3 = b2 + plane * 4;
+        float pf[IPT][4];
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+          const int vo = (tid + i * 256 < live) ? voff[i] : 0;
+          pf[i][0] = *reinterpret_cast<const float*>(b0 + vo);
+          pf[i][1] = *reinterpret_cast<const float*>(b1 + vo);
+          pf[i][2] = *reinterpret_cast<const float*>(b2 + vo);
+          pf[i][3] = *reinterpret_cast<const float*>(b3 + vo);
+        }
+#pragma unroll
+        for (int i = 0; i < IPT; ++i)
+          if (tid + i * 256 < live) lds[tid + i * 256] = make_float4(pf[i][0], pf[i][1], pf[i][2], pf[i][3]);
+      }
+      __syncthreads();
+      for (int i = tid; i < R * P; i += 256) {
+        const int pr = i / P;
+        const int ph = ph0 + pr, pw = i - pr * P;
+        float* o = a.out + ((size_t)k * a.C + cb) * PP + ph * P + pw;
+        if (G > 0) {
+          const float* ey = tab + ph * 8;
+          const float* ex = tab + (P + pw) * 8;
+          const int Ly = __float_as_int(ey[0]), Lx = __float_as_int(ex[0]);
+          const int base = min(max(Ly - fy0, 0), FH - S) * pitch + min(max(Lx - fx0, 0), pitch - S);
+          float W[G > 0 ? S * S : 1];
+#pragma unroll
+          for (int r = 0; r < S; ++r)
+#pragma unroll
+            for (int c = 0; c < S; ++c) W[G > 0 ? r * S + c : 0] = ey[1 + r] * ex[1 + c];
+          for (int q = 0; q < nq; ++q) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4* tq = lds + q * plane_px + base;
+#pragma unroll
+            for (int r = 0; r < S; ++r) {
+              const float4* tr = tq + r * pitch;
+#pragma unroll
+              for (int c = 0; c < S; ++c) {
+                const float4 v = tr[c];
+                const float wv = W[G > 0 ? r * S + c : 0];
+                acc.x += wv * v.x;
+                acc.y += wv * v.y;
+                acc.z += wv * v.z;
+                acc.w += wv * v.w;
+              }
+            }
+            o[(size_t)(4 * q) * PP] = acc.x;
+            o[(size_t)(4 * q + 1) * PP] = acc.y;
+            o[(size_t)(4 * q + 2) * PP] = acc.z;
+            o[(size_t)(4 * q + 3) * PP] = acc.w;
+          }
+        } else {
+          for (int q = 0; q < nq; ++q) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int iy = 0; iy < gh; ++iy) {
+              int lo, hi;
+              float yl_w, yh_w;
+              axis_sample(sh, bh, gh, ph, iy, Hl, lo, hi, yl_w, yh_w);
+              const int yo = min(max(lo - fy0, 0), FH - 2) * pitch;
+              yl_w *= inv_count;
+              yh_w *= inv_count;
+              for (int ix = 0; ix < gw; ++ix) {
+                float xl_w, xh_w;
+                axis_sample(sw, bw, gw, pw, ix, Wl, lo, hi, xl_w, xh_w);
+                const int xo = min(max(lo - fx0, 0), pitch - 2);
+                const float4* tp = lds + q * plane_px + yo + xo;
+                const float4 v1 = tp[0], v2 = tp[1], v3 = tp[pitch], v4 = tp[pitch + 1];
+                const float w0 = yl_w * xl_w, w1 = yl_w * xh_w, w2 = yh_w * xl_w, w3 = yh_w * xh_w;
+                acc.x += w0 * v1.x + w1 * v2.x + w2 * v3.x + w3 * v4.x;
+                acc.y += w0 * v1.y + w1 * v2.y + w2 * v3.y + w3 * v4.y;
+                acc.z += w0 * v1.z + w1 * v2.z + w2 * v3.z + w3 * v4.z;
+                acc.w += w0 * v1.w + w1 * v2.w + w2 * v3.w + w3 * v4.w;
+              }
+            }
+            o[(size_t)(4 * q) * PP] = acc.x;
+            o[(size_t)(4 * q + 1) * PP] = acc.y;
+            o[(size_t)(4 * q + 2) * PP] = acc.z;
+            o[(size_t)(4 * q + 3) * PP] = acc.w;
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 4) void roi_align_band_kernel(RoiArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float4 lds4[];
+  const int chunks = (a.C + a.CT - 1) / a.CT;
+  const int k = blockIdx.x / chunks;
+  const int chunk = blockIdx.x - k * chunks;
+  const int c0 = chunk * a.CT;
+  const int c1 = min(c0 + a.CT, a.C);
+  const float* r = a.rois + (size_t)k * 5;
+  const int b = (int)r[0];
+  const float x1 = r[1], y1 = r[2], x2 = r[3], y2 = r[4];
+  const int lvl = (a.L > 1) ? roi_level(x1, y1, x2, y2, a.finest, a.L) : 0;
+  if (a.levels && chunk == 0 && threadIdx.x == 0) a.levels[k] = lvl;
+  const bool bad_batch = (b < 0 || b >= a.B);
+  int Hl = a.H[0], Wl = a.W[0];
+  float sc = a.scale[0];
+  const float* flvl = a.feat[0];
+#pragma unroll
+  for (int l = 1; l < DM_MAX_LEVELS; ++l)
+    if (lvl == l) {
+      Hl = a.H[l];
+      Wl = a.W[l];
+      sc = a.scale[l];
+      flvl = a.feat[l];
+    }
+  const float sw = x1 * sc - 0.5f, sh = y1 * sc - 0.5f;
+  const float ew = x2 * sc - 0.5f, eh = y2 * sc - 0.5f;
+  const float rw = ew - sw, rh = eh - sh;
+  const int P = a.P, PP = P * P;
+  const float bh = rh / (float)P, bw = rw / (float)P;
+  const int gh = a.sr > 0 ? a.sr : (int)ceilf(rh / (float)P);
+  const int gw = a.sr > 0 ? a.sr : (int)ceilf(rw / (float)P);
+  const float inv_count = 1.0f / (float)max(gh * gw, 1);
+  const float* fimg = flvl + (bad_batch ? 0 : (size_t)b * a.C * Hl * Wl);
+  if (gh <= 0 || gw <= 0 || bad_batch) {
+    for (int i = threadIdx.x; i < (c1 - c0) * PP; i += blockDim.x) a.out[((size_t)k * a.C + c0) * PP + i] = 0.f;
+    return;
+  }
+  {
+    const float xf = sw + 0.5f * bw / (float)gw;
+    const float xl = sw + (float)(P - 1) * bw + ((float)(gw - 1) + 0.5f) * bw / (float)gw;
+    const int G = max(gh, gw);
+    const bool merged = G <= 4 && bh <= (float)gh && bw <= (float)gw;
+    const int pad = merged ? G : 1;
+    const int fx0 = min((int)fmaxf(fminf(xf, xl), 0.f), Wl - 1);
+    const int xlast = min((int)fmaxf(fmaxf(xf, xl), 0.f), Wl - 1);
+    const int pitch = xlast + pad - fx0 + 1;
+    const int xmax = min(xlast + 1, Wl - 1);
+    // rows of output per band: the band's tile has at most ceil(R * |bh|) + pad + 2 rows
+    const int fh_max = kTileFloats4 / pitch;
+    const float abh = fmaxf(fabsf(bh), 1e-6f);
+    int R = (int)fminf((float)P, floorf((float)(fh_max - pad - 2) / abh));
+    // prefer bands small enough for two channel quads per batch when that still leaves >= 4 rows
+    const int R2 = (int)fminf((float)P, floorf((float)(fh_max / 2 - pad - 2) / abh));
+    if (R2 >= 4) R = R2;
+    if (R >= 1) {
+#define DM_ROI_BAND(GG) roi_band_fwd<GG>(a, fimg, Hl, Wl, sh, sw, bh, bw, gh, gw, inv_count, k, c0, c1, fx0, pitch, xmax, R, lds4)
+      if (!merged) DM_ROI_BAND(0);
+      else if (G == 1) DM_ROI_BAND(1);
+      else if (G == 2) DM_ROI_BAND(2);
+      else if (G == 3) DM_ROI_BAND(3);
+      else DM_ROI_BAND(4);
+#undef DM_ROI_BAND
+      return;
+    }
+  }
+  for (int pos = threadIdx.x; pos < PP; pos += blockDim.x) {
+    const int ph = pos / P;
+    const int pw = pos - ph * P;
+    roi_bin_generic<false>(a, fimg, nullptr, Hl, Wl, sh, sw, bh, bw, gh, gw, inv_count, ph, pw, k, c0, c1);
+  }
+}
+
 int fill_args(RoiArgs& a, const int* H, const int* W, const float* spatial_scales, int num_levels, int B, int C,
               const float* rois, int N, int P, int sampling_ratio, float finest_scale) {
   if (!H || !W || !spatial_scales || (!rois && N > 0)) return DM_ERR_INVALID_ARG;
@@ -712,6 +943,15 @@ extern "C" int dm_roi_align_fwd(const float* const* feats, const int* H, const i
     a.CT = 32;
     const int chunks = dm_ceil_div(C, a.CT);
     DM_LAUNCH(roi_align_tile_kernel, dim3(N * chunks), dim3(256), (kTileFloats4 + 64) * sizeof(float4), (hipStream_t)stream, a);
+    return dm_check_launch();
+  }
+  bool band_ok = P > 16 && P <= 64 && C % 4 == 0;
+  for (int l = 0; l < num_levels; ++l) band_ok = band_ok && (long long)H[l] * W[l] <= (1 << 23);
+  if (band_ok) {
+    a.CT = 16;
+    const int chunks = dm_ceil_div(C, a.CT);
+    DM_LAUNCH(roi_align_band_kernel, dim3(N * chunks), dim3(256), (kTileFloats4 + kBandTabFloats4) * sizeof(float4),
+              (hipStream_t)stream, a);
     return dm_check_launch();
   }
   // Large output grids (56x56 extraction): planar LDS staging where the footprint fits,

@@ -356,6 +356,17 @@ def test_roi_align_tile_kernel_corner_cases(ops):
     ref = ref_ops.roi_align(feats[1], rois, 14, 1 / 8, sampling_ratio=2)
     out = ops.roi_align([fd[1]], _dev(rois), 14, [1 / 8], sampling_ratio=2)
     _close(out, ref)
+    # banded kernel (16 < P <= 64): 56x56 on P2 as the semantic extractor does (huge RoIs -> many bands,
+    # the whole-image RoI is too wide for a one-row band -> global path), 28x28 multi-level, fixed ratio
+    ref = ref_ops.roi_align(feats[0], rois, 56, 1 / 4, sampling_ratio=0)
+    out = ops.roi_align([fd[0]], _dev(rois), 56, [1 / 4])
+    _close(out, ref)
+    ref = ref_ops.single_roi_extractor(feats[:4], rois, 28, (4, 8, 16, 32))
+    out = ops.roi_align(fd, _dev(rois), 28, [1 / 4, 1 / 8, 1 / 16, 1 / 32])
+    _close(out, ref)
+    ref = ref_ops.roi_align(feats[2], rois, 20, 1 / 16, sampling_ratio=3)
+    out = ops.roi_align([fd[2]], _dev(rois), 20, [1 / 16], sampling_ratio=3)
+    _close(out, ref)
     # 20 channels: 5 quads -> the last batch of a workgroup is short; 6 channels: C % 4 != 0 -> old kernel
     for C in (20, 6):
         f2 = [f[:, :C].contiguous() for f in feats[:4]]
