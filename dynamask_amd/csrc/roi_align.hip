@@ -948,7 +948,10 @@ extern "C" int dm_roi_align_fwd(const float* const* feats, const int* H, const i
   bool band_ok = P > 16 && P <= 64 && C % 4 == 0;
   for (int l = 0; l < num_levels; ++l) band_ok = band_ok && (long long)H[l] * W[l] <= (1 << 23);
   if (band_ok) {
-    a.CT = 16;
+    // one channel quad per workgroup (swept 4 .. 32 at 128 RoIs on P2: 0.32 / 0.45 / 0.79 / 1.5 ms): the
+    // bands of a large RoI are a long chain of dependent staging round trips, so the parallelism has to
+    // come from the number of workgroups
+    a.CT = 4;
     const int chunks = dm_ceil_div(C, a.CT);
     DM_LAUNCH(roi_align_band_kernel, dim3(N * chunks), dim3(256), (kTileFloats4 + kBandTabFloats4) * sizeof(float4),
               (hipStream_t)stream, a);
