@@ -332,7 +332,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_igemm_kernel(ConvArgs a) {
               float v = acc[i][j][r] + b;
               if (a.relu & 2) v += *op;          // accumulate into the destination (gradient sums)
               if (a.relu & 1) v = fmaxf(v, 0.f);
-              *op = v;
+              if (a.relu & 4) __builtin_nontemporal_store(v, op);   // output larger than the Infinity Cache: stream it
+              else *op = v;
             }
           }
         } else {
@@ -503,8 +504,12 @@ extern "C" int dm_conv2d_fwd(const float* const* srcs, const int* src_channels, 
   a.KQ = packed_quads(num_srcs, src_channels);
   a.NB = NB; a.H = H; a.W = W; a.HW = H * W; a.Q = NB * H * W;
   a.wq = w_packed; a.bias = bias; a.Cout = Cout; a.CoutP = dm_conv_packed_cout(Cout);
-  a.relu = relu; a.out = out; a.out_ch_total = out_ch_total; a.out_ch_offset = out_ch_offset;
+  a.relu = relu & 3; a.out = out; a.out_ch_total = out_ch_total; a.out_ch_offset = out_ch_offset;
   a.shuffle = 0;
+  // outputs that cannot stay in the 256 MB Infinity Cache next to their consumer's other traffic are
+  // written with nontemporal stores (measured: -10 % on the 1.85 GB column-gradient GEMM, neutral
+  // below); accumulating launches read the destination and keep the default policy
+  if (!(relu & 2) && (long long)NB * Cout * H * W * 4 > (192LL << 20)) a.relu |= 4;
   hipStream_t st = (hipStream_t)stream;
   if (ksize == 3) {
     if (Cout > 64) return launch_conv<3, 2, 2, 2, 2, 8>(a, st);

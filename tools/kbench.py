@@ -50,6 +50,9 @@ def main():
     conv('out1x1 128->62 @28', [128], 62, 28, 1)
     conv('fuse1x1 130->64 @56', [64, 64, 2], 64, 56, 1)
     conv('out1x1 64->30 @56', [64], 30, 56, 1)
+    conv('colgrad1x1 64->576 @56 (256 rois)', [64], 576, 56, 1, nb=256)
+    conv('colgrad1x1 128->1152 @28 (256)', [128], 1152, 28, 1, nb=256)
+    conv('colgrad1x1 256->2304 @14 (256)', [256], 2304, 14, 1, nb=256)
     conv('sem1x1 256->256 P4', [256], 256, 0, 1, nb=1, hw=(50, 84))
     conv('sem1x1 256->128 P3', [256], 128, 0, 1, nb=1, hw=(100, 168))
     conv('sem1x1 256->64 P2', [256], 64, 0, 1, nb=1, hw=(200, 336))
