@@ -89,7 +89,7 @@ def test_simple_test_mask_logits_vs_oracle():
 
 
 def test_fcn_mask_head_matches_reference_golden(golden_dir):
-    from dynamask_amd import registry
+    from dynamask_amd import registry, mask_heads  # noqa: F401
     g = np.load(os.path.join(golden_dir, 'g6_fcn.npz'))
     x = _dev(gi.fcn_input())
     for up in ('deconv', 'carafe', 'bilinear'):

@@ -93,6 +93,10 @@ def main():
         x = torch.randn(N, C, S, S, device=dev)
         ms = t(lambda: ops.upsample2x(x, relu=True))
         rows.append((f'upsample {C} @{S}', ms, (N * C * S * S * 4 * 5) / ms / 1e6, 'GB/s(in+out)'))
+    x = torch.randn(N, 256, 14, 14, device=dev)
+    enc = torch.randn(N, 100, 14, 14, device=dev)
+    ms = t(lambda: ops.carafe(x, enc))
+    rows.append(('carafe 256 @14->28', ms, (N * 256 * 196 * 4 * 5 + N * 100 * 196 * 4) / ms / 1e6, 'GB/s(in+out)'))
     if os.environ.get('KB_WGRAD', '1') == '1':
         NT = 256          # training RoI batch (2 images x 128 positives)
         def wgrad(name, cin, cout, S, ks):
