@@ -87,10 +87,30 @@ class MaskPre(nn.Module):
 
     def forward(self, x):
         x = self._bn_pool(self.conv1.run(x), self.bn1)
+        return self._tail(x)
+
+    def _tail(self, x):
         x = self._bn_pool(self.conv2.run(x), self.bn2)
         x = x.reshape(x.size(0), 3136)
         x = self.fc1.run(x, relu=True)
         return self.fc2.run(x)
+
+    @torch.no_grad()
+    def forward_from_map(self, feat_map, rois, extractor):
+        """Inference shortcut (eval mode): ``conv1`` is 1x1, hence linear per pixel, and RoIAlign is
+        a linear interpolation, so  conv1(RoIAlign(x)) = RoIAlign(W1 x) + b1  (the bias is added
+        after the RoIAlign: samples outside the map count as 0 on both sides).  W1 is applied once
+        to the whole FPN map (4.4 GFLOP per image instead of 0.21 GFLOP per RoI) and RoIAlign56
+        extracts 128 channels instead of 256; b1 is folded into the BatchNorm shift.  Same value
+        as ``forward(extractor([feat_map], rois))`` up to fp32 rounding (~1e-6)."""
+        assert not self.training, 'train-mode BatchNorm statistics are taken on the per-RoI tensor'
+        wq = self.conv1.packed([feat_map.shape[1]])
+        y_map = ops.conv2d([feat_map], wq, None, self.conv1.out_channels, 1)          # no bias
+        roi = extractor([y_map], rois)                                               # [N, 128, 56, 56]
+        bn = self.bn1
+        x = ops.bn_relu_maxpool(roi, (bn.running_mean - self.conv1.bias.detach()).contiguous(), bn.running_var,
+                                bn.weight.detach(), bn.bias.detach(), bn.eps)
+        return self._tail(x)
 
 
 @HEADS.register_module()
@@ -281,11 +301,15 @@ class DynaMaskRoIHead(nn.Module):
         dev = det_bboxes.device
         rois = bbox2roi([det_bboxes[:, :4]]).contiguous()
         if exits is None:
-            sem = self.semantic_roi_extractor([x[0], ], rois)
             if noise is None:
                 noise = torch.full((n, 4), 0.5, device=dev)       # constant Gumbel shift: argmax(logits)
-            with torch.no_grad():
+            if self.mask_predictor.training:
+                sem = self.semantic_roi_extractor([x[0], ], rois)
                 _, idx, _, _ = self.get_mask_label(sem, noise, return_index=True)
+            else:
+                # conv1 commutes with RoIAlign: half the extraction, no per-RoI 256->128 conv
+                logits = self.mask_predictor.forward_from_map(x[0], rois, self.semantic_roi_extractor)
+                _, _, idx = ops.gumbel_select(logits, noise.contiguous(), 0.5)
             exits = idx.long()
         else:
             exits = torch.as_tensor(exits, device=dev).long()

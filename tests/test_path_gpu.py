@@ -468,3 +468,18 @@ def test_simple_test_boxes_then_masks():
         d, lab = ref_model.get_bboxes(rois, cs, bp, gi.BBOX_IMG_SHAPE, 1.0, cfg=gi.RCNN_TEST_CFG)
     got = np.concatenate([b for b in bbox_results if len(b)])
     assert abs(len(got) - len(d)) <= 2
+
+
+def test_mask_pre_conv1_commutes_with_roialign():
+    """MaskPre.forward_from_map (inference shortcut): conv1(RoIAlign56(x)) == RoIAlign56(W1 x) + b1."""
+    feats, rois, labels, _ = _dyn_case(seed=31, n=23)
+    rois = torch.cat([rois, torch.tensor([[0, -20.0, -10.0, 90.0, 70.0], [0, 250.0, 200.0, 330.0, 260.0]])])  # over the borders
+    m = _roi_head()
+    p2 = _dev(feats[0])
+    with torch.no_grad():
+        direct = m.mask_predictor(m.semantic_roi_extractor([p2], _dev(rois)))
+        fast = m.mask_predictor.forward_from_map(p2, _dev(rois), m.semantic_roi_extractor)
+        sd = {**gi.head_state(), **gi.mask_pre_state()}
+        ref = ref_model.mask_pre(sd, ref_ops.single_roi_extractor([feats[0]], rois, 56, (4,)), training=False)
+    _close(fast, direct.cpu().numpy(), atol=1e-4, rtol=1e-4)
+    _close(fast, ref.numpy(), atol=1e-4, rtol=1e-4)
