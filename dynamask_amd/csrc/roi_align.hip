@@ -1,20 +1,17 @@
-// K1/K2/K3: multi-level RoIAlign (avg, aligned=True, adaptive sampling grid),
-// FPN level mapping fused into the kernel (one launch for all levels).
+// K1/K2/K3: multi-level RoIAlign (avg, aligned=True, adaptive sampling grid), FPN level
+// mapping fused into the kernels (one launch for all levels).  Three forward kernels, all
+// "workgroup = RoI x channel chunk, lanes = output bins, NCHW output rows coalesced":
 //
-// Workgroup = one RoI x one chunk of channels.  A thread owns output bin(s)
-// (ph, pw) and computes the bin's sample rows/columns and bilinear weights ONCE
-// (they do not depend on the channel), keeps them in registers, then walks the
-// channel chunk: per channel only 4*g*g loads + FMAs, no address arithmetic.
-// Consecutive lanes own consecutive pw, so the NCHW output is written in
-// 4*P-byte coalesced rows.
+//   roi_align_tile_kernel   P*P <= 256 (14x14 mask / 7x7 bbox extraction) -- the tuned one:
+//                           channel-quad interleaved LDS tile, merged (g+1)^2 stencils
+//   roi_align_band_kernel   16 < P <= 64 (56x56 on P2 for MaskPre): same tile format, the RoI
+//                           is walked in bands of output rows so any footprint height fits
+//   roi_align_kernel        everything else (C % 4 != 0, P > 64: GT-bitmap mask targets) and
+//                           the backward (scatter atomics): planar LDS tile or direct global
+//                           taps, sample geometry kept in registers across the channel chunk
 //
-// Forward fast path: the RoI's footprint (the feature rows/columns its samples
-// touch) is first staged into LDS with coalesced row reads -- every feature
-// element is fetched from L2/HBM exactly once per workgroup -- and the 4*g*g
-// taps per output are then LDS reads (32 lanes/clk) instead of scattered global
-// loads (the v1 kernel was load-issue bound at 9 % of the HBM roofline).
-// Footprints that do not fit the LDS budget (56x56 extraction of large RoIs) and
-// the backward keep the direct global path.
+// (History: the direct-global kernel ran at 9 % of the HBM roofline on the 14x14 case, the
+// planar LDS version at 16.5 %, the tile kernel at 35 %; see DESIGN.md for what bounded each.)
 #include "common.h"
 
 namespace {
