@@ -98,3 +98,68 @@ def test_edge_cases_empty_single_and_ragged_rois():
         full_ = m._mask_forward(feats, hi['rois'].cuda(), hi['labels'].cuda())
     assert torch.allclose(r1['stage_instance_preds'][3], full_['stage_instance_preds'][3][:1], atol=1e-5)
     assert torch.allclose(r2['stage_detail_preds'][2], full_['stage_detail_preds'][2][sel.cuda()], atol=1e-5)
+
+
+def test_dynamic_inference_full_size_rows_identical_to_fixed_path(full):
+    """512 RoIs, exits spread over the four resolutions: every RoI's logits at its own exit equal
+    the all-exits path bit for bit (RoIs never interact), whatever the bucket sizes."""
+    feats, rois, labels = full
+    m = _head()
+    m.num_streams = 1
+    exits = (torch.arange(512) * 7 + 3) % 4
+    with torch.no_grad():
+        ref = m._mask_forward(feats, rois, labels)['stage_instance_preds']
+        res = m.dynamic_mask_logits(feats, rois[:, 1:].contiguous(), labels, merge=False, exits=exits)
+    order = res['order'].cpu().tolist()
+    assert res['n_ge'] == [int((exits >= k).sum()) for k in range(4)]
+    bad = 0
+    for p, j in enumerate(order):
+        e = int(exits[j])
+        bad += int(not torch.equal(res['preds'][e][p], ref[e][j]))
+    assert bad == 0
+
+
+def test_paste_rle_round_trip_full_size(ops):
+    """100 detections on a 1333x800 canvas: decode(device RLE) == pasted bitmap, fused == canvas form."""
+    from oracle import ref_ops
+    g = torch.Generator().manual_seed(11)
+    N, S, H, W = 100, 112, 800, 1333
+    masks = torch.randn(N, 1, S, S, generator=g) * 2 + 0.5
+    ctr = torch.rand(N, 2, generator=g) * torch.tensor([W, H])
+    wh = torch.rand(N, 2, generator=g) * 400 + 10
+    boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], 1)
+    canvas = ops.paste_masks(masks.cuda(), boxes.cuda(), H, W, 0.5, apply_sigmoid=True)
+    fused = ops.paste_rle(masks.cuda(), boxes.cuda(), H, W, 0.5, apply_sigmoid=True)
+    assert fused == ops.rle_encode(canvas)
+    cv = canvas.cpu().numpy()
+    for n in (0, 17, 99):
+        assert (ref_ops.rle_decode(fused[n]) == cv[n]).all()
+    # total foreground area from the run lengths == popcount of the canvas
+    area = [sum(ref_ops.rle_from_string(r['counts'])[1::2]) for r in fused]
+    assert area == cv.reshape(N, -1).sum(1).tolist()
+
+
+def test_nms_idempotent_and_separated_full_size(ops):
+    """5000 boxes: the kept set is NMS-stable (running NMS on it keeps everything) and every
+    suppressed box overlaps some higher-scored kept box by more than the threshold."""
+    g = torch.Generator().manual_seed(12)
+    n = 5000
+    ctr = torch.rand(n, 2, generator=g) * torch.tensor([1333.0, 800.0])
+    wh = torch.rand(n, 2, generator=g) * 200 + 8
+    boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], 1).cuda()
+    scores = torch.rand(n, generator=g).cuda()
+    dets, keep = ops.nms(boxes, scores, 0.5)
+    assert (dets[1:, 4] <= dets[:-1, 4]).all()                     # descending scores
+    d2, k2 = ops.nms(dets[:, :4].contiguous(), dets[:, 4].contiguous(), 0.5)
+    assert k2.tolist() == list(range(len(keep)))                   # idempotent
+    kb = boxes[keep]
+    def iou(a, b):
+        lt = torch.maximum(a[:, None, :2], b[None, :, :2]); rb = torch.minimum(a[:, None, 2:], b[None, :, 2:])
+        inter = (rb - lt).clamp(min=0).prod(-1)
+        aa = (a[:, 2:] - a[:, :2]).prod(-1); ab = (b[:, 2:] - b[:, :2]).prod(-1)
+        return inter / (aa[:, None] + ab[None] - inter)
+    mask = torch.ones(n, dtype=torch.bool, device='cuda'); mask[keep] = False
+    sup = boxes[mask]
+    m = iou(sup, kb)
+    higher = scores[mask][:, None] <= scores[keep][None]
+    assert ((m > 0.5) & higher).any(1).all()
