@@ -143,26 +143,21 @@ def batched_nms(boxes, scores, idxs, nms_cfg, class_agnostic=False):
 
 
 def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1, score_factors=None):
-    """core/post_processing/bbox_nms.py:5-68."""
-    num_classes = multi_scores.size(1) - 1
-    if multi_bboxes.shape[1] > 4:
-        bboxes = multi_bboxes.view(multi_scores.size(0), -1, 4)
-    else:
-        bboxes = multi_bboxes[:, None].expand(multi_scores.size(0), num_classes, 4)
-    scores = multi_scores[:, :-1]
-    valid_mask = scores > score_thr
-    bboxes = bboxes[valid_mask]
-    if score_factors is not None:
-        scores = scores * score_factors[:, None]
-    scores = scores[valid_mask]
-    labels = valid_mask.nonzero(as_tuple=False)[:, 1]
-    if bboxes.numel() == 0:
+    """core/post_processing/bbox_nms.py:5-68 -> (dets [k, 5], labels [k]), labels 0-based; the
+    last score column (background) is ignored."""
+    n, ncls = multi_scores.shape[0], multi_scores.shape[1] - 1
+    fg = multi_scores[:, :ncls]
+    cand = (fg > score_thr).nonzero(as_tuple=False)          # row-major: the reference's masked_select order
+    if cand.shape[0] == 0:
         return multi_bboxes.new_zeros((0, 5)), multi_bboxes.new_zeros((0,), dtype=torch.long)
-    dets, keep = batched_nms(bboxes, scores, labels, nms_cfg)
+    ri, ci = cand[:, 0], cand[:, 1]
+    per_class = multi_bboxes.view(n, -1, 4)
+    boxes = per_class[ri, ci] if per_class.shape[1] > 1 else per_class[ri, 0]
+    scores = fg[ri, ci] if score_factors is None else (fg * score_factors[:, None])[ri, ci]
+    dets, keep = batched_nms(boxes, scores, ci, nms_cfg)
     if max_num > 0:
-        dets = dets[:max_num]
-        keep = keep[:max_num]
-    return dets, labels[keep]
+        dets, keep = dets[:max_num], keep[:max_num]
+    return dets, ci[keep]
 
 
 def bbox2result(bboxes, labels, num_classes):

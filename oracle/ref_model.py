@@ -354,29 +354,25 @@ def bbox_head_forward(sd, x, pre='bbox_head.'):
 
 
 def delta2bbox(rois, deltas, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), max_shape=None, wh_ratio_clip=16 / 1000):
-    """core/bbox/coder/delta_xywh_bbox_coder.py:118-204."""
-    import numpy as np
-    n4 = deltas.size(1) // 4
-    means = deltas.new_tensor(means).view(1, -1).repeat(1, n4)
-    stds = deltas.new_tensor(stds).view(1, -1).repeat(1, n4)
-    d = deltas * stds + means
-    dx, dy, dw, dh = d[:, 0::4], d[:, 1::4], d[:, 2::4], d[:, 3::4]
-    max_ratio = float(np.abs(np.log(wh_ratio_clip)))
-    dw = dw.clamp(min=-max_ratio, max=max_ratio)
-    dh = dh.clamp(min=-max_ratio, max=max_ratio)
-    px = ((rois[:, 0] + rois[:, 2]) * 0.5).unsqueeze(1).expand_as(dx)
-    py = ((rois[:, 1] + rois[:, 3]) * 0.5).unsqueeze(1).expand_as(dy)
-    pw = (rois[:, 2] - rois[:, 0]).unsqueeze(1).expand_as(dw)
-    ph = (rois[:, 3] - rois[:, 1]).unsqueeze(1).expand_as(dh)
-    gw, gh = pw * dw.exp(), ph * dh.exp()
-    gx, gy = px + pw * dx, py + ph * dy
-    x1, y1, x2, y2 = gx - gw * 0.5, gy - gh * 0.5, gx + gw * 0.5, gy + gh * 0.5
+    """DeltaXYWH decoding -- core/bbox/coder/delta_xywh_bbox_coder.py:118-204, restated on a
+    [N, boxes-per-roi, 4] view: de-normalise, clamp the log-size deltas to |log(wh_ratio_clip)|,
+    move the proposal centre by delta * size, scale the size by exp(delta), corners = centre -/+
+    size/2, optional clamp to the image."""
+    import math
+    n = rois.shape[0]
+    d = deltas.reshape(n, -1, 4) * deltas.new_tensor(stds) + deltas.new_tensor(means)
+    lim = abs(math.log(wh_ratio_clip))
+    shift, logsz = d[..., :2], d[..., 2:].clamp(min=-lim, max=lim)
+    centre = ((rois[:, :2] + rois[:, 2:4]) * 0.5)[:, None, :]
+    size = (rois[:, 2:4] - rois[:, :2])[:, None, :]
+    new_size = size * logsz.exp()
+    new_centre = centre + size * shift
+    lo, hi = new_centre - new_size * 0.5, new_centre + new_size * 0.5
     if max_shape is not None:
-        x1 = x1.clamp(min=0, max=max_shape[1])
-        y1 = y1.clamp(min=0, max=max_shape[0])
-        x2 = x2.clamp(min=0, max=max_shape[1])
-        y2 = y2.clamp(min=0, max=max_shape[0])
-    return torch.stack([x1, y1, x2, y2], dim=-1).view(deltas.size())
+        bound = deltas.new_tensor([max_shape[1], max_shape[0]])
+        lo = torch.minimum(lo.clamp(min=0), bound)
+        hi = torch.minimum(hi.clamp(min=0), bound)
+    return torch.cat([lo, hi], dim=-1).reshape(deltas.shape)
 
 
 def nms(boxes, scores, iou_threshold, offset=0):
@@ -414,23 +410,20 @@ def batched_nms(boxes, scores, idxs, nms_cfg):
 
 
 def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1):
-    """core/post_processing/bbox_nms.py:5-68."""
-    num_classes = multi_scores.size(1) - 1
-    if multi_bboxes.shape[1] > 4:
-        bboxes = multi_bboxes.view(multi_scores.size(0), -1, 4)
-    else:
-        bboxes = multi_bboxes[:, None].expand(multi_scores.size(0), num_classes, 4)
-    scores = multi_scores[:, :-1]
-    valid_mask = scores > score_thr
-    bboxes = bboxes[valid_mask]
-    scores = scores[valid_mask]
-    labels = valid_mask.nonzero(as_tuple=False)[:, 1]
-    if bboxes.numel() == 0:
+    """core/post_processing/bbox_nms.py:5-68: every (roi, foreground class) pair whose score
+    exceeds the threshold is a candidate (row-major order), one class-aware NMS over all of
+    them, best ``max_num`` survivors."""
+    n, ncls = multi_scores.shape[0], multi_scores.shape[1] - 1
+    per_class = multi_bboxes.reshape(n, -1, 4)
+    cand = (multi_scores[:, :ncls] > score_thr).nonzero(as_tuple=False)
+    if cand.shape[0] == 0:
         return multi_bboxes.new_zeros((0, 5)), multi_bboxes.new_zeros((0,), dtype=torch.long)
-    dets, keep = batched_nms(bboxes, scores, labels, nms_cfg)
+    ri, ci = cand[:, 0], cand[:, 1]
+    boxes = per_class[ri, ci if per_class.shape[1] > 1 else torch.zeros_like(ci)]
+    dets, keep = batched_nms(boxes, multi_scores[ri, ci], ci, nms_cfg)
     if max_num > 0:
         dets, keep = dets[:max_num], keep[:max_num]
-    return dets, labels[keep]
+    return dets, ci[keep]
 
 
 def get_bboxes(rois, cls_score, bbox_pred, img_shape, scale_factor, rescale=False, cfg=None,
