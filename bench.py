@@ -495,8 +495,8 @@ def main():
                 t_bbox = time_kernel(lambda: rh._bbox_forward(feats, bbox2roi_([props])), iters=10, warmup=2)
             result['extra']['roi_head_simple_test'] = {
                 'ms': t_fh, 'detections': n_det, 'bbox_forward_1000_props_ms': t_bbox,
-                'what': 'DynaMaskRoIHead.simple_test on resident FPN maps: 1000 proposals -> RoIAlign7 + Shared2FC (library '
-                        'GEMMs) + softmax/decode + NMS -> masks of the kept detections -> RLE (random-init heads)'}
+                'what': 'DynaMaskRoIHead.simple_test on resident FPN maps: 1000 proposals -> RoIAlign7 + Shared2FC (dm_fc_fwd) '
+                        '+ softmax/decode + NMS -> masks of the kept detections -> RLE (random-init heads)'}
             result['extra']['end_to_end'] = {
                 'backbone_fpn_ms': t_bb, 'mask_path_100dets_ms': t_mask, 'backbone_plus_mask_path_ms': t_e2e,
                 'backbone_plus_mask_path_rle_ms': t_e2e_rle, 'img_per_s_rle': 1e3 / t_e2e_rle,

@@ -4,10 +4,9 @@
 (core/post_processing/bbox_nms.py) under their registry names, kwargs and ``state_dict`` keys.
 
 The 7x7 RoI extraction is the same HIP kernel as the mask branch's; softmax + box decoding and
-the NMS suppression matrix are HIP kernels (``dm_bbox_decode``, ``dm_nms_mask``).  The four
-fully connected layers are plain GEMMs ([N, 12544] x [12544, 1024] ...) and go to the vendor
-GEMM library through ``torch.addmm`` -- a library call, not a fallback: this module has no CPU
-path either.  Training losses of the bbox branch are not built."""
+the NMS suppression matrix are HIP kernels (``dm_bbox_decode``, ``dm_nms_mask``); the four fully
+connected layers run on ``dm_fc_fwd`` (fp32 MFMA GEMM with split-K over the long 12544 axis).
+Training losses of the bbox branch are not built."""
 import numpy as np
 import torch
 import torch.nn as nn
@@ -42,7 +41,7 @@ class DeltaXYWHBBoxCoder:
 
 
 class _FC(nn.Module):
-    """nn.Linear parameters; the product runs as a library GEMM on the device."""
+    """nn.Linear parameters; the product runs on the fp32 MFMA FC kernel (dm_fc_fwd)."""
 
     def __init__(self, cin, cout):
         super().__init__()
@@ -52,10 +51,7 @@ class _FC(nn.Module):
         nn.init.xavier_uniform_(self.weight)
 
     def run(self, x, relu=False):
-        if not x.is_cuda:
-            raise RuntimeError('dynamask_amd bbox head runs on the MI355X only; there is no CPU fallback')
-        y = torch.addmm(self.bias.detach(), x, self.weight.detach().t())
-        return torch.relu_(y) if relu else y
+        return ops.fc(x.contiguous(), self.weight.detach(), self.bias.detach(), relu=relu)
 
 
 @HEADS.register_module()

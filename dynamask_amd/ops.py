@@ -172,6 +172,20 @@ def paste_rle(masks, boxes, img_h, img_w, threshold=0.5, apply_sigmoid=False):
 
 
 # --------------------------------------------------------------- bbox branch (8f rank 4)
+def fc(x, weight, bias=None, relu=False):
+    """nn.Linear forward: x [N, K], weight [M, K], bias [M] -> [N, M] (fp32 MFMA, split-K)."""
+    _chk(x, 'x')
+    _chk(weight, 'weight')
+    if bias is not None:
+        _chk(bias, 'bias')
+    N, K = x.shape
+    M = weight.shape[0]
+    assert weight.shape[1] == K
+    out = torch.empty((N, M), device=x.device, dtype=torch.float32)
+    check(lib().dm_fc_fwd(_p(x), _p(weight), _p(bias), N, K, M, 1 if relu else 0, _p(out), _stream()), 'dm_fc_fwd')
+    return out
+
+
 def bbox_decode(rois, cls_score, bbox_pred, num_classes, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.),
                 wh_ratio_clip=16 / 1000, max_shape=None, scale=(1.0, 1.0), class_agnostic=False):
     """softmax(cls_score), delta2bbox(rois, bbox_pred) clipped to ``max_shape`` (h, w) and

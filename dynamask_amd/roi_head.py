@@ -42,7 +42,7 @@ class _BN(nn.Module):
 
 
 class _Linear(nn.Module):
-    """nn.Linear parameter holder; runs as a 1x1 conv on a 1x1 map (MFMA GEMM)."""
+    """nn.Linear parameter holder; runs on the fp32 MFMA FC kernel (dm_fc_fwd)."""
 
     def __init__(self, cin, cout):
         super().__init__()
@@ -51,13 +51,11 @@ class _Linear(nn.Module):
         self.weight = nn.Parameter(lin.weight.detach().clone())
         self.bias = nn.Parameter(lin.bias.detach().clone())
         from .mask_heads import _Packed
-        self._pk = _Packed()
+        self._pk = _Packed()      # packed (transposed) weights of the backward's data-gradient GEMM
 
     def run(self, x, relu=False):
-        wp = self._pk.get('w', self.weight, lambda w: ops.pack_conv_weight(w.view(self.out_features, self.in_features, 1, 1)))
-        n = x.shape[0]
-        y = ops.conv2d(x.reshape(n, self.in_features, 1, 1), wp, self.bias.detach(), self.out_features, 1, relu=relu)
-        return y.view(n, self.out_features)
+        return ops.fc(x.reshape(x.shape[0], self.in_features).contiguous(), self.weight.detach(), self.bias.detach(),
+                      relu=relu)
 
 
 class MaskPre(nn.Module):

@@ -286,6 +286,12 @@ int dm_paste_rle(const float* masks, const float* boxes, int N, int mask_h, int 
                  int* positions, int capacity, dm_stream_t stream);
 long long dm_rle_string(const int* positions, int runs, long long total_pixels, char* out, long long cap);
 
+/* K22  fully connected layer out[N, M] = x[N, K] . w[M, K]^T + bias (nn.Linear layouts), optional
+ * ReLU; fp32 MFMA with split-K.  replaces: the nn.Linear stack of Shared2FCBBoxHead
+ * (roi_heads/bbox_heads/convfc_bbox_head.py:101-108,143-186).  K % 4 == 0. */
+int dm_fc_fwd(const float* x, const float* w, const float* bias, int N, int K, int M, int relu, float* out,
+              dm_stream_t stream);
+
 /* K20  bbox branch post-processing: softmax over the class logits, DeltaXYWH decode, clip to
  * the image, rescale.  replaces: BBoxHead.get_bboxes up to the NMS
  * (roi_heads/bbox_heads/bbox_head.py:186-217) and delta2bbox
