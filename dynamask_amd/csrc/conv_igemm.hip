@@ -48,14 +48,20 @@ struct ConvArgs {
 };
 
 // CK input channels per chunk (multiple of 8); MAXPOS = plane positions per thread (3x3)
-template <int KS, int WGM, int WGN, int WM, int WN, int CK, int MAXPOS>
+// TAIL (0 or 4): output channels TM .. TM+3 are computed with v_mfma_f32_4x4x1 (16 blocks of
+// 4 x 4: the 4 lanes of a block hold the 4 tail couts as A and 4 pixels as B, so a lane
+// accumulates the 4 tail couts of ITS pixel) from the same B fragments -- the 36-cout offset
+// convs of the DCN layers then cost 32 + 4 rows of MFMA work instead of 64.
+template <int KS, int WGM, int WGN, int WM, int WN, int CK, int MAXPOS, int TAIL = 0>
 __global__ __launch_bounds__(WGM* WGN * 64) void conv_igemm_kernel(ConvArgs a) {
+  static_assert(TAIL == 0 || (TAIL == 4 && WGM == 1), "tail rows need a single cout tile");
   constexpr int TM = WGM * WM * 32;
+  constexpr int TMA = TM + TAIL;              // rows of the LDS A image
   constexpr int TN = WGN * WN * 32;
   constexpr int NT = WGM * WGN * 64;
   constexpr int TAPS = KS * KS;
   constexpr int NQ = CK / 4;                      // channel quads per chunk
-  constexpr int A_F4 = TAPS * NQ * TM;            // float4 slots of the A chunk
+  constexpr int A_F4 = TAPS * NQ * TMA;           // float4 slots of the A chunk
   constexpr int A_PER_T = (A_F4 + NT - 1) / NT;
   constexpr int B1_PER_T = (NQ * TN + NT - 1) / NT;   // 1x1: float4 slots per thread
   constexpr int BREG = (KS == 3) ? MAXPOS * NQ : B1_PER_T;
@@ -174,6 +180,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_igemm_kernel(ConvArgs a) {
     for (int j = 0; j < WN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  dm_f32x4 acct[WN];      // tail couts TM .. TM+3 of this lane's pixel (lanes >= 32: the other K half)
+#pragma unroll
+  for (int j = 0; j < WN; ++j) acct[j] = dm_f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- chunk iterator over (source, channel offset) ------------------------
   int cs = 0, cc0 = 0, ckq = 0;   // current source, channel offset in it, global quad index of the chunk
@@ -202,8 +211,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_igemm_kernel(ConvArgs a) {
       const int idx = tid + i * NT;
       dm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (idx < A_F4) {
-        const int m = idx % TM;
-        const int tq = idx / TM;
+        const int m = idx % TMA;
+        const int tq = idx / TMA;
         const int qd = tq % NQ;
         const int tap = tq / NQ;
         if (qd < nq && m0 + m < a.CoutP)
@@ -290,11 +299,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_igemm_kernel(ConvArgs a) {
         const int tap = st / NG, g = st - tap * NG;
         const int tapoff = (KS == 3) ? ((tap / 3) * Wp + (tap % 3)) : 0;
 #pragma unroll
-        for (int i = 0; i < WM; ++i) av[i] = ldsA[(tap * NQ + 2 * g + hi) * TM + (wave_m * WM + i) * 32 + l31];
+        for (int i = 0; i < WM; ++i) av[i] = ldsA[(tap * NQ + 2 * g + hi) * TMA + (wave_m * WM + i) * 32 + l31];
+        if (TAIL) av[WM] = ldsA[(tap * NQ + 2 * g + hi) * TMA + TM + (lane & 3)];
 #pragma unroll
         for (int j = 0; j < WN; ++j) bv[j] = ldsB[(2 * g) * plane + lane_base[j] + tapoff];
       };
-      dm_f32x4 av[2][WM], bv[2][WN];
+      dm_f32x4 av[2][WM + (TAIL ? 1 : 0)], bv[2][WN];
       load_frag(0, av[0], bv[0]);
 #pragma unroll
       for (int st = 0; st < STEPS; ++st) {
@@ -310,6 +320,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
               for (int j = 0; j < WN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i][e], bv[cur][j][e], acc[i][j], 0, 0, 0);
+          if (TAIL) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int j = 0; j < WN; ++j)
+                acct[j] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[cur][WM][e], bv[cur][j][e], acct[j], 0, 0, 0);
+          }
         }
       }
     }
@@ -350,6 +367,24 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_igemm_kernel(ConvArgs a) {
               a.out[(((size_t)col_n[j] * a.shuffle + oc) * (2 * H) + 2 * y + dy) * (2 * W) + 2 * x + dx] = v;
             }
           }
+        }
+      }
+    }
+  }
+  if (TAIL) {
+    // the two lane halves hold the two K halves of the same pixels
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v = acct[j][i] + __shfl_xor(acct[j][i], 32, 64);
+        const int co = m0 + TM + i;
+        if (hi == 0 && co < a.Cout && col_ok[j]) {
+          if (a.bias) v += a.bias[co];
+          float* op = a.out + ((size_t)col_n[j] * a.out_ch_total + a.out_ch_offset + co) * HW + col_p[j];
+          if (a.relu & 2) v += *op;
+          if (a.relu & 1) v = fmaxf(v, 0.f);
+          *op = v;
         }
       }
     }
@@ -409,37 +444,37 @@ int packed_quads(int nsrc, const int* src_c) {
   return kq;
 }
 
-template <int KS, int WGM, int WGN, int WM, int WN, int CK, int MAXPOS>
+template <int KS, int WGM, int WGN, int WM, int WN, int CK, int MAXPOS, int TAIL = 0>
 int launch_conv_mp(ConvArgs& a, hipStream_t st) {
   constexpr int TM = WGM * WM * 32;
   constexpr int TN = WGN * WN * 32;
   constexpr int NT = WGM * WGN * 64;
   const int NTiles = dm_ceil_div(a.Q, TN);
-  const size_t lds_bytes = 16 * ((size_t)KS * KS * (CK / 4) * TM + (size_t)(CK / 4) * a.plane);
+  const size_t lds_bytes = 16 * ((size_t)KS * KS * (CK / 4) * (TM + TAIL) + (size_t)(CK / 4) * a.plane);
   if (lds_bytes > 64 * 1024) return DM_ERR_UNSUPPORTED;
-  DM_LAUNCH((conv_igemm_kernel<KS, WGM, WGN, WM, WN, CK, MAXPOS>), dim3(a.MT * NTiles), dim3(NT), lds_bytes, st, a);
+  DM_LAUNCH((conv_igemm_kernel<KS, WGM, WGN, WM, WN, CK, MAXPOS, TAIL>), dim3(a.MT * NTiles), dim3(NT), lds_bytes, st, a);
   return dm_check_launch();
 }
 
-template <int KS, int WGM, int WGN, int WM, int WN, int CK>
+template <int KS, int WGM, int WGN, int WM, int WN, int CK, int TAIL = 0>
 int launch_conv(ConvArgs& a, hipStream_t st) {
   constexpr int TM = WGM * WM * 32;
   constexpr int TN = WGN * WN * 32;
   constexpr int NT = WGM * WGN * 64;
-  a.MT = dm_ceil_div(a.CoutP, TM);
+  a.MT = TAIL ? 1 : dm_ceil_div(a.CoutP, TM);
   if (KS == 3) {
     a.Wp = a.W + 2;
     const int nsegmax = dm_ceil_div(TN - 1, a.HW) + 1;
     const int rmax = dm_ceil_div(TN - 1, a.W) + 1 + 2 * nsegmax;
     a.plane = rmax * a.Wp;
-    if (a.plane <= NT) return launch_conv_mp<KS, WGM, WGN, WM, WN, CK, 1>(a, st);
-    if (a.plane <= 2 * NT) return launch_conv_mp<KS, WGM, WGN, WM, WN, CK, 2>(a, st);
-    if (a.plane <= 4 * NT) return launch_conv_mp<KS, WGM, WGN, WM, WN, CK, 4>(a, st);
+    if (a.plane <= NT) return launch_conv_mp<KS, WGM, WGN, WM, WN, CK, 1, TAIL>(a, st);
+    if (a.plane <= 2 * NT) return launch_conv_mp<KS, WGM, WGN, WM, WN, CK, 2, TAIL>(a, st);
+    if (a.plane <= 4 * NT) return launch_conv_mp<KS, WGM, WGN, WM, WN, CK, 4, TAIL>(a, st);
     return DM_ERR_UNSUPPORTED;
   }
   a.Wp = 0;
   a.plane = TN;
-  return launch_conv_mp<KS, WGM, WGN, WM, WN, CK, 1>(a, st);
+  return launch_conv_mp<KS, WGM, WGN, WM, WN, CK, 1, TAIL>(a, st);
 }
 
 int run_pack(PackArgs& p, hipStream_t st) {
@@ -513,6 +548,7 @@ extern "C" int dm_conv2d_fwd(const float* const* srcs, const int* src_channels, 
   hipStream_t st = (hipStream_t)stream;
   if (ksize == 3) {
     if (Cout > 64) return launch_conv<3, 2, 2, 2, 2, 8>(a, st);
+    if (Cout > 32 && Cout <= 36 && !(relu & 2)) return launch_conv<3, 1, 4, 1, 1, 8, 4>(a, st);   // DCN offset convs: 32 + 4
     if (Cout > 32) return launch_conv<3, 1, 4, 2, 1, 8>(a, st);
     return launch_conv<3, 1, 4, 1, 1, 8>(a, st);
   }

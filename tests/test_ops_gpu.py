@@ -373,3 +373,17 @@ def test_roi_align_tile_kernel_corner_cases(ops):
         ref = ref_ops.single_roi_extractor(f2, rois, 14, (4, 8, 16, 32))
         out = ops.roi_align([_dev(f) for f in f2], _dev(rois), 14, [1 / 4, 1 / 8, 1 / 16, 1 / 32])
         _close(out, ref)
+
+
+def test_conv3x3_tail_couts_vs_torch(ops):
+    """Cout in (32, 36]: 32 couts on 32x32x2 MFMA tiles + the last <= 4 on v_mfma_f32_4x4x1
+    (the DCN offset convs); ragged pixel counts, bias + ReLU, a concat of two sources."""
+    g = torch.Generator().manual_seed(17)
+    for cout, cins, S, nb in ((36, [64], 14, 5), (33, [24, 16], 9, 3), (35, [8], 28, 2), (36, [256], 14, 7)):
+        xs = [torch.randn(nb, c, S, S, generator=g) for c in cins]
+        w = torch.randn(cout, sum(cins), 3, 3, generator=g) / (9 * sum(cins)) ** 0.5
+        b = torch.randn(cout, generator=g)
+        ref = F.relu(F.conv2d(torch.cat(xs, 1), w, b, padding=1))
+        wq = ops.pack_conv_weight(_dev(w), src_channels=cins)
+        out = ops.conv2d([_dev(x) for x in xs], wq, _dev(b), cout, 3, relu=True)
+        _close(out, ref)
