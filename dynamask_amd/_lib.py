@@ -4,7 +4,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdynamask_hip.so')
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -31,7 +31,8 @@ SIGNATURES = {
     'dm_gumbel_select_fwd': ([_vp, _vp, _c_int, _c_int, _c_float, _vp, _vp, _vp, _vp], _c_int),
     'dm_gumbel_select_bwd': ([_vp, _vp, _c_int, _c_int, _c_float, _vp, _vp], _c_int),
     'dm_class_balance_fwd_bwd': ([_vp, _c_int, _c_int, _vp, _vp, _vp], _c_int),
-    'dm_bn_stats': ([_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_float, _vp], _c_int),
+    'dm_bn_stats': ([_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_float, _vp, _vp], _c_int),
+    'dm_bn_scratch_floats': ([_c_int], ctypes.c_longlong),
     'dm_bn_relu_maxpool_fwd': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_float, _vp, _vp], _c_int),
     'dm_relu_bwd': ([_vp, _vp, ctypes.c_longlong, _vp], _c_int),
     'dm_sigmoid_bwd': ([_vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _c_int, _c_int, _vp, _c_int, _vp], _c_int),
@@ -43,7 +44,7 @@ SIGNATURES = {
     'dm_deform_im2col': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp], _c_int),
     'dm_deform_col2im_coord': ([_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp], _c_int),
     'dm_dcn_weight_permute': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp], _c_int),
-    'dm_bn_relu_maxpool_bwd': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_float, _vp, _vp, _vp, _vp, _vp], _c_int),
+    'dm_bn_relu_maxpool_bwd': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_float, _vp, _vp, _vp, _vp, _vp, _vp], _c_int),
     'dm_rle_scratch_ints': ([_c_int, _c_int, _c_int], ctypes.c_longlong),
     'dm_rle_encode_canvas': ([_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp], _c_int),
     'dm_paste_rle': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp], _c_int),

@@ -60,6 +60,63 @@ __global__ __launch_bounds__(1024) void bn_stats_kernel(const float* __restrict_
   }
 }
 
+// Split form (scratch given): the channel's NB*HW elements are divided over kBnSplits
+// workgroups, so a 128-channel tensor fills the chip (one workgroup per channel leaves half
+// of the 256 CUs idle and ran at 1.6 TB/s); partial sums are combined in a fixed order ->
+// still deterministic.  Pass 0: partial sums; pass 1: partial centred second moments.
+constexpr int kBnSplits = 16;
+
+__device__ __forceinline__ float bn_partials_ordered(const float* part, int c) {
+  float r = 0.f;
+  for (int s = 0; s < kBnSplits; ++s) r += part[c * kBnSplits + s];
+  return r;
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void bn_stats_split_kernel(const float* __restrict__ x, int NB, int C, int HW,
+                                                             float* __restrict__ part_sum, float* __restrict__ part_sq) {
+  __shared__ float red[4];
+  const int c = blockIdx.x, sp = blockIdx.y;
+  const int n0 = (int)((long long)NB * sp / kBnSplits), n1 = (int)((long long)NB * (sp + 1) / kBnSplits);
+  const float m = PASS == 1 ? bn_partials_ordered(part_sum, c) / (float)((long long)NB * HW) : 0.f;
+  float acc = 0.f;
+  for (int n = n0; n < n1; ++n) {
+    const float* p = x + ((size_t)n * C + c) * HW;
+    if ((HW & 3) == 0) {
+      const dm_f32x4* p4 = reinterpret_cast<const dm_f32x4*>(p);
+      for (int i = threadIdx.x; i < (HW >> 2); i += 256) {
+        const dm_f32x4 v = p4[i];
+        if (PASS == 0) acc += (v[0] + v[1]) + (v[2] + v[3]);
+        else { const float a = v[0] - m, b = v[1] - m, cc = v[2] - m, d = v[3] - m; acc += (a * a + b * b) + (cc * cc + d * d); }
+      }
+    } else {
+      for (int i = threadIdx.x; i < HW; i += 256) {
+        const float v = p[i];
+        if (PASS == 0) acc += v;
+        else acc += (v - m) * (v - m);
+      }
+    }
+  }
+  const float r = block_sum_bcast(acc, red);
+  if (threadIdx.x == 0) (PASS == 0 ? part_sum : part_sq)[c * kBnSplits + sp] = r;
+}
+
+__global__ void bn_stats_finalize_kernel(const float* __restrict__ part_sum, const float* __restrict__ part_sq, int C,
+                                         long long total, float* __restrict__ mean, float* __restrict__ var,
+                                         float* __restrict__ running_mean, float* __restrict__ running_var, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float m = bn_partials_ordered(part_sum, c) / (float)total;
+  const float v = bn_partials_ordered(part_sq, c) / (float)total;
+  mean[c] = m;
+  var[c] = v;
+  if (running_mean && running_var) {
+    const float unbiased = total > 1 ? v * (float)total / (float)(total - 1) : v;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  }
+}
+
 __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __restrict__ x, int NB, int C, int H, int W,
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ var,
@@ -94,9 +151,25 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __res
 
 }  // namespace
 
+extern "C" long long dm_bn_scratch_floats(int C) { return C > 0 ? (long long)C * kBnSplits * 2 : -1; }
+
 extern "C" int dm_bn_stats(const float* x, int NB, int C, int HW, float* mean, float* var, float* running_mean,
-                           float* running_var, float momentum, dm_stream_t stream) {
+                           float* running_var, float momentum, float* scratch, dm_stream_t stream) {
   if (!x || !mean || !var || NB <= 0 || C <= 0 || HW <= 0) return DM_ERR_INVALID_ARG;
+  if (scratch && NB >= kBnSplits) {
+    hipStream_t st = (hipStream_t)stream;
+    float* ps = scratch;
+    float* pq = scratch + (size_t)C * kBnSplits;
+    DM_LAUNCH(bn_stats_split_kernel<0>, dim3(C, kBnSplits), dim3(256), 0, st, x, NB, C, HW, ps, pq);
+    int rc = dm_check_launch();
+    if (rc != DM_OK) return rc;
+    DM_LAUNCH(bn_stats_split_kernel<1>, dim3(C, kBnSplits), dim3(256), 0, st, x, NB, C, HW, ps, pq);
+    rc = dm_check_launch();
+    if (rc != DM_OK) return rc;
+    DM_LAUNCH(bn_stats_finalize_kernel, dim3(dm_ceil_div(C, 128)), dim3(128), 0, st, ps, pq, C, (long long)NB * HW, mean, var,
+              running_mean, running_var, momentum);
+    return dm_check_launch();
+  }
   DM_LAUNCH(bn_stats_kernel, dim3(C), dim3(1024), 0, (hipStream_t)stream, x, NB, C, HW, mean, var,
                      running_mean, running_var, momentum);
   return dm_check_launch();
@@ -202,11 +275,58 @@ __global__ __launch_bounds__(1024) void bn_bwd_kernel(const float* __restrict__ 
   }
 }
 
+// Split form of bn_bwd_kernel: pass 0 partial (sum gz, sum gz*xhat) per (channel, split), pass 1
+// combines them in a fixed order and rewrites its slice of gz.
+template <int PASS>
+__global__ __launch_bounds__(256) void bn_bwd_split_kernel(const float* __restrict__ x, float* __restrict__ gz, int NB, int C,
+                                                           int HW, const float* __restrict__ mean, const float* __restrict__ var,
+                                                           const float* __restrict__ gamma, float eps, float* __restrict__ part,
+                                                           float* __restrict__ g_gamma, float* __restrict__ g_beta) {
+  __shared__ float red[4];
+  const int c = blockIdx.x, sp = blockIdx.y;
+  const int n0 = (int)((long long)NB * sp / kBnSplits), n1 = (int)((long long)NB * (sp + 1) / kBnSplits);
+  const float invstd = 1.0f / sqrtf(var[c] + eps), m = mean[c];
+  float* p1 = part;                                   // [C][kBnSplits] sum gz
+  float* p2 = part + (size_t)C * kBnSplits;           // [C][kBnSplits] sum gz * xhat
+  if (PASS == 0) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int n = n0; n < n1; ++n) {
+      const size_t base = ((size_t)n * C + c) * HW;
+      for (int i = threadIdx.x; i < HW; i += 256) {
+        const float g = gz[base + i];
+        s1 += g;
+        s2 += g * (x[base + i] - m) * invstd;
+      }
+    }
+    const float sb = bsum(s1, red);
+    const float sg = bsum(s2, red);
+    if (threadIdx.x == 0) {
+      p1[c * kBnSplits + sp] = sb;
+      p2[c * kBnSplits + sp] = sg;
+    }
+  } else {
+    const float sb = bn_partials_ordered(p1, c), sg = bn_partials_ordered(p2, c);
+    if (sp == 0 && threadIdx.x == 0) {
+      g_beta[c] = sb;
+      g_gamma[c] = sg;
+    }
+    const float k = gamma[c] * invstd, invM = 1.0f / (float)((long long)NB * HW);
+    for (int n = n0; n < n1; ++n) {
+      const size_t base = ((size_t)n * C + c) * HW;
+      for (int i = threadIdx.x; i < HW; i += 256) {
+        const float xh = (x[base + i] - m) * invstd;
+        gz[base + i] = k * (gz[base + i] - sb * invM - xh * sg * invM);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int dm_bn_relu_maxpool_bwd(const float* x, int NB, int C, int H, int W, const float* mean, const float* var,
                                       const float* gamma, const float* beta, float eps, const float* grad_out,
-                                      float* grad_x, float* grad_gamma, float* grad_beta, dm_stream_t stream) {
+                                      float* grad_x, float* grad_gamma, float* grad_beta, float* scratch,
+                                      dm_stream_t stream) {
   if (!x || !mean || !var || !gamma || !beta || !grad_out || !grad_x || !grad_gamma || !grad_beta) return DM_ERR_INVALID_ARG;
   if (NB <= 0 || C <= 0 || H <= 0 || W <= 0) return DM_ERR_INVALID_ARG;
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
@@ -218,6 +338,15 @@ extern "C" int dm_bn_relu_maxpool_bwd(const float* x, int NB, int C, int H, int 
             grad_x, OH, OW);
   int rc = dm_check_launch();
   if (rc != DM_OK) return rc;
+  if (scratch && NB >= kBnSplits) {
+    DM_LAUNCH(bn_bwd_split_kernel<0>, dim3(C, kBnSplits), dim3(256), 0, st, x, grad_x, NB, C, H * W, mean, var, gamma, eps,
+              scratch, grad_gamma, grad_beta);
+    rc = dm_check_launch();
+    if (rc != DM_OK) return rc;
+    DM_LAUNCH(bn_bwd_split_kernel<1>, dim3(C, kBnSplits), dim3(256), 0, st, x, grad_x, NB, C, H * W, mean, var, gamma, eps,
+              scratch, grad_gamma, grad_beta);
+    return dm_check_launch();
+  }
   DM_LAUNCH(bn_bwd_kernel, dim3(C), dim3(1024), 0, st, x, grad_x, NB, C, H * W, mean, var, gamma, eps, grad_gamma,
             grad_beta);
   return dm_check_launch();

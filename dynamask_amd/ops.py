@@ -441,13 +441,29 @@ def class_balance(mask_labels):
     return loss[0], grad
 
 
+_BN_SCRATCH = {}
+
+
+def _bn_scratch(device, C):
+    """Partial-sum scratch of the split BatchNorm kernels, one buffer per (device, stream): no
+    allocation on the step path (kernels that share it are ordered by their stream)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    need = lib().dm_bn_scratch_floats(C)
+    buf = _BN_SCRATCH.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty((max(need, 1 << 15),), device=device, dtype=torch.float32)
+        _BN_SCRATCH[key] = buf
+    return buf
+
+
 def bn_stats(x, running_mean=None, running_var=None, momentum=0.1):
     _chk(x, 'x')
     NB, C, H, W = x.shape
     mean = torch.empty((C,), device=x.device, dtype=torch.float32)
     var = torch.empty((C,), device=x.device, dtype=torch.float32)
+    scratch = _bn_scratch(x.device, C)
     check(lib().dm_bn_stats(_p(x), NB, C, H * W, _p(mean), _p(var), _p(running_mean), _p(running_var), momentum,
-                            _stream()), 'dm_bn_stats')
+                            _p(scratch), _stream()), 'dm_bn_stats')
     return mean, var
 
 
@@ -604,8 +620,9 @@ def bn_relu_maxpool_backward(x, mean, var, gamma, beta, grad_out, eps=1e-5):
     gx = torch.empty_like(x)
     gg = torch.empty((C,), device=x.device, dtype=torch.float32)
     gb = torch.empty((C,), device=x.device, dtype=torch.float32)
+    scratch = _bn_scratch(x.device, C)
     check(lib().dm_bn_relu_maxpool_bwd(_p(x), NB, C, H, W, _p(mean), _p(var), _p(gamma), _p(beta), eps, _p(grad_out),
-                                       _p(gx), _p(gg), _p(gb), _stream()), 'dm_bn_relu_maxpool_bwd')
+                                       _p(gx), _p(gg), _p(gb), _p(scratch), _stream()), 'dm_bn_relu_maxpool_bwd')
     return gx, gg, gb
 
 

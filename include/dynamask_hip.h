@@ -222,7 +222,9 @@ int dm_mask_loss_fwd_bwd(const float* inst_pred, const float* det_pred, const fl
  * x [NB, C, H, W]; mean/var/gamma/beta [C]; out [NB, C, (H-1)/2+1, (W-1)/2+1]
  * ------------------------------------------------------------------------- */
 int dm_bn_stats(const float* x, int NB, int C, int HW, float* mean, float* var, float* running_mean,
-                float* running_var, float momentum, dm_stream_t stream);
+                float* running_var, float momentum, float* scratch, dm_stream_t stream);
+/* scratch for dm_bn_stats / dm_bn_relu_maxpool_bwd (may be null: one workgroup per channel) */
+long long dm_bn_scratch_floats(int C);
 int dm_bn_relu_maxpool_fwd(const float* x, int NB, int C, int H, int W, const float* mean, const float* var,
                            const float* gamma, const float* beta, float eps, float* out, dm_stream_t stream);
 
@@ -230,7 +232,7 @@ int dm_bn_relu_maxpool_fwd(const float* x, int NB, int C, int H, int W, const fl
  * returned by dm_bn_stats): grad_x [NB,C,H,W] (overwritten), grad_gamma/grad_beta [C]. */
 int dm_bn_relu_maxpool_bwd(const float* x, int NB, int C, int H, int W, const float* mean, const float* var,
                            const float* gamma, const float* beta, float eps, const float* grad_out, float* grad_x,
-                           float* grad_gamma, float* grad_beta, dm_stream_t stream);
+                           float* grad_gamma, float* grad_beta, float* scratch, dm_stream_t stream);
 
 /* K10 backward: gradient of the soft branch of the straight-through estimator
  * (y_hard = (one_hot - y).detach() + y, dynamask_roi_head.py:112-113). */
