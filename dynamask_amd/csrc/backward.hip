@@ -86,9 +86,12 @@ struct WgradArgs {
 // small-output layers (64 couts x 64 columns) -- over the K chunk, so narrow weight
 // matrices do not pad to 128 x 128.  Split-K over workgroups; partial sums land with
 // float atomics.  The next chunk's global loads are issued before the MFMA loop.
-template <int KS, int WGM, int WGN, int WGK>
+// TAIL: 32 < Cout <= 36 (the DCN offset convs): rows 0..31 on one 32x32x2 tile per column tile,
+// rows 32..35 on v_mfma_f32_4x4x1 (see conv_igemm.hip) instead of a second, 87 % empty tile row.
+template <int KS, int WGM, int WGN, int WGK, bool TAIL = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   static_assert(WGM * WGN * WGK == 4, "four waves");
+  static_assert(!TAIL || WGM == 1, "tail rows need a single cout tile");
   constexpr int TM = 64 * WGM, TN = 64 * WGN, KT = 32, LD = KT + 1, TAPS = KS * KS;
   constexpr int RA = TM / 8, RB = TN / 8, KW = KT / WGK;
   __shared__ float ldsA[TM * LD];
@@ -112,6 +115,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  dm_f32x4 acct[2];               // TAIL: couts 32..35 x this lane's column (lanes >= 32: the odd k)
+  acct[0] = acct[1] = dm_f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int kq = tid & 31;        // this thread's pixel column inside a chunk
   const int r0 = tid >> 5;        // rows r0 + 8*i
@@ -167,17 +172,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       const int kk = wave_k * KW + k2;
       float av[2], bv[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) av[i] = ldsA[((wave_m * 2 + i) * 32 + l31) * LD + kk + hi];
+      for (int i = 0; i < 2; ++i)
+        av[i] = (TAIL && i == 1) ? ldsA[(32 + (lane & 3)) * LD + kk + hi] : ldsA[((wave_m * 2 + i) * 32 + l31) * LD + kk + hi];
 #pragma unroll
       for (int j = 0; j < 2; ++j) bv[j] = ldsB[((wave_n * 2 + j) * 32 + l31) * LD + kk + hi];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < 2; ++j) {
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[j], acc[0][j], 0, 0, 0);
+        if (TAIL) acct[j] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[1], bv[j], acct[j], 0, 0, 0);
+        else acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[j], acc[1][j], 0, 0, 0);
+      }
     }
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < (TAIL ? 1 : 2); ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = m0 + (wave_m * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -189,6 +197,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         }
       }
     }
+  if (TAIL) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int jg = j0 + (wave_n * 2 + j) * 32 + l31;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float v = acct[j][i] + __shfl_xor(acct[j][i], 32, 64);      // the two k parities
+        const int co = m0 + 32 + i;
+        if (hi == 0 && co < a.Cout && jg < Jtot) atomicAdd(a.dw + (size_t)co * a.ldw + a.coloff + jg, v);
+      }
+    }
+  }
 }
 
 template <int KS>
@@ -214,6 +234,8 @@ void launch_wgrad(WgradArgs a, hipStream_t st) {
   const dim3 grid((unsigned)(a.MT * a.JT * a.nsplit));
   if (TM == 128 && TN == 128) DM_LAUNCH((conv_wgrad_kernel<KS, 2, 2, 1>), grid, dim3(256), 0, st, a);
   else if (TM == 128) DM_LAUNCH((conv_wgrad_kernel<KS, 2, 1, 2>), grid, dim3(256), 0, st, a);
+  else if (TN == 256 && a.Cout > 32 && a.Cout <= 36) DM_LAUNCH((conv_wgrad_kernel<KS, 1, 4, 1, true>), grid, dim3(256), 0, st, a);
+  else if (TN == 128 && a.Cout > 32 && a.Cout <= 36) DM_LAUNCH((conv_wgrad_kernel<KS, 1, 2, 2, true>), grid, dim3(256), 0, st, a);
   else if (TN == 256) DM_LAUNCH((conv_wgrad_kernel<KS, 1, 4, 1>), grid, dim3(256), 0, st, a);
   else if (TN == 128) DM_LAUNCH((conv_wgrad_kernel<KS, 1, 2, 2>), grid, dim3(256), 0, st, a);
   else DM_LAUNCH((conv_wgrad_kernel<KS, 1, 1, 4>), grid, dim3(256), 0, st, a);
