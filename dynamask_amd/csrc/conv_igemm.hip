@@ -553,7 +553,7 @@ extern "C" int dm_conv2d_fwd(const float* const* srcs, const int* src_channels, 
     return launch_conv<3, 1, 4, 1, 1, 8>(a, st);
   }
   if (Cout > 64) return launch_conv<1, 2, 2, 2, 2, 32>(a, st);
-  if (Cout > 32) return launch_conv<1, 1, 4, 2, 1, 32>(a, st);
+  if (Cout > 32) return launch_conv<1, 1, 4, 2, 2, 32>(a, st);   // 64 couts x 256 px (128 px: 0.69 -> 0.56 ms on 130->64 @56^2)
   return launch_conv<1, 1, 4, 1, 1, 32>(a, st);
 }
 
