@@ -517,19 +517,30 @@ __global__ __launch_bounds__(256) void deform_im2col_kernel(const float* __restr
   const DcnSample s = dcn_sample(offp, tap, HW, y, xx, H, W);
   const int cpg = C / dg;
   const int c0 = g * cpg + chunk * CT, c1 = min(c0 + CT, (g + 1) * cpg);
-  float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
-  int o1 = 0, o2 = 0, o3 = 0, o4 = 0;
+  // the 2x2 footprint as two 8-byte row pairs (as the forward kernel, deform_conv.hip): pair base column
+  // cb = clamp(w_low, 0, W-2); taps outside the image keep weight 0, so the loads stay in bounds and the
+  // four products are the reference's w1..w4 * v1..v4
+  struct __attribute__((packed, aligned(4))) F2 { float a, b; };
+  float wt0 = 0.f, wt1 = 0.f, wb0 = 0.f, wb1 = 0.f;
+  int ot = 0, ob = 0;
   if (s.valid) {
-    const int h_high = s.h_low + 1, w_high = s.w_low + 1;
     const float lh = s.h_im - (float)s.h_low, lw = s.w_im - (float)s.w_low, hh = 1.f - lh, hw = 1.f - lw;
-    if (s.h_low >= 0 && s.w_low >= 0) { o1 = s.h_low * W + s.w_low; w1 = hh * hw; }
-    if (s.h_low >= 0 && w_high <= W - 1) { o2 = s.h_low * W + w_high; w2 = hh * lw; }
-    if (h_high <= H - 1 && s.w_low >= 0) { o3 = h_high * W + s.w_low; w3 = lh * hw; }
-    if (h_high <= H - 1 && w_high <= W - 1) { o4 = h_high * W + w_high; w4 = lh * lw; }
+    const float wr_t = (s.h_low >= 0) ? hh : 0.f;
+    const float wr_b = (s.h_low + 1 <= H - 1) ? lh : 0.f;
+    const int rt = min(max(s.h_low, 0), H - 1), rbm = min(max(s.h_low + 1, 0), H - 1);
+    const int cb = min(max(s.w_low, 0), W - 2);
+    const float wc0 = (cb == s.w_low ? hw : 0.f) + (cb == s.w_low + 1 ? lw : 0.f);
+    const float wc1 = (cb + 1 == s.w_low ? hw : 0.f) + (cb + 1 == s.w_low + 1 ? lw : 0.f);
+    ot = rt * W + cb;
+    ob = rbm * W + cb;
+    wt0 = wr_t * wc0; wt1 = wr_t * wc1;
+    wb0 = wr_b * wc0; wb1 = wr_b * wc1;
   }
   for (int c = c0; c < c1; ++c) {
     const float* xc = x + ((size_t)n * C + c) * HW;
-    col[((size_t)n * 9 * C + (size_t)tap * C + c) * HW + p] = w1 * xc[o1] + w2 * xc[o2] + w3 * xc[o3] + w4 * xc[o4];
+    const F2 top = *reinterpret_cast<const F2*>(xc + ot);
+    const F2 bot = *reinterpret_cast<const F2*>(xc + ob);
+    col[((size_t)n * 9 * C + (size_t)tap * C + c) * HW + p] = wt0 * top.a + wt1 * top.b + wb0 * bot.a + wb1 * bot.b;
   }
 }
 
@@ -764,6 +775,7 @@ extern "C" int dm_deform_im2col(const float* x, const float* offset, int NB, int
                                 float* col, dm_stream_t stream) {
   if (!x || !offset || !col || NB < 0 || C <= 0 || H <= 0 || W <= 0 || deform_groups <= 0 || C % deform_groups)
     return DM_ERR_INVALID_ARG;
+  if (W < 2) return DM_ERR_UNSUPPORTED;      // the gather loads row pairs (as dm_deform_conv_fwd)
   if (NB == 0) return DM_OK;
   const int CT = 32;
   const int pblocks = dm_ceil_div(H * W, 256), chunks = dm_ceil_div(C / deform_groups, CT);
