@@ -569,16 +569,29 @@ __global__ __launch_bounds__(256) void dcn_coord_grad_kernel(const float* __rest
   }
   const int h_low = s.h_low, w_low = s.w_low, h_high = h_low + 1, w_high = w_low + 1;
   const float lh = s.h_im - (float)h_low, lw = s.w_im - (float)w_low, hh = 1.f - lh, hw = 1.f - lw;
-  const bool v1 = h_low >= 0 && w_low >= 0, v2 = h_low >= 0 && w_high <= W - 1;
-  const bool v3 = h_high <= H - 1 && w_low >= 0, v4 = h_high <= H - 1 && w_high <= W - 1;
-  const int o1 = v1 ? h_low * W + w_low : 0, o2 = v2 ? h_low * W + w_high : 0;
-  const int o3 = v3 ? h_high * W + w_low : 0, o4 = v4 ? h_high * W + w_high : 0;
+  // corner values through two 8-byte row-pair loads (pair base column cb = clamp(w_low, 0, W-2)); a
+  // corner outside the image contributes 0: its selector weights are 0
+  struct __attribute__((packed, aligned(4))) F2 { float a, b; };
+  const bool rt_ok = h_low >= 0, rb_ok = h_high <= H - 1;
+  const int rt = min(max(h_low, 0), H - 1), rbm = min(max(h_high, 0), H - 1);
+  const int cb = min(max(w_low, 0), W - 2);
+  // value at column w_low = sa0 * pair.a + sa1 * pair.b, at column w_high = sb0 * pair.a + sb1 * pair.b
+  const float sa0 = (w_low == cb) ? 1.f : 0.f, sa1 = (w_low == cb + 1) ? 1.f : 0.f;
+  const float sb0 = (w_high == cb) ? 1.f : 0.f, sb1 = (w_high == cb + 1) ? 1.f : 0.f;
+  const float mt = rt_ok ? 1.f : 0.f, mb = rb_ok ? 1.f : 0.f;
+  const int ot = rt * W + cb, ob = rbm * W + cb;
   const int cpg = C / dg;
   float acc_h = 0.f, acc_w = 0.f;
-  for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-    const float cg = colgrad[((size_t)n * 9 * C + (size_t)tap * C + c) * HW + p];
-    const float* xc = x + ((size_t)n * C + c) * HW;
-    const float x1 = v1 ? xc[o1] : 0.f, x2 = v2 ? xc[o2] : 0.f, x3 = v3 ? xc[o3] : 0.f, x4 = v4 ? xc[o4] : 0.f;
+  const float* cgp = colgrad + ((size_t)n * 9 * C + (size_t)tap * C + (size_t)g * cpg) * HW + p;
+  const float* xg = x + ((size_t)n * C + (size_t)g * cpg) * HW;
+#pragma unroll 4
+  for (int c = 0; c < cpg; ++c) {
+    const float cg = cgp[(size_t)c * HW];
+    const float* xc = xg + (size_t)c * HW;
+    const F2 top = *reinterpret_cast<const F2*>(xc + ot);
+    const F2 bot = *reinterpret_cast<const F2*>(xc + ob);
+    const float x1 = mt * (sa0 * top.a + sa1 * top.b), x2 = mt * (sb0 * top.a + sb1 * top.b);
+    const float x3 = mb * (sa0 * bot.a + sa1 * bot.b), x4 = mb * (sb0 * bot.a + sb1 * bot.b);
     // d val / d h_im and d val / d w_im  (get_coordinate_weight, :145-188)
     acc_h += cg * (-hw * x1 - lw * x2 + hw * x3 + lw * x4);
     acc_w += cg * (-hh * x1 + hh * x2 - lh * x3 + lh * x4);
