@@ -280,6 +280,223 @@ __global__ __launch_bounds__(WGM* WGN * 64) void deform_conv_kernel(DcnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Variant for small maps (128 <= H*W <= 256, i.e. the 14x14 stage): 128 couts x 128 pixels per
+// workgroup like the plain conv kernel.  What kept the kernel above at 128 x 64 is the register
+// cost of gathering from global memory (the raw row pairs of the next chunk live in VGPRs under
+// the MFMAs).  Here the 8 channel planes of the (at most two) images a pixel tile touches are
+// staged in LDS per chunk -- a 14x14 plane is 784 bytes -- and the bilinear gather reads LDS:
+// short latency, so a tap's B operand is produced just in time, three taps ahead of its MFMAs,
+// into a small ring; nothing but the next chunk's weights and planes is held in registers.
+__global__ __launch_bounds__(256, 2) void deform_conv_lds_kernel(DcnArgs a) {
+  constexpr int TM = 128, TN = 128, NT = 256;
+  constexpr int A_F4 = 9 * 2 * TM;                // [tap][quad][cout] float4
+  constexpr int A_PER_T = A_F4 / NT;              // 9
+  constexpr int XPL = 256;                        // floats reserved per channel plane
+  constexpr int X_F4 = 2 * 8 * XPL / 4;           // [image slot][channel][XPL]
+  constexpr int X_PER_T = 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  dm_f32x4* ldsA = reinterpret_cast<dm_f32x4*>(lds);
+  float* ldsX = lds + 4 * A_F4;
+  dm_f32x4* ldsB = reinterpret_cast<dm_f32x4*>(lds + 4 * A_F4 + 4 * X_F4);   // [2][3 taps][2 quads][TN]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_m = wave >> 1, wave_n = wave & 1;
+  const int hi = lane >> 5, l31 = lane & 31;
+  int m_tile, n_tile;
+  {
+    const int b = blockIdx.x, grp = 8 * a.MT;
+    const int full = (gridDim.x / grp) * grp;
+    if (b < full) {
+      const int g = b / grp, r = b - g * grp;
+      m_tile = r / 8;
+      n_tile = g * 8 + (r & 7);
+    } else {
+      const int r = b - full;
+      m_tile = r % a.MT;
+      n_tile = full / a.MT + r / a.MT;
+    }
+  }
+  const int m0 = m_tile * TM, q0 = n_tile * TN;
+  const int HW = a.HW, W = a.W, H = a.H;
+  const int n0 = q0 / HW;                          // first image of the tile; the tile touches n0 and n0 + 1 at most
+
+  int col_n[2], col_p[2];
+  bool col_ok[2];
+#pragma unroll
+  for (int wn = 0; wn < 2; ++wn) {
+    int q = q0 + (wave_n * 2 + wn) * 32 + l31;
+    col_ok[wn] = q < a.Q;
+    q = min(q, a.Q - 1);
+    col_n[wn] = q / HW;
+    col_p[wn] = q - col_n[wn] * HW;
+  }
+
+  // gather role: pixel gj of the tile, channel quad gh of the chunk
+  const int gj = tid & 127, gh = tid >> 7;
+  int gq = q0 + gj;
+  const bool g_ok = gq < a.Q;
+  gq = min(gq, a.Q - 1);
+  const int gn = gq / HW, gp = gq - gn * HW;
+  const int gy = gp / W, gx = gp - gy * W;
+  const int xbase = (gn - n0) * 8 * XPL + gh * 4 * XPL;      // this thread's 4 planes inside ldsX
+
+  int otb[9];                                      // top | bottom << 16: offsets inside a plane (< 256)
+  float wt0[9], wt1[9], wb0[9], wb1[9];
+  const int cpg = a.C / a.dg;
+  auto load_params = [&](int group) {
+    const float* offp = a.offset + ((size_t)gn * a.dg + group) * 18 * HW + gp;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      otb[tap] = 0;
+      wt0[tap] = wt1[tap] = wb0[tap] = wb1[tap] = 0.f;
+      if (g_ok) {
+        const int ki = tap / 3, kj = tap - ki * 3;
+        const float h_im = (float)(gy - 1 + ki) + offp[(size_t)(2 * tap) * HW];
+        const float w_im = (float)(gx - 1 + kj) + offp[(size_t)(2 * tap + 1) * HW];
+        if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+          const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+          const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+          const float hh = 1.f - lh, hw = 1.f - lw;
+          const float wr_t = (h_low >= 0) ? hh : 0.f;
+          const float wr_b = (h_low + 1 <= H - 1) ? lh : 0.f;
+          const int rt = min(max(h_low, 0), H - 1), rbm = min(max(h_low + 1, 0), H - 1);
+          const int cb = min(max(w_low, 0), W - 2);
+          const float wc0 = (cb == w_low ? hw : 0.f) + (cb == w_low + 1 ? lw : 0.f);
+          const float wc1 = (cb + 1 == w_low ? hw : 0.f) + (cb + 1 == w_low + 1 ? lw : 0.f);
+          otb[tap] = (rt * W + cb) | ((rbm * W + cb) << 16);
+          wt0[tap] = wr_t * wc0; wt1[tap] = wr_t * wc1;
+          wb0[tap] = wr_b * wc0; wb1[tap] = wr_b * wc1;
+        }
+      }
+    }
+  };
+
+  dm_f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  dm_f32x4 ra[A_PER_T], rx[X_PER_T];
+  const int x_f4_img = 8 * HW / 4;                 // float4 per image and chunk (8 contiguous planes; HW % 4 checked on the host)
+  auto prefetch = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      const int idx = tid + i * NT;
+      const int m = idx % TM, tq = idx / TM;
+      dm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m0 + m < a.CoutP)
+        v = *reinterpret_cast<const dm_f32x4*>(a.wp + (((size_t)(tq >> 1) * a.KQ + (c0 >> 2) + (tq & 1)) * a.CoutP + m0 + m) * 4);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < X_PER_T; ++i) {
+      const int idx = tid + i * NT;
+      const int img = idx / x_f4_img, r = idx - img * x_f4_img;
+      dm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (img < 2 && n0 + img < a.NB)
+        v = *reinterpret_cast<const dm_f32x4*>(a.x + ((size_t)(n0 + img) * a.C + c0) * HW + (size_t)r * 4);
+      rx[i] = v;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) ldsA[tid + i * NT] = ra[i];
+#pragma unroll
+    for (int i = 0; i < X_PER_T; ++i) {
+      const int idx = tid + i * NT;
+      const int img = idx / x_f4_img, r = idx - img * x_f4_img;
+      if (img < 2) {
+        // plane c of the image starts at c * XPL; the source run is 8 planes of HW floats back to back
+        const int f = r * 4, c = f / HW, p = f - c * HW;     // HW % 4 == 0: a float4 never straddles two planes
+        *reinterpret_cast<dm_f32x4*>(ldsX + img * 8 * XPL + c * XPL + p) = rx[i];
+      }
+    }
+  };
+  struct __attribute__((packed, aligned(4))) F2 { float a, b; };
+  auto gather3 = [&](int t0, int ring) {          // taps t0 .. t0+2 -> ldsB[ring]
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int tap = t0 + u;
+      dm_f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* pl = ldsX + xbase + e * XPL;
+        const F2 top = *reinterpret_cast<const F2*>(pl + (otb[tap] & 0xffff));
+        const F2 bot = *reinterpret_cast<const F2*>(pl + (otb[tap] >> 16));
+        v[e] = wt0[tap] * top.a + wt1[tap] * top.b + wb0[tap] * bot.a + wb1[tap] * bot.b;
+      }
+      ldsB[((ring * 3 + u) * 2 + gh) * TN + gj] = v;
+    }
+  };
+  auto mfma3 = [&](int t0, int ring) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int tap = t0 + u;
+      dm_f32x4 av[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) av[i] = ldsA[(tap * 2 + hi) * TM + (wave_m * 2 + i) * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bv[j] = ldsB[((ring * 3 + u) * 2 + hi) * TN + (wave_n * 2 + j) * 32 + l31];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  int cur_group = 0;
+  load_params(0);
+  prefetch(0);
+  commit();
+  __syncthreads();
+  for (int c0 = 0; c0 < a.C; c0 += 8) {
+    const int cn = c0 + 8;
+    const bool more = cn < a.C;
+    if (more) prefetch(cn);                  // in flight under the whole tap loop
+    gather3(0, 0);
+    __syncthreads();
+    gather3(3, 1);
+    mfma3(0, 0);
+    __syncthreads();
+    gather3(6, 0);
+    mfma3(3, 1);
+    __syncthreads();
+    mfma3(6, 0);
+    __syncthreads();                         // every read of A / X / B of this chunk is done
+    if (more) {
+      const int group = cn / cpg;
+      if (group != cur_group) {
+        cur_group = group;
+        load_params(group);
+      }
+      commit();
+      __syncthreads();
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = m0 + (wave_m * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (co < a.Cout) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (col_ok[j]) {
+            float v = acc[i][j][r];
+            if (a.relu) v = fmaxf(v, 0.f);
+            a.out[((size_t)col_n[j] * a.Cout + co) * HW + col_p[j]] = v;
+          }
+      }
+    }
+}
+
 template <int WGM, int WGN, int WM, int WN>
 int launch_dcn(DcnArgs& a, hipStream_t st) {
   constexpr int TM = WGM * WM * 32;
@@ -320,6 +537,21 @@ extern "C" int dm_deform_conv_fwd(const float* x, const float* offset, int NB, i
   // (a 256-cout tile would gather each sample once but needs > 256 VGPRs: it spills)
   // 4-wave workgroups of 128 x 64: two of them share a CU (the 8-wave 128 x 128 tile needs
   // > 128 VGPRs and runs alone: 1.81 ms vs 1.59 ms at 256 channels)
+  if (Cout > 64 && a.HW >= 128 && a.HW <= 256 && (a.HW & 3) == 0 && (C / deform_groups) % 8 == 0) {
+    // small maps (14x14): planes in LDS, 128 x 128 tile
+    a.MT = dm_ceil_div(a.CoutP, 128);
+    const int NTiles = dm_ceil_div(a.Q, 128);
+    const size_t lds_bytes = 16 * ((size_t)9 * 2 * 128 + (size_t)2 * 8 * 256 / 4 + (size_t)2 * 3 * 2 * 128);
+    static bool attr_lds = false;
+    if (!attr_lds) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&deform_conv_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds_bytes) != hipSuccess)
+        return DM_ERR_LAUNCH;
+      attr_lds = true;
+    }
+    DM_LAUNCH(deform_conv_lds_kernel, dim3(a.MT * NTiles), dim3(256), lds_bytes, st, a);
+    return dm_check_launch();
+  }
   if (Cout > 64) return launch_dcn<2, 2, 2, 1>(a, st);    // 128 couts x 64 px
   if (Cout > 32) return launch_dcn<2, 2, 1, 1>(a, st);    // 64 x 64 (2.57 -> 2.28 ms at 64 channels, 56x56)
   return launch_dcn<1, 4, 1, 1>(a, st);                   // 32 x 128 (4 waves)
