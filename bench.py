@@ -73,6 +73,21 @@ def time_kernel(fn, iters=20, warmup=3):
     return e0.elapsed_time(e1) / iters
 
 
+def time_kernel_median(fn, iters=7, warmup=2):
+    """Median duration (ms) of `fn` over `iters` individually timed calls: for the multi-kernel
+    extras, where one allocator refill inside a 5-call average would triple the figure."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for e0, e1 in ev:
+        e0.record()
+        fn()
+        e1.record()
+    torch.cuda.synchronize()
+    return sorted(e0.elapsed_time(e1) for e0, e1 in ev)[iters // 2]
+
+
 def time_kernel_graphed(fn, reps=20, iters=5, warmup=2):
     """Average duration (ms) of one `fn` when `reps` of them are replayed back to back as a
     HIP graph: for kernels shorter than the Python/ctypes call that launches them (RoIAlign:
@@ -345,7 +360,8 @@ def main():
         ms = time_kernel(lambda: ops.conv2d(x, wp, b, 256, 3, relu=True))
         flops = 2.0 * ROIS_PER_IMG * 196 * 256 * 256 * 9
         ach = flops / (ms * 1e-3) / 1e12
-        result['roofline'] = {'kernel': 'conv_igemm_kernel<3,2,2,2,2,8> (conv3x3 256->256 +bias+ReLU, 512 RoIs)',
+        result['roofline'] = {'kernel': 'conv_igemm_kernel<3,2,2,2,2,8> + its <3,4,1,1,1,8> last-round launch (conv3x3 256->256 '
+                                        '+bias+ReLU, 512 RoIs; ms_per_launch = both launches of one dm_conv2d_fwd call)',
                               'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                               'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': None, 'ms_per_launch': ms,
                               'flops_per_launch': flops}
@@ -399,7 +415,7 @@ def main():
             fcn = fcn.to(dev).eval()
             ext = head.mask_roi_extractor
             with torch.no_grad():
-                return time_kernel(lambda: fcn(ext(fpn_feats[:4], fpn_rois)), iters=5, warmup=2)
+                return time_kernel_median(lambda: fcn(ext(fpn_feats[:4], fpn_rois)))
         extra['fcn_deconv_28_ms'] = fcn_ms('deconv', feats, rois)
         f5 = [f.to(dev) for f in synth.make_fpn(1, 1024, 2048, 256, seed=20)]
         r5 = synth.make_rois(1, ROIS_PER_IMG, 1024, 2048, seed=21).to(dev)

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "dynamask_hip.h"
 
@@ -23,6 +24,19 @@ static inline int dm_ceil_div(long long a, long long b) { return (int)((a + b - 
 static inline int dm_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? DM_OK : DM_ERR_LAUNCH;
+}
+
+// Compute units of the current device (MI355X: 256), read once.
+static inline int dm_num_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      cus = n;
+    else
+      cus = 256;
+  }
+  return cus;
 }
 
 typedef float dm_f32x16 __attribute__((ext_vector_type(16)));

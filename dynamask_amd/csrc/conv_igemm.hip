@@ -44,6 +44,7 @@ struct ConvArgs {
   int out_ch_total, out_ch_offset;
   int Wp, plane;  // 3x3: W+2, Rmax*Wp ; 1x1: unused, TN
   int MT;         // number of cout tiles
+  int q_begin = 0;  // first flat pixel of this launch (Q is its end): a launch may cover a pixel range
   int shuffle;    // deconv 2x2/s2 epilogue: packed cout = phase*shuffle + co, stored at (2y+dy, 2x+dx)
 };
 
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_igemm_kernel(ConvArgs a) {
     }
   }
   const int m0 = m_tile * TM;
-  const int q0 = n_tile * TN;
+  const int q0 = a.q_begin + n_tile * TN;
   const int HW = a.HW, W = a.W, H = a.H;
   const int plane = a.plane;
 
@@ -449,7 +450,7 @@ int launch_conv_mp(ConvArgs& a, hipStream_t st) {
   constexpr int TM = WGM * WM * 32;
   constexpr int TN = WGN * WN * 32;
   constexpr int NT = WGM * WGN * 64;
-  const int NTiles = dm_ceil_div(a.Q, TN);
+  const int NTiles = dm_ceil_div(a.Q - a.q_begin, TN);
   const size_t lds_bytes = 16 * ((size_t)KS * KS * (CK / 4) * (TM + TAIL) + (size_t)(CK / 4) * a.plane);
   if (lds_bytes > 64 * 1024) return DM_ERR_UNSUPPORTED;
   DM_LAUNCH((conv_igemm_kernel<KS, WGM, WGN, WM, WN, CK, MAXPOS, TAIL>), dim3(a.MT * NTiles), dim3(NT), lds_bytes, st, a);
@@ -541,13 +542,39 @@ extern "C" int dm_conv2d_fwd(const float* const* srcs, const int* src_channels, 
   a.wq = w_packed; a.bias = bias; a.Cout = Cout; a.CoutP = dm_conv_packed_cout(Cout);
   a.relu = relu & 3; a.out = out; a.out_ch_total = out_ch_total; a.out_ch_offset = out_ch_offset;
   a.shuffle = 0;
+  a.q_begin = 0;
   // outputs that cannot stay in the 256 MB Infinity Cache next to their consumer's other traffic are
   // written with nontemporal stores (measured: -10 % on the 1.85 GB column-gradient GEMM, neutral
   // below); accumulating launches read the destination and keep the default policy
   if (!(relu & 2) && (long long)NB * Cout * H * W * 4 > (192LL << 20)) a.relu |= 4;
   hipStream_t st = (hipStream_t)stream;
   if (ksize == 3) {
-    if (Cout > 64) return launch_conv<3, 2, 2, 2, 2, 8>(a, st);
+    if (Cout > 64) {
+      // 128 x 128 tiles run two to a CU: a launch is a sequence of rounds of 512 workgroups, and a last
+      // round with few workgroups takes as long as a lone workgroup (measured: 501 RoIs of 14 x 14 =
+      // 1536 workgroups 0.916 ms, 502 RoIs 1.059 ms).  The pixels of an underfull last round go to a
+      // second launch with 128 x 32 tiles: four times the workgroups, a quarter of the time each.
+      // The split depends on the launch shape only, and both variants add an output's products
+      // in the same order (chunk, tap, channel pair), so results do not depend on it.
+      // Worth it while the last round is at most ~0.6 full (measured at 0.01 .. 0.99); DM_CONV_TAIL=0
+      // turns it off for tools/tail_probe.py.
+      static const int tail_mode = getenv("DM_CONV_TAIL") ? atoi(getenv("DM_CONV_TAIL")) : 1;
+      const int MT = dm_ceil_div(a.CoutP, 128), NTiles = dm_ceil_div(a.Q, 128);
+      const int slots = 2 * dm_num_cus();
+      const int full_rounds = (MT * NTiles) / slots;
+      const int rem = MT * NTiles - full_rounds * slots;
+      if (tail_mode && full_rounds >= 1 && rem > 0 && rem * 5 <= 3 * slots) {
+        const int n_main = full_rounds * slots / MT;
+        const int Q = a.Q;
+        a.Q = n_main * 128;
+        int rc = launch_conv<3, 2, 2, 2, 2, 8>(a, st);
+        if (rc != DM_OK) return rc;
+        a.q_begin = a.Q;
+        a.Q = Q;
+        return launch_conv<3, 4, 1, 1, 1, 8>(a, st);
+      }
+      return launch_conv<3, 2, 2, 2, 2, 8>(a, st);
+    }
     if (Cout > 32 && Cout <= 36 && !(relu & 2)) return launch_conv<3, 1, 4, 1, 1, 8, 4>(a, st);   // DCN offset convs: 32 + 4
     if (Cout > 32) return launch_conv<3, 1, 4, 2, 1, 8>(a, st);
     return launch_conv<3, 1, 4, 1, 1, 8>(a, st);
@@ -585,6 +612,6 @@ extern "C" int dm_deconv2x2_fwd(const float* x, int NB, int C, int H, int W, con
   a.KQ = packed_quads(1, a.src_c);
   a.NB = NB; a.H = H; a.W = W; a.HW = H * W; a.Q = NB * H * W;
   a.wq = w_packed; a.bias = bias; a.Cout = 4 * Cout; a.CoutP = dm_conv_packed_cout(4 * Cout);
-  a.relu = relu; a.out = out; a.out_ch_total = 0; a.out_ch_offset = 0; a.shuffle = Cout;
+  a.relu = relu; a.out = out; a.out_ch_total = 0; a.out_ch_offset = 0; a.shuffle = Cout; a.q_begin = 0;
   return launch_conv<1, 2, 2, 2, 2, 32>(a, (hipStream_t)stream);
 }

@@ -60,6 +60,12 @@ def test_zero_offset_dcn_equals_conv_kernel_full_size(ops):
     # and both agree with MIOpen's conv on a slice (independent implementation)
     ref = F.conv2d(x[:16], w, padding=1)
     assert torch.allclose(y_conv[:16], ref, atol=1e-4, rtol=1e-4)
+    # 512 RoIs = 3.06 rounds of 128 x 128 tiles: the last 2048 pixels go to a second launch with
+    # 128 x 32 tiles.  Same products in the same order: rows do not depend on where the split falls
+    assert torch.allclose(y_conv[-16:], F.conv2d(x[-16:], w, padding=1), atol=1e-4, rtol=1e-4)
+    assert torch.equal(y_conv[-16:], ops.conv2d(x[-16:].contiguous(), wq, None, 256, 3))
+    assert torch.equal(y_conv[:336], ops.conv2d(x[:336].contiguous(), wq, None, 256, 3))     # 2.01 rounds: other split
+    assert torch.equal(y_dcn[-16:], ops.deform_conv(x[-16:].contiguous(), torch.zeros(16, 36, 14, 14, device='cuda'), wq, 256, 2))
 
 
 def test_head_is_roi_permutation_equivariant_and_stream_invariant(full):
