@@ -286,19 +286,24 @@ __global__ __launch_bounds__(WGM* WGN * 64) void deform_conv_kernel(DcnArgs a) {
 // cost of gathering from global memory (the raw row pairs of the next chunk live in VGPRs under
 // the MFMAs).  Here the 8 channel planes of the (at most two) images a pixel tile touches are
 // staged in LDS per chunk -- a 14x14 plane is 784 bytes -- and the bilinear gather reads LDS:
-// short latency, so a tap's B operand is produced just in time, three taps ahead of its MFMAs,
-// into a small ring; nothing but the next chunk's weights and planes is held in registers.
+// short latency, so a tap's B operand is produced just in time, three taps ahead of its MFMAs.
+//
+// The K loop is a sequence of steps of 3 taps (3 steps per chunk of 8 channels).  Step s does the
+// MFMAs of its 3 taps from ring slot s & 1 of the A (weights) and B (gathered pixels) images while
+// it fills slot (s + 1) & 1 for the next step: B by the gather, A from registers loaded one step
+// earlier.  The channel planes are double buffered by chunk; the planes of chunk c + 1 are loaded
+// in step 0 of chunk c, stored in step 1, and first read by the gather of step 2.  One barrier per
+// step, no phase without MFMAs.
 __global__ __launch_bounds__(256, 2) void deform_conv_lds_kernel(DcnArgs a) {
   constexpr int TM = 128, TN = 128, NT = 256;
-  constexpr int A_F4 = 9 * 2 * TM;                // [tap][quad][cout] float4
-  constexpr int A_PER_T = A_F4 / NT;              // 9
-  constexpr int XPL = 256;                        // floats reserved per channel plane
-  constexpr int X_F4 = 2 * 8 * XPL / 4;           // [image slot][channel][XPL]
-  constexpr int X_PER_T = 4;
+  constexpr int AS_F4 = 3 * 2 * TM;               // one A slot: [tap of the step][quad][cout] float4
+  constexpr int BS_F4 = 3 * 2 * TN;               // one B slot: [tap of the step][quad][pixel] float4
+  constexpr int A_PER_T = AS_F4 / NT;             // 3
+  constexpr int X_PER_T = 4;                      // float4 per thread for 2 images x 8 planes (H*W <= 256)
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  dm_f32x4* ldsA = reinterpret_cast<dm_f32x4*>(lds);
-  float* ldsX = lds + 4 * A_F4;
-  dm_f32x4* ldsB = reinterpret_cast<dm_f32x4*>(lds + 4 * A_F4 + 4 * X_F4);   // [2][3 taps][2 quads][TN]
+  dm_f32x4* ldsA = reinterpret_cast<dm_f32x4*>(lds);                 // [2][AS_F4]
+  dm_f32x4* ldsB = ldsA + 2 * AS_F4;                                 // [2][BS_F4]
+  float* ldsX = reinterpret_cast<float*>(ldsB + 2 * BS_F4);          // [2 buffers][2 image slots][8 ch][H*W]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_m = wave >> 1, wave_n = wave & 1;
@@ -320,6 +325,7 @@ __global__ __launch_bounds__(256, 2) void deform_conv_lds_kernel(DcnArgs a) {
   const int m0 = m_tile * TM, q0 = n_tile * TN;
   const int HW = a.HW, W = a.W, H = a.H;
   const int n0 = q0 / HW;                          // first image of the tile; the tile touches n0 and n0 + 1 at most
+  const int xbuf = 2 * 8 * HW;                     // floats per plane buffer
 
   int col_n[2], col_p[2];
   bool col_ok[2];
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void deform_conv_lds_kernel(DcnArgs a) {
   gq = min(gq, a.Q - 1);
   const int gn = gq / HW, gp = gq - gn * HW;
   const int gy = gp / W, gx = gp - gy * W;
-  const int xbase = (gn - n0) * 8 * XPL + gh * 4 * XPL;      // this thread's 4 planes inside ldsX
+  const int xbase = ((gn - n0) * 8 + gh * 4) * HW;           // this thread's 4 planes inside a plane buffer
 
   int otb[9];                                      // top | bottom << 16: offsets inside a plane (< 256)
   float wt0[9], wt1[9], wb0[9], wb1[9];
@@ -382,16 +388,23 @@ __global__ __launch_bounds__(256, 2) void deform_conv_lds_kernel(DcnArgs a) {
 
   dm_f32x4 ra[A_PER_T], rx[X_PER_T];
   const int x_f4_img = 8 * HW / 4;                 // float4 per image and chunk (8 contiguous planes; HW % 4 checked on the host)
-  auto prefetch = [&](int c0) {
+  // weights of taps 3g .. 3g+2, channels c0 .. c0+7
+  auto load_a = [&](int c0, int g) {
 #pragma unroll
     for (int i = 0; i < A_PER_T; ++i) {
       const int idx = tid + i * NT;
-      const int m = idx % TM, tq = idx / TM;
+      const int m = idx % TM, tq = idx / TM;       // tq = (tap of the step) * 2 + quad
       dm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (m0 + m < a.CoutP)
-        v = *reinterpret_cast<const dm_f32x4*>(a.wp + (((size_t)(tq >> 1) * a.KQ + (c0 >> 2) + (tq & 1)) * a.CoutP + m0 + m) * 4);
+        v = *reinterpret_cast<const dm_f32x4*>(a.wp + (((size_t)(3 * g + (tq >> 1)) * a.KQ + (c0 >> 2) + (tq & 1)) * a.CoutP + m0 + m) * 4);
       ra[i] = v;
     }
+  };
+  auto store_a = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) ldsA[slot * AS_F4 + tid + i * NT] = ra[i];
+  };
+  auto load_x = [&](int c0) {
 #pragma unroll
     for (int i = 0; i < X_PER_T; ++i) {
       const int idx = tid + i * NT;
@@ -402,45 +415,38 @@ __global__ __launch_bounds__(256, 2) void deform_conv_lds_kernel(DcnArgs a) {
       rx[i] = v;
     }
   };
-  auto commit = [&]() {
-#pragma unroll
-    for (int i = 0; i < A_PER_T; ++i) ldsA[tid + i * NT] = ra[i];
+  auto store_x = [&](int buf) {                   // 8 planes of an image are one contiguous run, copied as is
 #pragma unroll
     for (int i = 0; i < X_PER_T; ++i) {
       const int idx = tid + i * NT;
-      const int img = idx / x_f4_img, r = idx - img * x_f4_img;
-      if (img < 2) {
-        // plane c of the image starts at c * XPL; the source run is 8 planes of HW floats back to back
-        const int f = r * 4, c = f / HW, p = f - c * HW;     // HW % 4 == 0: a float4 never straddles two planes
-        *reinterpret_cast<dm_f32x4*>(ldsX + img * 8 * XPL + c * XPL + p) = rx[i];
-      }
+      if (idx < 2 * x_f4_img) *reinterpret_cast<dm_f32x4*>(ldsX + buf * xbuf + idx * 4) = rx[i];
     }
   };
   struct __attribute__((packed, aligned(4))) F2 { float a, b; };
-  auto gather3 = [&](int t0, int ring) {          // taps t0 .. t0+2 -> ldsB[ring]
+  auto gather3 = [&](int t0, int slot, int buf) {   // taps t0 .. t0+2 of the chunk in plane buffer buf -> B slot
+    const float* xb = ldsX + buf * xbuf + xbase;
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       const int tap = t0 + u;
       dm_f32x4 v;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float* pl = ldsX + xbase + e * XPL;
+        const float* pl = xb + e * HW;
         const F2 top = *reinterpret_cast<const F2*>(pl + (otb[tap] & 0xffff));
         const F2 bot = *reinterpret_cast<const F2*>(pl + (otb[tap] >> 16));
         v[e] = wt0[tap] * top.a + wt1[tap] * top.b + wb0[tap] * bot.a + wb1[tap] * bot.b;
       }
-      ldsB[((ring * 3 + u) * 2 + gh) * TN + gj] = v;
+      ldsB[slot * BS_F4 + (u * 2 + gh) * TN + gj] = v;
     }
   };
-  auto mfma3 = [&](int t0, int ring) {
+  auto mfma3 = [&](int slot) {
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
-      const int tap = t0 + u;
       dm_f32x4 av[2], bv[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) av[i] = ldsA[(tap * 2 + hi) * TM + (wave_m * 2 + i) * 32 + l31];
+      for (int i = 0; i < 2; ++i) av[i] = ldsA[slot * AS_F4 + (u * 2 + hi) * TM + (wave_m * 2 + i) * 32 + l31];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bv[j] = ldsB[((ring * 3 + u) * 2 + hi) * TN + (wave_n * 2 + j) * 32 + l31];
+      for (int j = 0; j < 2; ++j) bv[j] = ldsB[slot * BS_F4 + (u * 2 + hi) * TN + (wave_n * 2 + j) * 32 + l31];
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -450,34 +456,53 @@ __global__ __launch_bounds__(256, 2) void deform_conv_lds_kernel(DcnArgs a) {
     }
   };
 
+  // prologue: planes of chunk 0, weights and gathered pixels of step 0, loads of step 1 in flight
   int cur_group = 0;
   load_params(0);
-  prefetch(0);
-  commit();
+  load_x(0);
+  load_a(0, 0);
+  store_x(0);
+  store_a(0);
+  load_a(0, 1);
   __syncthreads();
-  for (int c0 = 0; c0 < a.C; c0 += 8) {
+  gather3(0, 0, 0);
+  __syncthreads();
+  int slot = 0;                                   // ring slot of the current step
+  for (int c0 = 0, buf = 0; c0 < a.C; c0 += 8, buf ^= 1) {
     const int cn = c0 + 8;
     const bool more = cn < a.C;
-    if (more) prefetch(cn);                  // in flight under the whole tap loop
-    gather3(0, 0);
+    // step 0: MFMAs of taps 0..2; fills taps 3..5
+    if (more) load_x(cn);
+    gather3(3, slot ^ 1, buf);
+    store_a(slot ^ 1);
+    load_a(c0, 2);
+    mfma3(slot);
     __syncthreads();
-    gather3(3, 1);
-    mfma3(0, 0);
+    slot ^= 1;
+    // step 1: MFMAs of taps 3..5; fills taps 6..8; planes of the next chunk go to the other buffer
+    gather3(6, slot ^ 1, buf);
+    store_a(slot ^ 1);
+    if (more) {
+      load_a(cn, 0);
+      store_x(buf ^ 1);
+    }
+    mfma3(slot);
     __syncthreads();
-    gather3(6, 0);
-    mfma3(3, 1);
-    __syncthreads();
-    mfma3(6, 0);
-    __syncthreads();                         // every read of A / X / B of this chunk is done
+    slot ^= 1;
+    // step 2: MFMAs of taps 6..8; fills taps 0..2 of the next chunk
     if (more) {
       const int group = cn / cpg;
       if (group != cur_group) {
         cur_group = group;
         load_params(group);
       }
-      commit();
-      __syncthreads();
+      gather3(0, slot ^ 1, buf ^ 1);
+      store_a(slot ^ 1);
+      load_a(cn, 1);
     }
+    mfma3(slot);
+    __syncthreads();
+    slot ^= 1;
   }
 
 #pragma unroll
@@ -541,7 +566,8 @@ extern "C" int dm_deform_conv_fwd(const float* x, const float* offset, int NB, i
     // small maps (14x14): planes in LDS, 128 x 128 tile
     a.MT = dm_ceil_div(a.CoutP, 128);
     const int NTiles = dm_ceil_div(a.Q, 128);
-    const size_t lds_bytes = 16 * ((size_t)9 * 2 * 128 + (size_t)2 * 8 * 256 / 4 + (size_t)2 * 3 * 2 * 128);
+    // A ring + B ring (2 x 3 taps x 2 quads x 128 float4 each) + 2 plane buffers of 2 images x 8 channels
+    const size_t lds_bytes = 16 * ((size_t)2 * 2 * 3 * 2 * 128) + (size_t)4 * 2 * 2 * 8 * a.HW;
     static bool attr_lds = false;
     if (!attr_lds) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&deform_conv_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

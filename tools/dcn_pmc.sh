@@ -1,0 +1,12 @@
+#!/bin/bash
+# PMC passes over tools/dcn_probe.py (one counter group per run; per-kernel means printed)
+export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+i=0
+for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU" \
+           "SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INST_CYCLES_VMEM SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  rocprofv3 --pmc $grp --output-format csv -d gpurun_out/dpmc$i -- python3 tools/dcn_probe.py "$@" > /dev/null 2>&1
+  python3 tools/pmc_sum.py gpurun_out/dpmc$i conv
+done
