@@ -53,8 +53,12 @@ struct ConvArgs {
 // 4 x 4: the 4 lanes of a block hold the 4 tail couts as A and 4 pixels as B, so a lane
 // accumulates the 4 tail couts of ITS pixel) from the same B fragments -- the 36-cout offset
 // convs of the DCN layers then cost 32 + 4 rows of MFMA work instead of 64.
+// The 3x3 128 x 128 build with one plane position per thread is held to 168 VGPRs (5 dwords of
+// scratch): three workgroups per CU instead of two hide each other's barriers better
+// (14 x 14, 3 full rounds: 0.916 -> 0.876 ms; 752 RoIs: 135 TFLOP/s).  The 1x1 builds spill 35-55
+// dwords at 168 and lose a third of their rate: they stay at two per CU.
 template <int KS, int WGM, int WGN, int WM, int WN, int CK, int MAXPOS, int TAIL = 0>
-__global__ __launch_bounds__(WGM* WGN * 64) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && WM == 2 && WN == 2 && MAXPOS == 1) ? 3 : 1) void conv_igemm_kernel(ConvArgs a) {
   static_assert(TAIL == 0 || (TAIL == 4 && WGM == 1), "tail rows need a single cout tile");
   constexpr int TM = WGM * WM * 32;
   constexpr int TMA = TM + TAIL;              // rows of the LDS A image
@@ -550,20 +554,25 @@ extern "C" int dm_conv2d_fwd(const float* const* srcs, const int* src_channels, 
   hipStream_t st = (hipStream_t)stream;
   if (ksize == 3) {
     if (Cout > 64) {
-      // 128 x 128 tiles run two to a CU: a launch is a sequence of rounds of 512 workgroups, and a last
-      // round with few workgroups takes as long as a lone workgroup (measured: 501 RoIs of 14 x 14 =
-      // 1536 workgroups 0.916 ms, 502 RoIs 1.059 ms).  The pixels of an underfull last round go to a
+      // 128 x 128 tiles run two or three to a CU: a launch is a sequence of rounds of 512 / 768 workgroups,
+      // and a last round with few workgroups takes as long as a lone workgroup (measured at two per CU:
+      // 501 RoIs of 14 x 14 = 1536 workgroups 0.916 ms, 502 RoIs 1.059 ms).  The pixels of an underfull last round go to a
       // second launch with 128 x 32 tiles: four times the workgroups, a quarter of the time each.
       // The split depends on the launch shape only, and both variants add an output's products
-      // in the same order (chunk, tap, channel pair), so results do not depend on it.
+      // in the same order (chunk, tap, channel pair), so results do not depend on it.  A caller that
+      // keeps a second stream busy (flag bit 3) has that stream's workgroups fill the last round;
+      // the extra dependent launch then only delays its own stream (measured: 250 vs 241 img/s).
       // Worth it while the last round is at most ~0.6 full (measured at 0.01 .. 0.99); DM_CONV_TAIL=0
       // turns it off for tools/tail_probe.py.
       static const int tail_mode = getenv("DM_CONV_TAIL") ? atoi(getenv("DM_CONV_TAIL")) : 1;
       const int MT = dm_ceil_div(a.CoutP, 128), NTiles = dm_ceil_div(a.Q, 128);
-      const int slots = 2 * dm_num_cus();
+      // workgroups per CU: 3 when the staged plane needs one position per thread (the 168-VGPR build
+      // of the kernel; 14 x 14 maps), else 2
+      const int rmax128 = dm_ceil_div(127, a.W) + 1 + 2 * (dm_ceil_div(127, a.HW) + 1);
+      const int slots = (rmax128 * (a.W + 2) <= 256 ? 3 : 2) * dm_num_cus();
       const int full_rounds = (MT * NTiles) / slots;
       const int rem = MT * NTiles - full_rounds * slots;
-      if (tail_mode && full_rounds >= 1 && rem > 0 && rem * 5 <= 3 * slots) {
+      if (tail_mode && !(relu & 8) && full_rounds >= 1 && rem > 0 && rem * 5 <= 3 * slots) {
         const int n_main = full_rounds * slots / MT;
         const int Q = a.Q;
         a.Q = n_main * 128;

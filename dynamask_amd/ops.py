@@ -263,6 +263,22 @@ def pack_conv_weight(w, transpose_flip=False, src_channels=None):
     return wp
 
 
+_overlapped = 0
+
+
+class overlapped_streams:
+    """Context: launches inside run next to other work on a second stream (DynaMaskRoIHead splits
+    the RoIs over two streams).  Passed to dm_conv2d_fwd as flag bit 3, a scheduling hint."""
+
+    def __enter__(self):
+        global _overlapped
+        _overlapped += 1
+
+    def __exit__(self, *exc):
+        global _overlapped
+        _overlapped -= 1
+
+
 def conv2d(srcs, w_packed, bias, cout, ksize, relu=False, out=None, out_ch_offset=0, accumulate=False):
     """Fused concat(srcs) -> conv(ksize, same) -> +bias -> ReLU."""
     if isinstance(srcs, torch.Tensor):
@@ -283,7 +299,8 @@ def conv2d(srcs, w_packed, bias, cout, ksize, relu=False, out=None, out_ch_offse
         assert out.shape[0] == NB and out.shape[2] == H and out.shape[3] == W
     strides = (ctypes.c_longlong * len(srcs))(*[int(s.stride(0)) for s in srcs])
     rc = lib().dm_conv2d_fwd(_ptr_array(srcs), _int_array([s.shape[1] for s in srcs]), strides, len(srcs), NB, H, W,
-                             _p(w_packed), _p(bias), cout, ksize, (1 if relu else 0) | (2 if accumulate else 0), _p(out), out.shape[1],
+                             _p(w_packed), _p(bias), cout, ksize,
+                             (1 if relu else 0) | (2 if accumulate else 0) | (8 if _overlapped else 0), _p(out), out.shape[1],
                              out_ch_offset, _stream())
     check(rc, 'dm_conv2d_fwd')
     return out

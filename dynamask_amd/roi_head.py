@@ -180,7 +180,7 @@ class DynaMaskRoIHead(nn.Module):
         parts = []
         for st, lo, hi in zip(streams, bounds[:-1], bounds[1:]):
             st.wait_stream(cur)
-            with torch.cuda.stream(st):
+            with torch.cuda.stream(st), ops.overlapped_streams():
                 r, l = rois[lo:hi], roi_labels[lo:hi]
                 ins = self.mask_roi_extractor(x[:self.mask_roi_extractor.num_inputs], r)
                 parts.append(self.mask_head(ins, x, r, l, last_stage=last_stage, sems=sems))

@@ -92,7 +92,10 @@ int dm_conv_pack_weight(const float* w_oihw, int Cout, int Cin, int ksize, int t
  *            src_batch_strides are HOST arrays (of device pointers / ints).
  * w_packed : dm_conv_pack_weight layout, bias: [Cout] or NULL
  * relu     : flags -- bit 0: fused ReLU; bit 1: accumulate (out += result; used
- *            for gradient sums in the backward)
+ *            for gradient sums in the backward); bit 3: the caller overlaps this
+ *            launch with work on another stream (a scheduling hint: the 3x3
+ *            kernel then does not split off its last round of workgroups;
+ *            results are the same bits either way)
  * out      : written at channels [out_ch_offset, out_ch_offset+Cout) of a
  *            tensor [NB, out_ch_total, H, W]
  * ------------------------------------------------------------------------- */
