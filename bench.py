@@ -201,6 +201,8 @@ def train_step_bench(head, dev, rank, world, steps=4, warmup=4):
     for _ in range(warmup):
         step()
 
+    issue = []          # host time to issue a step's launches (ms): the step is close to host-bound
+
     def window():
         torch.cuda.synchronize()
         if world > 1:
@@ -210,6 +212,7 @@ def train_step_bench(head, dev, rank, world, steps=4, warmup=4):
         t0 = time.perf_counter()
         for _ in range(steps):
             r = step()
+        issue.append((time.perf_counter() - t0) / steps * 1e3)
         torch.cuda.synchronize()
         if world > 1:
             import torch.distributed as dist
@@ -227,6 +230,8 @@ def train_step_bench(head, dev, rank, world, steps=4, warmup=4):
     wins = [window() for _ in range(3)]
     res = wins[-1][1]
     dt = sorted(w for w, _ in wins)[1]
+    print('[bench] train-step windows (ms/step): ' + ', '.join(f'{w / steps * 1e3:.2f}' for w, _ in wins)
+          + '; host issue ' + ', '.join(f'{v:.2f}' for v in issue), file=sys.stderr)
     # communication alone: the flat-gradient all-reduce (16.65 MB) timed by itself, so that
     # the scaling curve can be read with and without it; 0 at world size 1
     comm_ms = 0.0

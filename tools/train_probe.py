@@ -34,3 +34,26 @@ for i in range(int(os.environ.get('TP_STEPS', 12))):
     t4 = time.perf_counter()
     print(f'step {i}: wall {1e3*(t4-t0):7.2f} ms  device {e0.elapsed_time(e1):7.2f} ms  host fwd {1e3*(t1-t0):6.2f} bwd {1e3*(t2-t1):6.2f} opt {1e3*(t3-t2):5.2f}  '
           f'mem {torch.cuda.memory_allocated()/2**30:.2f}/{torch.cuda.memory_reserved()/2**30:.2f} GiB', flush=True)
+
+# windows of 4 steps without a sync in between (what bench.py times): the host runs ahead of the GPU
+if os.environ.get('TP_WINDOWS'):
+    import gc
+    def stats():
+        s = torch.cuda.memory_stats()
+        return s['num_device_alloc'], s['num_device_free'], s['reserved_bytes.all.current'] / 2**30, s['active_bytes.all.peak'] / 2**30
+    for w in range(int(os.environ['TP_WINDOWS'])):
+        torch.cuda.synchronize()
+        a0 = stats(); g0 = gc.get_count()
+        t0 = time.perf_counter()
+        for _ in range(4):
+            grp.zero_grad()
+            res = head._mask_forward_train(feats, rois, labels, targets, noise=noise)
+            res['loss_mask']['loss_masks'].backward()
+            grp.all_reduce_async()
+            grp.sgd_step(lr=0.02, momentum=0.9, weight_decay=1e-4)
+        th = time.perf_counter()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        a1 = stats()
+        print(f'window {w}: {(t1 - t0) / 4 * 1e3:6.2f} ms/step (host issue {(th - t0) / 4 * 1e3:6.2f})  device allocs +{a1[0] - a0[0]} frees +{a1[1] - a0[1]}  '
+              f'reserved {a1[2]:.2f} GiB peak active {a1[3]:.2f} GiB  gc {g0}', flush=True)
