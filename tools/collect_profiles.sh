@@ -1,0 +1,32 @@
+#!/bin/bash
+# One pass over everything profiles/ holds for a round; run on the GPU box:
+#   gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh r01l'
+# Writes gpurun_out/<tag>_*; copy what is to be kept into profiles/.
+set -e -o pipefail
+tag=${1:-rXX}
+export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+out=gpurun_out
+stats() {  # stats <dir> <dest>: copy the kernel_stats.csv of a rocprofv3 --stats run
+  cp "$(ls -t $1/*/*kernel_stats.csv | head -1)" "$2"
+}
+python3 bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.stderr
+tail -1 $out/${tag}_bench.json | cut -c1-200
+python3 bench.py --end-to-end > $out/${tag}_bench_end_to_end.json 2>> $out/${tag}_bench.stderr
+echo "bench done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_bench -- python3 bench.py --cpu-sample 0 > /dev/null 2>&1
+stats $out/prof_bench $out/${tag}_bench_kernel_stats.csv
+PROBE_ITERS=40 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_roof -- python3 tools/pmc_probe.py > /dev/null 2>&1
+stats $out/prof_roof $out/${tag}_roofline_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_head -- python3 tools/headline_trace.py 20 > /dev/null 2>&1
+stats $out/prof_head $out/${tag}_headline_kernel_stats.csv
+TP_STEPS=6 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_train -- python3 tools/train_probe.py > /dev/null 2>&1
+stats $out/prof_train $out/${tag}_train_step_kernel_stats.csv
+echo "traces done"
+python3 tools/kbench.py > $out/${tag}_kbench.txt 2>&1
+python3 tools/tail_probe.py > $out/${tag}_tail_probe.txt 2>&1
+PROBE_ITERS=6 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/traffic_fetch -- python3 tools/pmc_probe.py > /dev/null 2>&1
+PROBE_ITERS=6 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/traffic_write -- python3 tools/pmc_probe.py > /dev/null 2>&1
+{ python3 tools/pmc_sum.py $out/traffic_fetch; python3 tools/pmc_sum.py $out/traffic_write; } > $out/${tag}_traffic_pmc.txt
+cat $out/${tag}_traffic_pmc.txt
+echo "all done"
