@@ -55,10 +55,12 @@ struct ConvArgs {
 // convs of the DCN layers then cost 32 + 4 rows of MFMA work instead of 64.
 // The 3x3 128 x 128 build with one plane position per thread is held to 168 VGPRs (5 dwords of
 // scratch): three workgroups per CU instead of two hide each other's barriers better
-// (14 x 14, 3 full rounds: 0.916 -> 0.876 ms; 752 RoIs: 135 TFLOP/s).  The 1x1 builds spill 35-55
-// dwords at 168 and lose a third of their rate: they stay at two per CU.
+// (14 x 14, 3 full rounds: 0.916 -> 0.876 ms; 752 RoIs: 135 TFLOP/s).  The 1x1 builds with 32-channel
+// chunks spill 35-55 dwords at 168 and lose a third of their rate; with 16-channel chunks (half the
+// prefetch registers) they fit without scratch, and three per CU beats the longer chunk: the DCN
+// column-gradient GEMMs 1.56 -> 1.20, 0.94 -> 0.78, 0.75 -> 0.67 ms, fusion 130->64 @56^2 0.56 -> 0.45 ms.
 template <int KS, int WGM, int WGN, int WM, int WN, int CK, int MAXPOS, int TAIL = 0>
-__global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && WM == 2 && WN == 2 && MAXPOS == 1) ? 3 : 1) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && WM == 2 && WN == 2 && MAXPOS == 1) || (KS == 1 && CK == 16) ? 3 : 1) void conv_igemm_kernel(ConvArgs a) {
   static_assert(TAIL == 0 || (TAIL == 4 && WGM == 1), "tail rows need a single cout tile");
   constexpr int TM = WGM * WM * 32;
   constexpr int TMA = TM + TAIL;              // rows of the LDS A image
@@ -588,8 +590,8 @@ extern "C" int dm_conv2d_fwd(const float* const* srcs, const int* src_channels, 
     if (Cout > 32) return launch_conv<3, 1, 4, 2, 1, 8>(a, st);
     return launch_conv<3, 1, 4, 1, 1, 8>(a, st);
   }
-  if (Cout > 64) return launch_conv<1, 2, 2, 2, 2, 32>(a, st);
-  if (Cout > 32) return launch_conv<1, 1, 4, 2, 2, 32>(a, st);   // 64 couts x 256 px (128 px: 0.69 -> 0.56 ms on 130->64 @56^2)
+  if (Cout > 64) return launch_conv<1, 2, 2, 2, 2, 16>(a, st);
+  if (Cout > 32) return launch_conv<1, 1, 4, 2, 2, 16>(a, st);   // 64 couts x 256 px (128 px: 0.69 -> 0.56 ms on 130->64 @56^2)
   return launch_conv<1, 1, 4, 1, 1, 32>(a, st);
 }
 
@@ -622,5 +624,5 @@ extern "C" int dm_deconv2x2_fwd(const float* x, int NB, int C, int H, int W, con
   a.NB = NB; a.H = H; a.W = W; a.HW = H * W; a.Q = NB * H * W;
   a.wq = w_packed; a.bias = bias; a.Cout = 4 * Cout; a.CoutP = dm_conv_packed_cout(4 * Cout);
   a.relu = relu; a.out = out; a.out_ch_total = 0; a.out_ch_offset = 0; a.shuffle = Cout; a.q_begin = 0;
-  return launch_conv<1, 2, 2, 2, 2, 32>(a, (hipStream_t)stream);
+  return launch_conv<1, 2, 2, 2, 2, 16>(a, (hipStream_t)stream);
 }

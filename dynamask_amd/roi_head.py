@@ -176,7 +176,11 @@ class DynaMaskRoIHead(nn.Module):
         cur = torch.cuda.current_stream()
         streams = self._side_streams(n_streams, rois.device)
         sems = self.mask_head.semantic_maps(x, last_stage)
-        bounds = [round(i * n / n_streams) for i in range(n_streams + 1)]
+        split = getattr(self, 'stream_split', None)      # optional cumulative fractions, e.g. (0.4, 1.0)
+        if split is not None and len(split) == n_streams:
+            bounds = [0] + [round(f * n) for f in split]
+        else:
+            bounds = [round(i * n / n_streams) for i in range(n_streams + 1)]
         parts = []
         for st, lo, hi in zip(streams, bounds[:-1], bounds[1:]):
             st.wait_stream(cur)
