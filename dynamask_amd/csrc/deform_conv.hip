@@ -569,9 +569,9 @@ extern "C" int dm_deform_conv_fwd(const float* x, const float* offset, int NB, i
     // A ring + B ring (2 x 3 taps x 2 quads x 128 float4 each) + 2 plane buffers of 2 images x 8 channels
     const size_t lds_bytes = 16 * ((size_t)2 * 2 * 3 * 2 * 128) + (size_t)4 * 2 * 2 * 8 * a.HW;
     static bool attr_lds = false;
-    if (!attr_lds) {
+    if (!attr_lds) {        // once, for the largest map this path takes (H*W = 256)
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&deform_conv_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds_bytes) != hipSuccess)
+                              16 * 2 * 2 * 3 * 2 * 128 + 4 * 2 * 2 * 8 * 256) != hipSuccess)
         return DM_ERR_LAUNCH;
       attr_lds = true;
     }

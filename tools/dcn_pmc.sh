@@ -8,5 +8,5 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_A
            "SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INST_CYCLES_VMEM SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   rocprofv3 --pmc $grp --output-format csv -d gpurun_out/dpmc$i -- python3 tools/dcn_probe.py "$@" > /dev/null 2>&1
-  python3 tools/pmc_sum.py gpurun_out/dpmc$i conv
+  python3 tools/pmc_sum.py gpurun_out/dpmc$i deform
 done

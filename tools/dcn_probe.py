@@ -6,11 +6,13 @@ from dynamask_amd import ops
 dev = torch.device('cuda')
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 501
 scale = float(sys.argv[2]) if len(sys.argv) > 2 else 1.5
-w = torch.randn(256, 256, 3, 3, device=dev) / 48
+C = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+S = int(sys.argv[4]) if len(sys.argv) > 4 else 14
+w = torch.randn(C, C, 3, 3, device=dev) / (9 * C) ** 0.5
 wq = ops.pack_conv_weight(w)
-x = torch.randn(n, 256, 14, 14, device=dev)
-off = torch.randn(n, 36, 14, 14, device=dev) * scale
+x = torch.randn(n, C, S, S, device=dev)
+off = torch.randn(n, 36, S, S, device=dev) * scale
 for _ in range(4):
-    ops.conv2d(x, wq, None, 256, 3, relu=True)
-    ops.deform_conv(x, off, wq, 256, 2, relu=True)
+    ops.conv2d(x, wq, None, C, 3, relu=True)
+    ops.deform_conv(x, off, wq, C, 2, relu=True)
 torch.cuda.synchronize()

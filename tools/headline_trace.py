@@ -12,8 +12,9 @@ feats_c, rois_c, labels_c = bench.make_inputs(0, dev)
 feats = [f.to(dev) for f in feats_c]
 rois, labels = rois_c.to(dev), labels_c.to(dev)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+last = None if (len(sys.argv) > 2 and sys.argv[2] == 'full') else 1      # 'full': all stages to 112x112
 with torch.no_grad():
     for _ in range(n):
-        head._mask_forward(feats, rois, labels, last_stage=1)
+        head._mask_forward(feats, rois, labels, last_stage=last)
 torch.cuda.synchronize()
 print('done', n)
