@@ -574,6 +574,13 @@ extern "C" int dm_conv2d_fwd(const float* const* srcs, const int* src_channels, 
       const int slots = (rmax128 * (a.W + 2) <= 256 ? 3 : 2) * dm_num_cus();
       const int full_rounds = (MT * NTiles) / slots;
       const int rem = MT * NTiles - full_rounds * slots;
+      // Launches that do not fill the chip: up to one 128 x 128 tile per CU costs a lone workgroup's
+      // 0.18 ms however few there are, up to two 0.31 ms; 128 x 32 tiles cost 0.04 + 0.046 ms per
+      // tile-per-CU (16 RoIs of 14 x 14: 0.175 -> 0.077 ms, 100 RoIs: 0.322 -> 0.275 ms).
+      {
+        const int wgs = MT * NTiles, cus = dm_num_cus();
+        if (tail_mode && (wgs * 10 <= cus * 7 || (wgs > cus && wgs * 20 <= cus * 29))) return launch_conv<3, 4, 1, 1, 1, 8>(a, st);
+      }
       if (tail_mode && !(relu & 8) && full_rounds >= 1 && rem > 0 && rem * 5 <= 3 * slots) {
         const int n_main = full_rounds * slots / MT;
         const int Q = a.Q;

@@ -65,6 +65,8 @@ def test_zero_offset_dcn_equals_conv_kernel_full_size(ops):
     assert torch.allclose(y_conv[-16:], F.conv2d(x[-16:], w, padding=1), atol=1e-4, rtol=1e-4)
     assert torch.equal(y_conv[-16:], ops.conv2d(x[-16:].contiguous(), wq, None, 256, 3))
     assert torch.equal(y_conv[:336], ops.conv2d(x[:336].contiguous(), wq, None, 256, 3))     # 2.01 rounds: other split
+    with ops.overlapped_streams():      # scheduling hint (flag bit 3): one launch, same bits
+        assert torch.equal(y_conv, ops.conv2d(x, wq, None, 256, 3))
     assert torch.equal(y_dcn[-16:], ops.deform_conv(x[-16:].contiguous(), torch.zeros(16, 36, 14, 14, device='cuda'), wq, 256, 2))
 
 
