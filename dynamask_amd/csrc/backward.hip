@@ -184,19 +184,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       }
     }
   }
+  {
+    // hoisted addresses: one base per column, one per-lane row offset (see conv_igemm.hip's epilogue)
+    float* pj[2];
+    bool j_ok[2];
 #pragma unroll
-  for (int i = 0; i < (TAIL ? 1 : 2); ++i)
+    for (int j = 0; j < 2; ++j) {
+      const int jg = j0 + (wave_n * 2 + j) * 32 + l31;
+      j_ok[j] = jg < Jtot;
+      pj[j] = a.dw + a.coloff + jg;
+    }
+    const int co_lane = m0 + wave_m * 64 + 4 * hi;
+    const size_t off_lane = (size_t)co_lane * a.ldw;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = m0 + (wave_m * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (co < a.Cout) {
+    for (int i = 0; i < (TAIL ? 1 : 2); ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int jg = j0 + (wave_n * 2 + j) * 32 + l31;
-          if (jg < Jtot) atomicAdd(a.dw + (size_t)co * a.ldw + a.coloff + jg, acc[i][j][r]);
+      for (int r = 0; r < 16; ++r) {
+        const int k = i * 32 + (r & 3) + 8 * (r >> 2);
+        if (co_lane + k < a.Cout) {
+          const size_t o = off_lane + (size_t)k * a.ldw;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            if (j_ok[j]) atomicAdd(pj[j] + o, acc[i][j][r]);
         }
       }
-    }
+  }
   if (TAIL) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {

@@ -26,6 +26,8 @@
 // the 128x128 tile): the NEXT chunk's global loads are issued into registers
 // before the MFMAs of the current chunk and written to LDS after them
 // (issue-early / write-late), so L2 latency hides under 144 MFMAs per wave.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -341,26 +343,81 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
   }
 
   // ---- epilogue: bias + ReLU, 32 consecutive pixels per register ------------
+  // Address arithmetic is hoisted: one 64-bit base per pixel column, one per-lane channel offset, the
+  // rest is uniform (SALU); the store modes are uniform too and pick one of three straight-line
+  // variants.  (Written naively -- the full index expression per store, mode tests inside -- the
+  // epilogue was 3700 VALU instructions per wave, as many as the 32 chunks of the main loop together,
+  // and VALU work is not free next to MFMAs: tools/micro/mfma_lds.hip.)
+  if (a.shuffle == 0) {
+    float* pj[WN];
 #pragma unroll
-  for (int i = 0; i < WM; ++i) {
+    for (int j = 0; j < WN; ++j)
+      pj[j] = a.out + ((size_t)col_n[j] * a.out_ch_total + a.out_ch_offset) * HW + col_p[j];
+    const int co_lane = m0 + wave_m * WM * 32 + 4 * hi;
+    const size_t off_lane = (size_t)co_lane * HW;
+    const bool relu = a.relu & 1;
+    // all bias values first: a load inside the store loop puts an s_waitcnt vmcnt(0) -- which also
+    // waits for the stores issued so far -- in front of every output row
+    float bias_r[WM][16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = m0 + (wave_m * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (co < a.Cout) {
-        if (a.shuffle == 0) {
-          const float b = a.bias ? a.bias[co] : 0.f;
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-          for (int j = 0; j < WN; ++j) {
-            if (col_ok[j]) {
-              float* op = a.out + ((size_t)col_n[j] * a.out_ch_total + a.out_ch_offset + co) * HW + col_p[j];
-              float v = acc[i][j][r] + b;
-              if (a.relu & 2) v += *op;          // accumulate into the destination (gradient sums)
-              if (a.relu & 1) v = fmaxf(v, 0.f);
-              if (a.relu & 4) __builtin_nontemporal_store(v, op);   // output larger than the Infinity Cache: stream it
-              else *op = v;
+      for (int r = 0; r < 16; ++r) bias_r[i][r] = 0.f;
+    if (a.bias) {
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bias_r[i][r] = a.bias[min(co_lane + i * 32 + (r & 3) + 8 * (r >> 2), a.Cout - 1)];
+      // land them all here: otherwise the compiler waits for each value at its use, with counts that
+      // include the stores issued meanwhile
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(bias_r[i][r]));
+    }
+    auto store_all = [&](auto acc_mode, auto nt_mode) {
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k = i * 32 + (r & 3) + 8 * (r >> 2);       // compile-time part of the channel
+          if (co_lane + k < a.Cout) {
+            const float b = bias_r[i][r];
+            const size_t o = off_lane + (size_t)k * HW;
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+              if (col_ok[j]) {
+                float* op = pj[j] + o;
+                float v = acc[i][j][r] + b;
+                if (decltype(acc_mode)::value) v += *op;          // accumulate into the destination (gradient sums)
+                if (relu) v = fmaxf(v, 0.f);
+                if (decltype(nt_mode)::value) __builtin_nontemporal_store(v, op);   // output larger than the Infinity Cache: stream it
+                else *op = v;
+              }
             }
           }
-        } else {
+        }
+      }
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    if (a.relu & 2) store_all(T{}, F{});
+    else if (a.relu & 4) store_all(F{}, T{});
+    else store_all(F{}, F{});
+  } else {
+    // deconv 2x2/s2: packed cout = phase * shuffle + oc, stored at (2y+dy, 2x+dx)
+    int sy[WN], sx[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      sy[j] = col_p[j] / W;
+      sx[j] = col_p[j] - sy[j] * W;
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = m0 + (wave_m * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (co < a.Cout) {
           const int phase = co / a.shuffle;
           const int oc = co - phase * a.shuffle;
           const int dy = phase >> 1, dx = phase & 1;
@@ -370,8 +427,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
             if (col_ok[j]) {
               float v = acc[i][j][r] + b;
               if (a.relu & 1) v = fmaxf(v, 0.f);
-              const int y = col_p[j] / W, x = col_p[j] - y * W;
-              a.out[(((size_t)col_n[j] * a.shuffle + oc) * (2 * H) + 2 * y + dy) * (2 * W) + 2 * x + dx] = v;
+              a.out[(((size_t)col_n[j] * a.shuffle + oc) * (2 * H) + 2 * sy[j] + dy) * (2 * W) + 2 * sx[j] + dx] = v;
             }
           }
         }

@@ -261,18 +261,28 @@ __global__ __launch_bounds__(WGM* WGN * 64) void deform_conv_kernel(DcnArgs a) {
     __syncthreads();
   }
 
+  // epilogue with hoisted addresses (one base per pixel column, one per-lane channel offset; see conv_igemm.hip)
+  {
+    float* pj[WN];
 #pragma unroll
-  for (int i = 0; i < WM; ++i) {
+    for (int j = 0; j < WN; ++j) pj[j] = a.out + (size_t)col_n[j] * a.Cout * HW + col_p[j];
+    const int co_lane = m0 + wave_m * WM * 32 + 4 * hi;
+    const size_t off_lane = (size_t)co_lane * HW;
+    const bool relu = a.relu != 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = m0 + (wave_m * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (co < a.Cout) {
+    for (int i = 0; i < WM; ++i) {
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-          if (col_ok[j]) {
-            float v = acc[i][j][r];
-            if (a.relu) v = fmaxf(v, 0.f);
-            a.out[((size_t)col_n[j] * a.Cout + co) * HW + col_p[j]] = v;
+      for (int r = 0; r < 16; ++r) {
+        const int k = i * 32 + (r & 3) + 8 * (r >> 2);
+        if (co_lane + k < a.Cout) {
+          const size_t o = off_lane + (size_t)k * HW;
+#pragma unroll
+          for (int j = 0; j < WN; ++j) {
+            if (col_ok[j]) {
+              float v = acc[i][j][r];
+              if (relu) v = fmaxf(v, 0.f);
+              pj[j][o] = v;
+            }
           }
         }
       }
@@ -505,21 +515,30 @@ __global__ __launch_bounds__(256, 2) void deform_conv_lds_kernel(DcnArgs a) {
     slot ^= 1;
   }
 
+  {
+    float* pj[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j) pj[j] = a.out + (size_t)col_n[j] * a.Cout * HW + col_p[j];
+    const int co_lane = m0 + wave_m * 64 + 4 * hi;
+    const size_t off_lane = (size_t)co_lane * HW;
+    const bool relu = a.relu != 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = m0 + (wave_m * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (co < a.Cout) {
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          if (col_ok[j]) {
-            float v = acc[i][j][r];
-            if (a.relu) v = fmaxf(v, 0.f);
-            a.out[((size_t)col_n[j] * a.Cout + co) * HW + col_p[j]] = v;
-          }
+      for (int r = 0; r < 16; ++r) {
+        const int k = i * 32 + (r & 3) + 8 * (r >> 2);
+        if (co_lane + k < a.Cout) {
+          const size_t o = off_lane + (size_t)k * HW;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            if (col_ok[j]) {
+              float v = acc[i][j][r];
+              if (relu) v = fmaxf(v, 0.f);
+              pj[j][o] = v;
+            }
+        }
       }
-    }
+  }
 }
 
 template <int WGM, int WGN, int WM, int WN>

@@ -93,25 +93,36 @@ __global__ __launch_bounds__(256) void fc_gemm_kernel(FcArgs a) {
           for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
     }
   }
-  // D[row = n][col = m]: lane & 31 = m
+  // D[row = n][col = m]: lane & 31 = m.  Addresses and the two bias values of the lane are hoisted.
+  float* pj[2];
+  float bj[2];
+  bool m_ok[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = m0 + (wave_c * 2 + j) * 32 + l31;
+    m_ok[j] = m < a.M;
+    pj[j] = a.out + m;
+    bj[j] = (split == 0 && a.bias && m_ok[j]) ? a.bias[m] : 0.f;
+  }
+  const int n_lane = n0 + wave_r * 64 + 4 * hi;
+  const size_t off_lane = (size_t)n_lane * a.M;
+  const bool single = a.splits == 1, relu = a.relu != 0;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int n = n0 + (wave_r * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (n < a.N) {
+      const int k = i * 32 + (r & 3) + 8 * (r >> 2);
+      if (n_lane + k < a.N) {
+        const size_t o = off_lane + (size_t)k * a.M;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const int m = m0 + (wave_c * 2 + j) * 32 + l31;
-          if (m < a.M) {
-            float v = acc[i][j][r];
-            if (split == 0 && a.bias) v += a.bias[m];
-            float* o = a.out + (size_t)n * a.M + m;
-            if (a.splits == 1) {
-              if (a.relu) v = fmaxf(v, 0.f);
-              *o = v;
+          if (m_ok[j]) {
+            float v = acc[i][j][r] + bj[j];
+            if (single) {
+              if (relu) v = fmaxf(v, 0.f);
+              pj[j][o] = v;
             } else {
-              atomicAdd(o, v);
+              atomicAdd(pj[j] + o, v);
             }
           }
         }
