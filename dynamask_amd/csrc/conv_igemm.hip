@@ -209,33 +209,48 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
 
   dm_f32x4 ra[A_PER_T];
   dm_f32x4 rb[BREG];
+  unsigned a_off[A_PER_T];          // float offset of A slot i inside a chunk's weights (fixed per thread)
+#pragma unroll
+  for (int i = 0; i < A_PER_T; ++i) {
+    const int idx = tid + i * NT;
+    const int m = idx % TMA, tq = idx / TMA;
+    a_off[i] = (unsigned)((((size_t)(tq / NQ) * a.KQ + tq % NQ) * a.CoutP + m0 + m) * 4);
+  }
+  constexpr int NPOS = (KS == 3) ? MAXPOS : 1;
+  size_t b_off[NPOS];               // float offset of this thread's pixel(s) inside the current source
+  int b_src = -1;
 
   // issue the global loads of the chunk at (cs, cc0, ckq) into registers
   auto prefetch = [&]() {
     const int Cs = a.src_c[cs];
     const int ckv = min(CK, Cs - cc0);
     const int nq = ((ckv + 7) / 8) * 2;    // quads of this chunk present in the packed weights
+    // the chunk's part of an address is uniform (ckq, cc0); the thread's part is fixed for the K loop
+    // (per source for B) and kept in a register: no 64-bit multiplies per load next to the MFMAs
+    const float* abase = a.wq + (size_t)ckq * a.CoutP * 4;
 #pragma unroll
     for (int i = 0; i < A_PER_T; ++i) {
       const int idx = tid + i * NT;
       dm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (idx < A_F4) {
         const int m = idx % TMA;
-        const int tq = idx / TMA;
-        const int qd = tq % NQ;
-        const int tap = tq / NQ;
-        if (qd < nq && m0 + m < a.CoutP)
-          v = *reinterpret_cast<const dm_f32x4*>(a.wq + (((size_t)tap * a.KQ + ckq + qd) * a.CoutP + m0 + m) * 4);
+        const int qd = (idx / TMA) % NQ;
+        if (qd < nq && m0 + m < a.CoutP) v = *reinterpret_cast<const dm_f32x4*>(abase + a_off[i]);
       }
       ra[i] = v;
     }
-    const float* sp = a.src[cs];
-    const size_t bs = (size_t)a.src_bs[cs];
+    if (b_src != cs) {
+      const size_t bs = (size_t)a.src_bs[cs];
+#pragma unroll
+      for (int k = 0; k < NPOS; ++k) b_off[k] = (size_t)max(st_n[k], 0) * bs + st_pix[k];
+      b_src = cs;
+    }
+    const float* sp = a.src[cs] + (size_t)cc0 * HW;
     if (KS == 3) {
 #pragma unroll
       for (int k = 0; k < MAXPOS; ++k) {
         const bool ok = st_n[k] >= 0;
-        const float* gp = sp + (size_t)max(st_n[k], 0) * bs + (size_t)cc0 * HW + st_pix[k];
+        const float* gp = sp + b_off[k];
 #pragma unroll
         for (int qd = 0; qd < NQ; ++qd) {
           dm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -249,7 +264,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
       }
     } else {
       const bool ok = st_n[0] >= 0;
-      const float* gp = sp + (size_t)max(st_n[0], 0) * bs + (size_t)cc0 * HW + st_pix[0];
+      const float* gp = sp + b_off[0];
 #pragma unroll
       for (int i = 0; i < B1_PER_T; ++i) {
         const int qd = tid / TN + i * (NT / TN);
