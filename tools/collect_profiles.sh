@@ -29,4 +29,6 @@ PROBE_ITERS=6 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/traffic_fet
 PROBE_ITERS=6 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/traffic_write -- python3 tools/pmc_probe.py > /dev/null 2>&1
 { python3 tools/pmc_sum.py $out/traffic_fetch; python3 tools/pmc_sum.py $out/traffic_write; } > $out/${tag}_traffic_pmc.txt
 cat $out/${tag}_traffic_pmc.txt
+hipcc --offload-arch=gfx950 -O3 tools/micro/mfma_lds.hip -o $out/mfma_lds && $out/mfma_lds > $out/${tag}_mfma_lds_micro.txt
+python3 tools/small_n.py > $out/${tag}_small_n.txt 2>&1
 echo "all done"
