@@ -4,7 +4,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdynamask_hip.so')
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
