@@ -240,7 +240,11 @@ void launch_wgrad(WgradArgs a, hipStream_t st) {
   a.MT = dm_ceil_div(a.Cout, TM);
   a.JT = dm_ceil_div(J, TN);
   const int chunks = dm_ceil_div(a.Q, 32);
-  int nsplit = max(1, min(chunks, 2048 / max(1, a.MT * a.JT)));
+  // split-K until the launch is one round of workgroups (two per CU): every further split adds an
+  // epilogue of 64 float atomics per lane onto the same addresses (2048 workgroups: 256->256 1x1 at
+  // 14x14 0.140 ms, 512: 0.091 ms; the 2304-row DCN GEMMs 0.63 -> 0.60 ms)
+  static const int target_wgs = getenv("DM_WGRAD_WGS") ? atoi(getenv("DM_WGRAD_WGS")) : 2 * dm_num_cus();
+  int nsplit = max(1, min(chunks, target_wgs / max(1, a.MT * a.JT)));
   a.chunks_per_split = dm_ceil_div(chunks, nsplit);
   a.nsplit = dm_ceil_div(chunks, a.chunks_per_split);
   const dim3 grid((unsigned)(a.MT * a.JT * a.nsplit));
