@@ -30,6 +30,13 @@ struct DcnArgs {
   int MT;
 };
 
+// One bilinear sample from its two row pairs.  Spelled as an explicit fma chain so that every kernel
+// variant rounds the same way (left to the compiler, the two gathers contracted differently and
+// results differed in the last bit depending on which variant a launch size selected).
+__device__ __forceinline__ float dcn_bilinear(float wt0, float wt1, float wb0, float wb1, float ta, float tb, float ba, float bb) {
+  return __builtin_fmaf(wb1, bb, __builtin_fmaf(wb0, ba, __builtin_fmaf(wt1, tb, wt0 * ta)));
+}
+
 template <int WGM, int WGN, int WM, int WN>
 __global__ __launch_bounds__(WGM* WGN * 64) void deform_conv_kernel(DcnArgs a) {
   constexpr int CK = 8;
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void deform_conv_kernel(DcnArgs a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const dm_f32x4 l = raw[t * 4 + e];
-      v[e] = wt0[t] * l[0] + wt1[t] * l[1] + wb0[t] * l[2] + wb1[t] * l[3];
+      v[e] = dcn_bilinear(wt0[t], wt1[t], wb0[t], wb1[t], l[0], l[1], l[2], l[3]);
     }
     return v;
   };
@@ -444,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void deform_conv_lds_kernel(DcnArgs a) {
         const float* pl = xb + e * HW;
         const F2 top = *reinterpret_cast<const F2*>(pl + (otb[tap] & 0xffff));
         const F2 bot = *reinterpret_cast<const F2*>(pl + (otb[tap] >> 16));
-        v[e] = wt0[tap] * top.a + wt1[tap] * top.b + wb0[tap] * bot.a + wb1[tap] * bot.b;
+        v[e] = dcn_bilinear(wt0[tap], wt1[tap], wb0[tap], wb1[tap], top.a, top.b, bot.a, bot.b);
       }
       ldsB[slot * BS_F4 + (u * 2 + gh) * TN + gj] = v;
     }
@@ -581,6 +588,12 @@ extern "C" int dm_deform_conv_fwd(const float* x, const float* offset, int NB, i
   // (a 256-cout tile would gather each sample once but needs > 256 VGPRs: it spills)
   // 4-wave workgroups of 128 x 64: two of them share a CU (the 8-wave 128 x 128 tile needs
   // > 128 VGPRs and runs alone: 1.81 ms vs 1.59 ms at 256 channels)
+  // Launches that leave most of the chip idle (a handful of RoIs: real inference) are bound by the time
+  // of one workgroup; 64 x 64 tiles give four times the workgroups of the 128 x 128 LDS kernel
+  // (14 x 14, 8 RoIs: 0.208 -> 0.108 ms, 32 RoIs: 0.213 -> 0.168 ms; from 64 RoIs on the big tiles win).
+  // Same products in the same order in every variant: results do not depend on the choice.
+  if (Cout > 64 && (long long)dm_ceil_div(a.CoutP, 128) * dm_ceil_div(a.Q, 128) * 20 <= (long long)dm_num_cus() * 9)
+    return launch_dcn<2, 2, 1, 1>(a, st);
   if (Cout > 64 && a.HW >= 128 && a.HW <= 256 && (a.HW & 3) == 0 && (C / deform_groups) % 8 == 0) {
     // small maps (14x14): planes in LDS, 128 x 128 tile
     a.MT = dm_ceil_div(a.CoutP, 128);
@@ -597,6 +610,8 @@ extern "C" int dm_deform_conv_fwd(const float* x, const float* offset, int NB, i
     DM_LAUNCH(deform_conv_lds_kernel, dim3(a.MT * NTiles), dim3(256), lds_bytes, st, a);
     return dm_check_launch();
   }
+  if (Cout > 64 && (long long)dm_ceil_div(a.CoutP, 128) * dm_ceil_div(a.Q, 64) * 20 <= (long long)dm_num_cus() * 9)
+    return launch_dcn<2, 2, 1, 1>(a, st);                 // same rule for the 128 x 64 tiles (28 x 28, 8 RoIs: 0.081 -> 0.056 ms)
   if (Cout > 64) return launch_dcn<2, 2, 2, 1>(a, st);    // 128 couts x 64 px
   if (Cout > 32) return launch_dcn<2, 2, 1, 1>(a, st);    // 64 x 64 (2.57 -> 2.28 ms at 64 channels, 56x56)
   return launch_dcn<1, 4, 1, 1>(a, st);                   // 32 x 128 (4 waves)

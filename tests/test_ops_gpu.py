@@ -195,6 +195,18 @@ def test_deform_conv(ops, N, C, S):
     _close(out0, F.conv2d(x, w, padding=1))
 
 
+def test_deform_conv_rows_do_not_depend_on_launch_size(ops):
+    # few RoIs run on 64 x 64 tiles, many on the 128 x 128 LDS-gather kernel (14 x 14) / 128 x 64 tiles:
+    # the same bits either way (the early-exit path relies on rows being independent of the batch)
+    for C, S in ((256, 14), (128, 28)):
+        x = torch.randn(64, C, S, S, generator=_g(63)).cuda()
+        off = (torch.randn(64, 36, S, S, generator=_g(64)) * 1.5).cuda()
+        wq = ops.pack_conv_weight((torch.randn(C, C, 3, 3, generator=_g(65)) / (9 * C) ** 0.5).cuda())
+        big = ops.deform_conv(x, off, wq, C, 2, relu=True)
+        for n in (3, 16):
+            assert torch.equal(ops.deform_conv(x[:n].contiguous(), off[:n].contiguous(), wq, C, 2, relu=True), big[:n])
+
+
 def test_upsample2x(ops):
     x = torch.randn(5, 7, 14, 14, generator=_g(70))
     _close(ops.upsample2x(_dev(x), align_corners=False, relu=True),
