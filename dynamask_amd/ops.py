@@ -315,7 +315,7 @@ def deform_conv(x, offset, w_packed, cout, deform_groups, relu=False):
     assert w_packed.numel() == packed_floats(cout, 3, [C])
     out = torch.empty((NB, cout, H, W), device=x.device, dtype=torch.float32)
     check(lib().dm_deform_conv_fwd(_p(x), _p(offset), NB, C, H, W, _p(w_packed), cout, deform_groups,
-                                   1 if relu else 0, _p(out), _stream()), 'dm_deform_conv_fwd')
+                                   (1 if relu else 0) | (8 if _overlapped else 0), _p(out), _stream()), 'dm_deform_conv_fwd')
     return out
 
 

@@ -136,6 +136,7 @@ int dm_class_logits_fwd(const float* x, int N, int C, int HW, const float* w_ins
  *           mmdet/ops/dcn/src/deform_conv_cuda.cpp:152-260.
  * x [NB, C, H, W]; offset [NB, deform_groups*18, H, W] (dh,dw interleaved per tap);
  * w_packed: dm_conv_pack_weight(ksize=3, one source) of the [Cout, C, 3, 3] weight; out [NB, Cout, H, W]
+ * relu: bit 0 fused ReLU; bit 3 the same scheduling hint as in dm_conv2d_fwd
  * ------------------------------------------------------------------------- */
 int dm_deform_conv_fwd(const float* x, const float* offset, int NB, int C, int H, int W,
                        const float* w_packed, int Cout, int deform_groups, int relu, float* out,
