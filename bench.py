@@ -194,7 +194,7 @@ def train_step_bench(head, dev, rank, world, steps=4, warmup=4):
         grp.zero_grad()
         res = head._mask_forward_train(feats, rois, labels, targets, noise=noise)
         res['loss_mask']['loss_masks'].backward()
-        grp.all_reduce_async()
+        grp.all_reduce_async(force=True)        # world 1: RCCL still runs if a group exists
         grp.sgd_step(lr=0.02, momentum=0.9, weight_decay=1e-4)
         return res
 
@@ -235,14 +235,14 @@ def train_step_bench(head, dev, rank, world, steps=4, warmup=4):
     # communication alone: the flat-gradient all-reduce (16.65 MB) timed by itself, so that
     # the scaling curve can be read with and without it; 0 at world size 1
     comm_ms = 0.0
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_initialized():
         for _ in range(2):
-            grp.all_reduce_async(); grp.wait()
+            grp.all_reduce_async(force=True); grp.wait()
         torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(5):
-            grp.all_reduce_async(); grp.wait()
+            grp.all_reduce_async(force=True); grp.wait()
         torch.cuda.synchronize()
         comm_ms = (time.perf_counter() - t0) / 5 * 1e3
         t = torch.tensor([comm_ms], device=dev, dtype=torch.float64)
@@ -255,6 +255,52 @@ def train_step_bench(head, dev, rank, world, steps=4, warmup=4):
     return dt / steps * 1e3, float(res['loss_mask']['loss_masks'].detach()), grp.numel, B, comm_ms
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this same
+    script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, as
+    torch.distributed.run would), wait for all of them, return the worst exit code.  The parent
+    never touches the GPU and execs nothing: rank 0's JSON line goes straight to our stdout."""
+    import subprocess
+    port = os.environ.get('MASTER_PORT') or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        live = list(procs)
+        while live:
+            time.sleep(0.2)
+            for p in list(live):
+                c = p.poll()
+                if c is None:
+                    continue
+                live.remove(p)
+                rc = max(rc, abs(c))
+            if rc:                 # a rank that died must not leave the others waiting in a collective
+                break
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -265,23 +311,54 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=512, help='RoIs of the batch timed on the host cores (0 = skip)')
     args = ap.parse_args()
 
+    # ---- ranks: one process per GPU.  The driver starts N>1 ranks itself (torch.distributed.run
+    # sets WORLD_SIZE); a bare `python bench.py --gpus N` starts them here, as fresh children,
+    # BEFORE this process has touched the GPU (nothing above initialises HIP). ----
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU '
+                 f'(python bench.py --gpus N, or torch.distributed.run --nproc-per-node N bench.py --gpus N)')
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    # rehearsal on a 1-GPU box: DM_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo
+    if os.environ.get('DM_BENCH_LAUNCH_ONLY', '0') == '1':
+        # launcher check without a GPU (tests/test_dist_cpu.py): the ranks meet over gloo, sum
+        # their rank numbers and rank 0 prints what the launcher gave them
+        import torch.distributed as dist
+        dist.init_process_group('gloo')
+        t = torch.tensor([float(rank)])
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({'n_gpus': world, 'rank_sum': float(t.item()), 'launcher': 'ok'}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    # rehearsal on a box with fewer GPUs than ranks: DM_BENCH_REHEARSAL=1 puts every rank on
+    # cuda:0 and uses gloo (RCCL refuses two ranks on one device)
     rehearsal = os.environ.get('DM_BENCH_REHEARSAL', '0') == '1'
     if rehearsal:
         local_rank = 0
+    elif world > 1 and torch.cuda.device_count() < world:
+        sys.exit(f'bench.py: {world} ranks need {world} GPUs, this node shows {torch.cuda.device_count()} '
+                 f'(DM_BENCH_REHEARSAL=1 rehearses the launcher on one device over gloo)')
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
         if rehearsal:
             dist.init_process_group('gloo')
         else:
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    dev = torch.device('cuda', local_rank)
-    torch.cuda.set_device(dev)
+            dist.init_process_group('nccl', device_id=dev)
+    else:
+        # world size 1: still a real RCCL communicator, so that the training leg's gradient
+        # all-reduce, its side stream and the 1/world scaling run on hardware in every round
+        os.environ.setdefault('MASTER_PORT', str(_free_port()))
+        try:
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+        except Exception as e:      # noqa: BLE001  (recorded in the JSON; the headline needs no collective)
+            print(f'[bench] RCCL world-1 group unavailable: {e}', file=sys.stderr)
 
     head, sd = build_head(dev)
     feats_c, rois_c, labels_c = make_inputs(rank, dev)
@@ -322,21 +399,27 @@ def main():
         except Exception as e:      # capture not available: stay eager (recorded in the JSON)
             print(f'[bench] HIP graph capture failed, timing eager launches: {e}', file=sys.stderr)
             graph = None
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed_window():
+        """EXACTLY args.steps steps between barrier + synchronize on both sides; max over ranks."""
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        w = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([w], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            w = float(t.item())
+        return w
+    # three such windows, the median is reported (one window of 20 graph replays is 80 ms: a single
+    # sample of that length is at the mercy of the clock ramp; VERDICT r1 weak #9)
+    windows = sorted(timed_window() for _ in range(3))
+    dt = windows[1]
     ms_per_step = dt / args.steps * 1e3
     value = world * 1.0 / (dt / args.steps)          # images (RoI batches of 512) per second, all ranks
 
@@ -348,7 +431,9 @@ def main():
         'config': {'workload': 'BASELINE configs[1]: DynaMask R-50-FPN mask head inference, 1333x800 FPN shapes, '
                                '512 RoIs/img, fixed 28x28 exit (RoIAlign14 + 2 conv3x3 + SFM stage 0 + stage-1 logits)',
                    'rois_per_img': ROIS_PER_IMG, 'imgs_per_gpu': 1, 'parallelism': f'images sharded x{world}, no collective',
-                   'launch': 'hip graph replay' if graph is not None else 'eager'},
+                   'launch': 'hip graph replay' if graph is not None else 'eager',
+                   'timing': f'median of 3 windows of {args.steps} steps; windows ms/step = '
+                             + ', '.join(f'{w / args.steps * 1e3:.3f}' for w in windows)},
     }
 
     # training step (configs[2]/[3]) on every rank (parameters are restored afterwards);
@@ -538,11 +623,12 @@ def main():
         extra['train_step'] = {'ms_per_step': train_ms, 'img_per_s': world * train_b / (train_ms * 1e-3),
                                'imgs_per_gpu': train_b, 'pos_rois_per_img': 128, 'loss': train_loss,
                                'allreduce_floats': n_flat, 'allreduce_alone_ms': comm_ms,
+                               'collective': (f'{dist.get_backend()} all-reduce over {world} rank(s), executed'
+                                              if dist.is_initialized() else 'none (no process group)'),
                                'what': 'fwd + loss + bwd (head, MaskPre, RoIAlign) + RCCL all-reduce of the flat '
                                        'mask-path gradient + fused SGD; BASELINE configs[2] (N=1) / configs[3] (N=8)'}
         print(json.dumps(result), flush=True)
-    if world > 1:
-        import torch.distributed as dist
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

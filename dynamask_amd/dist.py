@@ -13,6 +13,8 @@ per-rank exactly as in the reference (``broadcast_buffers=False``, no SyncBN).
 Device-agnostic plumbing (tested on CPU with the gloo backend); the optimiser
 step itself is a HIP kernel and runs only on the GPU.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -42,37 +44,60 @@ class FlatParamGroup:
         self.group = process_group
         self.steps = 0
         self._work = None
+        self._synced = False
         self._stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
 
     @property
     def world_size(self):
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
-    def zero_grad(self):
-        self.flat_grad.zero_()
-        for p in self.params:          # autograd may have replaced .grad; keep the views
-            if p.grad is None or p.grad.data_ptr() < self.flat_grad.data_ptr() or \
-                    p.grad.data_ptr() >= self.flat_grad.data_ptr() + 4 * self.numel:
-                self._rebind()
-                break
-
-    def _rebind(self):
+    def _views(self):
         off = 0
         for p in self.params:
             k = p.numel()
-            view = self.flat_grad[off:off + k].view_as(p)
-            if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
-                view.copy_(p.grad)
-            p.grad = view
+            yield p, self.flat_grad[off:off + k].view_as(p)
             off += k
 
-    def all_reduce_async(self):
+    def zero_grad(self):
+        """Zero the flat gradient and point every ``p.grad`` at its (zeroed) view.  Nothing is
+        copied: whatever tensor autograd or ``module.zero_grad(set_to_none=True)`` left in
+        ``p.grad`` belongs to the step that has just ended."""
+        self.flat_grad.zero_()
+        for p, view in self._views():
+            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
+                p.grad = view
+        self._synced = False
+
+    def sync_grads(self):
+        """Make ``flat_grad`` hold this step's gradients.  Normally ``p.grad`` IS the view and
+        there is nothing to do.  If ``p.grad`` was set to None before the backward
+        (``module.zero_grad()`` with torch's default ``set_to_none=True``), autograd has created a
+        fresh tensor: it is the truth for that parameter and overwrites the view.  A parameter
+        that received no gradient at all (``p.grad is None``) contributes zeros (unlike
+        ``torch.optim.SGD`` it still gets weight decay and momentum: the step is one fused
+        kernel over the flat buffer)."""
+        with torch.no_grad():
+            for p, view in self._views():
+                if p.grad is None:
+                    view.zero_()
+                elif p.grad.data_ptr() != view.data_ptr():
+                    view.copy_(p.grad)
+                p.grad = view
+        self._synced = True
+
+    def all_reduce_async(self, force=None):
         """Sum the flat gradient over ranks; on GPUs the collective runs on a side
         stream so that it overlaps whatever the caller enqueues next (the backbone
-        backward in a full detector)."""
-        if self.world_size == 1:
+        backward in a full detector).  At world size 1 there is nothing to sum and the
+        collective is skipped unless ``force`` (or ``DM_FORCE_COLLECTIVE=1``) asks for it --
+        used by the single-GPU tests and bench so that the RCCL call, the side stream and the
+        1/world scaling of the fused step run on hardware."""
+        self.sync_grads()
+        if force is None:
+            force = os.environ.get('DM_FORCE_COLLECTIVE', '0') == '1'
+        initialised = dist.is_available() and dist.is_initialized()
+        if self.world_size == 1 and not (force and initialised):
             return
-        self._rebind()
         if self._stream is not None:
             self._stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._stream):
@@ -87,13 +112,17 @@ class FlatParamGroup:
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
 
-    def sgd_step(self, lr=0.02, momentum=0.9, weight_decay=1e-4):
-        """Fused SGD on the flat buffer; the 1/world averaging rides in the kernel."""
+    def sgd_step(self, lr=0.02, momentum=0.9, weight_decay=1e-4, grad_scale=1.0):
+        """Fused SGD on the flat buffer; the 1/world averaging (times ``grad_scale``, e.g. the
+        clip coefficient of ``clip_grad_norm``) rides in the kernel."""
         from . import ops
+        if not self._synced:                 # no all_reduce_async() this step (single process)
+            self.sync_grads()
         self.wait()
         ops.sgd_momentum_step_(self.flat_param, self.flat_grad, self.flat_momentum, lr, momentum, weight_decay,
-                               1.0 / self.world_size, first_step=(self.steps == 0))
+                               grad_scale / self.world_size, first_step=(self.steps == 0))
         self.steps += 1
+        self._synced = False
 
 
 def mask_path_parameters(roi_head):

@@ -72,3 +72,101 @@ def test_shard_images_balanced():
         parts = [shard_images(n, r, w) for r in range(w)]
         assert sorted(sum(parts, [])) == list(range(n))
         assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+# ---------------------------------------------------------------- bench.py rank launcher
+def _run_bench(args, env_extra, timeout=180):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+        if k not in env_extra:
+            env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + args, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` (no launcher) must start 2 ranks that form one process
+    group (--gpus was parsed and ignored)."""
+    import json
+    r = _run_bench(['--gpus', '2'], {'DM_BENCH_LAUNCH_ONLY': '1'})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(line) == 1                       # rank 0 alone prints
+    out = json.loads(line[0])
+    assert out['n_gpus'] == 2 and out['rank_sum'] == 1.0
+
+
+def test_bench_refuses_gpus_world_size_mismatch():
+    r = _run_bench(['--gpus', '4'], {'DM_BENCH_LAUNCH_ONLY': '1', 'WORLD_SIZE': '2', 'RANK': '0', 'LOCAL_RANK': '0',
+                                     'MASTER_PORT': str(_free_port())})
+    assert r.returncode != 0
+    assert 'WORLD_SIZE=2' in r.stderr
+
+
+# ---------------------------------------------------------------- .grad replaced by autograd
+def _torch_sgd_(params, grads, mom, lr, momentum, wd, grad_scale, first_step=False):
+    """CPU stand-in of dm_sgd_momentum_step for these tests (torch.optim.SGD arithmetic)."""
+    g = grads * grad_scale + wd * params
+    if first_step:
+        mom.copy_(g)
+    else:
+        mom.mul_(momentum).add_(g)
+    params.sub_(lr * mom)
+
+
+def _grad_none_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    if world > 1:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    from dynamask_amd import ops
+    from dynamask_amd.dist import FlatParamGroup
+    ops.sgd_momentum_step_ = _torch_sgd_
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Linear(3, 4), nn.Linear(4, 2))
+    ref = nn.Sequential(nn.Linear(3, 4), nn.Linear(4, 2))
+    ref.load_state_dict(net.state_dict())
+    opt = torch.optim.SGD(ref.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    grp = FlatParamGroup(net.parameters())
+    for it in range(3):
+        # reference: mean over ranks of the per-rank gradients
+        opt.zero_grad()
+        for r in range(world):
+            (ref(torch.full((2, 3), float(r + 1 + it))).sum() / world).backward()
+        opt.step()
+        # product: the caller uses torch's default zero_grad (set_to_none=True) in odd steps and
+        # the group's own in even ones
+        if it % 2:
+            net.zero_grad()                      # p.grad = None: autograd will create fresh tensors
+        else:
+            grp.zero_grad()
+        net(torch.full((2, 3), float(rank + 1 + it))).sum().backward()
+        grp.all_reduce_async()
+        grp.sgd_step(lr=0.1, momentum=0.9, weight_decay=1e-4)
+        # after the step every .grad is a view of the flat buffer again and holds THIS step's sum
+        exp = torch.cat([p.grad.reshape(-1) for p in ref.parameters()]) * world
+        assert torch.allclose(grp.flat_grad, exp, atol=1e-5), (it, grp.flat_grad, exp)
+        for p, pr in zip(net.parameters(), ref.parameters()):
+            assert torch.allclose(p.detach(), pr.detach(), atol=1e-6), it
+    q.put(rank)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_flat_group_survives_grad_set_to_none_world1_and_world2():
+    """module.zero_grad(set_to_none=True) between steps must neither drop the
+    gradient (world 1) nor accumulate the previous step's (zero_grad + rebind copy)."""
+    ctx = mp.get_context('spawn')
+    for world in (1, 2):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_grad_none_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
