@@ -316,6 +316,12 @@ def main():
     # BEFORE this process has touched the GPU (nothing above initialises HIP). ----
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus))
+    # stdout carries exactly ONE line, the JSON: libraries that print banners from C (RCCL's
+    # version block at communicator creation) are sent to stderr by pointing fd 1 there; the
+    # result line is written to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
         sys.exit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU '
@@ -330,7 +336,7 @@ def main():
         t = torch.tensor([float(rank)])
         dist.all_reduce(t)
         if rank == 0:
-            print(json.dumps({'n_gpus': world, 'rank_sum': float(t.item()), 'launcher': 'ok'}), flush=True)
+            os.write(json_fd, (json.dumps({'n_gpus': world, 'rank_sum': float(t.item()), 'launcher': 'ok'}) + '\n').encode())
         dist.barrier()
         dist.destroy_process_group()
         return
@@ -355,10 +361,11 @@ def main():
         # world size 1: still a real RCCL communicator, so that the training leg's gradient
         # all-reduce, its side stream and the 1/world scaling run on hardware in every round
         os.environ.setdefault('MASTER_PORT', str(_free_port()))
-        try:
-            dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
-        except Exception as e:      # noqa: BLE001  (recorded in the JSON; the headline needs no collective)
-            print(f'[bench] RCCL world-1 group unavailable: {e}', file=sys.stderr)
+        if os.environ.get('DM_BENCH_NO_RCCL', '0') != '1':
+            try:
+                dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+            except Exception as e:      # noqa: BLE001  (recorded in the JSON; the headline needs no collective)
+                print(f'[bench] RCCL world-1 group unavailable: {e}', file=sys.stderr)
 
     head, sd = build_head(dev)
     feats_c, rois_c, labels_c = make_inputs(rank, dev)
@@ -627,7 +634,7 @@ def main():
                                               if dist.is_initialized() else 'none (no process group)'),
                                'what': 'fwd + loss + bwd (head, MaskPre, RoIAlign) + RCCL all-reduce of the flat '
                                        'mask-path gradient + fused SGD; BASELINE configs[2] (N=1) / configs[3] (N=8)'}
-        print(json.dumps(result), flush=True)
+        os.write(json_fd, (json.dumps(result) + '\n').encode())
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
