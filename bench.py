@@ -100,7 +100,9 @@ def time_kernel_graphed(fn, reps=20, iters=5, warmup=2):
         with torch.cuda.graph(g):
             for _ in range(reps):
                 fn()
-        return time_kernel(g.replay, iters=iters, warmup=warmup) / reps
+        # median over individually timed replays: one disturbed replay (seen once: 4x) must not
+        # set the figure
+        return time_kernel_median(g.replay, iters=max(iters, 7), warmup=warmup) / reps
     except Exception as e:      # noqa: BLE001
         print(f'[bench] graph capture failed ({e}); eager kernel timing', file=sys.stderr)
         return time_kernel(fn)
@@ -454,7 +456,8 @@ def main():
         x = torch.randn(ROIS_PER_IMG, 256, 14, 14, device=dev)
         conv = head.mask_head.instance_convs[0].conv
         wp, b = conv.packed([256]), conv.bias.detach()
-        ms = time_kernel(lambda: ops.conv2d(x, wp, b, 256, 3, relu=True))
+        conv_call = lambda: ops.conv2d(x, wp, b, 256, 3, relu=True)      # noqa: E731
+        ms = sorted(time_kernel(conv_call, iters=10, warmup=2) for _ in range(5))[2]     # median of 5 x 10 calls
         flops = 2.0 * ROIS_PER_IMG * 196 * 256 * 256 * 9
         ach = flops / (ms * 1e-3) / 1e12
         result['roofline'] = {'kernel': 'conv_igemm_kernel<3,2,2,2,2,8> + its <3,4,1,1,1,8> last-round launch (conv3x3 256->256 '
