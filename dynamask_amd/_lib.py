@@ -4,7 +4,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdynamask_hip.so')
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -58,6 +58,14 @@ SIGNATURES = {
     'dm_threshold_ge': ([_vp, ctypes.c_longlong, _c_float, _vp, _vp], _c_int),
     'dm_paste_masks': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _vp, _vp], _c_int),
     'dm_detail_target': ([_vp, _c_int, _c_int, _c_float, _c_float, _vp, _vp], _c_int),
+    'dm_bbox_overlaps': ([_vp, _c_int, _vp, _c_int, _c_int, _c_float, _vp, _vp], _c_int),
+    'dm_max_iou_assign': ([_vp, _c_int, _c_int, _c_float, _c_float, _c_float, _c_float, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp], _c_int),
+    'dm_bbox_encode': ([_vp, _vp, _c_int, _vp, _vp, _vp, _vp], _c_int),
+    'dm_softmax_ce_fwd_bwd': ([_vp, _vp, _vp, _c_int, _c_int, _c_float, _vp, _vp, _vp, _vp, _vp], _c_int),
+    'dm_l1_loss_fwd_bwd': ([_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_float, _vp, _vp, _vp, _vp], _c_int),
+    'dm_sumsq_scratch_floats': ([], ctypes.c_longlong),
+    'dm_sumsq': ([_vp, ctypes.c_longlong, _vp, _vp, _vp], _c_int),
+    'dm_clip_scale': ([_vp, ctypes.c_longlong, _vp, _c_float, _vp], _c_int),
     'dm_mask_loss_fwd_bwd': ([_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp], _c_int),
 }
 

@@ -6,7 +6,10 @@
 The 7x7 RoI extraction is the same HIP kernel as the mask branch's; softmax + box decoding and
 the NMS suppression matrix are HIP kernels (``dm_bbox_decode``, ``dm_nms_mask``); the four fully
 connected layers run on ``dm_fc_fwd`` (fp32 MFMA GEMM with split-K over the long 12544 axis).
-Training losses of the bbox branch are not built."""
+Training (second half): ``get_targets`` (bbox2delta = ``dm_bbox_encode``),
+``loss`` (softmax CE + accuracy = ``dm_softmax_ce_fwd_bwd``, L1 on the positive rows' class
+columns = ``dm_l1_loss_fwd_bwd``) and the backward of the FC stack (``BBoxHeadFn``: data and
+weight gradients as fp32-MFMA GEMMs through the implicit-GEMM kernels on [N, C, 1, 1] tensors)."""
 import numpy as np
 import torch
 import torch.nn as nn
@@ -23,7 +26,7 @@ def build_bbox_coder(cfg, **default_args):
 
 @BBOX_CODERS.register_module()
 class DeltaXYWHBBoxCoder:
-    """core/bbox/coder/delta_xywh_bbox_coder.py:9-60 (decode only; encode belongs to training)."""
+    """core/bbox/coder/delta_xywh_bbox_coder.py:9-60."""
 
     def __init__(self, target_means=(0., 0., 0., 0.), target_stds=(1., 1., 1., 1.)):
         self.means = tuple(target_means)
@@ -37,7 +40,10 @@ class DeltaXYWHBBoxCoder:
         return out
 
     def encode(self, bboxes, gt_bboxes):
-        raise NotImplementedError('bbox targets belong to the training of the bbox branch (not built)')
+        """delta_xywh_bbox_coder.py:33-50 -> bbox2delta."""
+        assert bboxes.size(0) == gt_bboxes.size(0)
+        assert bboxes.size(-1) == gt_bboxes.size(-1) == 4
+        return ops.bbox_encode(bboxes.float().contiguous(), gt_bboxes.float().contiguous(), self.means, self.stds)
 
 
 class _FC(nn.Module):
@@ -49,6 +55,8 @@ class _FC(nn.Module):
         self.weight = nn.Parameter(torch.empty(cout, cin))
         self.bias = nn.Parameter(torch.zeros(cout))
         nn.init.xavier_uniform_(self.weight)
+        from .mask_heads import _Packed
+        self._pk = _Packed()      # transposed packed weights of the backward's data-gradient GEMM
 
     def run(self, x, relu=False):
         return ops.fc(x.contiguous(), self.weight.detach(), self.bias.detach(), relu=relu)
@@ -74,7 +82,14 @@ class Shared2FCBBoxHead(nn.Module):
         self.reg_class_agnostic = reg_class_agnostic
         self.fc_out_channels = fc_out_channels
         self.bbox_coder = build_bbox_coder(bbox_coder)
+        self.reg_decoded_bbox = reg_decoded_bbox
+        if reg_decoded_bbox:
+            raise NotImplementedError('reg_decoded_bbox=False in configs/dynamask')
         self.loss_cls_cfg, self.loss_bbox_cfg = loss_cls, loss_bbox
+        # bbox_head.py:47-48 (no parameters; built when configured so that inference-only configs stay light)
+        from .registry import build_loss
+        self.loss_cls = build_loss(loss_cls) if loss_cls is not None else None
+        self.loss_bbox = build_loss(loss_bbox) if loss_bbox is not None else None
         self.shared_fcs = nn.ModuleList([_FC(in_channels * self.roi_feat_area, fc_out_channels),
                                          _FC(fc_out_channels, fc_out_channels)])
         self.fc_cls = _FC(fc_out_channels, num_classes + 1)
@@ -92,10 +107,62 @@ class Shared2FCBBoxHead(nn.Module):
 
     def forward(self, x):
         """convfc_bbox_head.py:138-186 for the Shared2FC configuration."""
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return BBoxHeadFn.apply(self, x, *list(self.parameters()))
         x = x.flatten(1)
         for fc in self.shared_fcs:
             x = fc.run(x, relu=True)
         return self.fc_cls.run(x), self.fc_reg.run(x)
+
+    # ------------------------------------------------------------------ training
+    def _get_target_single(self, pos_bboxes, neg_bboxes, pos_gt_bboxes, pos_gt_labels, cfg):
+        """bbox_head.py:85-116."""
+        num_pos, num_neg = pos_bboxes.size(0), neg_bboxes.size(0)
+        num_samples = num_pos + num_neg
+        labels = pos_bboxes.new_full((num_samples,), self.num_classes, dtype=torch.long)
+        label_weights = pos_bboxes.new_zeros(num_samples)
+        bbox_targets = pos_bboxes.new_zeros(num_samples, 4)
+        bbox_weights = pos_bboxes.new_zeros(num_samples, 4)
+        if num_pos > 0:
+            labels[:num_pos] = pos_gt_labels
+            pos_weight = 1.0 if cfg.pos_weight <= 0 else cfg.pos_weight
+            label_weights[:num_pos] = pos_weight
+            bbox_targets[:num_pos, :] = self.bbox_coder.encode(pos_bboxes, pos_gt_bboxes)
+            bbox_weights[:num_pos, :] = 1
+        if num_neg > 0:
+            label_weights[-num_neg:] = 1.0
+        return labels, label_weights, bbox_targets, bbox_weights
+
+    def get_targets(self, sampling_results, gt_bboxes, gt_labels, rcnn_train_cfg, concat=True):
+        """bbox_head.py:118-141."""
+        outs = [self._get_target_single(r.pos_bboxes, r.neg_bboxes, r.pos_gt_bboxes, r.pos_gt_labels, rcnn_train_cfg)
+                for r in sampling_results]
+        labels, label_weights, bbox_targets, bbox_weights = (list(t) for t in zip(*outs))
+        if concat:
+            labels = torch.cat(labels, 0)
+            label_weights = torch.cat(label_weights, 0)
+            bbox_targets = torch.cat(bbox_targets, 0)
+            bbox_weights = torch.cat(bbox_weights, 0)
+        return labels, label_weights, bbox_targets, bbox_weights
+
+    def loss(self, cls_score, bbox_pred, rois, labels, label_weights, bbox_targets, bbox_weights, reduction_override=None):
+        """bbox_head.py:143-184 -> {'loss_cls', 'acc', 'loss_bbox'}."""
+        from .losses import accuracy
+        losses = dict()
+        if cls_score is not None:
+            avg_factor = max(torch.sum(label_weights > 0).float().item(), 1.)
+            if cls_score.numel() > 0:
+                losses['loss_cls'] = self.loss_cls(cls_score, labels, label_weights, avg_factor=avg_factor,
+                                                   reduction_override=reduction_override)
+                losses['acc'] = accuracy(cls_score, labels)
+        if bbox_pred is not None:
+            # the reference gathers bbox_pred[pos, labels[pos]] and calls loss_bbox on the gathered rows
+            # (avg_factor = number of samples); rows with a background label contribute nothing, and
+            # with no positive row the loss is `bbox_pred.sum() * 0`: both are what the fused kernel gives
+            losses['loss_bbox'] = self.loss_bbox.forward_pos(bbox_pred, labels, bbox_targets, bbox_weights,
+                                                             self.num_classes, avg_factor=bbox_targets.size(0),
+                                                             reduction_override=reduction_override)
+        return losses
 
     def get_bboxes(self, rois, cls_score, bbox_pred, img_shape, scale_factor, rescale=False, cfg=None):
         """bbox_head.py:186-223."""
@@ -118,8 +185,60 @@ class Shared2FCBBoxHead(nn.Module):
             return bboxes, scores
         return multiclass_nms(bboxes, scores, cfg.score_thr, cfg.nms, cfg.max_per_img)
 
-    def loss(self, *args, **kwargs):
-        raise NotImplementedError('the training losses of the bbox branch are not built (SURVEY 8f rank 4: inference)')
+
+
+class BBoxHeadFn(torch.autograd.Function):
+    """Shared2FCBBoxHead.forward with a hand-sequenced backward.  Inputs: (head, bbox_feats
+    [N, C, 7, 7], *head.parameters()); outputs (cls_score, bbox_pred).  nn.Linear's three
+    products -- y = x W^T, dx = dy W, dW = dy^T x -- are the forward FC kernel and, for the
+    gradients, the implicit-GEMM conv kernels on [N, C, 1, 1] tensors (one "pixel" per sample)."""
+
+    @staticmethod
+    def forward(ctx, head, x, *params):
+        n = x.shape[0]
+        flat = x.detach().reshape(n, -1).contiguous()
+        acts = [flat]
+        for fc in head.shared_fcs:
+            acts.append(fc.run(acts[-1], relu=True))
+        cls_score, bbox_pred = head.fc_cls.run(acts[-1]), head.fc_reg.run(acts[-1])
+        ctx.head, ctx.acts, ctx.x_shape, ctx.need_x = head, acts, tuple(x.shape), x.requires_grad
+        return cls_score, bbox_pred
+
+    @staticmethod
+    def backward(ctx, g_cls, g_reg):
+        head, acts = ctx.head, ctx.acts
+        n = acts[0].shape[0]
+        pg = {}
+
+        def fc_bwd(fc, gy, xin, need_data=True, out=None, accumulate=False):
+            gy4 = gy.contiguous().view(n, fc.out_features, 1, 1)
+            x4 = xin.view(n, fc.in_features, 1, 1)
+            pg[fc.weight] = ops.conv2d_wgrad(gy4, x4, 1).view(fc.out_features, fc.in_features)
+            pg[fc.bias] = ops.channel_sum(gy4)
+            if not need_data:
+                return None
+            wq = fc._pk.get('flip', fc.weight, lambda t: ops.pack_conv_weight(
+                t.view(fc.out_features, fc.in_features, 1, 1), transpose_flip=True))
+            return ops.conv2d(gy4, wq, None, fc.in_features, 1, out=out, accumulate=accumulate)
+
+        h = acts[-1]
+        g_h = None
+        for fc, g in ((head.fc_cls, g_cls), (head.fc_reg, g_reg)):
+            if g is None:
+                continue
+            if g_h is None:
+                g_h = fc_bwd(fc, g, h)
+            else:
+                fc_bwd(fc, g, h, out=g_h, accumulate=True)
+        g_x = None
+        if g_h is not None:
+            for i in reversed(range(len(head.shared_fcs))):
+                ops.relu_backward_(g_h, acts[i + 1].view_as(g_h))
+                need = i > 0 or ctx.need_x
+                g_h = fc_bwd(head.shared_fcs[i], g_h, acts[i], need_data=need)
+            if ctx.need_x:
+                g_x = g_h.reshape(ctx.x_shape)
+        return (None, g_x, *[pg.get(p) for p in head.parameters()])
 
 
 def batched_nms(boxes, scores, idxs, nms_cfg, class_agnostic=False):

@@ -112,6 +112,32 @@ class FlatParamGroup:
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
 
+    def grad_sumsq(self):
+        """Sum of squares of the (reduced) flat gradient as a device scalar: this group's share of
+        the model-wide norm of ``clip_grad_norm_``."""
+        from . import ops
+        if not self._synced:
+            self.sync_grads()
+        self.wait()
+        return ops.sumsq(self.flat_grad)
+
+    def clip_grad_norm_(self, max_norm, other_sumsq=None):
+        """``optimizer_config = dict(grad_clip=dict(max_norm=35, norm_type=2))``
+        (configs/dynamask/coco/r50-dynamask-1x.py:274 -> OptimizerHook.clip_grads ->
+        ``clip_grad_norm_``): scale the flat gradient by min(1, max_norm / (||g|| + 1e-6)).  The
+        norm is taken over this group plus ``other_sumsq`` (device scalar: the squared norm of the
+        detector's remaining parameters, which the caller owns).  After the all-reduce the buffer
+        holds the SUM over ranks, so the mean's norm is ||sum|| / world.  No host sync.
+        Returns the total squared norm (of the mean gradient), device scalar."""
+        from . import ops
+        ss = self.grad_sumsq()
+        w = float(self.world_size)
+        total = ss / (w * w) if w != 1.0 else ss
+        if other_sumsq is not None:
+            total = total + other_sumsq
+        ops.clip_scale_(self.flat_grad, total.reshape(1).contiguous(), max_norm)
+        return total
+
     def sgd_step(self, lr=0.02, momentum=0.9, weight_decay=1e-4, grad_scale=1.0):
         """Fused SGD on the flat buffer; the 1/world averaging (times ``grad_scale``, e.g. the
         clip coefficient of ``clip_grad_norm``) rides in the kernel."""

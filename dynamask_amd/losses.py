@@ -113,15 +113,110 @@ class DynaCrossEntropyLoss(nn.Module):
         return {'loss_masks': loss}
 
 
+class _SoftmaxCEFn(torch.autograd.Function):
+    """cross_entropy (cross_entropy_loss.py:9-38): fused forward + gradient (dm_softmax_ce_fwd_bwd)."""
+
+    @staticmethod
+    def forward(ctx, cls_score, label, weight, scale):
+        loss, _, grad = ops.softmax_ce(cls_score.detach().contiguous(), label.long().contiguous(),
+                                       None if weight is None else weight.float().contiguous(), scale, need_grad=True)
+        ctx.save_for_backward(grad)
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None
+
+
+class _L1PosFn(torch.autograd.Function):
+    """L1 loss over the positive rows' class columns of ``bbox_pred`` (bbox_head.py:159-182 +
+    smooth_l1_loss.py:29-42): gather, |.|, weights, reduction and scatter of the gradient in one
+    kernel (dm_l1_loss_fwd_bwd)."""
+
+    @staticmethod
+    def forward(ctx, bbox_pred, labels, targets, weights, num_classes, scale):
+        loss, grad = ops.l1_loss_pos(bbox_pred.detach().contiguous(), labels.long().contiguous(), targets.contiguous(),
+                                     weights.contiguous(), num_classes, scale, need_grad=True)
+        ctx.save_for_backward(grad)
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None, None, None
+
+
+def accuracy(pred, target, topk=1, thresh=None):
+    """losses/accuracy.py:4-49 for top-1 without threshold -> percent, device scalar."""
+    if topk != 1 or thresh is not None:
+        raise NotImplementedError('BBoxHead.loss asks for plain top-1 accuracy')
+    if pred.size(0) == 0:
+        return pred.new_tensor(0.)
+    _, acc, _ = ops.softmax_ce(pred.detach().contiguous(), target.long().contiguous(), None, 1.0, need_grad=False)
+    return acc.reshape(1)
+
+
 @LOSSES.register_module()
 class CrossEntropyLoss(nn.Module):
-    """Accepted so that stock FCNMaskHead configs build; the fork's
-    ``use_mask=True`` loss path raises in the reference itself (Quirk Q5)."""
+    """losses/cross_entropy_loss.py:157-216.  The softmax form (``use_sigmoid=False,
+    use_mask=False``: the bbox head's ``loss_cls``) is built; the fork's ``use_mask=True``
+    path raises in the reference itself (Quirk Q5) and ``use_sigmoid=True`` belongs to the RPN."""
 
     def __init__(self, use_sigmoid=False, use_mask=False, reduction='mean', class_weight=None, loss_weight=1.0):
         super().__init__()
-        self.use_sigmoid, self.use_mask, self.loss_weight = use_sigmoid, use_mask, loss_weight
+        assert (use_sigmoid is False) or (use_mask is False)
+        self.use_sigmoid, self.use_mask = use_sigmoid, use_mask
+        self.reduction, self.class_weight, self.loss_weight = reduction, class_weight, loss_weight
 
-    def forward(self, *a, **k):
-        raise NotImplementedError('CrossEntropyLoss(use_mask=True) is broken in the reference fork (SURVEY Q5); '
-                                  'only FCNMaskHead.forward is on the path')
+    def forward(self, cls_score, label, weight=None, avg_factor=None, reduction_override=None, **kwargs):
+        if self.use_mask:
+            raise NotImplementedError('CrossEntropyLoss(use_mask=True) is broken in the reference fork (SURVEY Q5); '
+                                      'only FCNMaskHead.forward is on the path')
+        if self.use_sigmoid or self.class_weight is not None:
+            raise NotImplementedError('the RoI head uses the softmax form without class weights')
+        assert reduction_override in (None, 'none', 'mean', 'sum')
+        reduction = reduction_override if reduction_override else self.reduction
+        n = cls_score.shape[0]
+        if reduction == 'mean':
+            scale = self.loss_weight / (float(avg_factor) if avg_factor is not None else float(n))
+        elif reduction == 'sum':
+            if avg_factor is not None:
+                raise ValueError('avg_factor can not be used with reduction="sum"')
+            scale = self.loss_weight
+        else:
+            raise NotImplementedError("reduction='none' is not used by the RoI head")
+        return _SoftmaxCEFn.apply(cls_score, label, weight, scale)
+
+
+@LOSSES.register_module()
+class L1Loss(nn.Module):
+    """losses/smooth_l1_loss.py:94-136.  ``forward`` is the generic elementwise form on already
+    gathered rows; ``BBoxHead.loss`` uses ``forward_pos`` (gather + loss + scatter fused)."""
+
+    def __init__(self, reduction='mean', loss_weight=1.0):
+        super().__init__()
+        self.reduction, self.loss_weight = reduction, loss_weight
+
+    def _scale(self, numel, avg_factor, reduction_override):
+        assert reduction_override in (None, 'none', 'mean', 'sum')
+        reduction = reduction_override if reduction_override else self.reduction
+        if reduction == 'mean':
+            return self.loss_weight / (float(avg_factor) if avg_factor is not None else float(numel))
+        if reduction == 'sum' and avg_factor is None:
+            return self.loss_weight
+        raise NotImplementedError("reduction 'none' / 'sum' with avg_factor is not used by the RoI head")
+
+    def forward_pos(self, bbox_pred, labels, bbox_targets, bbox_weights, num_classes, avg_factor=None,
+                    reduction_override=None):
+        scale = self._scale(bbox_pred.shape[0] * 4, avg_factor, reduction_override)
+        return _L1PosFn.apply(bbox_pred, labels, bbox_targets, bbox_weights, num_classes, scale)
+
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
+        """Rows already gathered ([n, 4]): every row counts as positive of a 1-class head."""
+        assert pred.size() == target.size() and target.numel() > 0
+        n = pred.shape[0]
+        lab = torch.zeros((n,), device=pred.device, dtype=torch.long)
+        w = weight if weight is not None else torch.ones_like(pred)
+        scale = self._scale(pred.numel(), avg_factor, reduction_override)
+        return _L1PosFn.apply(pred.reshape(n, -1), lab, target.reshape(n, -1), w.reshape(n, -1), 1, scale)

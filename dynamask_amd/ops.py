@@ -686,3 +686,99 @@ def paste_masks(masks, boxes, img_h, img_w, threshold=0.5, apply_sigmoid=False, 
     check(lib().dm_paste_masks(_p(masks), _p(boxes), N, mh, mw, int(img_h), int(img_w), float(threshold),
                                1 if apply_sigmoid else 0, _p(out), _stream()), 'dm_paste_masks')
     return out.view(torch.bool) if N > 0 else out.bool()
+
+
+# ------------------------------------------------------- RoI sampling + bbox-branch training
+def bbox_overlaps(bboxes1, bboxes2, mode='iou', eps=1e-6):
+    """core/bbox/iou_calculators/iou2d_calculator.py:37-131 (is_aligned=False) -> [n1, n2]."""
+    assert mode in ('iou', 'iof')
+    n1, n2 = bboxes1.shape[0], bboxes2.shape[0]
+    out = torch.empty((n1, n2), device=bboxes1.device, dtype=torch.float32)
+    if n1 * n2 == 0:
+        return out
+    _chk(bboxes1, 'bboxes1')
+    _chk(bboxes2, 'bboxes2')
+    check(lib().dm_bbox_overlaps(_p(bboxes1), n1, _p(bboxes2), n2, 1 if mode == 'iof' else 0, float(eps), _p(out),
+                                 _stream()), 'dm_bbox_overlaps')
+    return out
+
+
+def max_iou_assign(overlaps, pos_iou_thr, neg_iou_thr, min_pos_iou=0.0, match_low_quality=True, gt_max_assign_all=True,
+                   gt_labels=None):
+    """max_iou_assigner.py:129-212 for non-empty inputs -> (gt_inds, max_overlaps, labels|None)."""
+    _chk(overlaps, 'overlaps')
+    k, n = overlaps.shape
+    dev = overlaps.device
+    lo, hi = (0.0, float(neg_iou_thr)) if isinstance(neg_iou_thr, float) else (float(neg_iou_thr[0]), float(neg_iou_thr[1]))
+    gt_inds = torch.empty((n,), device=dev, dtype=torch.int64)
+    max_ov = torch.empty((n,), device=dev, dtype=torch.float32)
+    labels = None
+    if gt_labels is not None:
+        _chk(gt_labels, 'gt_labels', torch.int64)
+        labels = torch.empty((n,), device=dev, dtype=torch.int64)
+    scratch = torch.empty((2 * k,), device=dev, dtype=torch.float32)
+    check(lib().dm_max_iou_assign(_p(overlaps), k, n, float(pos_iou_thr), lo, hi, float(min_pos_iou),
+                                  1 if match_low_quality else 0, 1 if gt_max_assign_all else 0, _p(gt_labels), _p(scratch),
+                                  _p(gt_inds), _p(max_ov), _p(labels), _stream()), 'dm_max_iou_assign')
+    return gt_inds, max_ov, labels
+
+
+def bbox_encode(proposals, gt, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.)):
+    """bbox2delta, delta_xywh_bbox_coder.py:74-116."""
+    _chk(proposals, 'proposals')
+    _chk(gt, 'gt')
+    assert proposals.shape == gt.shape
+    out = torch.empty_like(proposals)
+    check(lib().dm_bbox_encode(_p(proposals), _p(gt), proposals.shape[0], _float_array(means), _float_array(stds), _p(out),
+                               _stream()), 'dm_bbox_encode')
+    return out
+
+
+def softmax_ce(cls_score, labels, weight, scale, need_grad=True):
+    """-> (loss [1] = scale * sum_i w_i CE_i, acc [1] percent, grad [N, C] or None)."""
+    _chk(cls_score, 'cls_score')
+    _chk(labels, 'labels', torch.int64)
+    if weight is not None:
+        _chk(weight, 'weight')
+    N, C = cls_score.shape
+    dev = cls_score.device
+    out = torch.empty((2,), device=dev, dtype=torch.float32)
+    grad = torch.empty_like(cls_score) if need_grad else None
+    scratch = torch.empty((2 * N,), device=dev, dtype=torch.float32)
+    check(lib().dm_softmax_ce_fwd_bwd(_p(cls_score), _p(labels), _p(weight), N, C, float(scale), _p(scratch), _p(out[0:1]),
+                                      _p(out[1:2]), _p(grad), _stream()), 'dm_softmax_ce_fwd_bwd')
+    return out[0], out[1], grad
+
+
+def l1_loss_pos(bbox_pred, labels, targets, weights, num_classes, scale, need_grad=True):
+    """-> (loss [1], grad [N, NB*4] or None); NB = bbox_pred.shape[1] // 4."""
+    _chk(bbox_pred, 'bbox_pred')
+    _chk(labels, 'labels', torch.int64)
+    _chk(targets, 'targets')
+    _chk(weights, 'weights')
+    N = bbox_pred.shape[0]
+    nb = bbox_pred.shape[1] // 4
+    dev = bbox_pred.device
+    loss = torch.empty((1,), device=dev, dtype=torch.float32)
+    grad = torch.empty_like(bbox_pred) if need_grad else None
+    scratch = torch.empty((N,), device=dev, dtype=torch.float32)
+    check(lib().dm_l1_loss_fwd_bwd(_p(bbox_pred), _p(labels), _p(targets), _p(weights), N, nb, int(num_classes), float(scale),
+                                   _p(scratch), _p(loss), _p(grad), _stream()), 'dm_l1_loss_fwd_bwd')
+    return loss[0], grad
+
+
+def sumsq(x, out=None):
+    """Sum of squares of a flat fp32 buffer (fixed-order) -> device scalar [1]."""
+    _chk(x, 'x')
+    out = torch.empty((1,), device=x.device, dtype=torch.float32) if out is None else out
+    scratch = torch.empty((int(lib().dm_sumsq_scratch_floats()),), device=x.device, dtype=torch.float32)
+    check(lib().dm_sumsq(_p(x), x.numel(), _p(scratch), _p(out), _stream()), 'dm_sumsq')
+    return out
+
+
+def clip_scale_(x, sumsq_total, max_norm):
+    """x *= min(1, max_norm / (sqrt(sumsq_total) + 1e-6)); the coefficient is taken on the device."""
+    _chk(x, 'x')
+    _chk(sumsq_total, 'sumsq')
+    check(lib().dm_clip_scale(_p(x), x.numel(), _p(sumsq_total), float(max_norm), _stream()), 'dm_clip_scale')
+    return x

@@ -3,9 +3,10 @@
 Mirrors ``mmdet/models/roi_heads/dynamask_roi_head.py:10-158`` +
 ``base_roi_head.py:10-58`` for the MASK path: ``_mask_forward``,
 ``get_mask_label`` (MaskPre + straight-through Gumbel selector),
-``_mask_forward_train`` and ``simple_test_mask``.  The bbox branch, the
-assigner/sampler and mask-target generation are outside the hot path (SURVEY
-section 8: OOS / "next"); their config entries are accepted and kept, not built.
+``_mask_forward_train`` and ``simple_test_mask``, plus the callers either side of
+it under the reference's signatures: ``forward_train`` (assigner + sampler, bbox
+branch losses, mask targets on the device; dynamask_roi_head.py:21-46) and
+``simple_test``.
 """
 import torch
 import torch.nn as nn
@@ -133,6 +134,7 @@ class DynaMaskRoIHead(nn.Module):
             self.mask_roi_extractor = build_roi_extractor(mask_roi_extractor)
             self.share_roi_extractor = False
             self.mask_head = build_head(mask_head)
+        self.init_assigner_sampler()
         # base_roi_head.py:53-58 (created for every RoI head: Quirk Q4)
         self.semantic_roi_extractor = build_roi_extractor(dict(
             type='SingleRoIExtractor', roi_layer=dict(type='RoIAlign', output_size=56, sampling_ratio=0),
@@ -141,6 +143,15 @@ class DynaMaskRoIHead(nn.Module):
         # inference: RoI chunks on separate HIP streams (see _mask_forward)
         self.num_streams = 2
         self.stream_split_min = 128
+
+    def init_assigner_sampler(self):
+        """standard_roi_head.py:13-20."""
+        self.bbox_assigner = None
+        self.bbox_sampler = None
+        if self.train_cfg and getattr(self.train_cfg, 'get', None) and self.train_cfg.get('assigner') is not None:
+            from .assigners import build_assigner, build_sampler
+            self.bbox_assigner = build_assigner(self.train_cfg.assigner)
+            self.bbox_sampler = build_sampler(self.train_cfg.sampler, context=self)
 
     @property
     def with_bbox(self):
@@ -226,15 +237,76 @@ class DynaMaskRoIHead(nn.Module):
             y, hot, idx = ops.gumbel_select(logits, noise.contiguous(), 0.5)
         return (hot, idx, logits, y) if return_index else hot
 
-    def _mask_forward_train(self, x, pos_rois, pos_labels, stage_mask_targets, noise=None):
-        """dynamask_roi_head.py:48-73 from ``pos_rois`` on (sampling and
-        ``mask_head.get_targets`` are the caller's: SURVEY 8f rank 1)."""
+    # ------------------------------------------------------------------ training entry points
+    def forward_train(self, x, img_metas, proposal_list, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None,
+                      noise=None):
+        """dynamask_roi_head.py:21-46 (called from detectors/two_stage.py:161-164): assign gts and
+        sample proposals per image, bbox branch forward + loss, mask branch forward + loss.
+        Returns the dict of losses the detector's ``_parse_losses`` sums.  ``noise`` (extension):
+        the uniform draw of the Gumbel selector, for reproducible tests."""
+        num_imgs = len(img_metas)
+        if gt_bboxes_ignore is None:
+            gt_bboxes_ignore = [None for _ in range(num_imgs)]
+        sampling_results = []
+        for i in range(num_imgs):
+            assign_result = self.bbox_assigner.assign(proposal_list[i], gt_bboxes[i], gt_bboxes_ignore[i], gt_labels[i])
+            sampling_results.append(self.bbox_sampler.sample(assign_result, proposal_list[i], gt_bboxes[i], gt_labels[i],
+                                                             feats=[lvl_feat[i][None] for lvl_feat in x]))
+        bbox_results = self._bbox_forward_train(x, sampling_results, gt_bboxes, gt_labels, img_metas)
+        mask_results = self._mask_forward_train(x, sampling_results, bbox_results['bbox_feats'], gt_bboxes, gt_masks,
+                                                gt_labels, img_metas, noise=noise)
+        losses = {}
+        losses.update(bbox_results['loss_bbox'])
+        losses.update(mask_results['loss_mask'])
+        return losses
+
+    def _bbox_forward_train(self, x, sampling_results, gt_bboxes, gt_labels, img_metas):
+        """standard_roi_head.py:147-160."""
+        rois = bbox2roi([res.bboxes for res in sampling_results]).contiguous()
+        if torch.is_grad_enabled():
+            from . import train_path
+            bbox_feats = train_path.roi_extract_train(self.bbox_roi_extractor, x, rois)
+        else:
+            bbox_feats = self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois)
+        cls_score, bbox_pred = self.bbox_head(bbox_feats)
+        bbox_results = dict(cls_score=cls_score, bbox_pred=bbox_pred, bbox_feats=bbox_feats)
+        bbox_targets = self.bbox_head.get_targets(sampling_results, gt_bboxes, gt_labels, self.train_cfg)
+        loss_bbox = self.bbox_head.loss(cls_score, bbox_pred, rois, *bbox_targets)
+        bbox_results.update(loss_bbox=loss_bbox)
+        return bbox_results
+
+    def _mask_forward_train(self, x, sampling_results, bbox_feats=None, gt_bboxes=None, gt_masks=None, gt_labels=None,
+                            img_metas=None, noise=None):
+        """dynamask_roi_head.py:48-73, reference signature
+        ``(x, sampling_results, bbox_feats, gt_bboxes, gt_masks, gt_labels, img_metas)``:
+        positives of the sampler -> mask targets on the device -> the mask path.
+
+        The tensor-level form of round 1, ``(x, pos_rois, pos_labels, stage_mask_targets)``, is
+        still accepted (a tensor in the second position) and is what this method calls after
+        the sampling results have been unpacked."""
+        if isinstance(sampling_results, torch.Tensor):
+            return self._mask_forward_train_tensors(x, sampling_results, bbox_feats, gt_bboxes, noise=noise)
+        pos_bboxes = [res.pos_bboxes for res in sampling_results]
+        pos_labels = [res.pos_gt_labels for res in sampling_results]
+        pos_assigned_gt_inds = [res.pos_assigned_gt_inds for res in sampling_results]
+        pos_rois = bbox2roi(pos_bboxes).contiguous()
+        stage_mask_targets = self.mask_head.get_targets(pos_bboxes, pos_assigned_gt_inds, gt_masks)
+        return self._mask_forward_train_tensors(x, pos_rois, torch.cat(pos_labels), stage_mask_targets, noise=noise)
+
+    def _mask_forward_train_tensors(self, x, pos_rois, pos_labels, stage_mask_targets, noise=None):
+        """dynamask_roi_head.py:57-73 from ``pos_rois`` on."""
         mask_results = self._mask_forward(x, pos_rois, pos_labels)
         ins_semantic_feats = self.semantic_roi_extractor([x[0].detach(), ], pos_rois)
         mask_labels, idx, logits, y = self.get_mask_label(ins_semantic_feats, noise, return_index=True)
         loss_mask = self.mask_head.loss_func(mask_results['stage_instance_preds'], mask_results['stage_detail_preds'],
                                              stage_mask_targets, mask_labels)
         mask_results.update(loss_mask=loss_mask, mask_labels=mask_labels, mask_index=idx, mask_logits=logits)
+        if self.train_cfg is not None and getattr(self.train_cfg, 'get', None) and self.train_cfg.get('flops') is not None:
+            # dynamask_roi_head.py:68-71: computed and attached, never added to the losses (Quirk Q3)
+            fl = mask_labels.new_tensor(self.train_cfg.flops)
+            budget = (mask_labels.detach() * fl).sum() / len(mask_labels) - 1.0
+            mask_results['loss_flops'] = {'loss_flops': self.train_cfg.Lambda * torch.clamp(
+                budget / (self.train_cfg.flops[-1] - self.train_cfg.flops[0]), min=0)}
         return mask_results
 
     def merge_stage_preds(self, stage_instance_preds):

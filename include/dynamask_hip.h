@@ -377,6 +377,60 @@ int dm_dcn_weight_permute(const float* src, float* dst, int Cout, int C, int to_
 int dm_sgd_momentum_step(float* params, const float* grads, float* momentum_buf, long long count, float lr,
                          float momentum, float weight_decay, float grad_scale, int first_step, dm_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training side of the RoI head around the mask path (SURVEY 8b "forward_train", 8f rank 4):
+ * RoI assignment / sampling inputs, bbox regression targets and the two bbox-branch losses.
+ * ------------------------------------------------------------------------------------------ */
+
+/* bbox_overlaps(bboxes1 [n1,4], bboxes2 [n2,4], mode, is_aligned=False, eps) -> [n1, n2]
+ * (core/bbox/iou_calculators/iou2d_calculator.py:37-131); mode_iof: 0 = 'iou', 1 = 'iof'.
+ * Rounded exactly like the reference's separate torch ops (no fused multiply-add). */
+int dm_bbox_overlaps(const float* bboxes1, int n1, const float* bboxes2, int n2, int mode_iof, float eps, float* out,
+                     dm_stream_t stream);
+
+/* MaxIoUAssigner.assign_wrt_overlaps (core/bbox/assigners/max_iou_assigner.py:129-212) for
+ * num_gts > 0 and num_bboxes > 0: overlaps [num_gts, num_bboxes] -> gt_inds [n] (-1 ignore,
+ * 0 negative, i+1 = gt i), max_overlaps [n], labels [n] (gt label or -1; NULL with gt_labels
+ * NULL).  A float neg_iou_thr t is (neg_iou_lo, neg_iou_hi) = (0, t).  scratch: 2*num_gts floats. */
+int dm_max_iou_assign(const float* overlaps, int num_gts, int num_bboxes, float pos_iou_thr, float neg_iou_lo,
+                      float neg_iou_hi, float min_pos_iou, int match_low_quality, int gt_max_assign_all,
+                      const int64_t* gt_labels, float* scratch, int64_t* gt_inds, float* max_overlaps, int64_t* labels,
+                      dm_stream_t stream);
+
+/* bbox2delta (core/bbox/coder/delta_xywh_bbox_coder.py:74-116): proposals, gt [n,4] -> deltas [n,4]. */
+int dm_bbox_encode(const float* proposals, const float* gt, int n, const float* means, const float* stds, float* deltas,
+                   dm_stream_t stream);
+
+/* cross_entropy(pred, label, weight, reduction='mean', avg_factor) * loss_weight, forward and
+ * backward in one pass (losses/cross_entropy_loss.py:9-38, utils.py:26-52), plus
+ * accuracy(pred, label) top-1 in percent (losses/accuracy.py:4-49):
+ *   loss[0]    = scale * sum_i weight_i * (logsumexp(score_i) - score_i[label_i]),  scale = loss_weight / avg_factor
+ *   grad[i, c] = scale * weight_i * (softmax(score_i)[c] - [c == label_i])          (NULL: forward only)
+ *   correct[0] = 100 / N * #{i : argmax_c score_i[c] == label_i}                     (NULL: skipped)
+ * weight NULL = all ones.  scratch: 2*N floats.  Row sums are added in a fixed order. */
+int dm_softmax_ce_fwd_bwd(const float* cls_score, const int64_t* labels, const float* weight, int N, int C, float scale,
+                          float* scratch, float* loss, float* correct, float* grad, dm_stream_t stream);
+
+/* BBoxHead.loss, regression half (roi_heads/bbox_heads/bbox_head.py:159-182) with L1Loss
+ * (losses/smooth_l1_loss.py:29-42,104-136): rows with 0 <= label < num_classes are positive;
+ * their prediction is bbox_pred[i, label_i, :] (num_boxes_per_row = num_classes) or
+ * bbox_pred[i, 0, :] (class agnostic, num_boxes_per_row = 1):
+ *   loss[0] = scale * sum_pos sum_c |pred - target| * weight,   scale = loss_weight / avg_factor
+ *   grad    = d loss / d bbox_pred [N, num_boxes_per_row*4] (overwritten; NULL: forward only)
+ * No positive row: loss 0, grad 0 (the reference's `bbox_pred.sum() * 0`).  scratch: N floats. */
+int dm_l1_loss_fwd_bwd(const float* bbox_pred, const int64_t* labels, const float* targets, const float* weights, int N,
+                       int num_boxes_per_row, int num_classes, float scale, float* scratch, float* loss, float* grad,
+                       dm_stream_t stream);
+
+/* Gradient clipping of the flat gradient buffer (optimizer_config grad_clip,
+ * configs/dynamask/coco/r50-dynamask-1x.py:274; OptimizerHook.py:10-14 -> clip_grad_norm_):
+ * dm_sumsq: out[0] = sum x^2 (fixed-order two-stage sum; scratch dm_sumsq_scratch_floats());
+ * dm_clip_scale: x *= min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) with sumsq read on the device
+ * (the caller may have added the other parameter groups' sums into it). */
+long long dm_sumsq_scratch_floats(void);
+int dm_sumsq(const float* x, long long count, float* scratch, float* out, dm_stream_t stream);
+int dm_clip_scale(float* x, long long count, const float* sumsq, float max_norm, dm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

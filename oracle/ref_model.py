@@ -446,3 +446,167 @@ def get_bboxes(rois, cls_score, bbox_pred, img_shape, scale_factor, rescale=Fals
     if cfg is None:
         return bboxes, scores
     return multiclass_nms(bboxes, scores, cfg['score_thr'], cfg['nms'], cfg['max_per_img'])
+
+
+# ------------------------------------------------- training entry point (8b forward_train, 8f rank 4)
+def bbox_overlaps(b1, b2, mode='iou', eps=1e-6):
+    """bbox_overlaps(is_aligned=False) -- core/bbox/iou_calculators/iou2d_calculator.py:85-131,
+    restated per pair: intersection of the clamped extents over union (or over the first area)."""
+    b1, b2 = b1[:, :4].float(), b2[:, :4].float()
+    if b1.shape[0] * b2.shape[0] == 0:
+        return torch.zeros((b1.shape[0], b2.shape[0]))
+    x1 = torch.maximum(b1[:, None, 0], b2[None, :, 0])
+    y1 = torch.maximum(b1[:, None, 1], b2[None, :, 1])
+    x2 = torch.minimum(b1[:, None, 2], b2[None, :, 2])
+    y2 = torch.minimum(b1[:, None, 3], b2[None, :, 3])
+    inter = (x2 - x1).clamp(min=0) * (y2 - y1).clamp(min=0)
+    a1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
+    if mode == 'iou':
+        a2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+        union = a1[:, None] + a2[None, :] - inter
+    else:
+        union = a1[:, None].expand_as(inter)
+    return inter / torch.clamp(union, min=eps)
+
+
+def max_iou_assign(overlaps, pos_iou_thr, neg_iou_thr, min_pos_iou=0.0, match_low_quality=True, gt_max_assign_all=True,
+                   gt_labels=None):
+    """MaxIoUAssigner.assign_wrt_overlaps -- core/bbox/assigners/max_iou_assigner.py:129-212, as a
+    plain loop over the boxes (the four numbered steps of its docstring).  -> gt_inds, max_overlaps, labels."""
+    k, n = overlaps.shape
+    gt_inds = torch.full((n,), -1, dtype=torch.long)
+    if k == 0 or n == 0:
+        if k == 0:
+            gt_inds[:] = 0
+        return gt_inds, torch.zeros(n), (None if gt_labels is None else torch.full((n,), -1, dtype=torch.long))
+    lo, hi = (0.0, neg_iou_thr) if isinstance(neg_iou_thr, float) else neg_iou_thr
+    ov = overlaps.tolist()
+    col_max = [max(ov[i][j] for i in range(k)) for j in range(n)]
+    col_arg = [min(i for i in range(k) if ov[i][j] == col_max[j]) for j in range(n)]
+    row_max = [max(ov[i]) for i in range(k)]
+    row_arg = [ov[i].index(row_max[i]) for i in range(k)]
+    f32 = lambda v: float(torch.tensor(v, dtype=torch.float32))      # thresholds compare in fp32 as in torch  # noqa: E731
+    for j in range(n):
+        m = col_max[j]
+        g = -1
+        if lo <= m < f32(hi):
+            g = 0
+        if m >= f32(pos_iou_thr):
+            g = col_arg[j] + 1
+        if match_low_quality:
+            for i in range(k):
+                if row_max[i] >= f32(min_pos_iou):
+                    if (ov[i][j] == row_max[i]) if gt_max_assign_all else (row_arg[i] == j):
+                        g = i + 1
+        gt_inds[j] = g
+    labels = None
+    if gt_labels is not None:
+        labels = torch.full((n,), -1, dtype=torch.long)
+        pos = gt_inds > 0
+        labels[pos] = gt_labels[gt_inds[pos] - 1]
+    return gt_inds, torch.tensor(col_max, dtype=torch.float32), labels
+
+
+def random_sample(gt_inds, labels, bboxes, gt_bboxes, gt_labels, num, pos_fraction, neg_pos_ub=-1, add_gt_as_proposals=True):
+    """RandomSampler.sample -- core/bbox/samplers/base_sampler.py:35-101 + random_sampler.py:32-78 +
+    SamplingResult (sampling_result.py:21-56).  Draws ``torch.randperm`` on the default CPU generator in
+    the reference's order (positives first).  -> dict of the SamplingResult fields the heads read."""
+    bboxes = bboxes[:, :4]
+    G = gt_bboxes.shape[0]
+    is_gt = torch.zeros(bboxes.shape[0], dtype=torch.uint8)
+    if add_gt_as_proposals and G > 0:
+        bboxes = torch.cat([gt_bboxes, bboxes])
+        gt_inds = torch.cat([torch.arange(1, G + 1), gt_inds])
+        labels = torch.cat([gt_labels, labels])
+        is_gt = torch.cat([torch.ones(G, dtype=torch.uint8), is_gt])
+
+    def choose(cand, want):
+        if cand.numel() <= want:
+            return cand
+        return cand[torch.randperm(cand.numel())[:want]]
+    pos = choose(torch.nonzero(gt_inds > 0).flatten(), int(num * pos_fraction)).unique()
+    want_neg = num - pos.numel()
+    if neg_pos_ub >= 0:
+        want_neg = min(want_neg, int(neg_pos_ub * max(1, pos.numel())))
+    neg = choose(torch.nonzero(gt_inds == 0).flatten(), want_neg).unique()
+    assigned = gt_inds[pos] - 1
+    return dict(pos_inds=pos, neg_inds=neg, pos_bboxes=bboxes[pos], neg_bboxes=bboxes[neg], pos_is_gt=is_gt[pos],
+                pos_assigned_gt_inds=assigned, pos_gt_bboxes=gt_bboxes[assigned].view(-1, 4), pos_gt_labels=labels[pos],
+                bboxes=torch.cat([bboxes[pos], bboxes[neg]]))
+
+
+def bbox2delta(proposals, gt, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.)):
+    """core/bbox/coder/delta_xywh_bbox_coder.py:74-116: centre shift in units of the proposal size,
+    log size ratio, normalised by (means, stds)."""
+    p, g = proposals.float(), gt.float()
+    pw, ph = p[:, 2] - p[:, 0], p[:, 3] - p[:, 1]
+    d = torch.stack([((g[:, 0] + g[:, 2]) * 0.5 - (p[:, 0] + p[:, 2]) * 0.5) / pw,
+                     ((g[:, 1] + g[:, 3]) * 0.5 - (p[:, 1] + p[:, 3]) * 0.5) / ph,
+                     torch.log((g[:, 2] - g[:, 0]) / pw), torch.log((g[:, 3] - g[:, 1]) / ph)], dim=-1)
+    return (d - torch.tensor(means)) / torch.tensor(stds)
+
+
+def bbox_targets(samples, num_classes=80, means=(0., 0., 0., 0.), stds=(0.1, 0.1, 0.2, 0.2), pos_weight=-1):
+    """BBoxHead.get_targets -- roi_heads/bbox_heads/bbox_head.py:85-141 (positives first, then negatives,
+    background label = num_classes)."""
+    labs, lws, bts, bws = [], [], [], []
+    for s in samples:
+        npos, nneg = s['pos_bboxes'].shape[0], s['neg_bboxes'].shape[0]
+        lab = torch.full((npos + nneg,), num_classes, dtype=torch.long)
+        lw, bt, bw = torch.zeros(npos + nneg), torch.zeros(npos + nneg, 4), torch.zeros(npos + nneg, 4)
+        if npos > 0:
+            lab[:npos] = s['pos_gt_labels']
+            lw[:npos] = 1.0 if pos_weight <= 0 else pos_weight
+            bt[:npos] = bbox2delta(s['pos_bboxes'], s['pos_gt_bboxes'], means, stds)
+            bw[:npos] = 1
+        if nneg > 0:
+            lw[npos:] = 1.0
+        labs.append(lab); lws.append(lw); bts.append(bt); bws.append(bw)      # noqa: E702
+    return torch.cat(labs), torch.cat(lws), torch.cat(bts), torch.cat(bws)
+
+
+def bbox_loss(cls_score, bbox_pred, labels, label_weights, bbox_tgts, bbox_weights, num_classes=80, loss_weight_cls=1.0,
+              loss_weight_bbox=1.0):
+    """BBoxHead.loss -- bbox_head.py:143-184 with CrossEntropyLoss (losses/cross_entropy_loss.py:9-38,
+    utils.py:26-52), accuracy (accuracy.py:4-49) and L1Loss (smooth_l1_loss.py:29-42,104-136).
+    -> loss_cls, acc (percent), loss_bbox."""
+    avg = max(float((label_weights > 0).sum()), 1.0)
+    ce = F.cross_entropy(cls_score, labels, reduction='none')
+    loss_cls = loss_weight_cls * (ce * label_weights).sum() / avg
+    acc = (cls_score.argmax(1) == labels).float().sum() * (100.0 / cls_score.shape[0])
+    pos = (labels >= 0) & (labels < num_classes)
+    if pos.any():
+        pred = bbox_pred.view(bbox_pred.shape[0], -1, 4)[pos, labels[pos]]
+        loss_bbox = loss_weight_bbox * ((pred - bbox_tgts[pos]).abs() * bbox_weights[pos]).sum() / bbox_tgts.shape[0]
+    else:
+        loss_bbox = bbox_pred.sum() * 0
+    return loss_cls, acc, loss_bbox
+
+
+def forward_train(sd, fpn_feats, proposals, gt_bboxes, gt_labels, gt_masks, train_cfg, num_classes=80,
+                  loss_weight_cls=2.0, loss_weight_bbox=2.0):
+    """DynaMaskRoIHead.forward_train -- roi_heads/dynamask_roi_head.py:21-73 (+ standard_roi_head.py:147-160):
+    assign + sample per image, bbox branch losses, mask targets, mask path loss.  Random draws (sampler
+    permutations, then the Gumbel noise) come from the default CPU generator in the reference's order."""
+    a, s = train_cfg['assigner'], train_cfg['sampler']
+    samples = []
+    for i in range(len(proposals)):
+        ov = bbox_overlaps(gt_bboxes[i], proposals[i])
+        gi_, _, lab = max_iou_assign(ov, a['pos_iou_thr'], a['neg_iou_thr'], a.get('min_pos_iou', 0.0),
+                                     a.get('match_low_quality', True), a.get('gt_max_assign_all', True), gt_labels[i])
+        samples.append(random_sample(gi_, lab, proposals[i], gt_bboxes[i], gt_labels[i], s['num'], s['pos_fraction'],
+                                     s.get('neg_pos_ub', -1), s.get('add_gt_as_proposals', True)))
+    cat_rois = lambda boxes: torch.cat([torch.cat([torch.full((b.shape[0], 1), float(i)), b[:, :4]], 1)      # noqa: E731
+                                        for i, b in enumerate(boxes)])
+    rois = cat_rois([x['bboxes'] for x in samples])
+    bbox_feats = ref_ops.single_roi_extractor(fpn_feats[:4], rois, 7, (4, 8, 16, 32))
+    cls_score, bbox_pred = bbox_head_forward(sd, bbox_feats)
+    tg = bbox_targets(samples, num_classes, pos_weight=train_cfg.get('pos_weight', -1))
+    loss_cls, acc, loss_bbox = bbox_loss(cls_score, bbox_pred, *tg, num_classes=num_classes, loss_weight_cls=loss_weight_cls,
+                                         loss_weight_bbox=loss_weight_bbox)
+    pos_rois = cat_rois([x['pos_bboxes'] for x in samples])
+    stage_targets = get_targets([x['pos_bboxes'] for x in samples], [x['pos_assigned_gt_inds'] for x in samples], gt_masks)
+    pos_labels = torch.cat([x['pos_gt_labels'] for x in samples])
+    U = torch.rand((pos_rois.shape[0], 4))                   # sample_gumbel, dynamask_roi_head.py:89-92 (CPU generator)
+    loss_masks, mask_labels, ind, _ = mask_forward_train(sd, fpn_feats, pos_rois, pos_labels, stage_targets, U)
+    return dict(loss_cls=loss_cls, acc=acc, loss_bbox=loss_bbox, loss_masks=loss_masks), samples, tg, ind

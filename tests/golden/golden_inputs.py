@@ -197,3 +197,57 @@ def bbox_inputs(n=60):
     boxes[:, 1::2] = boxes[:, 1::2].clamp(0, 255)
     rois = torch.cat([torch.zeros(n, 1), boxes], 1)
     return x, rois
+
+
+# ------------------------------------------------------------------ forward_train (8b, 8f rank 4)
+RCNN_TRAIN_CFG = dict(
+    assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5, match_low_quality=True,
+                  ignore_iof_thr=-1),
+    sampler=dict(type='RandomSampler', num=16, pos_fraction=0.25, neg_pos_ub=-1, add_gt_as_proposals=True),
+    flops=[0.23, 0.62, 1.01, 1.4], Lambda=0.3, mask_size=28, pos_weight=-1, debug=False)
+TRAIN_SEED = 4321
+BBOX_GRAD_KEYS = ['shared_fcs.0.weight', 'shared_fcs.0.bias', 'shared_fcs.1.weight', 'fc_cls.weight', 'fc_cls.bias',
+                  'fc_reg.weight', 'fc_reg.bias']
+
+
+def train_inputs():
+    """Two 256x320 images on the FPN maps of ``head_inputs``: GT bitmaps + their boxes + labels and 40
+    proposals per image (jittered copies of the GT boxes at several IoUs, exact duplicates -- ties
+    in the IoU matrix -- and random boxes)."""
+    g = _g(301)
+    feats = synth.make_fpn(2, IMG_H, IMG_W, 256, seed=100)
+    out = dict(feats=feats, img_metas=[dict(img_shape=(IMG_H, IMG_W, 3), pad_shape=(IMG_H, IMG_W, 3)) for _ in range(2)],
+               gt_bboxes=[], gt_labels=[], gt_masks=[], proposals=[])
+    for G in (3, 2):
+        m = torch.zeros(G, IMG_H, IMG_W, dtype=torch.uint8)
+        boxes = []
+        for k in range(G):
+            y0, x0 = int(torch.randint(5, 120, (1,), generator=g)), int(torch.randint(5, 160, (1,), generator=g))
+            h, w = int(torch.randint(40, 120, (1,), generator=g)), int(torch.randint(40, 140, (1,), generator=g))
+            m[k, y0:y0 + h, x0:x0 + w] = 1
+            m[k, y0 + h // 3:y0 + h // 2, x0:x0 + w // 3] = 0
+            boxes.append([float(x0), float(y0), float(x0 + w), float(y0 + h)])
+        gtb = torch.tensor(boxes)
+        props = []
+        for k in range(G):
+            for s in (2.0, 6.0, 12.0, 25.0, 40.0):
+                props.append(gtb[k] + torch.randn(4, generator=g) * s)
+        props.append(gtb[0] + torch.tensor([3.0, 2.0, -4.0, 1.0]))
+        props.append(gtb[0] + torch.tensor([3.0, 2.0, -4.0, 1.0]))            # exact duplicate
+        p = torch.stack(props)
+        n_rand = 40 - p.shape[0]
+        c = torch.rand(n_rand, 2, generator=g) * torch.tensor([IMG_W - 40.0, IMG_H - 40.0]) + 20
+        wh = torch.rand(n_rand, 2, generator=g) * 100 + 12
+        p = torch.cat([p, torch.cat([c - wh / 2, c + wh / 2], 1)])
+        p[:, 0::2] = p[:, 0::2].clamp(0, IMG_W - 1)
+        p[:, 1::2] = p[:, 1::2].clamp(0, IMG_H - 1)
+        p = torch.cat([p, torch.rand(40, 1, generator=g)], 1)                # RPN proposals carry a score column
+        out['gt_bboxes'].append(gtb)
+        out['gt_labels'].append(torch.randint(0, 80, (G,), generator=g))
+        out['gt_masks'].append(m)
+        out['proposals'].append(p)
+    return out
+
+
+def bbox_train_head_state():
+    return synth.init_bbox_head_state(seed=302)

@@ -91,9 +91,9 @@ def test_training_step_through_rccl_matches_unreduced_step(rccl_world1):
             assert (grp._work is not None) == force
             grp.sgd_step(lr=0.02, momentum=0.9, weight_decay=1e-4)
         torch.cuda.synchronize()
-        return grp.flat_param.clone(), float(res['loss_mask']['loss_masks'])
+        return grp.flat_param.clone(), float(res['loss_mask']['loss_masks'].detach())
     p0, l0 = run(False)
     p1, l1 = run(True)
-    assert l0 == l1
+    assert abs(l0 - l1) <= 1e-5 * abs(l0)      # second step's loss: the first step's atomics-ordered last bits show
     # weight-gradient GEMMs accumulate split-K partials with float atomics: run-to-run last-bit noise
     torch.testing.assert_close(p1, p0, atol=1e-6, rtol=1e-5)

@@ -159,3 +159,89 @@ def test_bbox_branch_oracle_matches_reference_golden(golden_dir):
         # the reference's own docstring values (delta_xywh_bbox_coder.py:155-160)
         np.testing.assert_allclose(g['doc_example'], [[0, 0, 1, 1], [0.1409, 0.1409, 2.8591, 2.8591],
                                                        [0, 0.3161, 4.1945, 0.6839], [5, 5, 5, 5]], atol=1e-4)
+
+
+# ----------------------------------------------------------- training entry point (g11)
+def _g11(golden_dir):
+    return np.load(os.path.join(golden_dir, 'g11_train.npz'))
+
+
+def test_assigner_sampler_targets_match_reference(golden_dir):
+    """IoU matrix, MaxIoUAssigner (three configurations), RandomSampler under the reference's seed and
+    BBoxHead.get_targets: indices bit-exact, floats to 1e-6."""
+    g = _g11(golden_dir)
+    ti = gi.train_inputs()
+    a, s = gi.RCNN_TRAIN_CFG['assigner'], gi.RCNN_TRAIN_CFG['sampler']
+    torch.manual_seed(gi.TRAIN_SEED)
+    samples = []
+    for i in range(2):
+        ov = ref_model.bbox_overlaps(ti['gt_bboxes'][i], ti['proposals'][i])
+        np.testing.assert_array_equal(ov.numpy(), g[f'overlaps{i}'])          # same fp32 ops in the same order
+        np.testing.assert_array_equal(ref_model.bbox_overlaps(ti['gt_bboxes'][i], ti['proposals'][i], 'iof').numpy(),
+                                      g[f'iof{i}'])
+        gi_, mo, lab = ref_model.max_iou_assign(ov, a['pos_iou_thr'], a['neg_iou_thr'], a['min_pos_iou'], True, True,
+                                                ti['gt_labels'][i])
+        np.testing.assert_array_equal(gi_.numpy(), g[f'gt_inds{i}'])
+        np.testing.assert_array_equal(mo.numpy(), g[f'max_overlaps{i}'])
+        np.testing.assert_array_equal(lab.numpy(), g[f'assigned_labels{i}'])
+        sm = ref_model.random_sample(gi_, lab, ti['proposals'][i], ti['gt_bboxes'][i], ti['gt_labels'][i], s['num'],
+                                     s['pos_fraction'])
+        for k in ('pos_inds', 'neg_inds', 'pos_assigned_gt_inds', 'pos_is_gt'):
+            np.testing.assert_array_equal(sm[k].numpy(), g[f'{k}{i}'])
+        samples.append(sm)
+    ov0 = ref_model.bbox_overlaps(ti['gt_bboxes'][0], ti['proposals'][0])
+    np.testing.assert_array_equal(ref_model.max_iou_assign(ov0, 0.7, (0.1, 0.3), 0.3, True, False)[0].numpy(), g['alt_gt_inds'])
+    ov1 = ref_model.bbox_overlaps(ti['gt_bboxes'][1], ti['proposals'][1])
+    np.testing.assert_array_equal(ref_model.max_iou_assign(ov1, 0.5, 0.5, 0.5, False, True, ti['gt_labels'][1])[0].numpy(),
+                                  g['nolq_gt_inds'])
+    lab, lw, bt, bw = ref_model.bbox_targets(samples)
+    np.testing.assert_array_equal(lab.numpy(), g['labels'])
+    np.testing.assert_array_equal(lw.numpy(), g['label_weights'])
+    np.testing.assert_allclose(bt.numpy(), g['bbox_targets'], atol=1e-6, rtol=1e-6)
+    np.testing.assert_array_equal(bw.numpy(), g['bbox_weights'])
+
+
+def test_bbox_losses_match_reference(golden_dir):
+    g = _g11(golden_dir)
+    cs = torch.from_numpy(g['in_cls_score']).requires_grad_(True)
+    bp = torch.from_numpy(g['in_bbox_pred']).requires_grad_(True)
+    tg = [torch.from_numpy(g[k]) for k in ('labels', 'label_weights', 'bbox_targets', 'bbox_weights')]
+    lc, acc, lb = ref_model.bbox_loss(cs, bp, *tg, loss_weight_cls=2.0, loss_weight_bbox=2.0)
+    (lc * 1.5 + lb * 0.5).backward()
+    np.testing.assert_allclose(lc.item(), g['loss_cls_alone'], rtol=1e-6)
+    np.testing.assert_allclose(acc.item(), g['acc_alone'].item(), rtol=1e-6)
+    np.testing.assert_allclose(lb.item(), g['loss_bbox_alone'], rtol=1e-6)
+    np.testing.assert_allclose(cs.grad.numpy(), g['grad_cls_score'], atol=1e-7, rtol=1e-5)
+    np.testing.assert_allclose(bp.grad.numpy(), g['grad_bbox_pred'], atol=1e-7, rtol=1e-5)
+    tg[0] = torch.full_like(tg[0], 80)
+    assert ref_model.bbox_loss(cs.detach(), bp.detach(), *tg)[2].item() == g['loss_bbox_no_pos'] == 0.0
+
+
+def test_forward_train_matches_reference(golden_dir):
+    """The whole DynaMaskRoIHead.forward_train: four losses and gradients of bbox-head, mask-head, MaskPre
+    parameters and of the FPN maps."""
+    g = _g11(golden_dir)
+    ti = gi.train_inputs()
+    sd = {k: v.clone().requires_grad_(True) if v.is_floating_point() else v
+          for k, v in {**gi.head_state(), **gi.mask_pre_state(), **gi.bbox_train_head_state()}.items()}
+    feats = [f.clone().requires_grad_(True) for f in ti['feats']]
+    torch.manual_seed(gi.TRAIN_SEED)
+    losses, samples, _, _ = ref_model.forward_train(sd, feats, ti['proposals'], ti['gt_bboxes'], ti['gt_labels'],
+                                                    ti['gt_masks'], gi.RCNN_TRAIN_CFG)
+    for i in range(2):
+        np.testing.assert_array_equal(samples[i]['pos_inds'].numpy(), g[f'pos_inds{i}'])
+    for k in ('loss_cls', 'acc', 'loss_bbox', 'loss_masks'):
+        np.testing.assert_allclose(float(losses[k].detach()), float(g['ft.' + k].reshape(-1)[0]), rtol=2e-5, atol=1e-6)
+    (losses['loss_cls'] + losses['loss_bbox'] + losses['loss_masks']).backward()
+    for k in gi.BBOX_GRAD_KEYS:
+        np.testing.assert_allclose(gi.grad_slice(sd['bbox_head.' + k].grad).numpy(), g['ft.grad.bbox_head.' + k],
+                                   atol=1e-5, rtol=1e-4)
+    for k in gi.GRAD_KEYS:
+        np.testing.assert_allclose(gi.grad_slice(sd['mask_head.' + k].grad).numpy(), g['ft.grad.mask_head.' + k],
+                                   atol=1e-5, rtol=1e-4)
+    for k in ('conv1.weight', 'bn1.weight', 'fc2.weight'):
+        np.testing.assert_allclose(gi.grad_slice(sd['mask_predictor.' + k].grad).numpy(), g['ft.grad.mask_predictor.' + k],
+                                   atol=1e-5, rtol=1e-4)
+    for i in range(4):
+        if g[f'ft.grad_feat{i}'].size > 1:
+            np.testing.assert_allclose(gi.feat_grad_slice(feats[i].grad).numpy(), g[f'ft.grad_feat{i}'], atol=1e-5, rtol=1e-4)

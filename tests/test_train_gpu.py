@@ -1,0 +1,213 @@
+"""Training entry point of the RoI head on the MI355X, through the registry classes and the C ABI:
+assigner / sampler / bbox targets / bbox losses / ``DynaMaskRoIHead.forward_train`` against golden g11
+(produced by the reference's own modules, tests/golden/make_golden_train.py) and, at the config's real
+sizes (1000 proposals, 512 samples per image), against the oracle.  Indices bit-exact; floats 1e-4."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+from oracle import ref_model
+
+pytestmark = pytest.mark.gpu
+TOL = dict(atol=1e-4, rtol=1e-4)
+
+
+def _g11(golden_dir):
+    return np.load(os.path.join(golden_dir, 'g11_train.npz'))
+
+
+def _eq(t, ref):
+    np.testing.assert_array_equal(t.detach().cpu().numpy(), ref)
+
+
+def _close(t, ref, **kw):
+    np.testing.assert_allclose(t.detach().cpu().numpy(), ref, **(kw or TOL))
+
+
+def _full_roi_head(train_cfg=None):
+    from dynamask_amd import bbox_heads, losses, mask_heads, registry, roi_extractors, roi_head  # noqa: F401
+    cfg = dict(type='DynaMaskRoIHead',
+               bbox_roi_extractor=dict(type='SingleRoIExtractor', **gi.BBOX_ROI_EXTRACTOR_CFG),
+               bbox_head=dict(type='Shared2FCBBoxHead', **gi.BBOX_HEAD_CFG),
+               mask_roi_extractor=dict(type='SingleRoIExtractor', **gi.MASK_ROI_EXTRACTOR_CFG),
+               mask_head=dict(type='DynaMaskHead', **gi.MASK_HEAD_CFG),
+               train_cfg=registry._to_cfgdict(train_cfg or gi.RCNN_TRAIN_CFG), test_cfg=None)
+    m = registry.build_head(cfg)
+    m.load_state_dict({**gi.head_state(), **gi.mask_pre_state(), **gi.bbox_train_head_state()}, strict=True)
+    m = m.cuda().train()
+    m.bbox_sampler.cpu_rng = True          # the reference run that made the golden drew on the CPU generator
+    return m
+
+
+def test_overlaps_assigner_sampler_targets_match_reference_golden(golden_dir):
+    g = _g11(golden_dir)
+    ti = gi.train_inputs()
+    m = _full_roi_head()
+    from dynamask_amd import assigners
+    torch.manual_seed(gi.TRAIN_SEED)
+    srs = []
+    for i in range(2):
+        props, gtb, gtl = ti['proposals'][i].cuda(), ti['gt_bboxes'][i].cuda(), ti['gt_labels'][i].cuda()
+        calc = assigners.BboxOverlaps2D()
+        _eq(calc(gtb, props), g[f'overlaps{i}'])                      # bit-exact: thresholds decide on these
+        _eq(calc(gtb, props, mode='iof'), g[f'iof{i}'])
+        ar = m.bbox_assigner.assign(props, gtb, None, gtl)
+        _eq(ar.gt_inds, g[f'gt_inds{i}'])
+        _eq(ar.max_overlaps, g[f'max_overlaps{i}'])
+        _eq(ar.labels, g[f'assigned_labels{i}'])
+        sr = m.bbox_sampler.sample(ar, props, gtb, gtl)
+        for k in ('pos_inds', 'neg_inds', 'pos_assigned_gt_inds', 'pos_is_gt'):
+            _eq(getattr(sr, k), g[f'{k}{i}'])
+        srs.append(sr)
+    a2 = assigners.MaxIoUAssigner(pos_iou_thr=0.7, neg_iou_thr=(0.1, 0.3), min_pos_iou=0.3, gt_max_assign_all=False)
+    _eq(a2.assign(ti['proposals'][0].cuda(), ti['gt_bboxes'][0].cuda()).gt_inds, g['alt_gt_inds'])
+    a3 = assigners.MaxIoUAssigner(pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5, match_low_quality=False)
+    _eq(a3.assign(ti['proposals'][1].cuda(), ti['gt_bboxes'][1].cuda(), None, ti['gt_labels'][1].cuda()).gt_inds,
+        g['nolq_gt_inds'])
+    lab, lw, bt, bw = m.bbox_head.get_targets(srs, None, None, m.train_cfg)
+    _eq(lab, g['labels'])
+    _eq(lw, g['label_weights'])
+    _close(bt, g['bbox_targets'], atol=1e-6, rtol=1e-5)
+    _eq(bw, g['bbox_weights'])
+
+
+def test_assigner_empty_cases():
+    from dynamask_amd import assigners
+    a = assigners.MaxIoUAssigner(0.5, 0.5)
+    boxes = torch.tensor([[0., 0., 10., 10.], [10., 10., 20., 20.]]).cuda()
+    r = a.assign(boxes, torch.zeros((0, 4)).cuda(), None, torch.zeros((0,), dtype=torch.long).cuda())
+    assert r.gt_inds.tolist() == [0, 0] and r.labels.tolist() == [-1, -1]          # no gt: all background
+    r = a.assign(torch.zeros((0, 4)).cuda(), boxes)
+    assert r.gt_inds.numel() == 0
+    # the reference docstring example (max_iou_assigner.py:82-88)
+    r = a.assign(boxes, torch.tensor([[0., 0., 10., 9.]]).cuda())
+    assert r.gt_inds.tolist() == [1, 0]
+
+
+def test_bbox_losses_and_gradients_match_reference_golden(golden_dir):
+    g = _g11(golden_dir)
+    m = _full_roi_head()
+    cs = torch.from_numpy(g['in_cls_score']).cuda().requires_grad_(True)
+    bp = torch.from_numpy(g['in_bbox_pred']).cuda().requires_grad_(True)
+    tg = [torch.from_numpy(g[k]).cuda() for k in ('labels', 'label_weights', 'bbox_targets', 'bbox_weights')]
+    ls = m.bbox_head.loss(cs, bp, None, *tg)
+    (ls['loss_cls'] * 1.5 + ls['loss_bbox'] * 0.5).backward()
+    _close(ls['loss_cls'], g['loss_cls_alone'], atol=1e-5, rtol=1e-5)
+    assert float(ls['acc']) == float(g['acc_alone'].reshape(-1)[0])
+    _close(ls['loss_bbox'], g['loss_bbox_alone'], atol=1e-6, rtol=1e-5)
+    _close(cs.grad, g['grad_cls_score'], atol=1e-6, rtol=1e-4)
+    _close(bp.grad, g['grad_bbox_pred'], atol=1e-7, rtol=1e-5)
+    tg[0] = torch.full_like(tg[0], 80)                                              # no positive row
+    ls0 = m.bbox_head.loss(cs.detach(), bp.detach(), None, *tg)
+    assert float(ls0['loss_bbox']) == 0.0 == float(g['loss_bbox_no_pos'])
+
+
+def test_forward_train_matches_reference_golden(golden_dir):
+    """DynaMaskRoIHead.forward_train called with the reference's argument list
+    (x, img_metas, proposal_list, gt_bboxes, gt_labels, gt_bboxes_ignore, gt_masks) -- two_stage.py:161-164."""
+    g = _g11(golden_dir)
+    ti = gi.train_inputs()
+    m = _full_roi_head()
+    feats = [f.cuda().requires_grad_(True) for f in ti['feats']]
+    gt_masks = [t.cuda() for t in ti['gt_masks']]
+    torch.manual_seed(gi.TRAIN_SEED)
+    losses = m.forward_train(feats, ti['img_metas'], [p.cuda() for p in ti['proposals']], [b.cuda() for b in ti['gt_bboxes']],
+                             [l.cuda() for l in ti['gt_labels']], None, gt_masks)
+    assert set(losses) == {'loss_cls', 'acc', 'loss_bbox', 'loss_masks'}
+    for k in ('loss_cls', 'loss_bbox', 'loss_masks'):
+        _close(losses[k].reshape(-1), g['ft.' + k].reshape(-1))
+    assert float(losses['acc']) == float(g['ft.acc'].reshape(-1)[0])
+    sum(v for k, v in losses.items() if 'loss' in k).backward()
+    named = dict(m.named_parameters())
+    worst = 0.0
+    for pre, keys in (('bbox_head.', gi.BBOX_GRAD_KEYS), ('mask_head.', gi.GRAD_KEYS),
+                      ('mask_predictor.', ('conv1.weight', 'bn1.weight', 'fc2.weight'))):
+        for k in keys:
+            got, ref = gi.grad_slice(named[pre + k].grad).cpu().numpy(), g['ft.grad.' + pre + k]
+            worst = max(worst, float(np.abs(got - ref).max()))
+            np.testing.assert_allclose(got, ref, err_msg=pre + k, **TOL)
+    for i in range(4):
+        if g[f'ft.grad_feat{i}'].size > 1:
+            np.testing.assert_allclose(gi.feat_grad_slice(feats[i].grad).cpu().numpy(), g[f'ft.grad_feat{i}'], **TOL)
+    print('forward_train: worst parameter-gradient abs error', worst)
+
+
+def test_reference_signature_mask_forward_train_equals_tensor_form(golden_dir):
+    """_mask_forward_train(x, sampling_results, bbox_feats, gt_bboxes, gt_masks, gt_labels, img_metas)
+    (dynamask_roi_head.py:48) unpacks to the tensor-level call of round 1."""
+    ti = gi.train_inputs()
+    m = _full_roi_head()
+    feats = [f.cuda() for f in ti['feats']]
+    torch.manual_seed(gi.TRAIN_SEED)
+    srs = []
+    for i in range(2):
+        props, gtb, gtl = ti['proposals'][i].cuda(), ti['gt_bboxes'][i].cuda(), ti['gt_labels'][i].cuda()
+        srs.append(m.bbox_sampler.sample(m.bbox_assigner.assign(props, gtb, None, gtl), props, gtb, gtl))
+    gt_masks = [t.cuda() for t in ti['gt_masks']]
+    n = sum(len(s.pos_inds) for s in srs)
+    noise = torch.rand(n, 4).cuda()
+    r1 = m._mask_forward_train(feats, srs, None, None, gt_masks, None, ti['img_metas'], noise=noise)
+    from dynamask_amd.roi_head import bbox2roi
+    tg = m.mask_head.get_targets([s.pos_bboxes for s in srs], [s.pos_assigned_gt_inds for s in srs], gt_masks)
+    r2 = m._mask_forward_train(feats, bbox2roi([s.pos_bboxes for s in srs]).contiguous(),
+                               torch.cat([s.pos_gt_labels for s in srs]), tg, noise=noise)
+    assert torch.equal(r1['mask_index'], r2['mask_index'])
+    _close(r1['loss_mask']['loss_masks'], r2['loss_mask']['loss_masks'].detach().cpu().numpy(), atol=1e-6, rtol=1e-6)
+    assert 'loss_flops' in r1 and float(r1['loss_flops']['loss_flops']) >= 0.0      # attached, not summed (Q3)
+
+
+def test_assign_sample_targets_at_config_size_match_oracle():
+    """configs/dynamask sizes: 1000 proposals, 512 samples (25 % positives) per image, 15 / 7 gts."""
+    from dynamask_amd import assigners, bbox_heads, registry  # noqa: F401
+    g = torch.Generator().manual_seed(77)
+    a_cfg = dict(pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5, match_low_quality=True, ignore_iof_thr=-1)
+    asg = assigners.MaxIoUAssigner(**a_cfg)
+    smp = assigners.RandomSampler(num=512, pos_fraction=0.25, neg_pos_ub=-1, add_gt_as_proposals=True, cpu_rng=True)
+    coder = bbox_heads.DeltaXYWHBBoxCoder(target_means=[0., 0., 0., 0.], target_stds=[0.1, 0.1, 0.2, 0.2])
+    for G in (15, 7):
+        c = torch.rand(G, 2, generator=g) * torch.tensor([1100.0, 600.0]) + 100
+        wh = torch.rand(G, 2, generator=g) * 300 + 30
+        gtb = torch.cat([c - wh / 2, c + wh / 2], 1)
+        gtl = torch.randint(0, 80, (G,), generator=g)
+        near = gtb[torch.randint(0, G, (600,), generator=g)] + torch.randn(600, 4, generator=g) * 15
+        far = torch.rand(400, 2, generator=g) * torch.tensor([1200.0, 700.0])
+        far = torch.cat([far, far + torch.rand(400, 2, generator=g) * 250 + 8], 1)
+        props = torch.cat([near, far, ])
+        props = torch.cat([props, torch.rand(1000, 1, generator=g)], 1)
+        ov_ref = ref_model.bbox_overlaps(gtb, props)
+        gi_ref, mo_ref, lab_ref = ref_model.max_iou_assign(ov_ref, 0.5, 0.5, 0.5, True, True, gtl)
+        ar = asg.assign(props.cuda(), gtb.cuda(), None, gtl.cuda())
+        _eq(ar.gt_inds, gi_ref.numpy())
+        _eq(ar.max_overlaps, mo_ref.numpy())
+        _eq(ar.labels, lab_ref.numpy())
+        torch.manual_seed(5)
+        sm_ref = ref_model.random_sample(gi_ref, lab_ref, props, gtb, gtl, 512, 0.25)
+        torch.manual_seed(5)
+        sr = smp.sample(ar, props.cuda(), gtb.cuda(), gtl.cuda())
+        _eq(sr.pos_inds, sm_ref['pos_inds'].numpy())
+        _eq(sr.neg_inds, sm_ref['neg_inds'].numpy())
+        assert len(sr.pos_inds) == 128 and len(sr.neg_inds) == 384
+        _close(coder.encode(sr.pos_bboxes, sr.pos_gt_bboxes),
+               ref_model.bbox2delta(sm_ref['pos_bboxes'], sm_ref['pos_gt_bboxes'], stds=(0.1, 0.1, 0.2, 0.2)).numpy(),
+               atol=1e-5, rtol=1e-5)
+
+
+def test_clip_grad_norm_on_flat_group():
+    """optimizer_config grad_clip(max_norm=35, norm_type=2): dm_sumsq + dm_clip_scale vs torch."""
+    from dynamask_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(4162462, generator=g) * 0.05).cuda()
+    ss = ops.sumsq(x)
+    ref = float((x.double() ** 2).sum())
+    assert abs(float(ss) - ref) / ref < 1e-5
+    y = x.clone()
+    ops.clip_scale_(y, ss, 35.0)
+    coef = 35.0 / (ref ** 0.5 + 1e-6)
+    torch.testing.assert_close(y, x * min(1.0, coef), atol=1e-7, rtol=1e-5)
+    assert coef < 1.0                                                   # the clip was active
+    z = x.clone()
+    ops.clip_scale_(z, ss, 1e6)                                         # inactive: untouched, bit for bit
+    assert torch.equal(z, x)
