@@ -63,16 +63,20 @@ __device__ __forceinline__ void axis_sample(float start, float bin, int g, int p
 }
 
 __device__ __forceinline__ int roi_level(float x1, float y1, float x2, float y2, float finest, int L) {
-  // floor(log2(sqrt(w*h)/finest + 1e-6)) clamped to [0, L-1], evaluated as
-  // threshold compares (exact wherever log2 is correctly rounded).
+  // floor(log2(sqrt(w*h)/finest + 1e-6)) clamped to [0, L-1] (single_level_roi_extractor.py:32-51)
+  // with log2 the CORRECTLY ROUNDED fp32 function (what torch's CPU log2 returns at these points):
+  // level >= k  <=>  round_f32(log2(t)) >= k  <=>  t >= T[k], the smallest float whose rounded
+  // log2 reaches k.  Just below a power of two the true log2 is k - 1.2e-7*2^-? and rounds UP to k
+  // once the floats around k are coarser than that: T[3] and T[4] sit one ulp below 8 and 16, T[5..7]
+  // two ulps below 32, 64, 128 (tests/test_ops_gpu.py sweeps +-64 ulps around every threshold).
+  // sqrt and the division are IEEE-rounded (hipcc default), like the reference's torch ops.
   const float s = sqrtf((x2 - x1) * (y2 - y1));
   const float t = s / finest + 1e-6f;
+  const unsigned T[8] = {0u, 0x40000000u, 0x40800000u, 0x40ffffffu, 0x417fffffu, 0x41fffffeu, 0x427ffffeu, 0x42fffffeu};
   int lvl = 0;
-  float thr = 2.0f;
-  for (int k = 1; k < L; ++k) {
-    if (t >= thr) lvl = k;
-    thr *= 2.0f;
-  }
+#pragma unroll
+  for (int k = 1; k < 8; ++k)
+    if (k < L && t >= __uint_as_float(T[k])) lvl = k;
   return lvl;
 }
 

@@ -142,7 +142,7 @@ def gumbel_select(logits, U, temperature=0.5, eps=1e-20):
 # --------------------------------------------------------------------- losses
 def binary_cross_entropy(pred, label):
     """losses/cross_entropy_loss.py:56-87 (weight=None, reduction='mean')."""
-    return F.binary_cross_entropy_with_logits(pred, label.float(), reduction='none').mean()
+    return F.binary_cross_entropy_with_logits(pred, label.to(pred.dtype), reduction='none').mean()
 
 
 def mask_cross_entropy(pred, target, class_weight):

@@ -399,3 +399,39 @@ def test_conv3x3_tail_couts_vs_torch(ops):
         wq = ops.pack_conv_weight(_dev(w), src_channels=cins)
         out = ops.conv2d([_dev(x) for x in xs], wq, _dev(b), cout, 3, relu=True)
         _close(out, ref)
+
+
+def test_roi_level_adversarial_sweep_around_every_threshold(ops):
+    """FPN level indices must be bit-exact (north star): RoIs whose scale sits within +-64 ulps of every
+    level threshold sqrt(w*h)/56 + 1e-6 = 2^k, on both sides, against the reference formula evaluated by
+    torch on the CPU (floor(log2(.)), single_level_roi_extractor.py:32-51) and against a float64 ideal
+    of the same fp32 input.  Note what the sweep pins: just below 8 (and 16) the correctly rounded fp32
+    log2 already returns 3.0 (4.0), so the level changes ONE ulp below the power of two."""
+    feats = [torch.zeros(1, 4, 128 >> l, 128 >> l) for l in range(4)]
+    for L in (4, 3):            # DM_MAX_LEVELS = 4; L = 3 also checks the clamp at the top level
+        boxes, side = [], []
+        for k in range(1, L):
+            w = np.float32(56.0 * 2 ** k)
+            # h with sqrt(w*h)/56 + 1e-6 ~ 2^k, then +-64 ulps of h (each ulp of h moves t by ~half an ulp)
+            h0 = np.float32((np.float64(2.0 ** k) - 1e-6) ** 2 * 56.0 ** 2 / np.float64(w))
+            h = h0
+            for _ in range(64):
+                h = np.nextafter(h, np.float32(0))
+            for _ in range(129):
+                boxes.append([0.0, 3.0, 5.0, 3.0 + float(w), 5.0 + float(h)])
+                h = np.nextafter(h, np.float32(1e9))
+        # 3 + w and 5 + h round, so x2 - x1 / y2 - y1 are not exactly w / h: the expectation is recomputed from
+        # the differences the kernel will actually see
+        rois = torch.tensor(boxes, dtype=torch.float32)
+        ref = ref_ops.map_roi_levels(rois, L)
+        ww = (rois[:, 3] - rois[:, 1]).numpy()
+        hh = (rois[:, 4] - rois[:, 2]).numpy()
+        t = (np.sqrt(ww * hh) / np.float32(56.0) + np.float32(1e-6)).astype(np.float32)
+        ideal = np.clip(np.floor(np.log2(t.astype(np.float64)).astype(np.float32)), 0, L - 1).astype(np.int64)
+        np.testing.assert_array_equal(ref.numpy(), ideal)              # torch's CPU log2 is correctly rounded here
+        _, lv = ops.roi_align([_dev(f) for f in feats[:L]], _dev(rois), 7, [1 / 4 / 2 ** l for l in range(L)],
+                              return_levels=True)
+        np.testing.assert_array_equal(lv.cpu().numpy().astype(np.int64), ref.numpy())
+        for k in range(1, L):                                          # the sweep straddles every threshold
+            seg = ref.numpy()[(k - 1) * 129:k * 129]
+            assert seg.min() == k - 1 and seg.max() == k, (L, k, seg.min(), seg.max())
