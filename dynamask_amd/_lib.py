@@ -3,8 +3,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdynamask_hip.so')
-ABI_VERSION = 9
+LIB_PATH = os.environ.get('DYNAMASK_HIP_LIB') or os.path.join(_HERE, 'libdynamask_hip.so')      # override: kernel experiments
+ABI_VERSION = 10
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -57,7 +57,7 @@ SIGNATURES = {
     'dm_mask_target_rois': ([_vp, _vp, _c_int, _c_float, _c_float, _vp, _vp], _c_int),
     'dm_threshold_ge': ([_vp, ctypes.c_longlong, _c_float, _vp, _vp], _c_int),
     'dm_paste_masks': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _vp, _vp], _c_int),
-    'dm_detail_target': ([_vp, _c_int, _c_int, _c_float, _c_float, _vp, _vp], _c_int),
+    'dm_detail_target': ([_vp, _c_int, _c_int, _c_float, _c_float, _vp, _vp, _vp], _c_int),
     'dm_bbox_overlaps': ([_vp, _c_int, _vp, _c_int, _c_int, _c_float, _vp, _vp], _c_int),
     'dm_max_iou_assign': ([_vp, _c_int, _c_int, _c_float, _c_float, _c_float, _c_float, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp], _c_int),
     'dm_bbox_encode': ([_vp, _vp, _c_int, _vp, _vp, _vp, _vp], _c_int),

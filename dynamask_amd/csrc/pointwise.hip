@@ -320,8 +320,13 @@ __global__ void gumbel_kernel(const float* __restrict__ logits, const float* __r
 
 // ------------------------------------------------------------------ K13
 __global__ __launch_bounds__(256) void detail_target_kernel(const float* __restrict__ masks, int N, int S, float f0,
-                                                            float f1, float* __restrict__ out) {
+                                                            float f1, const float* __restrict__ fuse_dev,
+                                                            float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  if (fuse_dev) {          // the fuse kernel is a weight-decayed parameter: read its current value on the device
+    f0 = fuse_dev[0];
+    f1 = fuse_dev[1];
+  }
   float* m = lds;  // [S*S]
   const int r = blockIdx.x;
   const float* src = masks + (size_t)r * S * S;
@@ -453,13 +458,13 @@ extern "C" int dm_gumbel_select_fwd(const float* logits, const float* U, int N, 
   return dm_check_launch();
 }
 
-extern "C" int dm_detail_target(const float* masks, int N, int S, float fuse0, float fuse1, float* out,
-                                dm_stream_t stream) {
+extern "C" int dm_detail_target(const float* masks, int N, int S, float fuse0, float fuse1, const float* fuse_dev,
+                                float* out, dm_stream_t stream) {
   if (!masks || !out || N < 0 || S <= 0) return DM_ERR_INVALID_ARG;
   if ((size_t)S * S * sizeof(float) > 64 * 1024) return DM_ERR_UNSUPPORTED;
   if (N == 0) return DM_OK;
   DM_LAUNCH(detail_target_kernel, dim3(N), dim3(256), S * S * sizeof(float), (hipStream_t)stream, masks, N, S,
-                     fuse0, fuse1, out);
+                     fuse0, fuse1, fuse_dev, out);
   return dm_check_launch();
 }
 

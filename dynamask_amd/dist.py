@@ -40,6 +40,7 @@ class FlatParamGroup:
                 self.flat_param[off:off + k].copy_(p.detach().reshape(-1))
                 p.data = self.flat_param[off:off + k].view_as(p)
                 p.grad = self.flat_grad[off:off + k].view_as(p)
+                p._dm_direct_grad = True       # train_path._direct: backward kernels may accumulate into the view
                 off += k
         self.group = process_group
         self.steps = 0

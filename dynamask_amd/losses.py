@@ -22,8 +22,7 @@ class DetailTarget(nn.Module):
         self.fuse_kernel = nn.Parameter(torch.tensor([[7. / 10], [3. / 10]], dtype=torch.float32).reshape(1, 2, 1, 1))
 
     def forward(self, gtmasks):
-        fk = self.fuse_kernel.detach().reshape(-1).tolist()
-        return ops.detail_target(gtmasks.contiguous(), fk).unsqueeze(1)
+        return ops.detail_target(gtmasks.contiguous(), self.fuse_kernel.detach().reshape(-1).contiguous()).unsqueeze(1)
 
 
 class _DynaLossFn(torch.autograd.Function):
@@ -106,7 +105,7 @@ class DynaCrossEntropyLoss(nn.Module):
         n = len(stage_instance_preds)
         n_used = sum(1 for idx in range(n) if idx <= self.start_stage)
         assert len(self.stage_instance_loss_weight) == n_used      # cross_entropy_loss.py:482
-        fuse = self.detail_target.fuse_kernel.detach().reshape(-1).tolist()
+        fuse = self.detail_target.fuse_kernel.detach().reshape(-1).contiguous()      # stays on the device (no .tolist() sync)
         loss = _DynaLossFn.apply(mask_labels, list(self.stage_detail_loss_weight), float(self.cb_loss_weight),
                                  int(self.start_stage), fuse, n, *stage_instance_preds, *stage_detail_preds,
                                  *stage_instance_targets)

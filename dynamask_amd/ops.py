@@ -413,11 +413,17 @@ def gumbel_select(logits, U, temperature=0.5):
 
 
 def detail_target(masks, fuse=(0.7, 0.3)):
+    """fuse: two host floats, or a device tensor holding them (read by the kernel: no sync)."""
     _chk(masks, 'masks')
     N, S = masks.shape[0], masks.shape[-1]
     out = torch.empty((N, S, S), device=masks.device, dtype=torch.float32)
-    check(lib().dm_detail_target(_p(masks), N, S, float(fuse[0]), float(fuse[1]), _p(out), _stream()),
-          'dm_detail_target')
+    if isinstance(fuse, torch.Tensor):
+        fd = _chk(fuse.detach().reshape(-1), 'fuse')
+        assert fd.numel() == 2
+        rc = lib().dm_detail_target(_p(masks), N, S, 0.0, 0.0, _p(fd), _p(out), _stream())
+    else:
+        rc = lib().dm_detail_target(_p(masks), N, S, float(fuse[0]), float(fuse[1]), None, _p(out), _stream())
+    check(rc, 'dm_detail_target')
     return out
 
 
@@ -615,9 +621,10 @@ def dcn_weight_permute(src, cout, c, to_colmajor, dst=None, accumulate=False):
     return dst
 
 
-def deform_conv_backward(x, offset, weight, grad_out, deform_groups):
+def deform_conv_backward(x, offset, weight, grad_out, deform_groups, gw_accum=None):
     """(grad_x, grad_offset, grad_weight) of DCNv1 3x3.  The two GEMMs of the
-    reference's backward run as 1x1 convs over the tap-major column matrix."""
+    reference's backward run as 1x1 convs over the tap-major column matrix.
+    ``gw_accum``: [Cout, C, 3, 3] tensor the weight gradient is ADDED to (then None is returned for it)."""
     NB, C, H, W = x.shape
     cout = weight.shape[0]
     wt = dcn_weight_permute(weight.contiguous(), cout, C, True)                # [(tap,ci)][co]
@@ -626,6 +633,9 @@ def deform_conv_backward(x, offset, weight, grad_out, deform_groups):
     del colgrad
     col = deform_im2col(x, offset, deform_groups)
     gw_cm = conv2d_wgrad(grad_out, col, 1)                                     # [co][(tap,ci)]
+    if gw_accum is not None:
+        dcn_weight_permute(gw_cm, cout, C, False, dst=gw_accum, accumulate=True)
+        return gx, goff, None
     gw = dcn_weight_permute(gw_cm, cout, C, False)
     return gx, goff, gw
 

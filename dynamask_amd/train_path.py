@@ -35,6 +35,21 @@ class RoIExtractFn(torch.autograd.Function):
         return (None, None, None, None, None, *grads)
 
 
+def _direct(p):
+    """The tensor a parameter's gradient may be accumulated into IN PLACE, or None.
+
+    ``FlatParamGroup`` (dist.py) keeps every ``p.grad`` as a zero-filled view of its flat gradient
+    buffer and marks the parameter ``_dm_direct_grad``.  The weight-gradient kernels accumulate
+    (split-K atomics) anyway, so they add straight into that view and the backward returns None for
+    the parameter: no zero-filled temporary and no AccumulateGrad ``add_`` kernel per parameter
+    (about 120 small launches per training step).  Without the mark the gradient is returned to
+    autograd as usual."""
+    g = p.grad
+    if g is not None and getattr(p, '_dm_direct_grad', False) and g.is_contiguous() and g.dtype == torch.float32:
+        return g
+    return None
+
+
 def _flipped(conv, key, w):
     """Packed weights of the data-gradient convolution, cached on the module."""
     return conv._pk.get(('flip',) + key, w, lambda t: ops.pack_conv_weight(t, transpose_flip=True))
@@ -118,9 +133,28 @@ class MaskHeadFn(torch.autograd.Function):
             return g if g is not None else torch.zeros_like(like)
 
         def conv_params_bwd(conv, dy, srcs, ks):
-            pgrad[conv.weight] = ops.conv2d_wgrad(dy, srcs, ks)
+            tw = _direct(conv.weight)
+            if tw is not None:
+                ops.conv2d_wgrad(dy, srcs, ks, dw=tw)
+            else:
+                pgrad[conv.weight] = ops.conv2d_wgrad(dy, srcs, ks)
             if conv.bias is not None:
-                pgrad[conv.bias] = ops.channel_sum(dy)
+                tb = _direct(conv.bias)
+                if tb is not None:
+                    ops.channel_sum(dy, out=tb)
+                else:
+                    pgrad[conv.bias] = ops.channel_sum(dy)
+
+        def logit_grads(inst, det, nc, c):
+            """Accumulation targets of class_logits_backward (zero-filled temporaries, or the flat views)."""
+            outs, keep = [], []
+            for p_, shape in ((inst.weight, (nc, c)), (inst.bias, (nc,)), (det.weight, (nc, c)), (det.bias, (nc,))):
+                t = _direct(p_)
+                if t is None:
+                    t = zeros(shape)
+                    keep.append((p_, t))
+                outs.append(t.view(shape))
+            return outs, keep
 
         def data_grad(conv, dy, lo, hi, ks, out=None, accumulate=False):
             """d/d(input channels lo:hi) of a conv: forward kernel, transposed+rotated weights."""
@@ -142,11 +176,11 @@ class MaskHeadFn(torch.autograd.Function):
         fi, fd = head.final_instance_logits, head.final_detail_logits
         nc, c = head.stage_num_classes[-1], fi.in_channels
         g_x = torch.empty_like(x_last)
-        gwi, gwd, gbi, gbd = zeros((nc, c)), zeros((nc, c)), zeros((nc,)), zeros((nc,))
+        (gwi, gbi, gwd, gbd), keep = logit_grads(fi, fd, nc, c)
         ops.class_logits_backward(x_last, fi.weight.detach().view(nc, c), fd.weight.detach().view(nc, c), sv['lab_last'],
                                   g_ip, g_dp, g_x, False, gwi, gbi, gwd, gbd)
-        pgrad[fi.weight], pgrad[fi.bias] = gwi.view_as(fi.weight), gbi
-        pgrad[fd.weight], pgrad[fd.bias] = gwd.view_as(fd.weight), gbd
+        for p_, t in keep:
+            pgrad[p_] = t.view_as(p_)
 
         # ---------------- SFM stages, last to first; g_x = grad wrt the stage's output
         for idx in reversed(range(len(head.stages))):
@@ -165,8 +199,10 @@ class MaskHeadFn(torch.autograd.Function):
             g_f2 = data_grad(stage.fuse_transform_out, dy, 0, c, 1)
             ops.relu_backward_(g_f2, f2)
             dcn = stage.fuse_conv[1]
-            g_f1, g_off, gw_dcn = ops.deform_conv_backward(f1, off, dcn.weight.detach(), g_f2, dcn.deform_groups)
-            pgrad[dcn.weight] = gw_dcn
+            g_f1, g_off, gw_dcn = ops.deform_conv_backward(f1, off, dcn.weight.detach(), g_f2, dcn.deform_groups,
+                                                           gw_accum=_direct(dcn.weight))
+            if gw_dcn is not None:
+                pgrad[dcn.weight] = gw_dcn
             conv_params_bwd(dcn.conv_offset, g_off, f1, 3)
             data_grad(dcn.conv_offset, g_off, 0, c, 3, out=g_f1, accumulate=True)
             ops.relu_backward_(g_f1, f1)
@@ -182,11 +218,11 @@ class MaskHeadFn(torch.autograd.Function):
             ops.sigmoid_backward(tail[:, co - 1:co], g_tail[:, co - 1:co], g_sig[:, 1:2], g_logit=g_dp)
             il, dl = stage.instance_logits, stage.detail_logits
             nc = stage.num_classes
-            gwi, gwd, gbi, gbd = zeros((nc, c)), zeros((nc, c)), zeros((nc,)), zeros((nc,))
+            (gwi, gbi, gwd, gbd), keep = logit_grads(il, dl, nc, c)
             ops.class_logits_backward(xin, il.weight.detach().view(nc, c), dl.weight.detach().view(nc, c), labels, g_ip, g_dp,
                                       g_xin, True, gwi, gbi, gwd, gbd)
-            pgrad[il.weight], pgrad[il.bias] = gwi.view_as(il.weight), gbi
-            pgrad[dl.weight], pgrad[dl.bias] = gwd.view_as(dl.weight), gbd
+            for p_, t in keep:
+                pgrad[p_] = t.view_as(p_)
             # semantic branch: point sample adjoint -> relu -> 1x1 conv on the FPN map
             g_sem = ops.point_sample_backward(g_isf, tuple(sem.shape), rois, stage.spatial_scale)
             ops.relu_backward_(g_sem, sem)
@@ -261,11 +297,21 @@ class MaskPreFn(torch.autograd.Function):
         n = x.shape[0]
         pg = {}
 
+        def params_bwd(weight, bias, gy4, x4, ks, wshape):
+            tw, tb = _direct(weight), _direct(bias)
+            if tw is not None:
+                ops.conv2d_wgrad(gy4, x4, ks, dw=tw.view(wshape))
+            else:
+                pg[weight] = ops.conv2d_wgrad(gy4, x4, ks).view_as(weight)
+            if tb is not None:
+                ops.channel_sum(gy4, out=tb)
+            else:
+                pg[bias] = ops.channel_sum(gy4)
+
         def fc_bwd(fc, gy, xin, need_data=True):
             gy4 = gy.contiguous().view(n, fc.out_features, 1, 1)
             x4 = xin.contiguous().view(n, fc.in_features, 1, 1)
-            pg[fc.weight] = ops.conv2d_wgrad(gy4, x4, 1).view(fc.out_features, fc.in_features)
-            pg[fc.bias] = ops.channel_sum(gy4)
+            params_bwd(fc.weight, fc.bias, gy4, x4, 1, (fc.out_features, fc.in_features, 1, 1))
             if not need_data:
                 return None
             wq = fc._pk.get('flip', fc.weight, lambda t: ops.pack_conv_weight(
@@ -273,8 +319,7 @@ class MaskPreFn(torch.autograd.Function):
             return ops.conv2d(gy4, wq, None, fc.in_features, 1).view(n, fc.in_features)
 
         def conv_bwd(conv, gy, xin, need_data=True):
-            pg[conv.weight] = ops.conv2d_wgrad(gy, xin, conv.kernel_size)
-            pg[conv.bias] = ops.channel_sum(gy)
+            params_bwd(conv.weight, conv.bias, gy, xin, conv.kernel_size, tuple(conv.weight.shape))
             if not need_data:
                 return None
             wq = conv._pk.get(('flip', 0, conv.in_channels), conv.weight,

@@ -197,9 +197,11 @@ int dm_gumbel_select_fwd(const float* logits, const float* U, int N, int K, floa
 /* ---------------------------------------------------------------------------
  * K13  DetailTarget: Laplacian boundary pyramid target, bit-exact {0,1}.
  * replaces: DetailTarget.forward (losses/cross_entropy_loss.py:363-418).
- * masks [N, S, S] in {0,1} -> out [N, S, S]; fuse = the two fuse_kernel weights
+ * masks [N, S, S] in {0,1} -> out [N, S, S]; fuse = the two fuse_kernel weights, either as host
+ * values or (fuse_dev != NULL: two floats in device memory, read by the kernel -- the reference keeps
+ * them as an nn.Parameter that weight decay changes every step, Quirk Q7; no host round trip)
  * ------------------------------------------------------------------------- */
-int dm_detail_target(const float* masks, int N, int S, float fuse0, float fuse1, float* out,
+int dm_detail_target(const float* masks, int N, int S, float fuse0, float fuse1, const float* fuse_dev, float* out,
                      dm_stream_t stream);
 
 /* ---------------------------------------------------------------------------
