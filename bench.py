@@ -25,7 +25,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
 
 IMG_H, IMG_W = 800, 1333
 ROIS_PER_IMG = 512
@@ -34,11 +33,10 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 
 
 def build_head(dev):
-    import golden_inputs as gi
     from dynamask_amd import losses, mask_heads, registry, roi_extractors, roi_head, synth  # noqa: F401
     cfg = dict(type='DynaMaskRoIHead',
-               mask_roi_extractor=dict(type='SingleRoIExtractor', **gi.MASK_ROI_EXTRACTOR_CFG),
-               mask_head=dict(type='DynaMaskHead', **gi.MASK_HEAD_CFG))
+               mask_roi_extractor=dict(type='SingleRoIExtractor', **synth.MASK_ROI_EXTRACTOR_CFG),
+               mask_head=dict(type='DynaMaskHead', **synth.MASK_HEAD_CFG))
     m = registry.build_head(cfg)
     sd = {**synth.init_dynamask_head_state(seed=5, test_mode=True), **synth.init_mask_pre_state(seed=6)}
     m.load_state_dict(sd, strict=True)
@@ -108,21 +106,20 @@ def time_kernel_graphed(fn, reps=20, iters=5, warmup=2):
         return time_kernel(fn)
 
 
-def roialign_algorithmic_bytes(rois, feats, C=256, P=14):
-    """output write + rois + per-RoI footprint read (capped per level),
-    overall read capped by the size of the levels touched."""
-    from oracle import ref_ops
+def roialign_algorithmic_bytes(rois, levels, feat_shapes, C=256, P=14):
+    """output write + rois + per-RoI footprint read (capped per level), overall read capped
+    by the size of the levels touched.  ``levels`` = the FPN level of each RoI as the HIP kernel itself
+    reports it (levels_out of dm_roi_align_fwd): the denominator does not depend on the checker."""
     N = rois.shape[0]
     write = N * C * P * P * 4 + N * 20
-    lv = ref_ops.map_roi_levels(rois, 4)
     strides = (4, 8, 16, 32)
     read = 0
     touched = 0
     for l in range(4):
-        sel = rois[lv == l]
+        sel = rois[levels == l]
         if len(sel) == 0:
             continue
-        H, W = feats[l].shape[2:]
+        H, W = feat_shapes[l]
         touched += C * 4 * H * W
         w = torch.ceil((sel[:, 3] - sel[:, 1]) / strides[l]) + 2
         h = torch.ceil((sel[:, 4] - sel[:, 2]) / strides[l]) + 2
@@ -468,7 +465,8 @@ def main():
         # ---- RoIAlign 14x14 multi-level (the north star's HBM-roofline kernel) ----
         ext = head.mask_roi_extractor
         ms_r = time_kernel_graphed(lambda: ext(feats[:4], rois))
-        nbytes = roialign_algorithmic_bytes(rois_c, feats_c)
+        _, lv = ops.roi_align(feats[:4], rois, 14, [1 / 4, 1 / 8, 1 / 16, 1 / 32], return_levels=True)
+        nbytes = roialign_algorithmic_bytes(rois_c, lv.cpu().long(), [tuple(f.shape[2:]) for f in feats_c[:4]])
         ach_r = nbytes / (ms_r * 1e-3) / 1e9
         result['roofline_roialign'] = {'kernel': 'roi_align_tile_kernel (one launch; LDS-staged channel-quad tiles, merged stencils; P2..P5 -> [512,256,14,14])', 'bound': 'hbm',
                                        'achieved': ach_r, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
@@ -501,7 +499,7 @@ def main():
                     'with_selector adds RoIAlign56(P2) + MaskPre + argmax (random-init selector: histogram is arbitrary)'}
         # ---- SURVEY 8d reading (i) of cfg-2 and cfg-5: the fixed-28x28 FCN producers ----
         from dynamask_amd import registry, synth
-        import golden_inputs as gi
+        gi = synth          # the reference's config values
 
         def fcn_ms(up, fpn_feats, fpn_rois):
             cfg = dict(type='FCNMaskHead', **gi.FCN_HEAD_CFG)
@@ -593,6 +591,7 @@ def main():
             # whole RoI head at the reference's test shape: 1000 proposals -> bbox branch
             # (RoIAlign 7x7, 2 FC + predictors, decode, NMS) -> <= 100 detections -> mask branch -> RLE
             from dynamask_amd import bbox_heads  # noqa: F401
+            gi = synth
             rh = registry.build_head(dict(
                 type='DynaMaskRoIHead',
                 bbox_roi_extractor=dict(type='SingleRoIExtractor', **gi.BBOX_ROI_EXTRACTOR_CFG),

@@ -221,3 +221,37 @@ def init_bbox_head_state(seed=8, prefix='bbox_head.', in_channels=256, roi_feat=
     sd[prefix + 'fc_reg.weight'] = torch.randn((4 * num_classes, fc_out), generator=g) * 0.05
     sd[prefix + 'fc_reg.bias'] = torch.randn(4 * num_classes, generator=g) * 0.05
     return sd
+
+
+# ------------------------------------------------------------------ the reference's config values
+# configs/dynamask/coco/r50-dynamask-1x.py:60-91
+MASK_ROI_EXTRACTOR_CFG = dict(
+    roi_layer=dict(type='RoIAlign', output_size=14, sampling_ratio=0),
+    out_channels=256, featmap_strides=[4, 8, 16, 32])
+LOSS_CFG = dict(
+    stage_instance_loss_weight=[0.5, 0.75, 0.75, 1.0],
+    stage_detail_loss_weight=[0.5, 0.5, 0.5, 0.5],
+    detail_loss_weight=1.0, cb_loss_weight=0.8, boundary_width=2, start_stage=4)
+MASK_HEAD_CFG = dict(
+    num_convs_instance=2, num_convs_semantic=4,
+    conv_in_channels_instance=256, conv_in_channels_semantic=256,
+    conv_kernel_size_instance=3, conv_kernel_size_semantic=3,
+    conv_out_channels_instance=256, conv_out_channels_semantic=256,
+    conv_cfg=None, norm_cfg=None, semantic_out_stride=[16, 8, 4],
+    mask_use_sigmoid=True, pre_upsample_last_stage=False,
+    stage_num_classes=[80, 80, 80, 1], stage_sup_size=[14, 28, 56, 112],
+    upsample_cfg=dict(type='bilinear', scale_factor=2),
+    loss_cfg=dict(type='DynaCrossEntropyLoss', **LOSS_CFG))
+# configs/_base_/models/mask_rcnn_r50_fpn.py:57-68
+FCN_HEAD_CFG = dict(num_convs=4, in_channels=256, conv_out_channels=256, num_classes=80,
+                    loss_mask=dict(type='CrossEntropyLoss', use_mask=True, loss_weight=1.0))
+# configs/dynamask/coco/r50-dynamask-1x.py:41-59,141-150
+BBOX_HEAD_CFG = dict(in_channels=256, fc_out_channels=1024, roi_feat_size=7, num_classes=80,
+                     bbox_coder=dict(type='DeltaXYWHBBoxCoder', target_means=[0., 0., 0., 0.],
+                                     target_stds=[0.1, 0.1, 0.2, 0.2]),
+                     reg_class_agnostic=False,
+                     loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=2.0),
+                     loss_bbox=dict(type='L1Loss', loss_weight=2.0))
+BBOX_ROI_EXTRACTOR_CFG = dict(roi_layer=dict(type='RoIAlign', output_size=7, sampling_ratio=0), out_channels=256,
+                              featmap_strides=[4, 8, 16, 32])
+RCNN_TEST_CFG = dict(score_thr=0.05, nms=dict(type='nms', iou_threshold=0.5), max_per_img=100, mask_thr_binary=0.5)

@@ -1,5 +1,8 @@
-"""Parity of the backward kernels (C ABI) against autograd of the CPU oracle.
-Float atomics make sums order-dependent: atol 2e-4 on gradient sums."""
+"""Parity of the backward kernels (C ABI) against autograd of the CPU oracle at the north star's gate,
+atol = rtol = 1e-4.  One kind of output needs a second look: a weight gradient is a sum of 10^3..10^5
+products, and where those cancel to almost nothing an fp32 sum -- in ANY order, the oracle's included --
+is only good to a few ulps of the sum of the products' magnitudes, not of the result.  Such outputs are
+checked against an fp64 oracle: within the gate, or within 8 ulps of that magnitude sum (`_close_sum`)."""
 import numpy as np
 import pytest
 import torch
@@ -9,7 +12,7 @@ import golden_inputs as gi
 from oracle import ref_ops
 
 pytestmark = pytest.mark.gpu
-TOL = dict(atol=2e-4, rtol=2e-4)
+TOL = dict(atol=1e-4, rtol=1e-4)
 
 
 def _g(seed):
@@ -25,6 +28,16 @@ def _dev(t):
 def _close(a, b, **kw):
     kw = kw or TOL
     np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), **kw)
+
+
+def _close_sum(got, ref64, mag64, what=''):
+    """got: fp32 sums from the kernel; ref64: the same sums in fp64; mag64: sum of |products| per output."""
+    err = (got.detach().cpu().double() - ref64).abs()
+    gate = 1e-4 + 1e-4 * ref64.abs()
+    cond = 8 * 2.0 ** -24 * mag64
+    bad = (err > torch.maximum(gate, cond))
+    assert not bool(bad.any()), (what, int(bad.sum()), float(err.max()))
+    return int((err > gate).sum())          # how many outputs needed the conditioning bound
 
 
 @pytest.fixture(scope='module')
@@ -47,8 +60,14 @@ def test_conv_wgrad_bias_and_data_grad(ops, N, Cs, Cout, S, ks):
     y.backward(go)
     gy = _dev(go)
     ops.relu_backward_(gy, _dev(y))
-    _close(ops.conv2d_wgrad(gy, [_dev(t) for t in xs], ks), w.grad, atol=5e-4, rtol=2e-4)
-    _close(ops.channel_sum(gy), b.grad, atol=5e-4, rtol=2e-4)
+    # weight / bias gradients against fp64 sums of the same fp32 inputs
+    gyd, xd = gy.cpu().double(), xcat.detach().double()
+    ref64 = torch.nn.grad.conv2d_weight(xd, tuple(w.shape), gyd, padding=ks // 2)
+    mag64 = torch.nn.grad.conv2d_weight(xd.abs(), tuple(w.shape), gyd.abs(), padding=ks // 2)
+    n_cond = _close_sum(ops.conv2d_wgrad(gy, [_dev(t) for t in xs], ks), ref64, mag64, 'wgrad')
+    n_cond += _close_sum(ops.channel_sum(gy), gyd.sum((0, 2, 3)), gyd.abs().sum((0, 2, 3)), 'bias')
+    print(f'wgrad {N}x{Cs}->{Cout}@{S} k{ks}: {n_cond} of {w.numel() + Cout} sums outside 1e-4 but within 8 ulp of their magnitude sum')
+    assert n_cond <= 0.001 * w.numel()
     # data gradient: forward kernel with transposed / rotated weights, sources = [dy]
     gx = ops.conv2d(gy, ops.pack_conv_weight(_dev(w), transpose_flip=True), None, cin, ks)
     _close(gx, xcat.grad)
@@ -97,10 +116,10 @@ def test_class_logits_backward(ops):
     ops.class_logits_backward(_dev(x), _dev(wi.view(nc, C)), _dev(wd.view(nc, C)), _dev(labels), _dev(g1), _dev(g2), gx,
                               True, gwi, gbi, gwd, gbd)
     _close(gx - 1.0, x.grad)
-    _close(gwi, wi.grad.view(nc, C), atol=5e-4, rtol=2e-4)
-    _close(gwd, wd.grad.view(nc, C), atol=5e-4, rtol=2e-4)
-    _close(gbi, bi.grad, atol=5e-4, rtol=2e-4)
-    _close(gbd, bd.grad, atol=5e-4, rtol=2e-4)
+    _close(gwi, wi.grad.view(nc, C), atol=1e-4, rtol=1e-4)
+    _close(gwd, wd.grad.view(nc, C), atol=1e-4, rtol=1e-4)
+    _close(gbi, bi.grad, atol=1e-4, rtol=1e-4)
+    _close(gbd, bd.grad, atol=1e-4, rtol=1e-4)
 
 
 def test_sigmoid_backward(ops):
@@ -114,7 +133,7 @@ def test_sigmoid_backward(ops):
     gw = torch.zeros(4, 3, 9, 9).cuda()
     gw[:, 1:2] = _dev(ga)
     out = ops.sigmoid_backward(wide[:, 3:4], gw[:, 1:2], _dev(gb))
-    _close(out, logit.grad, atol=1e-5, rtol=1e-4)
+    _close(out, logit.grad, atol=1e-4, rtol=1e-4)
 
 
 @pytest.mark.parametrize('N,C,S', [(5, 64, 14), (3, 32, 28), (2, 16, 9)])
@@ -128,6 +147,6 @@ def test_deform_conv_backward(ops, N, C, S):
     go = torch.randn(y.shape, generator=_g(73))
     y.backward(go)
     gx, goff, gw = ops.deform_conv_backward(_dev(x), _dev(off), _dev(w), _dev(go), 2)
-    _close(gx, x.grad, atol=5e-4, rtol=2e-4)
-    _close(goff, off.grad, atol=5e-4, rtol=2e-4)
-    _close(gw, w.grad, atol=5e-4, rtol=2e-4)
+    _close(gx, x.grad, atol=1e-4, rtol=1e-4)
+    _close(goff, off.grad, atol=1e-4, rtol=1e-4)
+    _close(gw, w.grad, atol=1e-4, rtol=1e-4)

@@ -7,6 +7,7 @@ tag=${1:-rXX}
 export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 out=gpurun_out
+rm -rf $out/traffic_fetch $out/traffic_write $out/traffic_mfma $out/prof_bench $out/prof_roof $out/prof_head $out/prof_train
 stats() {  # stats <dir> <dest>: copy the kernel_stats.csv of a rocprofv3 --stats run
   cp "$(ls -t $1/*/*kernel_stats.csv | head -1)" "$2"
 }
@@ -27,8 +28,12 @@ python3 tools/kbench.py > $out/${tag}_kbench.txt 2>&1
 python3 tools/tail_probe.py > $out/${tag}_tail_probe.txt 2>&1
 PROBE_ITERS=6 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/traffic_fetch -- python3 tools/pmc_probe.py > /dev/null 2>&1
 PROBE_ITERS=6 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/traffic_write -- python3 tools/pmc_probe.py > /dev/null 2>&1
-{ python3 tools/pmc_sum.py $out/traffic_fetch; python3 tools/pmc_sum.py $out/traffic_write; } > $out/${tag}_traffic_pmc.txt
+PROBE_ITERS=6 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/traffic_mfma -- python3 tools/pmc_probe.py > /dev/null 2>&1
+{ python3 tools/pmc_sum.py $out/traffic_fetch; python3 tools/pmc_sum.py $out/traffic_write; python3 tools/pmc_sum.py $out/traffic_mfma; } > $out/${tag}_traffic_pmc.txt
 cat $out/${tag}_traffic_pmc.txt
+# the file bench.py reads roofline.traffic from: regenerated with every collection (copy to profiles/pmc_traffic.json)
+python3 tools/make_pmc_json.py $out/traffic_fetch $out/traffic_write $out/traffic_mfma $out/${tag}_roofline_kernel_stats.csv 6 $out/${tag}_pmc_traffic.json > /dev/null
+echo "pmc json done"
 hipcc --offload-arch=gfx950 -O3 tools/micro/mfma_lds.hip -o $out/mfma_lds && $out/mfma_lds > $out/${tag}_mfma_lds_micro.txt
 python3 tools/small_n.py > $out/${tag}_small_n.txt 2>&1
 echo "all done"
