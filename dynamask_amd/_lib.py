@@ -4,7 +4,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DYNAMASK_HIP_LIB') or os.path.join(_HERE, 'libdynamask_hip.so')      # override: kernel experiments
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -58,6 +58,11 @@ SIGNATURES = {
     'dm_threshold_ge': ([_vp, ctypes.c_longlong, _c_float, _vp, _vp], _c_int),
     'dm_paste_masks': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _vp, _vp], _c_int),
     'dm_detail_target': ([_vp, _c_int, _c_int, _c_float, _c_float, _vp, _vp, _vp], _c_int),
+    'dm_carafe_bwd_scratch_floats': ([_c_int, _c_int, _c_int, _c_int, _c_int], ctypes.c_longlong),
+    'dm_carafe_bwd': ([_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp], _c_int),
+    'dm_upsample2x_nearest_fwd': ([_vp, _c_int, _c_int, _c_int, _vp, _vp], _c_int),
+    'dm_upsample2x_nearest_bwd': ([_vp, _c_int, _c_int, _c_int, _vp, _vp], _c_int),
+    'dm_pixel_unshuffle2x': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp], _c_int),
     'dm_bbox_overlaps': ([_vp, _c_int, _vp, _c_int, _c_int, _c_float, _vp, _vp], _c_int),
     'dm_max_iou_assign': ([_vp, _c_int, _c_int, _c_float, _c_float, _c_float, _c_float, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp], _c_int),
     'dm_bbox_encode': ([_vp, _vp, _c_int, _vp, _vp, _vp, _vp], _c_int),

@@ -393,6 +393,45 @@ __global__ __launch_bounds__(256) void mask_loss_kernel(const float* __restrict_
   }
 }
 
+// nearest x2 (nn.Upsample(scale_factor=2, mode='nearest'), FCNMaskHead upsample_cfg type 'nearest',
+// fcn_mask_head.py:88-96), its adjoint (sum of the 2x2 block), and the space-to-depth of a x2 map
+// (out[n, (dy*2+dx)*C + c, y, x] = in[n, c, 2y+dy, 2x+dx]) that turns the 2x2 stride-2 deconvolution's
+// backward into plain 1x1 GEMMs.
+__global__ __launch_bounds__(256) void nearest2x_kernel(const float* __restrict__ in, long long total_out, int H, int W,
+                                                        float* __restrict__ out) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total_out) return;
+  const int OW = 2 * W, OH = 2 * H;
+  const int ox = (int)(idx % OW);
+  const int oy = (int)((idx / OW) % OH);
+  const long long nc = idx / ((long long)OW * OH);
+  out[idx] = in[(nc * H + (oy >> 1)) * W + (ox >> 1)];
+}
+
+__global__ __launch_bounds__(256) void nearest2x_bwd_kernel(const float* __restrict__ gout, long long total_in, int H, int W,
+                                                            float* __restrict__ gin) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total_in) return;
+  const int x = (int)(idx % W);
+  const int y = (int)((idx / W) % H);
+  const long long nc = idx / ((long long)W * H);
+  const float* g = gout + (nc * 2 * H + 2 * y) * (2 * W) + 2 * x;
+  gin[idx] = (g[0] + g[1]) + (g[2 * W] + g[2 * W + 1]);
+}
+
+__global__ __launch_bounds__(256) void unshuffle2x_kernel(const float* __restrict__ in, int NB, int C, int H, int W,
+                                                          float* __restrict__ out) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;      // over out [NB, 4C, H, W]
+  const long long total = (long long)NB * 4 * C * H * W;
+  if (idx >= total) return;
+  const int x = (int)(idx % W);
+  const int y = (int)((idx / W) % H);
+  const int oc = (int)((idx / ((long long)W * H)) % (4 * C));
+  const int n = (int)(idx / ((long long)W * H * 4 * C));
+  const int d = oc / C, c = oc - d * C;
+  out[idx] = in[(((size_t)n * C + c) * 2 * H + 2 * y + (d >> 1)) * (2 * W) + 2 * x + (d & 1)];
+}
+
 }  // namespace
 
 extern "C" int dm_point_sample_fwd(const float* feat, int B, int C, int H, int W, const float* rois, int N, int S,
@@ -633,5 +672,30 @@ extern "C" int dm_paste_masks(const float* masks, const float* boxes, int N, int
   const int bx = min(dm_ceil_div((long long)img_h * img_w, 256 * 4), 1024);
   DM_LAUNCH(paste_masks_kernel, dim3(bx, N), dim3(256), 0, (hipStream_t)stream, masks, boxes, N, mask_h, mask_w, img_h, img_w,
             threshold, apply_sigmoid, out);
+  return dm_check_launch();
+}
+
+extern "C" int dm_upsample2x_nearest_fwd(const float* in, int NC, int H, int W, float* out, dm_stream_t stream) {
+  if (!in || !out || NC < 0 || H <= 0 || W <= 0) return DM_ERR_INVALID_ARG;
+  if (NC == 0) return DM_OK;
+  const long long total = (long long)NC * 4 * H * W;
+  DM_LAUNCH(nearest2x_kernel, dim3((unsigned)dm_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, in, total, H, W, out);
+  return dm_check_launch();
+}
+
+extern "C" int dm_upsample2x_nearest_bwd(const float* grad_out, int NC, int H, int W, float* grad_in, dm_stream_t stream) {
+  if (!grad_out || !grad_in || NC < 0 || H <= 0 || W <= 0) return DM_ERR_INVALID_ARG;
+  if (NC == 0) return DM_OK;
+  const long long total = (long long)NC * H * W;
+  DM_LAUNCH(nearest2x_bwd_kernel, dim3((unsigned)dm_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, grad_out, total,
+            H, W, grad_in);
+  return dm_check_launch();
+}
+
+extern "C" int dm_pixel_unshuffle2x(const float* in, int NB, int C, int H, int W, float* out, dm_stream_t stream) {
+  if (!in || !out || NB < 0 || C <= 0 || H <= 0 || W <= 0) return DM_ERR_INVALID_ARG;
+  if (NB == 0) return DM_OK;
+  const long long total = (long long)NB * 4 * C * H * W;
+  DM_LAUNCH(unshuffle2x_kernel, dim3((unsigned)dm_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, in, NB, C, H, W, out);
   return dm_check_launch();
 }

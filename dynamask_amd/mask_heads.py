@@ -439,6 +439,20 @@ class _BilinearUp(nn.Module):
         return ops.upsample2x(x, align_corners=self.align_corners, relu=relu)
 
 
+@UPSAMPLE_LAYERS.register_module(name='nearest')
+class _NearestUp(nn.Module):
+    """nn.Upsample(scale_factor=2, mode='nearest') (fcn_mask_head.py:88-96)."""
+
+    def __init__(self, scale_factor=2, mode='nearest', align_corners=None):
+        super().__init__()
+        if scale_factor != 2:
+            raise NotImplementedError('x2 upsampling only')
+
+    def forward(self, x, relu=False):
+        assert not relu
+        return ops.upsample2x_nearest(x)
+
+
 def build_upsample_layer(cfg):
     cfg = dict(cfg)
     t = cfg.pop('type')
@@ -450,8 +464,9 @@ def build_upsample_layer(cfg):
 
 @HEADS.register_module()
 class FCNMaskHead(nn.Module):
-    """fcn_mask_head.py:19-126 (forward only: the fork's loss path is broken,
-    SURVEY App. C Q5)."""
+    """fcn_mask_head.py:19-126.  Forward and (train_path.FCNMaskHeadFn) its backward for every upsample
+    type; the fork's own ``loss`` is broken (``mask_cross_entropy`` changed its signature),
+    so the head is differentiable but the reference cannot train it through ``loss_mask``."""
 
     def __init__(self, num_convs=4, roi_feat_size=14, in_channels=256, conv_kernel_size=3, conv_out_channels=256,
                  num_classes=80, class_agnostic=False, upsample_cfg=dict(type='deconv', scale_factor=2),
@@ -489,7 +504,8 @@ class FCNMaskHead(nn.Module):
             cfg_.update(scale_factor=self.scale_factor, mode='bilinear', align_corners=False)
             self.upsample = build_upsample_layer(cfg_)
         else:
-            raise NotImplementedError('nearest upsampling is not on the measured path')
+            cfg_.update(scale_factor=self.scale_factor, mode='nearest', align_corners=None)
+            self.upsample = build_upsample_layer(cfg_)
         out_channels = 1 if class_agnostic else num_classes
         logits_in = conv_out_channels if self.upsample_method == 'deconv' else up_in
         self.conv_logits = _Conv(logits_in, out_channels, 1)
@@ -505,6 +521,9 @@ class FCNMaskHead(nn.Module):
                 nn.init.constant_(m.bias, 0)
 
     def forward(self, x):
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from .train_path import FCNMaskHeadFn
+            return FCNMaskHeadFn.apply(self, x, *list(self.parameters()))
         for conv in self.convs:
             x = conv(x)
         if self.upsample is not None:

@@ -792,3 +792,45 @@ def clip_scale_(x, sumsq_total, max_norm):
     _chk(sumsq_total, 'sumsq')
     check(lib().dm_clip_scale(_p(x), x.numel(), _p(sumsq_total), float(max_norm), _stream()), 'dm_clip_scale')
     return x
+
+
+# ------------------------------------------------------- FCNMaskHead upsample layers: backward
+def carafe_backward(x, enc, grad_out, up_kernel=5, group=1, scale=2):
+    """-> (grad_x, grad_enc) of ``carafe`` (mask-head shape: scale 2, H*W <= 256)."""
+    _chk(x, 'x')
+    _chk(enc, 'enc')
+    _chk(grad_out, 'grad_out')
+    NB, C, H, W = x.shape
+    assert grad_out.shape == (NB, C, H * scale, W * scale)
+    gx, genc = torch.empty_like(x), torch.empty_like(enc)
+    scratch = torch.empty((int(lib().dm_carafe_bwd_scratch_floats(NB, H, W, up_kernel, group)),), device=x.device,
+                          dtype=torch.float32)
+    check(lib().dm_carafe_bwd(_p(x), _p(enc), _p(grad_out), NB, C, H, W, up_kernel, group, scale, _p(gx), _p(genc),
+                              _p(scratch), _stream()), 'dm_carafe_bwd')
+    return gx, genc
+
+
+def upsample2x_nearest(x):
+    _chk(x, 'x')
+    NB, C, H, W = x.shape
+    out = torch.empty((NB, C, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+    check(lib().dm_upsample2x_nearest_fwd(_p(x), NB * C, H, W, _p(out), _stream()), 'dm_upsample2x_nearest_fwd')
+    return out
+
+
+def upsample2x_nearest_backward(grad_out):
+    _chk(grad_out, 'grad_out')
+    NB, C, OH, OW = grad_out.shape
+    gin = torch.empty((NB, C, OH // 2, OW // 2), device=grad_out.device, dtype=torch.float32)
+    check(lib().dm_upsample2x_nearest_bwd(_p(grad_out), NB * C, OH // 2, OW // 2, _p(gin), _stream()),
+          'dm_upsample2x_nearest_bwd')
+    return gin
+
+
+def pixel_unshuffle2x(x):
+    """[N, C, 2H, 2W] -> [N, 4C, H, W] with channel (dy*2+dx)*C + c."""
+    _chk(x, 'x')
+    NB, C, OH, OW = x.shape
+    out = torch.empty((NB, 4 * C, OH // 2, OW // 2), device=x.device, dtype=torch.float32)
+    check(lib().dm_pixel_unshuffle2x(_p(x), NB, C, OH // 2, OW // 2, _p(out), _stream()), 'dm_pixel_unshuffle2x')
+    return out

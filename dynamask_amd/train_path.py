@@ -353,3 +353,88 @@ class GumbelSelectFn(torch.autograd.Function):
     def backward(ctx, g_hot, _g_idx):
         (y,) = ctx.saved_tensors
         return ops.gumbel_select_backward(y, g_hot.contiguous(), ctx.t), None, None
+
+
+class FCNMaskHeadFn(torch.autograd.Function):
+    """FCNMaskHead.forward (fcn_mask_head.py:117-126) with a hand-sequenced backward: conv stack,
+    upsample (deconv / CARAFE / bilinear / nearest) and the 1x1 logits conv.  Inputs: (head, x, *head.parameters())."""
+
+    @staticmethod
+    def forward(ctx, head, x, *params):
+        acts = [x.detach().contiguous()]
+        for conv in head.convs:
+            acts.append(conv(acts[-1]))
+        h = acts[-1]
+        up = head.upsample
+        aux = None
+        if up is None:
+            u = h
+        elif head.upsample_method == 'carafe':
+            comp = up.channel_compressor.run(h)
+            enc = up.content_encoder.run(comp)
+            u = ops.carafe(h, enc, up.up_kernel, up.up_group, up.scale_factor)
+            aux = (comp, enc)
+        else:
+            u = up(h, relu=(head.upsample_method == 'deconv'))
+        out = head.conv_logits.run(u)
+        ctx.head, ctx.acts, ctx.u, ctx.aux, ctx.need_x = head, acts, u, aux, x.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        head, acts, u, aux = ctx.head, ctx.acts, ctx.u, ctx.aux
+        pg = {}
+
+        def params_bwd(conv, dy, xin, ks):
+            tw, tb = _direct(conv.weight), _direct(conv.bias)
+            if tw is not None:
+                ops.conv2d_wgrad(dy, xin, ks, dw=tw)
+            else:
+                pg[conv.weight] = ops.conv2d_wgrad(dy, xin, ks)
+            if tb is not None:
+                ops.channel_sum(dy, out=tb)
+            else:
+                pg[conv.bias] = ops.channel_sum(dy)
+
+        def data_grad(conv, dy, ks, out=None, accumulate=False):
+            wq = conv._pk.get(('flip', 0, conv.in_channels), conv.weight,
+                              lambda t: ops.pack_conv_weight(t, transpose_flip=True))
+            return ops.conv2d(dy, wq, None, conv.in_channels, ks, out=out, accumulate=accumulate)
+
+        g = g.contiguous()
+        params_bwd(head.conv_logits, g, u, 1)
+        g_u = data_grad(head.conv_logits, g, 1)
+        h = acts[-1]
+        up = head.upsample
+        m = head.upsample_method
+        if up is None:
+            g_h = g_u
+        elif m == 'deconv':
+            ops.relu_backward_(g_u, u)
+            gyu = ops.pixel_unshuffle2x(g_u)                                   # [N, 4*Cout, H, W]
+            cin, cout = up.in_channels, up.out_channels
+            dwp = ops.conv2d_wgrad(gyu, h, 1)                                  # [(d, co), ci, 1, 1]
+            pg[up.weight] = dwp.view(2, 2, cout, cin).permute(3, 2, 0, 1).contiguous()
+            pg[up.bias] = ops.channel_sum(g_u)
+            wb = up._pk.get('bwd', up.weight, lambda t: ops.pack_conv_weight(
+                t.permute(0, 2, 3, 1).reshape(cin, 4 * cout, 1, 1).contiguous()))
+            g_h = ops.conv2d(gyu, wb, None, cin, 1)
+        elif m == 'carafe':
+            comp, enc = aux
+            g_h, g_enc = ops.carafe_backward(h, enc, g_u, up.up_kernel, up.up_group, up.scale_factor)
+            params_bwd(up.content_encoder, g_enc, comp, 3)
+            g_comp = data_grad(up.content_encoder, g_enc, 3)
+            params_bwd(up.channel_compressor, g_comp, h, 1)
+            data_grad(up.channel_compressor, g_comp, 1, out=g_h, accumulate=True)
+        elif m == 'bilinear':
+            g_h = ops.upsample2x_backward(g_u, None, tuple(h.shape), False)
+        else:
+            g_h = ops.upsample2x_nearest_backward(g_u)
+        for i in reversed(range(len(head.convs))):
+            conv = head.convs[i].conv
+            ops.relu_backward_(g_h, acts[i + 1])
+            params_bwd(conv, g_h, acts[i], conv.kernel_size)
+            if i > 0 or ctx.need_x:
+                g_h = data_grad(conv, g_h, conv.kernel_size)
+        g_x = g_h if ctx.need_x else None
+        return (None, g_x, *[pg.get(p) for p in head.parameters()])

@@ -379,6 +379,21 @@ int dm_dcn_weight_permute(const float* src, float* dst, int Cout, int C, int to_
 int dm_sgd_momentum_step(float* params, const float* grads, float* momentum_buf, long long count, float lr,
                          float momentum, float weight_decay, float grad_scale, int first_step, dm_stream_t stream);
 
+/* Backward of the FCNMaskHead upsample layers (mask_heads/fcn_mask_head.py:84-96; the forward of the
+ * deconv / CARAFE / bilinear forms is above).
+ * dm_carafe_bwd: gradients of dm_carafe_fwd with respect to x and enc (mmcv carafe backward +
+ *   kernel_normalizer backward), for scale 2 and H*W <= 256 (the mask head: 14x14 -> 28x28); other shapes
+ *   return DM_ERR_UNSUPPORTED.  scratch: dm_carafe_bwd_scratch_floats() floats.
+ * dm_upsample2x_nearest_fwd / _bwd: nn.Upsample(scale_factor=2, mode='nearest') and its adjoint.
+ * dm_pixel_unshuffle2x: out[n, (dy*2+dx)*C + c, y, x] = in[n, c, 2y+dy, 2x+dx]: with it the backward of the
+ *   2x2 stride-2 ConvTranspose2d is dm_conv2d_fwd (data) + dm_conv2d_wgrad (weights) on 1x1 GEMMs. */
+long long dm_carafe_bwd_scratch_floats(int NB, int H, int W, int up_kernel, int group);
+int dm_carafe_bwd(const float* x, const float* enc, const float* grad_out, int NB, int C, int H, int W, int up_kernel,
+                  int group, int scale, float* grad_x, float* grad_enc, float* scratch, dm_stream_t stream);
+int dm_upsample2x_nearest_fwd(const float* in, int NC, int H, int W, float* out, dm_stream_t stream);
+int dm_upsample2x_nearest_bwd(const float* grad_out, int NC, int H, int W, float* grad_in, dm_stream_t stream);
+int dm_pixel_unshuffle2x(const float* in, int NB, int C, int H, int W, float* out, dm_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Training side of the RoI head around the mask path (SURVEY 8b "forward_train", 8f rank 4):
  * RoI assignment / sampling inputs, bbox regression targets and the two bbox-branch losses.

@@ -435,3 +435,39 @@ def test_roi_level_adversarial_sweep_around_every_threshold(ops):
         for k in range(1, L):                                          # the sweep straddles every threshold
             seg = ref.numpy()[(k - 1) * 129:k * 129]
             assert seg.min() == k - 1 and seg.max() == k, (L, k, seg.min(), seg.max())
+
+
+def test_roi_align_on_the_reference_tests_own_roi(ops):
+    """tests/test_models/test_roi_extractor.py:40 of the reference (shape-only there): that RoI on those FPN
+    shapes, 7x7, sampling_ratio 2 and adaptive, multi-level extraction vs the oracle and the f64 brute force."""
+    rois = torch.tensor([[0.0000, 587.8285, 52.1405, 886.2484, 341.5644]])
+    g = torch.Generator().manual_seed(40)
+    feats = [torch.rand(1, 8, 200 >> l, 336 >> l, generator=g) for l in range(4)]
+    for sr in (2, 0):
+        out, lv = ops.roi_align([_dev(f) for f in feats], _dev(rois), 7, [1 / 4, 1 / 8, 1 / 16, 1 / 32], sampling_ratio=sr,
+                                return_levels=True)
+        assert lv.tolist() == [2]
+        ref = ref_ops.single_roi_extractor(feats, rois, 7, (4, 8, 16, 32), sampling_ratio=sr)
+        _close(out, ref)
+        bf = ref_ops.roi_align_bruteforce_f64(feats[2], rois, 7, 1 / 16, sr, True)
+        _close(out, bf.float(), atol=1e-5, rtol=1e-5)
+
+
+def test_deform_conv_integer_shifts_at_every_border(ops):
+    """Whole-pixel offsets: DCN == conv of the shifted, zero-extended image, borders included (both DCN kernels:
+    the LDS-gather build at 14x14 and the global-gather build at 28x28)."""
+    import torch.nn.functional as F
+    for S, C in ((14, 32), (28, 16)):
+        g = torch.Generator().manual_seed(41)
+        x = torch.randn(3, C, S, S, generator=g)
+        w = torch.randn(C, C, 3, 3, generator=g) / (9 * C) ** 0.5
+        wq = ops.pack_conv_weight(_dev(w))
+        for dh, dw in ((-1, 0), (1, 0), (0, -1), (0, 1), (2, 2), (-2, -3), (S, 0), (0, -S)):
+            off = torch.zeros(3, 36, S, S)
+            off[:, 0::2] = float(dh)
+            off[:, 1::2] = float(dw)
+            out = ops.deform_conv(_dev(x), _dev(off), wq, C, 2)
+            pad = S + 2
+            shifted = torch.roll(F.pad(x, (pad, pad, pad, pad)), shifts=(-dh, -dw), dims=(2, 3))
+            exp = F.conv2d(shifted, w, padding=1)[:, :, pad:pad + S, pad:pad + S]
+            _close(out, exp, atol=1e-5, rtol=1e-5)

@@ -128,3 +128,35 @@ def test_rle_oracle_known_answers_and_round_trip():
         for _ in range(10):
             m = (rng.random(shape) < rng.random()).astype(np.uint8)
             assert (R.rle_decode(R.rle_encode(m)) == m).all()
+
+
+def test_roi_align_on_the_reference_tests_own_roi_matches_f64_bruteforce():
+    """The one RoI the reference's tests hold for this op (tests/test_models/test_roi_extractor.py:40,
+    FPN shapes 200x336 ... 25x42, output 7x7, sampling_ratio 2 -- asserted there for shape only): the
+    oracle against the float64 sample-by-sample restatement, on the level the extractor picks."""
+    rois = torch.tensor([[0.0000, 587.8285, 52.1405, 886.2484, 341.5644]])
+    lvl = int(ref_ops.map_roi_levels(rois, 4)[0])
+    assert lvl == 2                                   # sqrt(298.4 * 289.4) = 293.9 -> floor(log2(293.9 / 56)) = 2
+    H, W = (200 >> lvl), (336 >> lvl)
+    feat = torch.rand(1, 6, H, W, generator=_g(40))
+    for sr in (2, 0):
+        a = ref_ops.roi_align(feat, rois, 7, 1.0 / (4 << lvl), sr, True)
+        b = ref_ops.roi_align_bruteforce_f64(feat, rois, 7, 1.0 / (4 << lvl), sr, True)
+        assert torch.allclose(a.double(), b, atol=1e-6), sr
+
+
+def test_deform_conv_integer_shifts_at_every_border():
+    """Whole-pixel offsets turn DCN into a plain conv of the shifted, zero-extended image -- including the
+    rows / columns where the shifted taps leave the map (deform_conv_cuda_kernel.cu:220-243 validity rule)."""
+    x = torch.randn(2, 4, 9, 11, generator=_g(41))
+    w = torch.randn(5, 4, 3, 3, generator=_g(42))
+    for dh, dw in ((-1, 0), (1, 0), (0, -1), (0, 1), (2, 2), (-2, -3), (9, 0), (0, -11)):
+        off = torch.zeros(2, 18, 9, 11)
+        off[:, 0::2] = float(dh)
+        off[:, 1::2] = float(dw)
+        out = ref_ops.deform_conv2d(x, off, w, 1, 1, 1, 1)
+        pad = 12
+        xs = F.pad(x, (pad, pad, pad, pad))
+        shifted = torch.roll(xs, shifts=(-dh, -dw), dims=(2, 3))           # sample (h + dh, w + dw)
+        exp = F.conv2d(shifted, w, padding=1)[:, :, pad:pad + 9, pad:pad + 11]
+        assert torch.allclose(out, exp, atol=1e-5), (dh, dw)

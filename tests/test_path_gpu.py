@@ -489,3 +489,44 @@ def test_mask_pre_conv1_commutes_with_roialign():
         ref = ref_model.mask_pre(sd, ref_ops.single_roi_extractor([feats[0]], rois, 56, (4,)), training=False)
     _close(fast, direct.cpu().numpy(), atol=1e-4, rtol=1e-4)
     _close(fast, ref.numpy(), atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize('up', ['deconv', 'carafe', 'bilinear', 'nearest'])
+def test_fcn_mask_head_backward_matches_oracle_autograd(up):
+    """FCNMaskHead (fcn_mask_head.py:117-126) forward AND backward for every upsample type: gradients of
+    all parameters and of the RoI features against autograd of the oracle (CARAFE: mmcv's carafe backward +
+    kernel_normalizer backward restated through F.softmax / pixel_shuffle).  atol = rtol = 1e-4 on the
+    tensor's scale."""
+    from dynamask_amd import registry, mask_heads  # noqa: F401
+    cfg = dict(type='FCNMaskHead', **gi.FCN_HEAD_CFG)
+    cfg.pop('loss_mask')
+    if up == 'carafe':
+        cfg['upsample_cfg'] = dict(type='carafe', scale_factor=2, up_kernel=5, up_group=1, encoder_kernel=3,
+                                   encoder_dilation=1, compressed_channels=64)
+    elif up != 'deconv':
+        cfg['upsample_cfg'] = dict(type=up, scale_factor=2)
+    sd = {k[len('mask_head.'):]: v for k, v in gi.fcn_state(up).items()}
+    if up == 'carafe':      # the reference's std 0.001 encoder gives a uniform kernel: make the softmax matter
+        sd['upsample.content_encoder.weight'] = sd['upsample.content_encoder.weight'] * 12.0
+    head = registry.build_head(cfg)
+    head.load_state_dict(sd, strict=True)
+    head = head.cuda().train()
+    x = gi.fcn_input()
+    G = torch.randn(3, 80, 28, 28, generator=torch.Generator().manual_seed(7)) * 0.1
+    xg = _dev(x).requires_grad_(True)
+    out = head(xg)
+    (out * _dev(G)).sum().backward()
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xo = x.clone().requires_grad_(True)
+    ref = ref_model.fcn_mask_head_forward(sdo, xo, upsample=up)
+    (ref * G).sum().backward()
+    _close(out, ref)
+
+    def scaled(got, want, what):
+        got, want = got.detach().cpu().numpy(), want.detach().numpy()
+        tol = 1e-4 * max(1.0, float(np.abs(want).max()))
+        assert np.abs(got - want).max() <= tol, (what, float(np.abs(got - want).max()), tol)
+    scaled(xg.grad, xo.grad, 'x')
+    for k, p in head.named_parameters():
+        assert p.grad is not None, k
+        scaled(p.grad, sdo[k].grad, k)
