@@ -243,7 +243,8 @@ void launch_wgrad(WgradArgs a, hipStream_t st) {
   // split-K until the launch is one round of workgroups (two per CU): every further split adds an
   // epilogue of 64 float atomics per lane onto the same addresses (2048 workgroups: 256->256 1x1 at
   // 14x14 0.140 ms, 512: 0.091 ms; the 2304-row DCN GEMMs 0.63 -> 0.60 ms)
-  static const int target_wgs = getenv("DM_WGRAD_WGS") ? atoi(getenv("DM_WGRAD_WGS")) : 2 * dm_num_cus();
+  static const int wgs_env = getenv("DM_WGRAD_WGS") ? atoi(getenv("DM_WGRAD_WGS")) : 0;      // tuning knob (read once)
+  const int target_wgs = wgs_env > 0 ? wgs_env : 2 * dm_num_cus();
   int nsplit = max(1, min(chunks, target_wgs / max(1, a.MT * a.JT)));
   a.chunks_per_split = dm_ceil_div(chunks, nsplit);
   a.nsplit = dm_ceil_div(chunks, a.chunks_per_split);
@@ -359,6 +360,8 @@ __global__ __launch_bounds__(256) void point_sample_bwd_kernel(const float* __re
                                                                const float* __restrict__ rois, int N, int S, float scale,
                                                                float* __restrict__ gfeat, int lds_elems) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long tile[];   // [CT][TH][TW] fixed point
+  __shared__ int bad[CT];            // a NaN / Inf gradient cannot be represented in fixed point: it poisons its plane
+  if (threadIdx.x < CT) bad[threadIdx.x] = 0;
   const int n = blockIdx.y;
   const int c0 = blockIdx.x * CT;
   const float* r = rois + (size_t)n * 5;
@@ -400,6 +403,9 @@ __global__ __launch_bounds__(256) void point_sample_bwd_kernel(const float* __re
 #pragma unroll
     for (int c = 0; c < CT; ++c) gv[c] = (c < nch) ? go[(size_t)c * S * S] : 0.f;
     if (use_lds) {
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+        if (!isfinite(gv[c])) { bad[c] = 1; gv[c] = 0.f; }
       const int tx0 = x0 - fx0, ty0 = y0 - fy0;     // in range by construction of the footprint
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
@@ -427,11 +433,12 @@ __global__ __launch_bounds__(256) void point_sample_bwd_kernel(const float* __re
     __syncthreads();
     for (int i = threadIdx.x; i < nch * TH * TW; i += blockDim.x) {
       const long long q = (long long)tile[i];
-      if (q != 0) {
-        const int c = i / (TH * TW);
+      const int c = i / (TH * TW);
+      if (q != 0 || bad[c]) {
         const int rem = i - c * TH * TW;
         const int ty = rem / TW, tx = rem - ty * TW;
-        atomicAdd(gf + (size_t)c * plane + (size_t)(fy0 + ty) * W + fx0 + tx, (float)((double)q * (1.0 / DM_FIX_SCALE)));
+        const float v = bad[c] ? __builtin_nanf("") : (float)((double)q * (1.0 / DM_FIX_SCALE));
+        atomicAdd(gf + (size_t)c * plane + (size_t)(fy0 + ty) * W + fx0 + tx, v);
       }
     }
   }
@@ -630,6 +637,8 @@ __global__ __launch_bounds__(256) void dcn_col2im_lds_kernel(const float* __rest
                                                              const float* __restrict__ offset, int NB, int C, int H, int W,
                                                              int dg, float* __restrict__ gx) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long lds[];   // [CT][HW] fixed point
+  __shared__ int bad[CT];            // non-finite column gradients poison their plane (see the header's contract)
+  if (threadIdx.x < CT) bad[threadIdx.x] = 0;
   const int HW = H * W;
   const int chunks = C / CT;
   const int n = blockIdx.x / chunks;
@@ -658,7 +667,10 @@ __global__ __launch_bounds__(256) void dcn_col2im_lds_kernel(const float* __rest
     for (int u = 0; u < U; ++u) {
       const float* cgp = colgrad + ((size_t)n * 9 * C + (size_t)tapv[u] * C + c0) * HW + pv[u];
 #pragma unroll
-      for (int c = 0; c < CT; ++c) cg[u][c] = cgp[(size_t)c * HW];
+      for (int c = 0; c < CT; ++c) {
+        cg[u][c] = cgp[(size_t)c * HW];
+        if (!isfinite(cg[u][c])) { bad[c] = 1; cg[u][c] = 0.f; }
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -689,7 +701,7 @@ __global__ __launch_bounds__(256) void dcn_col2im_lds_kernel(const float* __rest
   __syncthreads();
   float* dst = gx + ((size_t)n * C + c0) * HW;
   for (int i = threadIdx.x; i < CT * HW; i += blockDim.x)
-    dst[i] = (float)((double)(long long)lds[i] * (1.0 / DM_FIX_SCALE));
+    dst[i] = bad[i / HW] ? __builtin_nanf("") : (float)((double)(long long)lds[i] * (1.0 / DM_FIX_SCALE));
 }
 
 // W[co][ci][tap]  <->  Wt[(tap*C + ci)][co]  (the two DCN GEMMs run as 1x1 convs over

@@ -369,11 +369,10 @@ int launch_carafe_bwd(const float* x, const float* enc, const float* gout, int N
   const size_t lds_b = (size_t)4 * KK * HW * sizeof(float) + (size_t)4 * HW * sizeof(float4);
   if (lds_a > 64 * 1024 || lds_b > 160 * 1024) return DM_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)(NB * group * (cpg / CT)));
-  if (lds_b > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&carafe_bwd_x_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds_b) != hipSuccess)
-      return DM_ERR_LAUNCH;
-  }
+  static bool attr_set[DM_MAX_DEVICES] = {false};
+  if (lds_b > 64 * 1024 &&
+      dm_ensure_lds_limit(reinterpret_cast<const void*>(&carafe_bwd_x_kernel<K>), 160 * 1024, attr_set) != DM_OK)
+    return DM_ERR_LAUNCH;
   DM_LAUNCH(carafe_bwd_mask_kernel<K>, grid, dim3(256), lds_a, st, x, gout, C, H, W, group, gm, CT);
   int rc = dm_check_launch();
   if (rc != DM_OK) return rc;

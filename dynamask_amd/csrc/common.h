@@ -26,17 +26,38 @@ static inline int dm_check_launch() {
   return e == hipSuccess ? DM_OK : DM_ERR_LAUNCH;
 }
 
-// Compute units of the current device (MI355X: 256), read once.
+// Per-device facts.  One process may drive several devices (a rehearsal of ranks on one box, a
+// single-process multi-GPU caller): compute-unit counts and "this kernel's LDS limit has been
+// raised" flags are properties of a device, not of the process, so they are kept per device.
+// (A benign race between two host threads only repeats an idempotent call.)
+#define DM_MAX_DEVICES 64
+
+static inline int dm_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DM_MAX_DEVICES) dev = 0;
+  return dev;
+}
+
+// Compute units of the current device (MI355X: 256).
 static inline int dm_num_cus() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-      cus = n;
-    else
-      cus = 256;
+  static int cus[DM_MAX_DEVICES] = {0};
+  const int dev = dm_current_device();
+  if (cus[dev] == 0) {
+    int n = 0;
+    cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
   }
-  return cus;
+  return cus[dev];
+}
+
+// Raise a kernel's dynamic-LDS limit once per device.  `flags` is a static array of
+// DM_MAX_DEVICES bools owned by the call site (one per kernel).
+static inline int dm_ensure_lds_limit(const void* kernel, int bytes, bool* flags) {
+  const int dev = dm_current_device();
+  if (!flags[dev]) {
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return DM_ERR_LAUNCH;
+    flags[dev] = true;
+  }
+  return DM_OK;
 }
 
 typedef float dm_f32x16 __attribute__((ext_vector_type(16)));

@@ -557,13 +557,10 @@ int launch_dcn(DcnArgs& a, hipStream_t st) {
   a.MT = dm_ceil_div(a.CoutP, TM);
   const int NTiles = dm_ceil_div(a.Q - a.q_begin, TN);
   const size_t lds_bytes = 16 * ((size_t)9 * 2 * TM + (size_t)2 * 9 * TN);
-  static bool attr_set = false;
-  if (lds_bytes > 64 * 1024 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&deform_conv_kernel<WGM, WGN, WM, WN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return DM_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static bool attr_set[DM_MAX_DEVICES] = {false};
+  if (lds_bytes > 64 * 1024 &&
+      dm_ensure_lds_limit(reinterpret_cast<const void*>(&deform_conv_kernel<WGM, WGN, WM, WN>), (int)lds_bytes, attr_set) != DM_OK)
+    return DM_ERR_LAUNCH;
   DM_LAUNCH((deform_conv_kernel<WGM, WGN, WM, WN>), dim3(a.MT * NTiles), dim3(NT), lds_bytes, st, a);
   return dm_check_launch();
 }
@@ -601,13 +598,10 @@ extern "C" int dm_deform_conv_fwd(const float* x, const float* offset, int NB, i
     const int NTiles = dm_ceil_div(a.Q, 128);
     // A ring + B ring (2 x 3 taps x 2 quads x 128 float4 each) + 2 plane buffers of 2 images x 8 channels
     const size_t lds_bytes = 16 * ((size_t)2 * 2 * 3 * 2 * 128) + (size_t)4 * 2 * 2 * 8 * a.HW;
-    static bool attr_lds = false;
-    if (!attr_lds) {        // once, for the largest map this path takes (H*W = 256)
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&deform_conv_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              16 * 2 * 2 * 3 * 2 * 128 + 4 * 2 * 2 * 8 * 256) != hipSuccess)
-        return DM_ERR_LAUNCH;
-      attr_lds = true;
-    }
+    static bool attr_lds[DM_MAX_DEVICES] = {false};      // once per device, for the largest map this path takes (H*W = 256)
+    if (dm_ensure_lds_limit(reinterpret_cast<const void*>(&deform_conv_lds_kernel), 16 * 2 * 2 * 3 * 2 * 128 + 4 * 2 * 2 * 8 * 256,
+                            attr_lds) != DM_OK)
+      return DM_ERR_LAUNCH;
     // rounds (see conv_igemm.hip): the LDS kernel runs two workgroups per CU; the pixels of a nearly empty
     // last round go to a second launch with 64 x 64 tiles (same bits): 512 RoIs 1.24 -> 1.19 ms.  Only
     // for small remainders (the 64 x 64 build is slower per pixel: at 0.5 of a round the split loses), and

@@ -152,7 +152,8 @@ extern "C" int dm_fc_fwd(const float* x, const float* w, const float* bias, int 
   const int tiles = a.MT * a.NT;
   // split K until the launch is one round of workgroups (148 VGPRs: three per CU); measured on
   // 1000 x 12544 -> 1024: 1024 workgroups 0.361 ms, 768: 0.300 ms, 512: 0.314 ms
-  static const int target_wgs = getenv("DM_FC_WGS") ? atoi(getenv("DM_FC_WGS")) : 3 * dm_num_cus();
+  static const int wgs_env = getenv("DM_FC_WGS") ? atoi(getenv("DM_FC_WGS")) : 0;      // tuning knob (read once)
+  const int target_wgs = wgs_env > 0 ? wgs_env : 3 * dm_num_cus();
   int splits = max(1, min(chunks / 8, target_wgs / max(tiles, 1)));     // >= 8 chunks per split
   a.chunks_per_split = dm_ceil_div(chunks, splits);
   a.splits = dm_ceil_div(chunks, a.chunks_per_split);

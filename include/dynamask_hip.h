@@ -5,9 +5,20 @@
  * Contract:
  *   - plain pointers and sizes only; every pointer is a DEVICE pointer to fp32
  *     (or int32 / int64 where stated), NCHW-contiguous, owned by the caller;
- *   - no allocation, no global state, re-entrant; work is enqueued on `stream`
- *     (a hipStream_t passed as void*; NULL = the null stream) and the call
- *     returns without synchronising;
+ *   - no allocation; no state that a caller can observe or has to manage; work is
+ *     enqueued on `stream` (a hipStream_t passed as void*; NULL = the null
+ *     stream) on the CURRENT device and the call returns without synchronising.
+ *     What the library does keep, per device and only as a cache: the device's
+ *     compute-unit count and "this kernel's dynamic-LDS limit has been raised"
+ *     flags (hipFuncSetAttribute once per device).  Four tuning knobs are read
+ *     from the environment on first use and never change results, only tile /
+ *     split choices: DM_CONV_TAIL, DM_DCN_TAIL, DM_WGRAD_WGS, DM_FC_WGS.
+ *     Calls from several host threads are safe (a race only repeats an
+ *     idempotent attribute call);
+ *   - LDS scatter-accumulators (dm_deform_col2im_coord, dm_point_sample_bwd) are
+ *     64-bit fixed point with 2^-36 resolution: exact and order-independent for
+ *     gradient magnitudes in [1.5e-11, 1.3e8]; a non-finite contribution poisons
+ *     its output plane with NaN (it is not silently dropped);
  *   - return value: 0 = enqueued, negative = error (DM_ERR_*); the host binding
  *     raises on any non-zero code (dm_error_string()).
  *
@@ -34,7 +45,7 @@ extern "C" {
 typedef void* dm_stream_t; /* hipStream_t */
 
 const char* dm_error_string(int code);
-/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd). */
+/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward). */
 int dm_abi_version(void);
 
 /* ---------------------------------------------------------------------------

@@ -150,3 +150,32 @@ def test_deform_conv_backward(ops, N, C, S):
     _close(gx, x.grad, atol=1e-4, rtol=1e-4)
     _close(goff, off.grad, atol=1e-4, rtol=1e-4)
     _close(gw, w.grad, atol=1e-4, rtol=1e-4)
+
+
+def test_fixed_point_scatter_accumulators_propagate_non_finite_gradients(ops):
+    """The LDS accumulators of the DCN col2im and the point-sample adjoint are 64-bit fixed point; a NaN or
+    Inf gradient has no fixed-point value and must show up as NaN in the plane it belongs to (a diverged step
+    has to be visible in the FPN / feature gradients), without touching the other planes."""
+    g = _g(90)
+    N, C, S = 2, 16, 14
+    x = torch.randn(N, C, S, S, generator=g)
+    off = torch.randn(N, 36, S, S, generator=g) * 0.5
+    colgrad = torch.randn(N, 9 * C, S, S, generator=g)
+    gx0, _ = ops.deform_col2im_coord(_dev(colgrad), _dev(x), _dev(off), 2)
+    bad = colgrad.clone()
+    bad[1, 4 * C + 5, 3, 3] = float('nan')          # tap 4, channel 5 of image 1
+    bad[0, 2 * C + 9, 0, 0] = float('inf')
+    gx1, _ = ops.deform_col2im_coord(_dev(bad), _dev(x), _dev(off), 2)
+    assert torch.isnan(gx1[1, 5]).all() and torch.isnan(gx1[0, 9]).all()
+    keep = torch.ones(N, C, dtype=torch.bool)
+    keep[1, 5] = keep[0, 9] = False
+    assert torch.equal(gx1.cpu()[keep], gx0.cpu()[keep])
+    hi = gi.head_inputs()
+    feat_shape = (2, 8, 64, 80)
+    go = torch.randn(hi['rois'].shape[0], 8, 14, 14, generator=g)
+    go[2, 3, 7, 7] = float('nan')
+    gf = ops.point_sample_backward(_dev(go), feat_shape, _dev(hi['rois']), 0.25)
+    b = int(hi['rois'][2, 0])
+    assert torch.isnan(gf[b, 3]).any()
+    others = [c for c in range(8) if c != 3]
+    assert torch.isfinite(gf[:, others]).all()
