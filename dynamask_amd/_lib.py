@@ -4,7 +4,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DYNAMASK_HIP_LIB') or os.path.join(_HERE, 'libdynamask_hip.so')      # override: kernel experiments
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -52,7 +52,8 @@ SIGNATURES = {
     'dm_bbox_decode': ([_vp, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _vp, _vp, _c_float, _c_float, _c_float, _c_float, _c_float, _vp, _vp, _vp], _c_int),
     'dm_nms_mask': ([_vp, _c_int, _c_float, _c_int, _vp, _vp], _c_int),
     'dm_nms_reduce': ([_vp, _c_int, _vp, _c_int], _c_int),
-    'dm_fc_fwd': ([_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp], _c_int),
+    'dm_fc_scratch_floats': ([_c_int, _c_int, _c_int], ctypes.c_longlong),
+    'dm_fc_fwd': ([_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp], _c_int),
     'dm_sgd_momentum_step': ([_vp, _vp, _vp, ctypes.c_longlong, _c_float, _c_float, _c_float, _c_float, _c_int, _vp], _c_int),
     'dm_mask_target_rois': ([_vp, _vp, _c_int, _c_float, _c_float, _vp, _vp], _c_int),
     'dm_threshold_ge': ([_vp, ctypes.c_longlong, _c_float, _vp, _vp], _c_int),

@@ -9,8 +9,11 @@
 // K into the quad images of the conv kernels ([k/4][row][4]: one ds_read_b128 per operand
 // feeds 4 MFMA k-steps).  Workgroup = 128 x 128 outputs, 4 waves x (2 x 2) tiles, K chunks of
 // 32 with register prefetch.  The layers here have few output tiles (N = 1000, M = 1024:
-// 64) and a long K, so K is split over workgroups until the chip is full (one round); partial sums are
-// added with float atomics into a zero-filled output and ReLU runs as a second pass.
+// 64) and a long K, so K is split over workgroups.  The split is a function of K ALONE (segments of
+// 256 or 1024, see fc_seg): every split writes its partial tile to a scratch slab and a second pass adds the slabs in
+// a fixed order, then bias and ReLU.  A row of the output therefore has the same bits whatever the number
+// of rows in the launch and from run to run (round 1 added partials with float atomics and chose the
+// split from N: the selector logits of an RoI depended on how many RoIs shared the launch).
 #include "common.h"
 
 namespace {
@@ -20,6 +23,7 @@ struct FcArgs {
   const float* w;
   const float* bias;
   float* out;
+  float* part;      // [splits][N][M] partial sums (splits > 1)
   int N, K, M;
   int relu, splits, chunks_per_split, MT, NT;
 };
@@ -97,16 +101,17 @@ __global__ __launch_bounds__(256) void fc_gemm_kernel(FcArgs a) {
   float* pj[2];
   float bj[2];
   bool m_ok[2];
+  const bool single = a.splits == 1, relu = a.relu != 0;
+  float* dst = single ? a.out : a.part + (size_t)split * a.N * a.M;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int m = m0 + (wave_c * 2 + j) * 32 + l31;
     m_ok[j] = m < a.M;
-    pj[j] = a.out + m;
-    bj[j] = (split == 0 && a.bias && m_ok[j]) ? a.bias[m] : 0.f;
+    pj[j] = dst + m;
+    bj[j] = (single && a.bias && m_ok[j]) ? a.bias[m] : 0.f;
   }
   const int n_lane = n0 + wave_r * 64 + 4 * hi;
   const size_t off_lane = (size_t)n_lane * a.M;
-  const bool single = a.splits == 1, relu = a.relu != 0;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -118,55 +123,77 @@ __global__ __launch_bounds__(256) void fc_gemm_kernel(FcArgs a) {
         for (int j = 0; j < 2; ++j) {
           if (m_ok[j]) {
             float v = acc[i][j][r] + bj[j];
-            if (single) {
-              if (relu) v = fmaxf(v, 0.f);
-              pj[j][o] = v;
-            } else {
-              atomicAdd(pj[j] + o, v);
-            }
+            if (single && relu) v = fmaxf(v, 0.f);
+            pj[j][o] = v;
           }
         }
       }
     }
 }
 
-__global__ __launch_bounds__(256) void relu_inplace_kernel(float* __restrict__ x, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    x[i] = fmaxf(x[i], 0.f);
+// out = relu?(bias + part[0] + part[1] + ... ) in that order
+__global__ __launch_bounds__(256) void fc_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias, int splits,
+                                                        size_t NM, int M, int relu, float* __restrict__ out) {
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < NM; i += (size_t)gridDim.x * blockDim.x * 4) {
+    // M % 4 == 0 is not guaranteed (81 classes): fall back to scalars at the row tails
+    if (i + 3 < NM && (M & 3) == 0) {
+      dm_f32x4 v = *reinterpret_cast<const dm_f32x4*>(part + i);
+      for (int s = 1; s < splits; ++s) {
+        const dm_f32x4 p = *reinterpret_cast<const dm_f32x4*>(part + (size_t)s * NM + i);
+        v += p;
+      }
+      if (bias) {
+        const int m = (int)(i % M);
+        v[0] += bias[m]; v[1] += bias[m + 1]; v[2] += bias[m + 2]; v[3] += bias[m + 3];
+      }
+      if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+      *reinterpret_cast<dm_f32x4*>(out + i) = v;
+    } else {
+      for (size_t e = i; e < NM && e < i + 4; ++e) {
+        float v = part[e];
+        for (int s = 1; s < splits; ++s) v += part[(size_t)s * NM + e];
+        if (bias) v += bias[e % M];
+        out[e] = relu ? fmaxf(v, 0.f) : v;
+      }
+    }
+  }
 }
 
 }  // namespace
 
+// K elements per split: a function of K alone, so that the order of the partial sums does not depend on the
+// launch.  Short K (the 1024 -> 1024 / 320 / 81 layers of the bbox head: 8 .. 64 output tiles) is cut finer:
+// with one workgroup per tile those layers were a chain of 32 dependent staging round trips (0.105 ms);
+// long K (12544) coarser, or the partial slabs would cost more traffic than the operands.
+static inline int fc_seg(int K) { return K <= 4096 ? 256 : 1024; }
+
+extern "C" long long dm_fc_scratch_floats(int N, int K, int M) {
+  const int splits = (K + fc_seg(K) - 1) / fc_seg(K);
+  return splits > 1 ? (long long)splits * N * M : 0;
+}
+
 extern "C" int dm_fc_fwd(const float* x, const float* w, const float* bias, int N, int K, int M, int relu, float* out,
-                         dm_stream_t stream) {
+                         float* scratch, dm_stream_t stream) {
   if (N < 0 || K <= 0 || M <= 0) return DM_ERR_INVALID_ARG;
   if (N == 0) return DM_OK;
   if (!x || !w || !out) return DM_ERR_INVALID_ARG;
   if (K % 4 != 0) return DM_ERR_UNSUPPORTED;      // 16-byte staging loads along K
   hipStream_t st = (hipStream_t)stream;
   FcArgs a;
-  a.x = x; a.w = w; a.bias = bias; a.out = out; a.N = N; a.K = K; a.M = M; a.relu = relu;
+  a.x = x; a.w = w; a.bias = bias; a.out = out; a.part = scratch; a.N = N; a.K = K; a.M = M; a.relu = relu;
   a.MT = dm_ceil_div(M, 128);
   a.NT = dm_ceil_div(N, 128);
-  const int chunks = dm_ceil_div(K, 32);
   const int tiles = a.MT * a.NT;
-  // split K until the launch is one round of workgroups (148 VGPRs: three per CU); measured on
-  // 1000 x 12544 -> 1024: 1024 workgroups 0.361 ms, 768: 0.300 ms, 512: 0.314 ms
-  static const int wgs_env = getenv("DM_FC_WGS") ? atoi(getenv("DM_FC_WGS")) : 0;      // tuning knob (read once)
-  const int target_wgs = wgs_env > 0 ? wgs_env : 3 * dm_num_cus();
-  int splits = max(1, min(chunks / 8, target_wgs / max(tiles, 1)));     // >= 8 chunks per split
-  a.chunks_per_split = dm_ceil_div(chunks, splits);
-  a.splits = dm_ceil_div(chunks, a.chunks_per_split);
-  if (a.splits > 1) {
-    hipError_t e = hipMemsetAsync(out, 0, (size_t)N * M * sizeof(float), st);
-    if (e != hipSuccess) return DM_ERR_LAUNCH;
-  }
+  a.chunks_per_split = fc_seg(K) / 32;
+  a.splits = dm_ceil_div(K, fc_seg(K));
+  if (a.splits > 1 && !scratch) return DM_ERR_INVALID_ARG;
   DM_LAUNCH(fc_gemm_kernel, dim3((unsigned)(tiles * a.splits)), dim3(256), 0, st, a);
   int rc = dm_check_launch();
   if (rc != DM_OK) return rc;
-  if (a.splits > 1 && relu) {
-    const size_t n = (size_t)N * M;
-    DM_LAUNCH(relu_inplace_kernel, dim3((unsigned)min((size_t)2048, (n + 255) / 256)), dim3(256), 0, st, out, n);
+  if (a.splits > 1) {
+    const size_t NM = (size_t)N * M;
+    DM_LAUNCH(fc_reduce_kernel, dim3((unsigned)min((size_t)2048, (NM / 4 + 255) / 256 + 1)), dim3(256), 0, st,
+              (const float*)scratch, bias, a.splits, NM, M, relu, out);
     rc = dm_check_launch();
   }
   return rc;

@@ -173,7 +173,7 @@ def paste_rle(masks, boxes, img_h, img_w, threshold=0.5, apply_sigmoid=False):
 
 # --------------------------------------------------------------- bbox branch (8f rank 4)
 def fc(x, weight, bias=None, relu=False):
-    """nn.Linear forward: x [N, K], weight [M, K], bias [M] -> [N, M] (fp32 MFMA, split-K)."""
+    """nn.Linear forward: x [N, K], weight [M, K], bias [M] -> [N, M] (fp32 MFMA, deterministic split-K)."""
     _chk(x, 'x')
     _chk(weight, 'weight')
     if bias is not None:
@@ -182,7 +182,10 @@ def fc(x, weight, bias=None, relu=False):
     M = weight.shape[0]
     assert weight.shape[1] == K
     out = torch.empty((N, M), device=x.device, dtype=torch.float32)
-    check(lib().dm_fc_fwd(_p(x), _p(weight), _p(bias), N, K, M, 1 if relu else 0, _p(out), _stream()), 'dm_fc_fwd')
+    ns = int(lib().dm_fc_scratch_floats(N, K, M))
+    scratch = torch.empty((ns,), device=x.device, dtype=torch.float32) if ns > 0 else None
+    check(lib().dm_fc_fwd(_p(x), _p(weight), _p(bias), N, K, M, 1 if relu else 0, _p(out), _p(scratch), _stream()),
+          'dm_fc_fwd')
     return out
 
 

@@ -45,7 +45,7 @@ extern "C" {
 typedef void* dm_stream_t; /* hipStream_t */
 
 const char* dm_error_string(int code);
-/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward). */
+/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K). */
 int dm_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -306,10 +306,14 @@ int dm_paste_rle(const float* masks, const float* boxes, int N, int mask_h, int 
 long long dm_rle_string(const int* positions, int runs, long long total_pixels, char* out, long long cap);
 
 /* K22  fully connected layer out[N, M] = x[N, K] . w[M, K]^T + bias (nn.Linear layouts), optional
- * ReLU; fp32 MFMA with split-K.  replaces: the nn.Linear stack of Shared2FCBBoxHead
- * (roi_heads/bbox_heads/convfc_bbox_head.py:101-108,143-186).  K % 4 == 0. */
+ * ReLU; fp32 MFMA.  replaces: the nn.Linear stack of Shared2FCBBoxHead
+ * (roi_heads/bbox_heads/convfc_bbox_head.py:101-108,143-186) and MaskPre's fc1 / fc2
+ * (roi_heads/base_roi_head.py:17-18,24-26).  K % 4 == 0.  K is split over workgroups in segments
+ * whose length depends on K alone; the partial sums go to `scratch` (dm_fc_scratch_floats() floats; may be NULL when that
+ * is 0) and are added in a fixed order: an output row has the same bits whatever N is, run to run. */
+long long dm_fc_scratch_floats(int N, int K, int M);
 int dm_fc_fwd(const float* x, const float* w, const float* bias, int N, int K, int M, int relu, float* out,
-              dm_stream_t stream);
+              float* scratch, dm_stream_t stream);
 
 /* K20  bbox branch post-processing: softmax over the class logits, DeltaXYWH decode, clip to
  * the image, rescale.  replaces: BBoxHead.get_bboxes up to the NMS

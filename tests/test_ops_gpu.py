@@ -471,3 +471,22 @@ def test_deform_conv_integer_shifts_at_every_border(ops):
             shifted = torch.roll(F.pad(x, (pad, pad, pad, pad)), shifts=(-dh, -dw), dims=(2, 3))
             exp = F.conv2d(shifted, w, padding=1)[:, :, pad:pad + S, pad:pad + S]
             _close(out, exp, atol=1e-5, rtol=1e-5)
+
+
+def test_fc_rows_do_not_depend_on_batch_size_and_match_torch(ops):
+    """dm_fc_fwd: a row of the output has the same bits whether 8 or 512 rows share the launch and from run
+    to run (the K split is a function of K alone, partial sums are added in a fixed order) -- the selector
+    logits of an RoI, hence its exit, must not depend on how many RoIs are in the batch."""
+    g = torch.Generator().manual_seed(8)
+    for K, M, relu in ((3136, 512, True), (12544, 1024, True), (1024, 81, False), (512, 4, False)):
+        x = torch.randn(512, K, generator=g)
+        w = torch.randn(M, K, generator=g) / K ** 0.5
+        b = torch.randn(M, generator=g)
+        xd, wd, bd = _dev(x), _dev(w), _dev(b)
+        full = ops.fc(xd, wd, bd, relu=relu)
+        assert torch.equal(full, ops.fc(xd, wd, bd, relu=relu))                       # run to run
+        for n in (1, 8, 200):
+            assert torch.equal(full[:n], ops.fc(xd[:n].contiguous(), wd, bd, relu=relu)), (K, M, n)
+        ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+        ref = ref.relu() if relu else ref
+        _close(full, ref.float(), atol=1e-4, rtol=1e-4)
