@@ -97,3 +97,30 @@ def test_training_step_through_rccl_matches_unreduced_step(rccl_world1):
     assert abs(l0 - l1) <= 1e-5 * abs(l0)      # second step's loss: the first step's atomics-ordered last bits show
     # weight-gradient GEMMs accumulate split-K partials with float atomics: run-to-run last-bit noise
     torch.testing.assert_close(p1, p0, atol=1e-6, rtol=1e-5)
+
+
+def test_clip_grad_norm_on_the_flat_group_matches_torch(rccl_world1):
+    """optimizer_config grad_clip(max_norm=35, norm_type=2) (config :274) through FlatParamGroup: same
+    coefficient as torch.nn.utils.clip_grad_norm_, applied on the device without a host sync; a second
+    parameter group's squared norm can be folded in (the detector's other parameters)."""
+    from dynamask_amd.dist import FlatParamGroup
+    dev = rccl_world1
+    torch.manual_seed(1)
+    net = nn.Sequential(nn.Linear(64, 96), nn.Linear(96, 8)).to(dev)
+    ref = nn.Sequential(nn.Linear(64, 96), nn.Linear(96, 8)).to(dev)
+    ref.load_state_dict(net.state_dict())
+    grp = FlatParamGroup(net.parameters())
+    x = torch.randn(32, 64, device=dev) * 5
+    for max_norm, other in ((0.5, None), (1e6, None), (0.5, 7.0)):
+        grp.zero_grad()
+        ref.zero_grad()
+        net(x).square().mean().backward()
+        ref(x).square().mean().backward()
+        grp.all_reduce_async(force=True)
+        extra = None if other is None else torch.full((1,), other, device=dev)
+        total = grp.clip_grad_norm_(max_norm, other_sumsq=extra)
+        gref = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+        norm = float((gref.double().square().sum() + (other or 0.0)).sqrt())
+        coef = min(1.0, max_norm / (norm + 1e-6))
+        torch.testing.assert_close(float(total.sqrt()), norm, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(grp.flat_grad, gref * coef, rtol=1e-5, atol=1e-7)
