@@ -317,6 +317,10 @@ class DynaMaskHead(nn.Module):
         (the reference goes through numpy per image and size)."""
         per_stage = [[] for _ in self.stage_sup_size]
         for boxes, inds, masks in zip(pos_bboxes_list, pos_assigned_gt_inds_list, gt_masks_list):
+            if boxes.shape[0] == 0:              # an image without positives (no GT): nothing to crop
+                for i, size in enumerate(self.stage_sup_size):
+                    per_stage[i].append(boxes.new_zeros((0, size, size)))
+                continue
             if hasattr(masks, 'masks'):           # a BitmapMasks-like holder of a numpy array
                 masks = torch.from_numpy(masks.masks).to(boxes.device)
             m = masks.to(torch.float32).contiguous()[:, None]

@@ -290,6 +290,11 @@ class DynaMaskRoIHead(nn.Module):
         pos_labels = [res.pos_gt_labels for res in sampling_results]
         pos_assigned_gt_inds = [res.pos_assigned_gt_inds for res in sampling_results]
         pos_rois = bbox2roi(pos_bboxes).contiguous()
+        if pos_rois.shape[0] == 0:
+            # no positive RoI on this rank (no GT in the batch).  The reference has no guard here (Quirk Q11: it
+            # fails inside the head); the stock head returns no mask loss (standard_roi_head.py:167-170).  A zero
+            # that keeps the graph connected serves a training loop better than either.
+            return dict(loss_mask={'loss_masks': x[0].sum() * 0})
         stage_mask_targets = self.mask_head.get_targets(pos_bboxes, pos_assigned_gt_inds, gt_masks)
         return self._mask_forward_train_tensors(x, pos_rois, torch.cat(pos_labels), stage_mask_targets, noise=noise)
 

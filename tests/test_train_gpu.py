@@ -211,3 +211,25 @@ def test_clip_grad_norm_on_flat_group():
     z = x.clone()
     ops.clip_scale_(z, ss, 1e6)                                         # inactive: untouched, bit for bit
     assert torch.equal(z, x)
+
+
+def test_forward_train_with_an_image_without_ground_truth():
+    """One of the two images has no GT box: everything of it is background; the mask branch sees only the
+    other image's positives.  And a batch with no GT at all: zero mask loss, bbox losses still defined."""
+    ti = gi.train_inputs()
+    m = _full_roi_head()
+    feats = [f.cuda() for f in ti['feats']]
+    props = [p.cuda() for p in ti['proposals']]
+    gtb = [ti['gt_bboxes'][0].cuda(), torch.zeros((0, 4)).cuda()]
+    gtl = [ti['gt_labels'][0].cuda(), torch.zeros((0,), dtype=torch.long).cuda()]
+    gtm = [ti['gt_masks'][0].cuda(), torch.zeros((0, gi.IMG_H, gi.IMG_W), dtype=torch.uint8).cuda()]
+    torch.manual_seed(3)
+    losses = m.forward_train(feats, ti['img_metas'], props, gtb, gtl, None, gtm)
+    assert all(torch.isfinite(v).all() for v in losses.values())
+    sum(v for k, v in losses.items() if 'loss' in k).backward()
+    gtb0 = [torch.zeros((0, 4)).cuda() for _ in range(2)]
+    gtl0 = [torch.zeros((0,), dtype=torch.long).cuda() for _ in range(2)]
+    gtm0 = [torch.zeros((0, gi.IMG_H, gi.IMG_W), dtype=torch.uint8).cuda() for _ in range(2)]
+    losses0 = m.forward_train(feats, ti['img_metas'], props, gtb0, gtl0, None, gtm0)
+    assert float(losses0['loss_masks'].detach()) == 0.0 and float(losses0['loss_bbox'].detach()) == 0.0
+    assert torch.isfinite(losses0['loss_cls']).all()
