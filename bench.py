@@ -180,17 +180,6 @@ def train_step_bench(head, dev, rank, world, steps=4, warmup=4):
     from dynamask_amd import synth
     from dynamask_amd.dist import FlatParamGroup, mask_path_parameters
     import torch.distributed as dist
-    own_group = False
-    if world == 1 and not dist.is_initialized() and os.environ.get('DM_BENCH_NO_RCCL', '0') != '1':
-        # world size 1: still a real RCCL communicator, so that the gradient all-reduce, its side stream
-        # and the 1/world scaling run on hardware in every round
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', str(_free_port()))
-        try:
-            dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
-            own_group = True
-        except Exception as e:      # noqa: BLE001  (recorded in the JSON; the headline needs no collective)
-            print(f'[bench] RCCL world-1 group unavailable: {e}', file=sys.stderr)
     B, per = 2, 128
     feats = [f.to(dev) for f in synth.make_fpn(B, IMG_H, IMG_W, 256, seed=10 + 1000 * rank)]
     rois = synth.make_rois(B, per, IMG_H, IMG_W, seed=11 + 1000 * rank).to(dev)
@@ -205,7 +194,7 @@ def train_step_bench(head, dev, rank, world, steps=4, warmup=4):
         grp.zero_grad()
         res = head._mask_forward_train(feats, rois, labels, targets, noise=noise)
         res['loss_mask']['loss_masks'].backward()
-        grp.all_reduce_async(force=True)        # world 1: RCCL still runs if a group exists
+        grp.all_reduce_async(force=True)        # world 1: nothing to reduce unless a one-rank communicator exists (below)
         grp.sgd_step(lr=0.02, momentum=0.9, weight_decay=1e-4)
         return res
 
@@ -246,7 +235,23 @@ def train_step_bench(head, dev, rank, world, steps=4, warmup=4):
     # communication alone: the flat-gradient all-reduce (16.65 MB) timed by itself, so that
     # the scaling curve can be read with and without it; 0 at world size 1
     comm_ms = 0.0
-    import torch.distributed as dist
+    forced_ms = None
+    own_group = False
+    if world == 1 and not dist.is_initialized() and os.environ.get('DM_BENCH_NO_RCCL', '0') != '1':
+        # World size 1: the step above ran without a collective (a single-GPU job has nothing to reduce: this
+        # is the N = 1 point of the scaling curve).  So that the RCCL call, its side stream and the 1/world
+        # scaling of the fused SGD step still run on hardware in EVERY round, a one-rank communicator is
+        # created now, one window is timed with the all-reduce forced through it, and it is torn down again
+        # (left alive, its watchdog thread slowed eager multi-stream launch sequences by 10 %).
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(_free_port()))
+        try:
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+            own_group = True
+            step()
+            forced_ms = window()[0] / steps * 1e3
+        except Exception as e:      # noqa: BLE001  (recorded in the JSON; the headline needs no collective)
+            print(f'[bench] RCCL world-1 group unavailable: {e}', file=sys.stderr)
     if dist.is_initialized():
         for _ in range(2):
             grp.all_reduce_async(force=True); grp.wait()
@@ -268,7 +273,7 @@ def train_step_bench(head, dev, rank, world, steps=4, warmup=4):
     if own_group:
         torch.cuda.synchronize()
         dist.destroy_process_group()
-    return dt / steps * 1e3, float(res['loss_mask']['loss_masks'].detach()), grp.numel, B, comm_ms, collective
+    return dt / steps * 1e3, float(res['loss_mask']['loss_masks'].detach()), grp.numel, B, comm_ms, collective, forced_ms
 
 
 def _free_port():
@@ -456,7 +461,7 @@ def main():
     # training step (configs[2]/[3]) on every rank (parameters are restored afterwards);
     # reported in `extra`, not the headline.  Runs before the CPU leg: the oracle's host
     # threads keep spinning for a while and would slow the launch thread.
-    train_ms, train_loss, n_flat, train_b, comm_ms, collective = train_step_bench(head, dev, rank, world)
+    train_ms, train_loss, n_flat, train_b, comm_ms, collective, forced_ms = train_step_bench(head, dev, rank, world)
 
     if rank == 0:
         from dynamask_amd import ops
@@ -643,7 +648,7 @@ def main():
         extra['train_step'] = {'ms_per_step': train_ms, 'img_per_s': world * train_b / (train_ms * 1e-3),
                                'imgs_per_gpu': train_b, 'pos_rois_per_img': 128, 'loss': train_loss,
                                'allreduce_floats': n_flat, 'allreduce_alone_ms': comm_ms,
-                               'collective': collective,
+                               'collective': collective, 'ms_per_step_with_forced_one_rank_allreduce': forced_ms,
                                'what': 'fwd + loss + bwd (head, MaskPre, RoIAlign) + RCCL all-reduce of the flat '
                                        'mask-path gradient + fused SGD; BASELINE configs[2] (N=1) / configs[3] (N=8)'}
         os.write(json_fd, (json.dumps(result) + '\n').encode())

@@ -16,6 +16,9 @@ targets = [t.to(dev) for t in synth.make_targets(B * per, seed=13)]
 noise = synth.make_gumbel_noise(B * per, seed=14).to(dev)
 head.train()
 grp = FlatParamGroup(mask_path_parameters(head))
+if os.environ.get('TP_NO_DIRECT_GRAD'):          # A/B: gradients through autograd's AccumulateGrad as in round 1
+    for p in grp.params:
+        p._dm_direct_grad = False
 for i in range(int(os.environ.get('TP_STEPS', 12))):
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
