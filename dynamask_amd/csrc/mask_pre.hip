@@ -230,6 +230,64 @@ __global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(const float* __re
   }
 }
 
+// The same scatter with the plane staged in LDS (round 2).  The kernel above reads the 9 window taps of every
+// pooled output from global memory (recomputing BatchNorm's affine per tap), adds with global float atomics
+// into a zero-filled g_z and needs a memset of the whole tensor first: 0.59 ms per step.  Here a workgroup takes
+// one (image, channel) plane at a time: z = relu(bn(x)) is staged once with 16-byte loads, the pooled
+// gradients are scattered into an LDS gradient plane and the plane is written out whole (no memset, no global
+// atomics).  LDS float atomics are slow (0.38 per clock and CU) but there is only one per pooled output.
+// Needs H*W % 4 == 0 and 2 planes of H*W floats in LDS.
+__global__ __launch_bounds__(256) void maxpool_relu_bwd_lds_kernel(const float* __restrict__ x, int NB, int C, int H, int W,
+                                                                   const float* __restrict__ mean, const float* __restrict__ var,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   float eps, const float* __restrict__ gout,
+                                                                   float* __restrict__ gz, int OH, int OW) {
+  extern __shared__ __attribute__((aligned(16))) float pl[];       // z plane [HW], then g_z plane [HW]
+  const int HW = H * W, OHW = OH * OW;
+  float* zp = pl;
+  float* gp = pl + HW;
+  for (int nc = blockIdx.x; nc < NB * C; nc += gridDim.x) {
+    const int c = nc % C;
+    const float invstd = 1.0f / sqrtf(var[c] + eps);
+    const float g = gamma[c], b = beta[c], m = mean[c];
+    const dm_f32x4* x4 = reinterpret_cast<const dm_f32x4*>(x + (size_t)nc * HW);
+    for (int i = threadIdx.x; i < HW / 4; i += 256) {
+      const dm_f32x4 v = x4[i];
+      dm_f32x4 z;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) z[e] = fmaxf((v[e] - m) * invstd * g + b, 0.f);      // the expression of the kernel above
+      reinterpret_cast<dm_f32x4*>(zp)[i] = z;
+      reinterpret_cast<dm_f32x4*>(gp)[i] = dm_f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < OHW; o += 256) {
+      const int oy = o / OW, ox = o - oy * OW;
+      float best = -INFINITY;
+      int bi = -1;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const int y = 2 * oy - 1 + dy;
+        if (y < 0 || y >= H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int xx = 2 * ox - 1 + dx;
+          if (xx < 0 || xx >= W) continue;
+          const float v = zp[y * W + xx];
+          if (v > best) {
+            best = v;
+            bi = y * W + xx;
+          }
+        }
+      }
+      if (bi >= 0 && best > 0.f) atomicAdd(gp + bi, gout[(size_t)nc * OHW + o]);
+    }
+    __syncthreads();
+    dm_f32x4* o4 = reinterpret_cast<dm_f32x4*>(gz + (size_t)nc * HW);
+    for (int i = threadIdx.x; i < HW / 4; i += 256) o4[i] = reinterpret_cast<const dm_f32x4*>(gp)[i];
+    __syncthreads();
+  }
+}
+
 __device__ __forceinline__ float bsum(float v, float* smem) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   v = wave_sum_(v);
@@ -332,11 +390,19 @@ extern "C" int dm_bn_relu_maxpool_bwd(const float* x, int NB, int C, int H, int 
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
   const size_t total = (size_t)NB * C * OH * OW;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(grad_x, 0, (size_t)NB * C * H * W * sizeof(float), st) != hipSuccess) return DM_ERR_LAUNCH;
-  const int blocks = (int)min((size_t)dm_ceil_div((long long)total, 256), (size_t)16384);
-  DM_LAUNCH(maxpool_relu_bwd_kernel, dim3(blocks), dim3(256), 0, st, x, NB, C, H, W, mean, var, gamma, beta, eps, grad_out,
-            grad_x, OH, OW);
-  int rc = dm_check_launch();
+  int rc;
+  if ((H * W) % 4 == 0 && (size_t)H * W * 8 <= 64 * 1024) {
+    const int blocks = min(NB * C, 16 * dm_num_cus());
+    DM_LAUNCH(maxpool_relu_bwd_lds_kernel, dim3(blocks), dim3(256), (size_t)H * W * 8, st, x, NB, C, H, W, mean, var, gamma, beta,
+              eps, grad_out, grad_x, OH, OW);
+    rc = dm_check_launch();
+  } else {
+    if (hipMemsetAsync(grad_x, 0, (size_t)NB * C * H * W * sizeof(float), st) != hipSuccess) return DM_ERR_LAUNCH;
+    const int blocks = (int)min((size_t)dm_ceil_div((long long)total, 256), (size_t)16384);
+    DM_LAUNCH(maxpool_relu_bwd_kernel, dim3(blocks), dim3(256), 0, st, x, NB, C, H, W, mean, var, gamma, beta, eps, grad_out,
+              grad_x, OH, OW);
+    rc = dm_check_launch();
+  }
   if (rc != DM_OK) return rc;
   if (scratch && NB >= kBnSplits) {
     DM_LAUNCH(bn_bwd_split_kernel<0>, dim3(C, kBnSplits), dim3(256), 0, st, x, grad_x, NB, C, H * W, mean, var, gamma, eps,
