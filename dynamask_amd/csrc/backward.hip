@@ -31,6 +31,18 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(float* __restrict__ g, co
     if (!(y[i] > 0.f)) g[i] = 0.f;
 }
 
+// 16 bytes per lane (both pointers 16-byte aligned, n % 4 == 0): the mask pass is pure streaming
+__global__ __launch_bounds__(256) void relu_bwd4_kernel(dm_f32x4* __restrict__ g, const dm_f32x4* __restrict__ y, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const dm_f32x4 m = y[i];
+    dm_f32x4 v = g[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (!(m[e] > 0.f)) v[e] = 0.f;
+    g[i] = v;
+  }
+}
+
 // g_logit[n,p] (+)= (ga[n,p] + gb[n,p]) * s * (1 - s),  s = sig[n, ch, p] taken from a
 // channel of a wider tensor; ga / gb are channel slices too (gb optional).
 __global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restrict__ sig, long long sig_bs,
@@ -57,10 +69,21 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
   const int c = blockIdx.x;
   float s = 0.f;
   const long long total = (long long)NB * HW;
-  for (long long i = (long long)blockIdx.y * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.y * blockDim.x) {
-    const long long n = i / HW;
-    const long long p = i - n * HW;
-    s += g[n * bs + (long long)c * HW + p];
+  if ((HW & 3) == 0 && (bs & 3) == 0 && ((uintptr_t)g & 15) == 0) {
+    const int HWq = HW >> 2;
+    const long long total4 = (long long)NB * HWq;
+    for (long long i = (long long)blockIdx.y * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.y * blockDim.x) {
+      const long long n = i / HWq;
+      const long long p = i - n * HWq;
+      const dm_f32x4 v = *reinterpret_cast<const dm_f32x4*>(g + n * bs + (long long)c * HW + p * 4);
+      s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+  } else {
+    for (long long i = (long long)blockIdx.y * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.y * blockDim.x) {
+      const long long n = i / HW;
+      const long long p = i - n * HW;
+      s += g[n * bs + (long long)c * HW + p];
+    }
   }
   s = wsum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -870,6 +893,11 @@ int grid_for(size_t n) { return (int)min((size_t)dm_ceil_div((long long)n, 256),
 extern "C" int dm_relu_bwd(float* grad, const float* out, long long count, dm_stream_t stream) {
   if (!grad || !out || count < 0) return DM_ERR_INVALID_ARG;
   if (count == 0) return DM_OK;
+  if (count % 4 == 0 && ((uintptr_t)grad & 15) == 0 && ((uintptr_t)out & 15) == 0) {
+    DM_LAUNCH(relu_bwd4_kernel, dim3(grid_for((size_t)count / 4)), dim3(256), 0, (hipStream_t)stream,
+              reinterpret_cast<dm_f32x4*>(grad), reinterpret_cast<const dm_f32x4*>(out), (size_t)count / 4);
+    return dm_check_launch();
+  }
   DM_LAUNCH(relu_bwd_kernel, dim3(grid_for((size_t)count)), dim3(256), 0, (hipStream_t)stream, grad, out, (size_t)count);
   return dm_check_launch();
 }
