@@ -407,6 +407,63 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_lds_kernel(const float* __
   }
 }
 
+// align_corners=True adjoint as an LDS-staged gather.  The scatter form (upsample2x_bwd_kernel) sends four global
+// atomics per output pixel into a plane a quarter of the size, i.e. 16 colliding atomics per address: 150 us for
+// the 12.8 MB of the final 56 -> 112 logits.  Here the gradient plane is staged once (16-byte loads) and every
+// input pixel gathers the output rows / columns whose forward footprint (y0, y1) contains it, with the
+// forward's own weights: the source coordinate is rh * oy with rh = (H-1)/(2H-1) just under 1/2, so the
+// candidates of input row y are the integers of the open interval ((y-1)/rh, (y+1)/rh), at most 7 of them.
+__global__ __launch_bounds__(256) void upsample2x_bwd_ac_lds_kernel(const float* __restrict__ gout,
+                                                                    const float* __restrict__ yout, int NC, int H, int W,
+                                                                    float* __restrict__ gin) {
+  extern __shared__ __attribute__((aligned(16))) float plane[];     // [2H][2W] masked gradients
+  const int OH = 2 * H, OW = 2 * W, OHW = OH * OW, HW = H * W;
+  const float rh = (float)(H - 1) / (float)(OH - 1), rw = (float)(W - 1) / (float)(OW - 1);
+  const float ih = (float)(OH - 1) / (float)(H - 1), iw = (float)(OW - 1) / (float)(W - 1);
+  for (int nc = blockIdx.x; nc < NC; nc += gridDim.x) {
+    const dm_f32x4* g4 = reinterpret_cast<const dm_f32x4*>(gout + (size_t)nc * OHW);
+    const dm_f32x4* m4 = yout ? reinterpret_cast<const dm_f32x4*>(yout + (size_t)nc * OHW) : nullptr;
+    for (int i = threadIdx.x; i < OHW / 4; i += 256) {
+      dm_f32x4 v = g4[i];
+      if (m4) {
+        const dm_f32x4 m = m4[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (!(m[e] > 0.f)) v[e] = 0.f;
+      }
+      reinterpret_cast<dm_f32x4*>(plane)[i] = v;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < HW; idx += 256) {
+      const int y = idx / W, x = idx - y * W;
+      // one candidate more on either side than the interval needs: rounding of the bounds cannot lose a row
+      const int oy_lo = max((int)((float)(y - 1) * ih) - 1, 0), oy_hi = min((int)((float)(y + 1) * ih) + 2, OH - 1);
+      const int ox_lo = max((int)((float)(x - 1) * iw) - 1, 0), ox_hi = min((int)((float)(x + 1) * iw) + 2, OW - 1);
+      float acc = 0.f;
+      for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+        const float sy = rh * (float)oy;
+        const int y0 = (int)sy;
+        const int y1 = y0 + ((y0 < H - 1) ? 1 : 0);
+        const float ly = sy - (float)y0;
+        const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
+        if (wy == 0.f) continue;
+        float row = 0.f;
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+          const float sx = rw * (float)ox;
+          const int x0 = (int)sx;
+          const int x1 = x0 + ((x0 < W - 1) ? 1 : 0);
+          const float lx = sx - (float)x0;
+          const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
+          row += wx * plane[oy * OW + ox];
+        }
+        acc += wy * row;
+      }
+      gin[(size_t)nc * HW + idx] = acc;
+    }
+    __syncthreads();
+  }
+}
+
 // ----------------------------------------------------------------- K4 backward
 // Adjoint of the point sample.  A small RoI maps its S x S lattice onto a handful of
 // feature pixels, so thousands of samples of one workgroup hit the same addresses:
@@ -954,6 +1011,14 @@ extern "C" int dm_upsample2x_bilinear_bwd(const float* grad_out, const float* fw
               fwd_out_for_relu, NC, H, W, grad_in);
     return dm_check_launch();
   }
+  if (align_corners && H >= 2 && W >= 2 && (size_t)16 * H * W <= 64 * 1024) {
+    const int blocks = min(NC, 8 * dm_num_cus());
+    DM_LAUNCH(upsample2x_bwd_ac_lds_kernel, dim3(blocks), dim3(256), (size_t)16 * H * W, (hipStream_t)stream, grad_out,
+              fwd_out_for_relu, NC, H, W, grad_in);
+    return dm_check_launch();
+  }
+  // scatter form (1-pixel inputs, planes beyond 64 KB with align_corners): accumulates, so clear the output first
+  if (hipMemsetAsync(grad_in, 0, (size_t)NC * H * W * sizeof(float), (hipStream_t)stream) != hipSuccess) return DM_ERR_LAUNCH;
   DM_LAUNCH(upsample2x_bwd_kernel, dim3(grid_for((size_t)NC * 4 * H * W)), dim3(256), 0, (hipStream_t)stream, grad_out,
             fwd_out_for_relu, NC, H, W, align_corners, grad_in);
   return dm_check_launch();

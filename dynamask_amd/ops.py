@@ -562,7 +562,7 @@ def upsample2x_backward(grad_out, fwd_out, in_shape, align_corners=False):
     if fwd_out is not None:
         _chk(fwd_out, 'fwd_out')
     N, C, H, W = in_shape
-    gin = torch.zeros(in_shape, device=grad_out.device, dtype=torch.float32)
+    gin = torch.empty(in_shape, device=grad_out.device, dtype=torch.float32)
     check(lib().dm_upsample2x_bilinear_bwd(_p(grad_out), _p(fwd_out), N * C, H, W, 1 if align_corners else 0, _p(gin),
                                            _stream()), 'dm_upsample2x_bilinear_bwd')
     return gin
@@ -607,7 +607,7 @@ def deform_col2im_coord(colgrad, x, offset, deform_groups):
     _chk(x, 'x')
     _chk(offset, 'offset')
     NB, C, H, W = x.shape
-    gx = torch.zeros_like(x)
+    gx = torch.empty_like(x)
     goff = torch.empty_like(offset)
     check(lib().dm_deform_col2im_coord(_p(colgrad), _p(x), _p(offset), NB, C, H, W, deform_groups, _p(gx), _p(goff),
                                        _stream()), 'dm_deform_col2im_coord')

@@ -362,7 +362,8 @@ int dm_conv2d_wgrad(const float* dy, long long dy_batch_stride, int Cout, const 
                     int Cs, int NB, int H, int W, int ksize, float* dw, int ldw, int col_offset, dm_stream_t stream);
 
 /* adjoint of dm_upsample2x_bilinear_fwd; fwd_out_for_relu (optional) masks the
- * fused ReLU; grad_in is accumulated into (caller zero-fills). */
+ * fused ReLU; grad_in is overwritten (no zero-fill needed; planes up to 64 KB of
+ * output gradient are gathered through LDS, larger ones are cleared and scattered). */
 int dm_upsample2x_bilinear_bwd(const float* grad_out, const float* fwd_out_for_relu, int NC, int H, int W,
                                int align_corners, float* grad_in, dm_stream_t stream);
 

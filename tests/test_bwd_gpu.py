@@ -73,9 +73,12 @@ def test_conv_wgrad_bias_and_data_grad(ops, N, Cs, Cout, S, ks):
     _close(gx, xcat.grad)
 
 
-def test_upsample_backward(ops):
-    for ac, relu in ((False, True), (True, False)):
-        x = torch.randn(5, 6, 14, 14, generator=_g(30), requires_grad=True)
+@pytest.mark.parametrize('shape', [(5, 6, 14, 14), (3, 1, 56, 56), (2, 3, 9, 13), (2, 2, 2, 2), (1, 2, 72, 72), (2, 1, 1, 5)])
+def test_upsample_backward(ops, shape):
+    """LDS-staged gathers (half-pixel and align_corners), the plain gather, and the scatter fallback for planes
+    beyond 64 KB / one-pixel inputs; the output buffer is handed over uninitialised."""
+    for ac, relu in ((False, True), (True, False), (True, True)):
+        x = torch.randn(*shape, generator=_g(30), requires_grad=True)
         y = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=ac)
         if relu:
             y = F.relu(y)
