@@ -246,6 +246,203 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   }
 }
 
+// Narrow 3x3 weight gradients (Cout <= 36: the DCN offset convs, MaskPre's 128 -> 16 conv).  The general kernel above
+// stages the nine shifted copies of x as separate B rows -- nine bounds-checked dword loads per x element, and the
+// address arithmetic of that fetch costs as much issue time as the MFMAs it feeds (13-49 TFLOP/s on these shapes).
+// Here a workgroup owns 32 input channels and walks (image, row band) units: the band of x (R + 2 rows, one shared
+// zero column between rows, zero rows outside the image) and the band of dy sit in LDS, and the B operand of tap
+// (ky, kx) is read straight from the x band at a per-lane base (lane = input channel, odd plane stride: no bank
+// conflicts) plus a wave-uniform offset -- no transposed staging, no bounds checks in the K loop.  N index = tap-major
+// (nine 32-column tiles, one per tap), M = one 32-row tile (+ rows 32..35 on v_mfma_f32_4x4x1, TAIL), K = pixel pairs
+// of the band, dealt round-robin to the four waves (every wave holds all nine accumulator tiles); the waves' sums are
+// added through LDS and leave with one float atomic per element and workgroup.
+struct WgradNarrowArgs {
+  const float* dy;
+  long long dy_bs;
+  const float* x;
+  long long x_bs;
+  int Cout, Cs, NB, H, W, HW;
+  float* dw;
+  int ldw, coloff;
+  int R, Wp, PL, LDA, bands, units, units_per_split, groups;
+  unsigned magic_w2, magic_rr, magic_band;      // ceil(2^32 / d) for d = W/2, R + 2, R * W/2
+};
+
+template <bool TAIL>
+__global__ __launch_bounds__(256, 2) void conv_wgrad3_narrow_kernel(WgradNarrowArgs a) {
+  constexpr int MR = TAIL ? 36 : 32, CG = 32, SB = TAIL ? 6 : 8;     // SB: what fits next to the accumulators without spilling
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+  const int group = blockIdx.x % a.groups, split = blockIdx.x / a.groups;
+  const int ci0 = group * CG;
+  const int W = a.W, H = a.H, Wp = a.Wp, PL = a.PL, LDA = a.LDA, R = a.R, W2 = a.W >> 1, RR = a.R + 2;
+  float* xb = smem;                 // [CG][PL]: element (row rr in -1..R, column c in -1..W) at (rr + 1) * Wp + c + 1
+  float* dyb = smem + CG * PL;      // [MR][LDA]
+  // zero once: the shared pad column, channels past Cs, cout rows past Cout are never written again
+  for (int i = tid; i < CG * PL + MR * LDA; i += 256) smem[i] = 0.f;
+
+  dm_f32x16 acc[9];
+  dm_f32x4 acct[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    acct[t] = dm_f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int u0 = split * a.units_per_split, u1 = min(a.units, u0 + a.units_per_split);
+  const int band_items = R * W2;
+  for (int u = u0; u < u1; ++u) {
+    const int n = u / a.bands, band = u - n * a.bands;
+    const int r0 = band * R, rows = min(R, H - r0);
+    __syncthreads();                // the previous unit's operand reads (first pass: the zero fill) are done
+    // staging in batches of SB independent 8-byte loads per lane (issued together, then written to LDS)
+    const float* xn = a.x + (size_t)n * a.x_bs + (size_t)ci0 * a.HW;
+    const int xtotal = CG * RR * W2;
+    for (int base = tid; base < xtotal; base += 256 * SB) {
+      float2 v[SB];
+      int dst[SB];
+#pragma unroll
+      for (int j = 0; j < SB; ++j) {
+        const int i = base + j * 256;
+        const int t = (int)__umulhi((unsigned)i, a.magic_w2), c2 = i - t * W2;
+        const int ch = (int)__umulhi((unsigned)t, a.magic_rr), rr = t - ch * RR;
+        const int gy = r0 - 1 + rr;
+        const bool live = i < xtotal && rr < rows + 2;
+        dst[j] = live ? ch * PL + rr * Wp + 2 * c2 + 1 : -1;
+        v[j] = make_float2(0.f, 0.f);
+        if (live && ci0 + ch < a.Cs && gy >= 0 && gy < H)
+          v[j] = *reinterpret_cast<const float2*>(xn + (size_t)ch * a.HW + gy * W + 2 * c2);
+      }
+#pragma unroll
+      for (int j = 0; j < SB; ++j)
+        if (dst[j] >= 0) {
+          xb[dst[j]] = v[j].x;
+          xb[dst[j] + 1] = v[j].y;
+        }
+    }
+    const float* dyn = a.dy + (size_t)n * a.dy_bs + (size_t)r0 * W;
+    const int live_pairs = rows * W2;
+    const int dtotal = a.Cout * band_items;
+    for (int base = tid; base < dtotal; base += 256 * SB) {
+      float2 v[SB];
+      int dst[SB];
+#pragma unroll
+      for (int j = 0; j < SB; ++j) {
+        const int i = base + j * 256;
+        const int co = (int)__umulhi((unsigned)i, a.magic_band), e = i - co * band_items;
+        const bool live = i < dtotal && e < live_pairs;
+        dst[j] = live ? co * LDA + 2 * e : -1;
+        v[j] = make_float2(0.f, 0.f);
+        if (live) v[j] = *reinterpret_cast<const float2*>(dyn + (size_t)co * a.HW + 2 * e);
+      }
+#pragma unroll
+      for (int j = 0; j < SB; ++j)
+        if (dst[j] >= 0) {
+          dyb[dst[j]] = v[j].x;
+          dyb[dst[j] + 1] = v[j].y;
+        }
+    }
+    const int live = live_pairs;
+    __syncthreads();
+    const float* ap = dyb + l31 * LDA + hi;
+    const float* at = dyb + (32 + (lane & 3)) * LDA + hi;
+    const float* bp = xb + l31 * PL + hi;
+    int r = 0, c2 = wave;           // W2 >= 4 is checked by the launcher: one wrap per step at most
+    for (int kp = wave; kp < live; kp += 4) {
+      const float a0 = ap[2 * kp];
+      const float a1 = TAIL ? at[2 * kp] : 0.f;
+      const float* b0 = bp + r * Wp + 2 * c2;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const float b = b0[ky * Wp + kx];
+          acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[ky * 3 + kx], 0, 0, 0);
+          if (TAIL) acct[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, b, acct[ky * 3 + kx], 0, 0, 0);
+        }
+      c2 += 4;
+      if (c2 >= W2) { c2 -= W2; ++r; }
+    }
+  }
+  // the four waves' partial sums -> red[tap][row][channel] (wave after wave: 4 short phases), then one atomic each
+  float* red = smem;
+#pragma unroll 1
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float* d = red + (t * MR + (r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l31;
+          *d = (w == 0) ? acc[t][r] : *d + acc[t][r];
+        }
+        if (TAIL) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float v = acct[t][i] + __shfl_xor(acct[t][i], 32, 64);      // the two pixel parities
+            float* d = red + (t * MR + 32 + i) * 32 + l31;
+            if (hi == 0) *d = (w == 0) ? v : *d + v;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int ncols = min(CG, a.Cs - ci0) * 9;
+  for (int i = tid; i < a.Cout * CG * 9; i += 256) {
+    const int co = i / (CG * 9), jj = i - co * (CG * 9);
+    if (jj >= ncols) continue;
+    const int cil = jj / 9, t = jj - cil * 9;
+    atomicAdd(a.dw + (size_t)co * a.ldw + a.coloff + (size_t)ci0 * 9 + jj, red[(t * MR + co) * 32 + cil]);
+  }
+}
+
+static unsigned dm_magic(unsigned d) { return (unsigned)((0x100000000ULL + d - 1) / d); }
+
+// returns DM_OK after launching, or 1 when the shape is not this kernel's
+static int launch_wgrad3_narrow(const WgradArgs& g, hipStream_t st) {
+  static const bool off = getenv("DM_WGRAD_NARROW_OFF") != nullptr;          // A/B switch
+  if (off || g.Cout > 36 || (g.W & 1) || g.W < 8 || g.H < 1) return 1;
+  if (((uintptr_t)g.dy | (uintptr_t)g.x) & 7u) return 1;
+  if ((g.dy_bs | g.x_bs) & 1LL) return 1;
+  const bool tail = g.Cout > 32;
+  const int MR = tail ? 36 : 32, Wp = g.W + 1;
+  const size_t budget = 78 * 1024;
+  auto bytes_for = [&](int R, int* PL, int* LDA) {
+    *PL = ((R + 2) * Wp + 1) | 1;
+    *LDA = (R * g.W) | 1;
+    return sizeof(float) * ((size_t)32 * *PL + (size_t)MR * *LDA);
+  };
+  int PL = 0, LDA = 0, Rmax = 0;
+  for (int R = min(g.H, 64); R >= 1; --R)
+    if (bytes_for(R, &PL, &LDA) <= budget) { Rmax = R; break; }
+  if (Rmax < 1) return 1;
+  const int nb = dm_ceil_div(g.H, Rmax);
+  const int R = dm_ceil_div(g.H, nb);
+  size_t bytes = bytes_for(R, &PL, &LDA);
+  bytes = max(bytes, sizeof(float) * (size_t)9 * MR * 32);                   // the epilogue's reduction buffer
+  if ((long long)32 * (R + 2) * (g.W / 2) >= 65536 || (long long)g.Cout * R * (g.W / 2) >= 65536) return 1;   // magic-division range
+  WgradNarrowArgs a;
+  a.dy = g.dy; a.dy_bs = g.dy_bs; a.x = g.x; a.x_bs = g.x_bs; a.Cout = g.Cout; a.Cs = g.Cs; a.NB = g.NB; a.H = g.H; a.W = g.W;
+  a.HW = g.HW; a.dw = g.dw; a.ldw = g.ldw; a.coloff = g.coloff;
+  a.R = R; a.Wp = Wp; a.PL = PL; a.LDA = LDA; a.bands = nb; a.units = g.NB * nb; a.groups = dm_ceil_div(g.Cs, 32);
+  a.magic_w2 = dm_magic(g.W / 2); a.magic_rr = dm_magic(R + 2); a.magic_band = dm_magic(R * (g.W / 2));
+  const int target = 2 * dm_num_cus();
+  const int nsplit = max(1, min(a.units, target / a.groups));
+  a.units_per_split = dm_ceil_div(a.units, nsplit);
+  const int splits = dm_ceil_div(a.units, a.units_per_split);
+  static bool attr_t[DM_MAX_DEVICES] = {false}, attr_n[DM_MAX_DEVICES] = {false};
+  if (tail) {
+    if (dm_ensure_lds_limit(reinterpret_cast<const void*>(&conv_wgrad3_narrow_kernel<true>), 80 * 1024, attr_t) != DM_OK) return DM_ERR_LAUNCH;
+    DM_LAUNCH((conv_wgrad3_narrow_kernel<true>), dim3((unsigned)(a.groups * splits)), dim3(256), bytes, st, a);
+  } else {
+    if (dm_ensure_lds_limit(reinterpret_cast<const void*>(&conv_wgrad3_narrow_kernel<false>), 80 * 1024, attr_n) != DM_OK) return DM_ERR_LAUNCH;
+    DM_LAUNCH((conv_wgrad3_narrow_kernel<false>), dim3((unsigned)(a.groups * splits)), dim3(256), bytes, st, a);
+  }
+  return DM_OK;
+}
+
 template <int KS>
 void launch_wgrad(WgradArgs a, hipStream_t st) {
   const int J = a.Cs * KS * KS;
@@ -989,8 +1186,13 @@ extern "C" int dm_conv2d_wgrad(const float* dy, long long dy_batch_stride, int C
   WgradArgs a;
   a.dy = dy; a.dy_bs = dy_batch_stride; a.x = x; a.x_bs = x_batch_stride; a.Cout = Cout; a.Cs = Cs;
   a.NB = NB; a.H = H; a.W = W; a.HW = H * W; a.Q = NB * H * W; a.dw = dw; a.ldw = ldw; a.coloff = col_offset;
-  if (ksize == 3) launch_wgrad<3>(a, (hipStream_t)stream);
-  else launch_wgrad<1>(a, (hipStream_t)stream);
+  if (ksize == 3) {
+    const int rc = launch_wgrad3_narrow(a, (hipStream_t)stream);
+    if (rc < 0) return rc;
+    if (rc == 1) launch_wgrad<3>(a, (hipStream_t)stream);
+  } else {
+    launch_wgrad<1>(a, (hipStream_t)stream);
+  }
   return dm_check_launch();
 }
 

@@ -1,0 +1,58 @@
+"""Event-timed single ops at the training step's shapes (256 RoIs on the 800x1333 pyramid).
+  python tools/op_probe.py [case ...]      cases: psb (point-sample adjoint), wgrad (narrow weight gradients)"""
+import os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+import bench
+from dynamask_amd import synth, ops
+
+dev = torch.device('cuda')
+B, per = 2, 128
+rois = synth.make_rois(B, per, bench.IMG_H, bench.IMG_W, seed=11).to(dev)
+N = B * per
+
+
+def timed(fn, reps=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / reps)
+    return sorted(ts)[len(ts) // 2]
+
+
+cases = sys.argv[1:] or ['psb', 'wgrad']
+g = torch.Generator().manual_seed(5)
+if 'psb' in cases:
+    for C, S, (H, W), sc in ((64, 56, (200, 336), 0.25), (128, 28, (100, 168), 0.125), (256, 14, (50, 84), 0.0625)):
+        go = torch.randn(N, C, S, S, generator=g).to(dev)
+        gf = torch.zeros(B, C, H, W, device=dev)
+        ms = timed(lambda: ops.point_sample_backward(go, (B, C, H, W), rois, sc, grad_feat=gf))
+        print(f'point_sample_backward {N}x{C}x{S}x{S} -> {B}x{C}x{H}x{W}: {ms:.3f} ms  ({go.numel() * 4 / ms / 1e9:.2f} TB/s of gradient read)', flush=True)
+if 'psb_split' in cases:       # by RoI size: which share of the 56 x 56 adjoint goes to the LDS-tile path / the global-atomic path
+    C, S, (H, W), sc = 64, 56, (200, 336), 0.25
+    side = ((rois[:, 3] - rois[:, 1]) * (rois[:, 4] - rois[:, 2])).sqrt()
+    for lo, hi in ((0, 100), (100, 180), (180, 300), (300, 450), (450, 2000)):
+        sel = rois[(side >= lo) & (side < hi)].contiguous()
+        if sel.shape[0] == 0:
+            continue
+        go = torch.randn(sel.shape[0], C, S, S, generator=g).to(dev)
+        gf = torch.zeros(B, C, H, W, device=dev)
+        ms = timed(lambda: ops.point_sample_backward(go, (B, C, H, W), sel, sc, grad_feat=gf))
+        print(f'point_sample_backward sqrt(wh) in [{lo},{hi}): {sel.shape[0]} RoIs {ms:.3f} ms = {1e3 * ms / sel.shape[0]:.2f} us/RoI', flush=True)
+if 'wgrad' in cases:
+    for cout, cin, S, ks in ((36, 64, 56, 3), (36, 128, 28, 3), (36, 256, 14, 3), (16, 128, 28, 3), (30, 64, 56, 1), (62, 128, 28, 1),
+                             (126, 256, 14, 1), (256, 256, 14, 3), (64, 576, 56, 1)):
+        dy = torch.randn(N, cout, S, S, generator=g).to(dev)
+        x = torch.randn(N, cin, S, S, generator=g).to(dev)
+        dw = torch.zeros(cout, cin, ks, ks, device=dev)
+        ms = timed(lambda: ops.conv2d_wgrad(dy, x, ks, dw=dw))
+        fl = 2.0 * N * S * S * cout * cin * ks * ks
+        print(f'conv2d_wgrad {cout}x{cin}x{ks}x{ks} @{S}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s  ({(dy.numel() + x.numel()) * 4 / ms / 1e9:.2f} TB/s of operands)', flush=True)
