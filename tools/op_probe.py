@@ -47,6 +47,21 @@ if 'psb_split' in cases:       # by RoI size: which share of the 56 x 56 adjoint
         gf = torch.zeros(B, C, H, W, device=dev)
         ms = timed(lambda: ops.point_sample_backward(go, (B, C, H, W), sel, sc, grad_feat=gf))
         print(f'point_sample_backward sqrt(wh) in [{lo},{hi}): {sel.shape[0]} RoIs {ms:.3f} ms = {1e3 * ms / sel.shape[0]:.2f} us/RoI', flush=True)
+if 'dcnfwd' in cases:       # fused DCN forward vs column matrix + 1x1 GEMM (the column matrix is what the backward needs anyway)
+    for C, S in ((64, 56), (128, 28), (256, 14)):
+        x = torch.randn(N, C, S, S, generator=g).to(dev)
+        off = torch.randn(N, 36, S, S, generator=g).to(dev)
+        w = (torch.randn(C, C, 3, 3, generator=g) / (9 * C) ** 0.5).to(dev)
+        pk = ops.pack_conv_weight(w)
+        wt = ops.dcn_weight_permute(w, C, C, True)
+        pk_cm = ops.pack_conv_weight(wt, transpose_flip=True)
+        t_f = timed(lambda: ops.deform_conv(x, off, pk, C, 2, relu=True))
+        t_i = timed(lambda: ops.deform_im2col(x, off, 2), reps=5)
+        col = ops.deform_im2col(x, off, 2)
+        t_g = timed(lambda: ops.conv2d([col], pk_cm, None, C, 1, relu=True))
+        a, b = ops.deform_conv(x, off, pk, C, 2, relu=True), ops.conv2d([col], pk_cm, None, C, 1, relu=True)
+        print(f'DCN fwd C={C} @{S}: fused {t_f:.3f} ms; im2col {t_i:.3f} + GEMM {t_g:.3f} ms; max diff {float((a - b).abs().max()):.2e}', flush=True)
+        del col
 if 'wgrad' in cases:
     for cout, cin, S, ks in ((36, 64, 56, 3), (36, 128, 28, 3), (36, 256, 14, 3), (16, 128, 28, 3), (30, 64, 56, 1), (62, 128, 28, 1),
                              (126, 256, 14, 1), (256, 256, 14, 3), (64, 576, 56, 1)):
