@@ -624,25 +624,37 @@ def dcn_weight_permute(src, cout, c, to_colmajor, dst=None, accumulate=False):
     return dst
 
 
-def deform_conv_backward(x, offset, weight, grad_out, deform_groups, gw_accum=None, col=None):
-    """(grad_x, grad_offset, grad_weight) of DCNv1 3x3.  The two GEMMs of the
-    reference's backward run as 1x1 convs over the tap-major column matrix.
-    ``gw_accum``: [Cout, C, 3, 3] tensor the weight gradient is ADDED to (then None is returned for it).
-    ``col``: the column matrix of (x, offset) if the forward kept it (it is released here)."""
+def deform_conv_backward_data(x, offset, weight, grad_out, deform_groups):
+    """(grad_x, grad_offset) of DCNv1 3x3: column gradient = W^T . dY as a 1x1 conv, then the coordinate
+    gradient and col2im over it."""
     NB, C, H, W = x.shape
     cout = weight.shape[0]
     wt = dcn_weight_permute(weight.contiguous(), cout, C, True)                # [(tap,ci)][co]
     colgrad = conv2d(grad_out, pack_conv_weight(wt), None, 9 * C, 1)           # W^T . dY
-    gx, goff = deform_col2im_coord(colgrad, x, offset, deform_groups)
-    del colgrad
+    return deform_col2im_coord(colgrad, x, offset, deform_groups)
+
+
+def deform_conv_backward_weight(x, offset, grad_out, deform_groups, gw_accum=None, col=None):
+    """grad_weight [Cout, C, 3, 3] of DCNv1 3x3 = dY . col^T as a 1x1 weight gradient over the tap-major column
+    matrix.  ``gw_accum``: tensor the gradient is ADDED to (then None is returned); ``col``: the column matrix of
+    (x, offset) if the forward kept it."""
+    NB, C, H, W = x.shape
+    cout = grad_out.shape[1]
     if col is None:
         col = deform_im2col(x, offset, deform_groups)
     gw_cm = conv2d_wgrad(grad_out, col, 1)                                     # [co][(tap,ci)]
     del col
     if gw_accum is not None:
         dcn_weight_permute(gw_cm, cout, C, False, dst=gw_accum, accumulate=True)
-        return gx, goff, None
-    gw = dcn_weight_permute(gw_cm, cout, C, False)
+        return None
+    return dcn_weight_permute(gw_cm, cout, C, False)
+
+
+def deform_conv_backward(x, offset, weight, grad_out, deform_groups, gw_accum=None, col=None):
+    """(grad_x, grad_offset, grad_weight) of DCNv1 3x3.  The two GEMMs of the
+    reference's backward run as 1x1 convs over the tap-major column matrix."""
+    gx, goff = deform_conv_backward_data(x, offset, weight, grad_out, deform_groups)
+    gw = deform_conv_backward_weight(x, offset, grad_out, deform_groups, gw_accum=gw_accum, col=col)
     return gx, goff, gw
 
 

@@ -300,9 +300,25 @@ class DynaMaskRoIHead(nn.Module):
 
     def _mask_forward_train_tensors(self, x, pos_rois, pos_labels, stage_mask_targets, noise=None):
         """dynamask_roi_head.py:57-73 from ``pos_rois`` on."""
-        mask_results = self._mask_forward(x, pos_rois, pos_labels)
-        ins_semantic_feats = self.semantic_roi_extractor([x[0].detach(), ], pos_rois)
-        mask_labels, idx, logits, y = self.get_mask_label(ins_semantic_feats, noise, return_index=True)
+        # The resolution selector (56x56 extraction of P2 -> MaskPre -> ST-Gumbel) shares nothing with the mask head
+        # until the loss: it is issued on a second stream and runs beside the head (autograd replays each node on
+        # the stream of its forward, so the two backward passes overlap the same way and are joined by the engine).
+        from . import train_path
+        side = train_path.side_stream(pos_rois.device, 'selector') if torch.is_grad_enabled() else None
+        if side is not None:
+            main = torch.cuda.current_stream(pos_rois.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                ins_semantic_feats = self.semantic_roi_extractor([x[0].detach(), ], pos_rois)
+                mask_labels, idx, logits, y = self.get_mask_label(ins_semantic_feats, noise, return_index=True)
+            mask_results = self._mask_forward(x, pos_rois, pos_labels)
+            main.wait_stream(side)
+            for t in (mask_labels, idx, logits):
+                t.record_stream(main)
+        else:
+            mask_results = self._mask_forward(x, pos_rois, pos_labels)
+            ins_semantic_feats = self.semantic_roi_extractor([x[0].detach(), ], pos_rois)
+            mask_labels, idx, logits, y = self.get_mask_label(ins_semantic_feats, noise, return_index=True)
         loss_mask = self.mask_head.loss_func(mask_results['stage_instance_preds'], mask_results['stage_detail_preds'],
                                              stage_mask_targets, mask_labels)
         mask_results.update(loss_mask=loss_mask, mask_labels=mask_labels, mask_index=idx, mask_logits=logits)

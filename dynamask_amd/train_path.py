@@ -12,9 +12,76 @@ Reference graph: ``DynaMaskHead.forward`` / ``SFMStage.forward``
 autograd derives for them plus mmcv's DeformConv2d / RoIAlign backward
 (mmdet/ops/dcn/src/deform_conv_cuda.cpp:262-486).
 """
+import os
+
 import torch
 
 from . import ops
+
+_SIDE_STREAMS = {}
+
+
+def side_stream(dev, which='leaf'):
+    """A side stream of the training path on ``dev`` (None on the CPU, or with DM_TRAIN_SIDE_STREAM=0):
+    'leaf' carries the leaf work of the mask head's passes, 'selector' the resolution-selector branch."""
+    if dev.type != 'cuda' or os.environ.get('DM_TRAIN_SIDE_STREAM', '1') == '0':
+        return None
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), which)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[key]
+
+
+def _join_caller_after_backward(dev):
+    """Called from a backward that runs on a side stream (autograd replays a node on the stream of its forward)
+    and adds into gradient buffers in place: the stream that called ``backward()`` must not read those buffers
+    before this stream is done.  The engine joins the streams of its AccumulateGrad nodes only, so the wait is
+    queued as a final callback of the running backward pass (it runs on the caller's stream, before
+    ``backward()`` returns)."""
+    if dev.type != 'cuda':
+        return
+    cur = torch.cuda.current_stream(dev)
+    if cur == torch.cuda.default_stream(dev):
+        return
+    torch.autograd.Variable._execution_engine.queue_callback(lambda: torch.cuda.current_stream(dev).wait_stream(cur))
+
+
+class _SideWork:
+    """Leaf work of a backward pass on a second HIP stream.
+
+    Weight / bias gradients and the semantic branch (point-sample adjoint -> 1x1 conv on the FPN map) feed
+    nothing further down the chain of data gradients, and the chain's own kernels are partly bound by LDS
+    atomics, global atomics or HBM (DCN col2im / coordinate gradient, upsample and ReLU adjoints) while the
+    leaves are MFMA GEMMs: issued on a second stream they fill each other's idle units.  ``run`` orders the
+    side stream after everything issued so far on the main stream and keeps the tensors it is given alive
+    until ``join`` (the caching allocator would otherwise hand a tensor the main stream has dropped to the
+    main stream's next allocation while the side stream still reads it).  ``DM_TRAIN_SIDE_STREAM=0`` runs
+    everything on the caller's stream."""
+
+    def __init__(self, dev):
+        self.side = side_stream(dev)
+        self.enabled = self.side is not None
+        self.keep = []
+        if self.enabled:
+            self.main = torch.cuda.current_stream(dev)
+            self.enabled = self.side != self.main
+
+    def run(self, fn, *tensors):
+        if not self.enabled:
+            return fn()
+        self.keep.extend(t for t in tensors if t is not None)
+        self.side.wait_stream(self.main)
+        with torch.cuda.stream(self.side):
+            return fn()
+
+    def join(self, *outs):
+        """The main stream waits for the side stream; ``outs`` = tensors the side stream produced that live on."""
+        if self.enabled:
+            self.main.wait_stream(self.side)
+            for t in outs:
+                if t is not None:
+                    t.record_stream(self.main)
+        self.keep.clear()
 
 
 class RoIExtractFn(torch.autograd.Function):
@@ -72,10 +139,22 @@ class MaskHeadFn(torch.autograd.Function):
         rois = rois.contiguous()
         saved = {}
         x = ins_feats.contiguous()
+        # semantic branch of every stage (1x1 conv on the FPN map + point sample): independent of the instance
+        # chain until the stage's fusion conv, so it runs beside the four instance convs
+        sw = _SideWork(rois.device)
+        sems, isfs = [], []
+
+        def semantic_branches():
+            for idx, stage in enumerate(head.stages):
+                sem = stage.semantic_transform_in.run(feats[len(feats) - idx - 3], relu=True)
+                sems.append(sem)
+                isfs.append(ops.point_sample(sem, rois, stage.out_size, stage.spatial_scale))
+        sw.run(semantic_branches)
         conv_in = []
         for conv in head.instance_convs:
             conv_in.append(x)
             x = conv(x)
+        sw.join(*sems, *isfs)
         saved['conv_in'] = conv_in
         saved['stages'] = []
         ips, dps = [], []
@@ -85,8 +164,7 @@ class MaskHeadFn(torch.autograd.Function):
             n, c, s, co = x.shape[0], stage.instance_in_channel, stage.out_size, stage.instance_out_channel
             feat = feats[len(feats) - idx - 3]
             st['feat_idx'] = len(feats) - idx - 3
-            sem = stage.semantic_transform_in.run(feat, relu=True)
-            isf = ops.point_sample(sem, rois, s, stage.spatial_scale)
+            sem, isf = sems[idx], isfs[idx]
             tail = torch.empty((n, co, s, s), device=x.device, dtype=torch.float32)
             nc = stage.num_classes
             ip, dp = ops.class_logits(x, stage.instance_logits.weight.detach().view(nc, c),
@@ -139,6 +217,7 @@ class MaskHeadFn(torch.autograd.Function):
         g_dps = [g.contiguous() if g is not None else None for g in grads[n_st:]]
         pgrad = {}                      # parameter -> gradient tensor
         g_feats = [None] * len(feats)
+        sw = _SideWork(dev)
 
         def zeros(shape):
             return torch.zeros(shape, device=dev, dtype=torch.float32)
@@ -209,19 +288,24 @@ class MaskHeadFn(torch.autograd.Function):
             # masking the whole tensor by tail > 0 only touches the conv channels
             ops.relu_backward_(g_tail, tail)
             dy = g_tail[:, :co - 2]
-            conv_params_bwd(stage.fuse_transform_out, dy, f2, 1)
+            sw.run(lambda: conv_params_bwd(stage.fuse_transform_out, dy, f2, 1), g_tail)
             g_f2 = data_grad(stage.fuse_transform_out, dy, 0, c, 1)
             ops.relu_backward_(g_f2, f2)
             dcn = stage.fuse_conv[1]
-            g_f1, g_off, gw_dcn = ops.deform_conv_backward(f1, off, dcn.weight.detach(), g_f2, dcn.deform_groups,
-                                                           gw_accum=_direct(dcn.weight), col=st.pop('col', None))
-            if gw_dcn is not None:
-                pgrad[dcn.weight] = gw_dcn
-            conv_params_bwd(dcn.conv_offset, g_off, f1, 3)
+
+            col = st.pop('col', None)          # allocated by the forward on the main stream: kept alive until the join
+
+            def dcn_weight_grad():
+                gw_dcn = ops.deform_conv_backward_weight(f1, off, g_f2, dcn.deform_groups, gw_accum=_direct(dcn.weight), col=col)
+                if gw_dcn is not None:
+                    pgrad[dcn.weight] = gw_dcn
+            sw.run(dcn_weight_grad, g_f2, col)
+            g_f1, g_off = ops.deform_conv_backward_data(f1, off, dcn.weight.detach(), g_f2, dcn.deform_groups)
+            sw.run(lambda: conv_params_bwd(dcn.conv_offset, g_off, f1, 3), g_off)
             data_grad(dcn.conv_offset, g_off, 0, c, 3, out=g_f1, accumulate=True)
             ops.relu_backward_(g_f1, f1)
             f0 = stage.fuse_conv[0]
-            conv_params_bwd(f0, g_f1, [xin, isf, tail[:, co - 2:]], 1)
+            sw.run(lambda: conv_params_bwd(f0, g_f1, [xin, isf, tail[:, co - 2:]], 1), g_f1)
             g_xin = data_grad(f0, g_f1, 0, c, 1)
             g_isf = data_grad(f0, g_f1, c, 2 * c, 1)
             g_sig = data_grad(f0, g_f1, 2 * c, 2 * c + 2, 1)
@@ -238,15 +322,17 @@ class MaskHeadFn(torch.autograd.Function):
             for p_, t in keep:
                 pgrad[p_] = t.view_as(p_)
             # semantic branch: point sample adjoint -> relu -> 1x1 conv on the FPN map
-            g_sem = ops.point_sample_backward(g_isf, tuple(sem.shape), rois, stage.spatial_scale)
-            ops.relu_backward_(g_sem, sem)
-            fidx = st['feat_idx']
-            feat = feats[fidx]
-            conv_params_bwd(stage.semantic_transform_in, g_sem, feat, 1)
-            if g_feats[fidx] is None:
-                g_feats[fidx] = data_grad(stage.semantic_transform_in, g_sem, 0, feat.shape[1], 1)
-            else:
-                data_grad(stage.semantic_transform_in, g_sem, 0, feat.shape[1], 1, out=g_feats[fidx], accumulate=True)
+            def semantic_branch(stage=stage, st=st, sem=sem, g_isf=g_isf):
+                g_sem = ops.point_sample_backward(g_isf, tuple(sem.shape), rois, stage.spatial_scale)
+                ops.relu_backward_(g_sem, sem)
+                fidx = st['feat_idx']
+                feat = feats[fidx]
+                conv_params_bwd(stage.semantic_transform_in, g_sem, feat, 1)
+                if g_feats[fidx] is None:
+                    g_feats[fidx] = data_grad(stage.semantic_transform_in, g_sem, 0, feat.shape[1], 1)
+                else:
+                    data_grad(stage.semantic_transform_in, g_sem, 0, feat.shape[1], 1, out=g_feats[fidx], accumulate=True)
+            sw.run(semantic_branch, g_isf)
             g_x = g_xin
 
         # ---------------- instance convs
@@ -255,9 +341,10 @@ class MaskHeadFn(torch.autograd.Function):
             x_in = sv['conv_in'][i]
             y = sv['conv_in'][i + 1] if i + 1 < len(sv['conv_in']) else sv['stages'][0]['xin']
             ops.relu_backward_(g_x, y)
-            conv_params_bwd(conv, g_x, x_in, conv.kernel_size)
+            sw.run(lambda conv=conv, g_x=g_x, x_in=x_in: conv_params_bwd(conv, g_x, x_in, conv.kernel_size), g_x)
             g_x = data_grad(conv, g_x, 0, conv.in_channels, conv.kernel_size)
 
+        sw.join(*g_feats, *pgrad.values())
         params = list(head.parameters())
         out_p = [pgrad.get(p) for p in params]
         for p, g in zip(params, out_p):
@@ -349,6 +436,7 @@ class MaskPreFn(torch.autograd.Function):
         g_y1, gg1, gb1 = ops.bn_relu_maxpool_backward(y1, m1, v1, mp.bn1.weight.detach(), mp.bn1.bias.detach(), g_p1, mp.bn1.eps)
         pg[mp.bn1.weight], pg[mp.bn1.bias] = gg1, gb1
         conv_bwd(mp.conv1, g_y1, x, need_data=False)
+        _join_caller_after_backward(x.device)
         return (None, None, *[pg.get(p) for p in mp.parameters()])
 
 
