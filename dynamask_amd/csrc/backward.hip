@@ -1284,22 +1284,28 @@ extern "C" int dm_deform_im2col(const float* x, const float* offset, int NB, int
   return dm_check_launch();
 }
 
-extern "C" int dm_deform_col2im_coord(const float* colgrad, const float* x, const float* offset, int NB, int C, int H,
-                                      int W, int deform_groups, float* grad_x, float* grad_offset, dm_stream_t stream) {
-  if (!colgrad || !x || !offset || !grad_x || !grad_offset || NB < 0 || C <= 0 || H <= 0 || W <= 0 || deform_groups <= 0 ||
-      C % deform_groups)
-    return DM_ERR_INVALID_ARG;
+static int dcn_bwd_args_ok(const float* colgrad, const float* offset, int NB, int C, int H, int W, int deform_groups) {
+  return colgrad && offset && NB >= 0 && C > 0 && H > 0 && W > 0 && deform_groups > 0 && C % deform_groups == 0;
+}
+
+extern "C" int dm_deform_coord_grad(const float* colgrad, const float* x, const float* offset, int NB, int C, int H, int W,
+                                    int deform_groups, float* grad_offset, dm_stream_t stream) {
+  if (!dcn_bwd_args_ok(colgrad, offset, NB, C, H, W, deform_groups) || !x || !grad_offset) return DM_ERR_INVALID_ARG;
+  if (NB == 0) return DM_OK;
+  const int pblocks = dm_ceil_div(H * W, 256);
+  DM_LAUNCH(dcn_coord_grad_kernel, dim3((unsigned)(NB * deform_groups * 9 * pblocks)), dim3(256), 0, (hipStream_t)stream,
+            colgrad, x, offset, NB, C, H, W, deform_groups, grad_offset);
+  return dm_check_launch();
+}
+
+extern "C" int dm_deform_col2im(const float* colgrad, const float* offset, int NB, int C, int H, int W, int deform_groups,
+                                float* grad_x, dm_stream_t stream) {
+  if (!dcn_bwd_args_ok(colgrad, offset, NB, C, H, W, deform_groups) || !grad_x) return DM_ERR_INVALID_ARG;
   if (NB == 0) return DM_OK;
   hipStream_t st = (hipStream_t)stream;
-  const int HW = H * W;
-  const int pblocks = dm_ceil_div(HW, 256);
-  DM_LAUNCH(dcn_coord_grad_kernel, dim3((unsigned)(NB * deform_groups * 9 * pblocks)), dim3(256), 0, st, colgrad, x, offset,
-            NB, C, H, W, deform_groups, grad_offset);
-  int rc = dm_check_launch();
-  if (rc != DM_OK) return rc;
   // channels per workgroup: LDS planes of CT x HW 64-bit accumulators, CT | C/deform_groups
   const int cpg = C / deform_groups;
-  const size_t plane_b = (size_t)HW * sizeof(unsigned long long);
+  const size_t plane_b = (size_t)H * W * sizeof(unsigned long long);
   if (cpg % 8 == 0 && 8 * plane_b <= 64 * 1024) {
     DM_LAUNCH(dcn_col2im_lds_kernel<8>, dim3((unsigned)(NB * (C / 8))), dim3(256), 8 * plane_b, st, colgrad, offset, NB, C, H,
               W, deform_groups, grad_x);
@@ -1316,6 +1322,13 @@ extern "C" int dm_deform_col2im_coord(const float* colgrad, const float* x, cons
     return DM_ERR_UNSUPPORTED;
   }
   return dm_check_launch();
+}
+
+extern "C" int dm_deform_col2im_coord(const float* colgrad, const float* x, const float* offset, int NB, int C, int H,
+                                      int W, int deform_groups, float* grad_x, float* grad_offset, dm_stream_t stream) {
+  const int rc = dm_deform_coord_grad(colgrad, x, offset, NB, C, H, W, deform_groups, grad_offset, stream);
+  if (rc != DM_OK) return rc;
+  return dm_deform_col2im(colgrad, offset, NB, C, H, W, deform_groups, grad_x, stream);
 }
 
 extern "C" int dm_dcn_weight_permute(const float* src, float* dst, int Cout, int C, int to_colmajor, int accumulate,

@@ -614,6 +614,28 @@ def deform_col2im_coord(colgrad, x, offset, deform_groups):
     return gx, goff
 
 
+def deform_coord_grad(colgrad, x, offset, deform_groups, out=None):
+    """Offset gradient of DCNv1 from the column gradient (first half of deform_col2im_coord)."""
+    _chk(colgrad, 'colgrad')
+    _chk(x, 'x')
+    _chk(offset, 'offset')
+    NB, C, H, W = x.shape
+    goff = torch.empty_like(offset) if out is None else out
+    check(lib().dm_deform_coord_grad(_p(colgrad), _p(x), _p(offset), NB, C, H, W, deform_groups, _p(goff), _stream()),
+          'dm_deform_coord_grad')
+    return goff
+
+
+def deform_col2im(colgrad, offset, x_shape, deform_groups, out=None):
+    """Input gradient of DCNv1 from the column gradient (second half of deform_col2im_coord)."""
+    _chk(colgrad, 'colgrad')
+    _chk(offset, 'offset')
+    NB, C, H, W = x_shape
+    gx = torch.empty(x_shape, device=colgrad.device, dtype=torch.float32) if out is None else out
+    check(lib().dm_deform_col2im(_p(colgrad), _p(offset), NB, C, H, W, deform_groups, _p(gx), _stream()), 'dm_deform_col2im')
+    return gx
+
+
 def dcn_weight_permute(src, cout, c, to_colmajor, dst=None, accumulate=False):
     _chk(src, 'src')
     if dst is None:
@@ -624,14 +646,24 @@ def dcn_weight_permute(src, cout, c, to_colmajor, dst=None, accumulate=False):
     return dst
 
 
-def deform_conv_backward_data(x, offset, weight, grad_out, deform_groups):
+def deform_conv_backward_data(x, offset, weight, grad_out, deform_groups, side=None):
     """(grad_x, grad_offset) of DCNv1 3x3: column gradient = W^T . dY as a 1x1 conv, then the coordinate
-    gradient and col2im over it."""
+    gradient and col2im over it.  ``side``: a second stream -- the coordinate gradient (bound by its gathers) then
+    runs there, beside col2im (bound by LDS atomics) on the caller's stream; both only read the column gradient."""
     NB, C, H, W = x.shape
     cout = weight.shape[0]
     wt = dcn_weight_permute(weight.contiguous(), cout, C, True)                # [(tap,ci)][co]
     colgrad = conv2d(grad_out, pack_conv_weight(wt), None, 9 * C, 1)           # W^T . dY
-    return deform_col2im_coord(colgrad, x, offset, deform_groups)
+    if side is None:
+        return deform_col2im_coord(colgrad, x, offset, deform_groups)
+    main = torch.cuda.current_stream(x.device)
+    goff = torch.empty_like(offset)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        deform_coord_grad(colgrad, x, offset, deform_groups, out=goff)
+    gx = deform_col2im(colgrad, offset, tuple(x.shape), deform_groups)
+    main.wait_stream(side)             # colgrad (main-stream memory) is released after this point
+    return gx, goff
 
 
 def deform_conv_backward_weight(x, offset, grad_out, deform_groups, gw_accum=None, col=None):

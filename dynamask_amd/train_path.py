@@ -23,7 +23,8 @@ _SIDE_STREAMS = {}
 
 def side_stream(dev, which='leaf'):
     """A side stream of the training path on ``dev`` (None on the CPU, or with DM_TRAIN_SIDE_STREAM=0):
-    'leaf' carries the leaf work of the mask head's passes, 'selector' the resolution-selector branch."""
+    'leaf' carries the leaf work of the mask head's passes, 'selector' the resolution-selector branch, 'pair'
+    the second of two kernels of the chain that only share their inputs."""
     if dev.type != 'cuda' or os.environ.get('DM_TRAIN_SIDE_STREAM', '1') == '0':
         return None
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), which)
@@ -300,7 +301,8 @@ class MaskHeadFn(torch.autograd.Function):
                 if gw_dcn is not None:
                     pgrad[dcn.weight] = gw_dcn
             sw.run(dcn_weight_grad, g_f2, col)
-            g_f1, g_off = ops.deform_conv_backward_data(f1, off, dcn.weight.detach(), g_f2, dcn.deform_groups)
+            g_f1, g_off = ops.deform_conv_backward_data(f1, off, dcn.weight.detach(), g_f2, dcn.deform_groups,
+                                                        side=side_stream(dev, 'pair'))
             sw.run(lambda: conv_params_bwd(dcn.conv_offset, g_off, f1, 3), g_off)
             data_grad(dcn.conv_offset, g_off, 0, c, 3, out=g_f1, accumulate=True)
             ops.relu_backward_(g_f1, f1)

@@ -45,7 +45,7 @@ extern "C" {
 typedef void* dm_stream_t; /* hipStream_t */
 
 const char* dm_error_string(int code);
-/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K). */
+/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_upsample2x_bilinear_bwd overwrites). */
 int dm_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -387,6 +387,12 @@ int dm_deform_im2col(const float* x, const float* offset, int NB, int C, int H, 
                      float* col, dm_stream_t stream);
 int dm_deform_col2im_coord(const float* colgrad, const float* x, const float* offset, int NB, int C, int H, int W,
                            int deform_groups, float* grad_x, float* grad_offset, dm_stream_t stream);
+/* the two halves of dm_deform_col2im_coord as separate launches (ABI 13): they share only their inputs, so a caller
+ * may issue them on two streams -- the coordinate gradient is bound by its gathers, col2im by LDS atomics. */
+int dm_deform_coord_grad(const float* colgrad, const float* x, const float* offset, int NB, int C, int H, int W,
+                         int deform_groups, float* grad_offset, dm_stream_t stream);
+int dm_deform_col2im(const float* colgrad, const float* offset, int NB, int C, int H, int W, int deform_groups,
+                     float* grad_x, dm_stream_t stream);
 int dm_dcn_weight_permute(const float* src, float* dst, int Cout, int C, int to_colmajor, int accumulate,
                           dm_stream_t stream);
 

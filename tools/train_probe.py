@@ -44,6 +44,10 @@ if os.environ.get('TP_WINDOWS'):
     def stats():
         s = torch.cuda.memory_stats()
         return s['num_device_alloc'], s['num_device_free'], s['reserved_bytes.all.current'] / 2**30, s['active_bytes.all.peak'] / 2**30
+    from dynamask_amd import ops
+    import contextlib
+    hint = ops.overlapped_streams() if os.environ.get('TP_OVERLAPPED') else contextlib.nullcontext()
+    hint.__enter__()
     for w in range(int(os.environ['TP_WINDOWS'])):
         torch.cuda.synchronize()
         a0 = stats(); g0 = gc.get_count()
