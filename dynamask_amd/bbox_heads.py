@@ -246,6 +246,8 @@ class BBoxHeadFn(torch.autograd.Function):
                 g_h = fc_bwd(head.shared_fcs[i], g_h, acts[i], need_data=need)
             if ctx.need_x:
                 g_x = g_h.reshape(ctx.x_shape)
+        from .train_path import _join_caller_after_backward
+        _join_caller_after_backward(acts[0].device)
         return (None, g_x, *[pg.get(p) for p in head.parameters()])
 
 

@@ -252,9 +252,26 @@ class DynaMaskRoIHead(nn.Module):
             assign_result = self.bbox_assigner.assign(proposal_list[i], gt_bboxes[i], gt_bboxes_ignore[i], gt_labels[i])
             sampling_results.append(self.bbox_sampler.sample(assign_result, proposal_list[i], gt_bboxes[i], gt_labels[i],
                                                              feats=[lvl_feat[i][None] for lvl_feat in x]))
-        bbox_results = self._bbox_forward_train(x, sampling_results, gt_bboxes, gt_labels, img_metas)
+        # the bbox branch and the mask branch meet only in the sum of the losses: the bbox branch is issued on its own
+        # stream (its backward follows it there) and joined before the losses are handed back
+        side = None
+        if torch.is_grad_enabled() and x[0].is_cuda:
+            from . import train_path
+            side = train_path.side_stream(x[0].device, 'bbox')
+        if side is not None:
+            main = torch.cuda.current_stream(x[0].device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                bbox_results = self._bbox_forward_train(x, sampling_results, gt_bboxes, gt_labels, img_metas)
+        else:
+            bbox_results = self._bbox_forward_train(x, sampling_results, gt_bboxes, gt_labels, img_metas)
         mask_results = self._mask_forward_train(x, sampling_results, bbox_results['bbox_feats'], gt_bboxes, gt_masks,
                                                 gt_labels, img_metas, noise=noise)
+        if side is not None:
+            main.wait_stream(side)
+            for v in bbox_results['loss_bbox'].values():
+                if isinstance(v, torch.Tensor):
+                    v.record_stream(main)
         losses = {}
         losses.update(bbox_results['loss_bbox'])
         losses.update(mask_results['loss_mask'])

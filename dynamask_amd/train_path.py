@@ -24,7 +24,7 @@ _SIDE_STREAMS = {}
 def side_stream(dev, which='leaf'):
     """A side stream of the training path on ``dev`` (None on the CPU, or with DM_TRAIN_SIDE_STREAM=0):
     'leaf' carries the leaf work of the mask head's passes, 'selector' the resolution-selector branch, 'coord'
-    the second of two kernels of the chain that only share their inputs."""
+    the second of two kernels of the chain that only share their inputs, 'bbox' the bbox branch of ``forward_train``."""
     if dev.type != 'cuda' or os.environ.get('DM_TRAIN_SIDE_STREAM', '1') == '0':
         return None
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), which)
