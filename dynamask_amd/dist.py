@@ -46,7 +46,8 @@ class FlatParamGroup:
         self.steps = 0
         self._work = None
         self._synced = False
-        self._stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
+        from . import streams
+        self._stream = streams.side(dev, 2) if dev.type == 'cuda' else None      # shared pool: hardware queues are few
 
     @property
     def world_size(self):

@@ -210,10 +210,9 @@ class DynaMaskRoIHead(nn.Module):
         return dict(stage_instance_preds=ips, stage_detail_preds=dps)
 
     def _side_streams(self, k, device):
-        if getattr(self, '_streams', None) is None or len(self._streams) < k or self._streams_dev != device:
-            self._streams = [torch.cuda.Stream(device=device) for _ in range(k)]
-            self._streams_dev = device
-        return self._streams[:k]
+        """k streams for k RoI chunks, from the package's shared pool (streams.py: hardware queues are few)."""
+        from . import streams
+        return [streams.side(device, i) for i in range(k)]      # more chunks than pool streams: they share (still ordered)
 
     def sample_uniform(self, shape, device):
         """The reference draws on the CPU generator and copies (dynamask_roi_head.py:90-91, Q9)."""

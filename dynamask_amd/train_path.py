@@ -18,7 +18,7 @@ import torch
 
 from . import ops
 
-_SIDE_STREAMS = {}
+_SIDE_STREAMS = {'leaf': 0, 'selector': 1, 'bbox': 1, 'coord': 2}      # slots of the shared pool (streams.py)
 
 
 def side_stream(dev, which='leaf'):
@@ -27,10 +27,8 @@ def side_stream(dev, which='leaf'):
     the second of two kernels of the chain that only share their inputs, 'bbox' the bbox branch of ``forward_train``."""
     if dev.type != 'cuda' or os.environ.get('DM_TRAIN_SIDE_STREAM', '1') == '0':
         return None
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), which)
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
-    return _SIDE_STREAMS[key]
+    from . import streams
+    return streams.side(dev, _SIDE_STREAMS[which])
 
 
 def _join_caller_after_backward(dev):

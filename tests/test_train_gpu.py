@@ -233,3 +233,24 @@ def test_forward_train_with_an_image_without_ground_truth():
     losses0 = m.forward_train(feats, ti['img_metas'], props, gtb0, gtl0, None, gtm0)
     assert float(losses0['loss_masks'].detach()) == 0.0 and float(losses0['loss_bbox'].detach()) == 0.0
     assert torch.isfinite(losses0['loss_cls']).all()
+
+
+def test_side_streams_come_from_one_shared_pool():
+    """Hardware queues are few (4 per process unless GPU_MAX_HW_QUEUES says otherwise): the inference path, the
+    training step and the gradient all-reduce must draw their side streams from one pool of ``streams.POOL``,
+    or streams meant to run beside each other end up sharing a queue (training step 23.7 -> 25.5 ms after an
+    inference pass in the same process, round 2)."""
+    from dynamask_amd import streams, train_path, registry, roi_head, mask_heads, roi_extractors, losses  # noqa: F401
+    from dynamask_amd.dist import FlatParamGroup
+    dev = torch.device('cuda', torch.cuda.current_device())
+    pool = {streams.side(dev, i).cuda_stream for i in range(8)}
+    assert len(pool) == streams.POOL
+    used = {train_path.side_stream(dev, w).cuda_stream for w in ('leaf', 'selector', 'coord', 'bbox')}
+    head = registry.build_head(dict(type='DynaMaskRoIHead',
+                                    mask_roi_extractor=dict(type='SingleRoIExtractor', **gi.MASK_ROI_EXTRACTOR_CFG),
+                                    mask_head=dict(type='DynaMaskHead', **gi.MASK_HEAD_CFG)))
+    used |= {s.cuda_stream for s in head._side_streams(4, dev)}
+    grp = FlatParamGroup([torch.nn.Parameter(torch.zeros(8, device=dev))])
+    used.add(grp._stream.cuda_stream)
+    assert used <= pool
+    assert torch.cuda.default_stream(dev).cuda_stream not in pool
