@@ -549,6 +549,249 @@ __global__ __launch_bounds__(256, 2) void deform_conv_lds_kernel(DcnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Variant for the large maps (28 x 28, 56 x 56): the bilinear gather runs IN the wave that consumes it.
+// What holds the kernel at the top to a third of the MFMA rate at 64 channels is the path of a sample:
+// two 8-byte global loads (texture path, L2 hits), a combine, a 16-byte LDS write, and an LDS read back by
+// every cout wave -- with 64 couts a sample feeds 128 flop.  Here a workgroup owns 128 pixels of ONE image
+// and all couts; a wave owns 32 of those pixels and ALL cout tiles, so the B operand of an MFMA
+// (lane = pixel, lane half = channel quad) is exactly what the lane itself can gather: four LDS reads from a
+// band of the chunk's 8 channel planes (BR rows around the tile's rows; a 128-pixel tile spans <= 4 rows of
+// a 56-wide map, offsets of +-6 rows stay inside), one fma chain, and the value goes straight into WM
+// MFMAs.  No B image in LDS, no texture-path gathers; a sample outside the band (rare: large offsets) is
+// loaded from global memory by the lanes concerned.  Per chunk: A (weights) and the band are loaded into
+// registers under the MFMAs of the previous chunk and stored to LDS between two barriers.
+// Same products, same K order (chunk of 8 -> tap -> element -> quad) and the same fma chain as the kernels
+// above: results do not depend on which variant a shape takes.
+constexpr int DCN_NEAR_ROWS = 5;
+
+template <int WM, int WGM, int XR>
+__global__ __launch_bounds__(256, 2) void deform_conv_band_kernel(DcnArgs a, int tiles_per_img, int BR) {
+  // WGM waves share a pixel column (each with WM of the cout tiles: 128 couts = 2 x 2 -- four tiles in one wave spill)
+  constexpr int TM = WM * WGM * 32, TN = (4 / WGM) * 32, NT = 256;
+  constexpr int A_F4 = 9 * 2 * TM;                       // float4 of one chunk's weights: [tap][quad][cout]
+  constexpr int A_PER_T = (A_F4 + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  dm_f32x4* ldsA = reinterpret_cast<dm_f32x4*>(lds);
+  float* ldsX = lds + 4 * A_F4;                          // [8][BR * W]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int wave_m = wave % WGM, wave_n = wave / WGM;
+  const int HW = a.HW, W = a.W, H = a.H;
+  const int PS = BR * W, PS4 = PS >> 2;                  // W % 4 == 0 (host)
+  const int n = blockIdx.x / tiles_per_img, tile = blockIdx.x - n * tiles_per_img;
+  const int p0 = tile * TN;
+  const int p_end = min(p0 + TN, HW);
+  const int y_first = p0 / W, y_last = (p_end - 1) / W;
+  const int band_y0 = min(max(y_first - (BR - (y_last - y_first + 1)) / 2, 0), H - BR);     // H >= BR (host)
+  int gp = p0 + wave_n * 32 + l31;
+  const bool g_ok = gp < HW;
+  gp = min(gp, HW - 1);
+  const int gy = gp / W, gx = gp - gy * W;
+
+  int otb[9];                          // top | bottom << 16.  In band: offsets inside a band plane; else: inside the image plane (H * W < 65536, host)
+  float wt0[9], wt1[9], wb0[9], wb1[9];
+  unsigned oob = 0, any_oob = 0;       // taps of this lane / of any lane of the wave that leave the band
+  const int cpg = a.C / a.dg;
+  auto load_params = [&](int group) {
+    const float* offp = a.offset + ((size_t)n * a.dg + group) * 18 * HW + gp;
+    oob = 0;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      otb[tap] = 0;
+      wt0[tap] = wt1[tap] = wb0[tap] = wb1[tap] = 0.f;
+      if (g_ok) {
+        const int ki = tap / 3, kj = tap - ki * 3;
+        const float h_im = (float)(gy - 1 + ki) + offp[(size_t)(2 * tap) * HW];
+        const float w_im = (float)(gx - 1 + kj) + offp[(size_t)(2 * tap + 1) * HW];
+        if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+          const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+          const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+          const float hh = 1.f - lh, hw = 1.f - lw;
+          const float wr_t = (h_low >= 0) ? hh : 0.f;
+          const float wr_b = (h_low + 1 <= H - 1) ? lh : 0.f;
+          const int rt = min(max(h_low, 0), H - 1), rbm = min(max(h_low + 1, 0), H - 1);
+          const int cb = min(max(w_low, 0), W - 2);
+          const float wc0 = (cb == w_low ? hw : 0.f) + (cb == w_low + 1 ? lw : 0.f);
+          const float wc1 = (cb + 1 == w_low ? hw : 0.f) + (cb + 1 == w_low + 1 ? lw : 0.f);
+          if (rt >= gy - DCN_NEAR_ROWS && rbm <= gy + DCN_NEAR_ROWS) {     // inside the band of every tiling (host checks the pad)
+            otb[tap] = ((rt - band_y0) * W + cb) | (((rbm - band_y0) * W + cb) << 16);
+            wt0[tap] = wr_t * wc0; wt1[tap] = wr_t * wc1;
+            wb0[tap] = wr_b * wc0; wb1[tap] = wr_b * wc1;
+          } else {
+            oob |= 1u << tap;          // weight 0 here; the sample is added by the slow pass of every chunk
+          }
+        }
+      }
+    }
+    any_oob = 0;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+      if (__ballot((oob >> tap) & 1u) != 0ull) any_oob |= 1u << tap;
+  };
+
+  dm_f32x16 acc[WM];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  dm_f32x4 ra[A_PER_T], rx[XR];        // XR * 256 float4 cover the 8 band planes (host)
+  auto load_a = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      const int idx = tid + i * NT;
+      dm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < A_F4) {
+        const int m = idx % TM, tq = idx / TM;           // tq = tap * 2 + quad
+        if (m < a.CoutP)
+          v = *reinterpret_cast<const dm_f32x4*>(a.wp + (((size_t)(tq >> 1) * a.KQ + (c0 >> 2) + (tq & 1)) * a.CoutP + m) * 4);
+      }
+      ra[i] = v;
+    }
+  };
+  auto load_x = [&](int c0) {          // the band of a plane is one contiguous run of BR * W floats
+    const float* xb = a.x + ((size_t)n * a.C + c0) * HW + (size_t)band_y0 * W;
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+      const int idx = tid + i * NT;
+      const int ch = idx / PS4, f = idx - ch * PS4;
+      dm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ch < 8) v = *reinterpret_cast<const dm_f32x4*>(xb + (size_t)ch * HW + f * 4);
+      rx[i] = v;
+    }
+  };
+  auto store_ax = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      const int idx = tid + i * NT;
+      if (idx < A_F4) ldsA[idx] = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+      const int idx = tid + i * NT;
+      if (idx < 8 * PS4) *reinterpret_cast<dm_f32x4*>(ldsX + idx * 4) = rx[i];      // [ch][PS] is one run too
+    }
+  };
+  struct __attribute__((packed, aligned(4))) F2 { float a, b; };
+
+  int cur_group = 0;
+  load_params(0);
+  load_a(0);
+  load_x(0);
+  for (int c0 = 0; c0 < a.C; c0 += 8) {
+    __syncthreads();                   // the previous chunk's operand reads are done
+    store_ax();
+    __syncthreads();
+    const int cn = c0 + 8;
+    if (cn < a.C) {
+      load_a(cn);
+      load_x(cn);
+    }
+    const unsigned any_oob_s = __builtin_amdgcn_readfirstlane(any_oob);
+    const float* pl = ldsX + 4 * hi * PS;                                   // this lane half's quad of planes
+    const float* gl = a.x + ((size_t)n * a.C + c0 + 4 * hi) * HW;          // the same planes in global memory
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      dm_f32x4 av[WM];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) av[i] = ldsA[(tap * 2 + hi) * TM + (wave_m * WM + i) * 32 + l31];
+      float v[4];
+      const int o_t = otb[tap] & 0xffff, o_b = otb[tap] >> 16;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* pc = pl + e * PS;
+        const F2 top = *reinterpret_cast<const F2*>(pc + o_t);
+        const F2 bot = *reinterpret_cast<const F2*>(pc + o_b);
+        v[e] = dcn_bilinear(wt0[tap], wt1[tap], wb0[tap], wb1[tap], top.a, top.b, bot.a, bot.b);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < WM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], v[e], acc[i], 0, 0, 0);
+    }
+    if (any_oob_s) {
+      // Slow pass: taps that leave the band for some lane of this wave.  The lanes concerned recompute the tap
+      // from the offsets and gather from global memory; the others contribute 0.  (Kept out of the loop above:
+      // with the two sources in one place the compiler selects between the POINTERS and every sample becomes a
+      // flat load, and a branch per tap keeps it from overlapping one tap's LDS reads with another's MFMAs.)
+      const float* offp = a.offset + ((size_t)n * a.dg + cur_group) * 18 * HW + gp;
+#pragma unroll 1
+      for (int tap = 0; tap < 9; ++tap) {
+        if (!((any_oob_s >> tap) & 1u)) continue;
+        const bool mine = (oob >> tap) & 1u;
+        float w00 = 0.f, w01 = 0.f, w10 = 0.f, w11 = 0.f;
+        int g_t = 0, g_b = 0;
+        if (mine) {
+          const int ki = tap / 3, kj = tap - ki * 3;
+          const float h_im = (float)(gy - 1 + ki) + offp[(size_t)(2 * tap) * HW];
+          const float w_im = (float)(gx - 1 + kj) + offp[(size_t)(2 * tap + 1) * HW];
+          const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+          const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+          const float hh = 1.f - lh, hw = 1.f - lw;
+          const float wr_t = (h_low >= 0) ? hh : 0.f;
+          const float wr_b = (h_low + 1 <= H - 1) ? lh : 0.f;
+          const int rt = min(max(h_low, 0), H - 1), rbm = min(max(h_low + 1, 0), H - 1);
+          const int cb = min(max(w_low, 0), W - 2);
+          const float wc0 = (cb == w_low ? hw : 0.f) + (cb == w_low + 1 ? lw : 0.f);
+          const float wc1 = (cb + 1 == w_low ? hw : 0.f) + (cb + 1 == w_low + 1 ? lw : 0.f);
+          g_t = rt * W + cb;
+          g_b = rbm * W + cb;
+          w00 = wr_t * wc0; w01 = wr_t * wc1;
+          w10 = wr_b * wc0; w11 = wr_b * wc1;
+        }
+        dm_f32x4 av[WM];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) av[i] = ldsA[(tap * 2 + hi) * TM + (wave_m * WM + i) * 32 + l31];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float* gc = gl + (size_t)e * HW;
+          const F2 top = *reinterpret_cast<const F2*>(gc + g_t);
+          const F2 bot = *reinterpret_cast<const F2*>(gc + g_b);
+          const float g = dcn_bilinear(w00, w01, w10, w11, top.a, top.b, bot.a, bot.b);
+#pragma unroll
+          for (int i = 0; i < WM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], g, acc[i], 0, 0, 0);
+        }
+      }
+    }
+    if (cn < a.C) {
+      const int group = cn / cpg;      // 8 divides cpg (host)
+      if (group != cur_group) {
+        cur_group = group;
+        load_params(group);
+      }
+    }
+  }
+  // epilogue: lane = pixel column, registers walk the couts
+  {
+    const int p = p0 + wave_n * 32 + l31;
+    if (p < HW) {
+      float* po = a.out + (size_t)n * a.Cout * HW + p;
+      const bool relu = a.relu != 0;
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = (wave_m * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (co < a.Cout) {
+            float v = acc[i][r];
+            if (relu) v = fmaxf(v, 0.f);
+            po[(size_t)co * HW] = v;
+          }
+        }
+    }
+  }
+}
+
+template <int WM, int WGM, int XR>
+int launch_dcn_band(DcnArgs& a, hipStream_t st) {
+  const int BR = 16;
+  const int tiles = dm_ceil_div(a.HW, (4 / WGM) * 32);
+  const size_t lds_bytes = 16 * (size_t)(9 * 2 * WM * WGM * 32) + 4 * (size_t)8 * BR * a.W;
+  DM_LAUNCH((deform_conv_band_kernel<WM, WGM, XR>), dim3((unsigned)(a.NB * tiles)), dim3(256), lds_bytes, st, a, tiles, BR);
+  return dm_check_launch();
+}
+
 template <int WGM, int WGN, int WM, int WN>
 int launch_dcn(DcnArgs& a, hipStream_t st) {
   constexpr int TM = WGM * WM * 32;
@@ -590,6 +833,25 @@ extern "C" int dm_deform_conv_fwd(const float* x, const float* offset, int NB, i
   // of one workgroup; 64 x 64 tiles give four times the workgroups of the 128 x 128 LDS kernel
   // (14 x 14, 8 RoIs: 0.208 -> 0.108 ms, 32 RoIs: 0.213 -> 0.168 ms; from 64 RoIs on the big tiles win).
   // Same products in the same order in every variant: results do not depend on the choice.
+  {
+    // large maps: gather in the consuming wave from an LDS band of 16 rows (BR * W / 4 <= 256 lanes copy the band).
+    // Every launch size of an eligible shape takes this kernel (rows must not depend on the batch).
+    static const bool band_off = getenv("DM_DCN_BAND_OFF") != nullptr;      // A/B switch
+    const int max_rows = (W - 1 + 128 + W - 1) / W;                         // rows a 128-pixel tile can span
+    if (!band_off && H >= 16 && (W & 3) == 0 && 16 * W / 4 <= 256 && (16 - max_rows) / 2 >= DCN_NEAR_ROWS && a.HW > 256 &&
+        a.HW < 65536 && (a.CoutP == 64 || a.CoutP == 128) && Cout > 32) {
+      const bool narrow = 8 * 16 * W / 4 <= 4 * 256;                        // band planes fit 4 float4 per thread
+      // a handful of RoIs (real inference): the launch is bound by the time of one workgroup -- one cout tile per
+      // wave, the waves sharing a pixel column (2-4 x the workgroups, 1/2-1/4 of the K-loop time each; same bits)
+      const bool few = (long long)NB * dm_ceil_div(a.HW, 128) * 4 < (long long)dm_num_cus() * 3;
+      if (a.CoutP == 64) {
+        if (few) return narrow ? launch_dcn_band<1, 2, 4>(a, st) : launch_dcn_band<1, 2, 7>(a, st);
+        return narrow ? launch_dcn_band<2, 1, 4>(a, st) : launch_dcn_band<2, 1, 7>(a, st);
+      }
+      if (few) return narrow ? launch_dcn_band<1, 4, 4>(a, st) : launch_dcn_band<1, 4, 7>(a, st);
+      return narrow ? launch_dcn_band<4, 1, 4>(a, st) : launch_dcn_band<2, 2, 7>(a, st);
+    }
+  }
   if (Cout > 64 && (long long)dm_ceil_div(a.CoutP, 128) * dm_ceil_div(a.Q, 128) * 20 <= (long long)dm_num_cus() * 9)
     return launch_dcn<2, 2, 1, 1>(a, st);
   if (Cout > 64 && a.HW >= 128 && a.HW <= 256 && (a.HW & 3) == 0 && (C / deform_groups) % 8 == 0) {

@@ -195,10 +195,27 @@ def test_deform_conv(ops, N, C, S):
     _close(out0, F.conv2d(x, w, padding=1))
 
 
+@pytest.mark.parametrize('N,C,S', [(3, 64, 56), (4, 128, 28), (2, 64, 32)])
+def test_deform_conv_large_offsets_leave_the_lds_band(ops, N, C, S):
+    """The 28 x 28 / 56 x 56 kernel gathers from a 16-row LDS band around the tile and sends samples that fall
+    outside it to global memory: offsets of up to +-25 pixels make most taps of some pixels take that road,
+    others (offset 0, +-5) stay inside, and the far corners clamp at every border."""
+    x = torch.randn(N, C, S, S, generator=_g(66))
+    w = torch.randn(C, C, 3, 3, generator=_g(67)) / (9 * C) ** 0.5
+    off = torch.randn(N, 36, S, S, generator=_g(68)) * 8.0
+    off[0, :18] = 0.0                                         # group 0 of image 0: plain taps
+    off[1, 18:] = torch.randn(36 - 18, S, S, generator=_g(69)) * 2.0
+    off[-1, ::2, S // 2] = 25.0                               # one row of pixels looks 25 rows down
+    off[-1, ::2, S // 2 + 1] = -25.0
+    ref = F.relu(ref_ops.deform_conv2d(x, off, w, 1, 1, 1, 2))
+    out = ops.deform_conv(_dev(x), _dev(off), ops.pack_conv_weight(_dev(w)), C, 2, relu=True)
+    _close(out, ref)
+
+
 def test_deform_conv_rows_do_not_depend_on_launch_size(ops):
     # few RoIs run on 64 x 64 tiles, many on the 128 x 128 LDS-gather kernel (14 x 14) / 128 x 64 tiles:
     # the same bits either way (the early-exit path relies on rows being independent of the batch)
-    for C, S in ((256, 14), (128, 28)):
+    for C, S in ((256, 14), (128, 28), (64, 56)):
         x = torch.randn(64, C, S, S, generator=_g(63)).cuda()
         off = (torch.randn(64, 36, S, S, generator=_g(64)) * 1.5).cuda()
         wq = ops.pack_conv_weight((torch.randn(C, C, 3, 3, generator=_g(65)) / (9 * C) ** 0.5).cuda())

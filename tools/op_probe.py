@@ -62,6 +62,45 @@ if 'dcnfwd' in cases:       # fused DCN forward vs column matrix + 1x1 GEMM (the
         a, b = ops.deform_conv(x, off, pk, C, 2, relu=True), ops.conv2d([col], pk_cm, None, C, 1, relu=True)
         print(f'DCN fwd C={C} @{S}: fused {t_f:.3f} ms; im2col {t_i:.3f} + GEMM {t_g:.3f} ms; max diff {float((a - b).abs().max()):.2e}', flush=True)
         del col
+if 'dcnchunk' in cases:     # inference DCN at 512 RoIs: fused kernel vs RoI chunks of (im2col -> 1x1 GEMM) small enough for the
+    from dynamask_amd import streams      # column matrix to stay in the Infinity Cache, the two kernels of successive chunks on two streams
+    NI = 512
+    for C, S in ((64, 56), (128, 28)):
+        x = torch.randn(NI, C, S, S, generator=g).to(dev)
+        off = torch.randn(NI, 36, S, S, generator=g).to(dev)
+        w = (torch.randn(C, C, 3, 3, generator=g) / (9 * C) ** 0.5).to(dev)
+        pk = ops.pack_conv_weight(w)
+        pk_cm = ops.pack_conv_weight(ops.dcn_weight_permute(w, C, C, True), transpose_flip=True)
+        t_f = timed(lambda: ops.deform_conv(x, off, pk, C, 2, relu=True), reps=5)
+        print(f'DCN fwd C={C} @{S} x{NI}: fused {t_f:.3f} ms', flush=True)
+        out = torch.empty(NI, C, S, S, device=dev)
+        s1 = streams.side(dev, 0)
+        for chunk in (16, 32, 64, 128):
+            cols = [torch.empty(chunk, 9 * C, S, S, device=dev) for _ in range(2)]
+
+            def run(two):
+                main = torch.cuda.current_stream()
+                evs = []
+                for k, lo in enumerate(range(0, NI, chunk)):
+                    col = cols[k & 1]
+                    if two and len(evs) >= 2:
+                        main.wait_event(evs[-2])          # the GEMM that last read this buffer
+                    lib_call = ops.lib().dm_deform_im2col
+                    ops.check(lib_call(ops._p(x[lo:lo + chunk]), ops._p(off[lo:lo + chunk]), chunk, C, S, S, 2, ops._p(col), ops._stream()), 'im2col')
+                    if two:
+                        e = torch.cuda.Event(); e.record(main); s1.wait_event(e)
+                        with torch.cuda.stream(s1):
+                            ops.conv2d([col], pk_cm, None, C, 1, relu=True, out=out[lo:lo + chunk])
+                            e2 = torch.cuda.Event(); e2.record(s1); evs.append(e2)
+                    else:
+                        ops.conv2d([col], pk_cm, None, C, 1, relu=True, out=out[lo:lo + chunk])
+                if two:
+                    main.wait_stream(s1)
+            for two in (False, True):
+                t = timed(lambda: run(two), reps=3)
+                print(f'   chunks of {chunk:3d} RoIs ({chunk * 9 * C * S * S * 4 / 2**20:.0f} MiB), {"two streams" if two else "one stream"}: {t:.3f} ms', flush=True)
+        ref = ops.deform_conv(x, off, pk, C, 2, relu=True)
+        print('   max diff vs fused', float((ref - out).abs().max()), flush=True)
 if 'wgrad' in cases:
     for cout, cin, S, ks in ((36, 64, 56, 3), (36, 128, 28, 3), (36, 256, 14, 3), (16, 128, 28, 3), (30, 64, 56, 1), (62, 128, 28, 1),
                              (126, 256, 14, 1), (256, 256, 14, 3), (64, 576, 56, 1)):
