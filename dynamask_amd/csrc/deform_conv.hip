@@ -691,24 +691,31 @@ __global__ __launch_bounds__(256, 2) void deform_conv_band_kernel(DcnArgs a, int
     const unsigned any_oob_s = __builtin_amdgcn_readfirstlane(any_oob);
     const float* pl = ldsX + 4 * hi * PS;                                   // this lane half's quad of planes
     const float* gl = a.x + ((size_t)n * a.C + c0 + 4 * hi) * HW;          // the same planes in global memory
+    // 36 steps (tap, element), software-pipelined by one: the four LDS reads of step s + 1 (and, at a tap boundary,
+    // the next tap's weight fragments) are issued before the combine + MFMAs of step s, so their latency runs under
+    // 2 * WM MFMAs instead of in front of them (left to the compiler, every step waited for its own reads)
+    dm_f32x4 av[2][WM];
+    F2 top[2], bot[2];
+    auto issue = [&](int s, int slot) {
+      const int tap = s >> 2, e = s & 3;
+      const float* pc = pl + e * PS;
+      top[slot] = *reinterpret_cast<const F2*>(pc + (otb[tap] & 0xffff));
+      bot[slot] = *reinterpret_cast<const F2*>(pc + (otb[tap] >> 16));
+      if (e == 0) {
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      dm_f32x4 av[WM];
-#pragma unroll
-      for (int i = 0; i < WM; ++i) av[i] = ldsA[(tap * 2 + hi) * TM + (wave_m * WM + i) * 32 + l31];
-      float v[4];
-      const int o_t = otb[tap] & 0xffff, o_b = otb[tap] >> 16;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float* pc = pl + e * PS;
-        const F2 top = *reinterpret_cast<const F2*>(pc + o_t);
-        const F2 bot = *reinterpret_cast<const F2*>(pc + o_b);
-        v[e] = dcn_bilinear(wt0[tap], wt1[tap], wb0[tap], wb1[tap], top.a, top.b, bot.a, bot.b);
+        for (int i = 0; i < WM; ++i) av[tap & 1][i] = ldsA[(tap * 2 + hi) * TM + (wave_m * WM + i) * 32 + l31];
       }
+    };
+    issue(0, 0);
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+    for (int s = 0; s < 36; ++s) {
+      const int tap = s >> 2, e = s & 3, slot = s & 1;
+      if (s + 1 < 36) issue(s + 1, slot ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const float v = dcn_bilinear(wt0[tap], wt1[tap], wb0[tap], wb1[tap], top[slot].a, top[slot].b, bot[slot].a, bot[slot].b);
 #pragma unroll
-        for (int i = 0; i < WM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], v[e], acc[i], 0, 0, 0);
+      for (int i = 0; i < WM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tap & 1][i][e], v, acc[i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (any_oob_s) {
       // Slow pass: taps that leave the band for some lane of this wave.  The lanes concerned recompute the tap
