@@ -74,6 +74,7 @@ SIGNATURES = {
     'dm_sumsq_scratch_floats': ([], ctypes.c_longlong),
     'dm_sumsq': ([_vp, ctypes.c_longlong, _vp, _vp, _vp], _c_int),
     'dm_clip_scale': ([_vp, ctypes.c_longlong, _vp, _c_float, _vp], _c_int),
+    'dm_scale': ([_vp, ctypes.c_longlong, _c_float, _vp], _c_int),
     'dm_mask_loss_fwd_bwd': ([_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp], _c_int),
 }
 

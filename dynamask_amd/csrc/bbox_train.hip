@@ -235,6 +235,11 @@ __global__ __launch_bounds__(256) void clip_scale_kernel(float* __restrict__ x, 
   if (i < n) x[i] *= coef;
 }
 
+__global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long long n, float factor) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) x[i] *= factor;
+}
+
 }  // namespace
 
 extern "C" int dm_bbox_overlaps(const float* bboxes1, int n1, const float* bboxes2, int n2, int mode_iof, float eps,
@@ -324,5 +329,12 @@ extern "C" int dm_clip_scale(float* x, long long count, const float* sumsq, floa
   if (count < 0 || !sumsq || !(max_norm > 0.f) || (count > 0 && !x)) return DM_ERR_INVALID_ARG;
   if (count == 0) return DM_OK;
   DM_LAUNCH(clip_scale_kernel, dim3(dm_ceil_div(count, 256)), dim3(256), 0, (hipStream_t)stream, x, count, sumsq, max_norm);
+  return dm_check_launch();
+}
+
+extern "C" int dm_scale(float* x, long long count, float factor, dm_stream_t stream) {
+  if (count < 0 || (count > 0 && !x)) return DM_ERR_INVALID_ARG;
+  if (count == 0) return DM_OK;
+  DM_LAUNCH(scale_kernel, dim3(dm_ceil_div(count, 256)), dim3(256), 0, (hipStream_t)stream, x, count, factor);
   return dm_check_launch();
 }

@@ -140,6 +140,27 @@ class FlatParamGroup:
         ops.clip_scale_(self.flat_grad, total.reshape(1).contiguous(), max_norm)
         return total
 
+    def scale_grads_(self, params, factor):
+        """Multiply the gradients of ``params`` (a subset of this group) by ``factor``, e.g. the reference's optional
+        ``OptimizerHook_`` (OptimizerHook.py:27-29): ``roi_head.mask_predictor`` gradients x 0.05 between the
+        clipping and the optimizer step.  Adjacent parameters are scaled as one run of the flat buffer."""
+        from . import ops
+        if not self._synced:
+            self.sync_grads()
+        self.wait()
+        want = {id(p) for p in params}
+        off, runs = 0, []
+        for p in self.params:
+            k = p.numel()
+            if id(p) in want:
+                if runs and runs[-1][1] == off:
+                    runs[-1][1] = off + k
+                else:
+                    runs.append([off, off + k])
+            off += k
+        for lo, hi in runs:
+            ops.scale_(self.flat_grad[lo:hi], factor)
+
     def sgd_step(self, lr=0.02, momentum=0.9, weight_decay=1e-4, grad_scale=1.0):
         """Fused SGD on the flat buffer; the 1/world averaging (times ``grad_scale``, e.g. the
         clip coefficient of ``clip_grad_norm``) rides in the kernel."""

@@ -134,7 +134,7 @@ class SFMStage(nn.Module):
         not depend on the RoIs, so RoI chunks running on different streams share it."""
         return self.semantic_transform_in.run(semantic_feat, relu=True)
 
-    def forward(self, instance_feats, semantic_feat, rois, roi_labels, upsample=True, sem=None):
+    def forward(self, instance_feats, semantic_feat, rois, roi_labels, upsample=True, sem=None, pred_out=None):
         n, c, s = instance_feats.shape[0], self.instance_in_channel, self.out_size
         co = self.instance_out_channel
         # instance-wise semantic feats: relu(conv1x1) on the whole FPN map, then point sample
@@ -146,7 +146,8 @@ class SFMStage(nn.Module):
         nc = self.num_classes
         ip, dp = ops.class_logits(instance_feats, self.instance_logits.weight.detach().view(nc, c),
                                   self.instance_logits.bias.detach(), self.detail_logits.weight.detach().view(nc, c),
-                                  self.detail_logits.bias.detach(), roi_labels, sig_out=tail, sig_ch_offset=co - 2)
+                                  self.detail_logits.bias.detach(), roi_labels, sig_out=tail, sig_ch_offset=co - 2,
+                                  out=pred_out)
         fused = self.fuse_conv[0].run([instance_feats, ins_sem, tail[:, co - 2:]], relu=True)
         fused = self.fuse_conv[1](fused, relu=True)
         self.fuse_transform_out.run(fused, relu=True, out=tail, out_ch_offset=0)
@@ -212,12 +213,23 @@ class DynaMaskHead(nn.Module):
         n = len(self.stages) if last_stage is None else min(last_stage, len(self.stages))
         return [self.stages[i].semantic_map(semantic_feats[-i - 3]) for i in range(n)]
 
-    def forward(self, instance_feats, semantic_feats, rois, roi_labels, last_stage=None, sems=None):
+    def pred_sizes(self, last_stage=None):
+        """Spatial size of every (instance, detail) logit pair ``forward`` returns, in order."""
+        n = len(self.stages) if last_stage is None else min(last_stage, len(self.stages))
+        sizes = [self.stages[i].out_size for i in range(n)]
+        if last_stage is not None and last_stage < len(self.stages):
+            return sizes + [self.stages[last_stage].out_size]
+        return sizes + [2 * self.stages[-1].out_size]
+
+    def forward(self, instance_feats, semantic_feats, rois, roi_labels, last_stage=None, sems=None, pred_out=None):
         """Returns (stage_instance_preds, stage_detail_preds) as the reference.
 
         ``last_stage`` (extension, default None = all): stop after the logits of
         that exit (1 = the fixed 28x28 exit of BASELINE configs[1]).
-        ``sems`` (extension): precomputed ``semantic_maps`` (multi-stream inference)."""
+        ``sems`` (extension): precomputed ``semantic_maps`` (multi-stream inference).
+        ``pred_out`` (extension): one ``(instance, detail)`` pair of [N, 1, S, S] tensors per returned logit pair
+        (``pred_sizes``) to write into -- the row slices of a chunked, multi-stream caller's buffers."""
+        po = (lambda i: None) if pred_out is None else (lambda i: pred_out[i])
         for conv in self.instance_convs:
             instance_feats = conv(instance_feats)
         stage_instance_preds, stage_detail_preds = [], []
@@ -229,13 +241,13 @@ class DynaMaskHead(nn.Module):
                 ip, dp = ops.class_logits(instance_feats, stage.instance_logits.weight.detach().view(nc, c),
                                           stage.instance_logits.bias.detach(),
                                           stage.detail_logits.weight.detach().view(nc, c),
-                                          stage.detail_logits.bias.detach(), roi_labels)
+                                          stage.detail_logits.bias.detach(), roi_labels, out=po(idx))
                 stage_instance_preds.append(ip)
                 stage_detail_preds.append(dp)
                 return stage_instance_preds, stage_detail_preds
             upsample_flag = self.pre_upsample_last_stage or idx < len(self.stages) - 1
             ip, dp, instance_feats = stage(instance_feats, semantic_feats[-idx - 3], rois, roi_labels, upsample_flag,
-                                           sem=None if sems is None else sems[idx])
+                                           sem=None if sems is None else sems[idx], pred_out=po(idx))
             stage_instance_preds.append(ip)
             stage_detail_preds.append(dp)
         if self.stage_num_classes[-1] == 1:
@@ -245,10 +257,12 @@ class DynaMaskHead(nn.Module):
         ip, dp = ops.class_logits(instance_feats, self.final_instance_logits.weight.detach().view(nc, c),
                                   self.final_instance_logits.bias.detach(),
                                   self.final_detail_logits.weight.detach().view(nc, c),
-                                  self.final_detail_logits.bias.detach(), roi_labels)
+                                  self.final_detail_logits.bias.detach(), roi_labels,
+                                  out=po(len(self.stages)) if self.pre_upsample_last_stage else None)
         if not self.pre_upsample_last_stage:
-            ip = ops.upsample2x(ip, align_corners=True)
-            dp = ops.upsample2x(dp, align_corners=True)
+            fin = po(len(self.stages))
+            ip = ops.upsample2x(ip, align_corners=True, out=None if fin is None else fin[0])
+            dp = ops.upsample2x(dp, align_corners=True, out=None if fin is None else fin[1])
         stage_instance_preds.append(ip)
         stage_detail_preds.append(dp)
         return stage_instance_preds, stage_detail_preds

@@ -364,15 +364,21 @@ def point_sample(feat, rois, output_size, spatial_scale):
     return out
 
 
-def class_logits(x, w_inst, b_inst, w_det, b_det, labels, sig_out=None, sig_ch_offset=0):
+def class_logits(x, w_inst, b_inst, w_det, b_det, labels, sig_out=None, sig_ch_offset=0, out=None):
     _chk(x, 'x')
     for t, n in ((w_inst, 'w_inst'), (b_inst, 'b_inst'), (w_det, 'w_det'), (b_det, 'b_det')):
         _chk(t, n)
     _chk(labels, 'labels', torch.int64)
     N, C, H, W = x.shape
     nc = w_inst.shape[0]
-    inst = torch.empty((N, 1, H, W), device=x.device, dtype=torch.float32)
-    det = torch.empty((N, 1, H, W), device=x.device, dtype=torch.float32)
+    if out is None:
+        inst = torch.empty((N, 1, H, W), device=x.device, dtype=torch.float32)
+        det = torch.empty((N, 1, H, W), device=x.device, dtype=torch.float32)
+    else:                                   # (inst, det): e.g. row slices of the buffers of a chunked launch sequence
+        inst, det = out
+        for t, nm in ((inst, 'out[0]'), (det, 'out[1]')):
+            _chk(t, nm)
+            assert tuple(t.shape) == (N, 1, H, W)
     sig_ct = 0
     if sig_out is not None:
         _chk(sig_out, 'sig_out')
@@ -384,10 +390,14 @@ def class_logits(x, w_inst, b_inst, w_det, b_det, labels, sig_out=None, sig_ch_o
     return inst, det
 
 
-def upsample2x(x, align_corners=False, relu=False):
+def upsample2x(x, align_corners=False, relu=False, out=None):
     _chk(x, 'x')
     N, C, H, W = x.shape
-    out = torch.empty((N, C, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((N, C, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+    else:
+        _chk(out, 'out')
+        assert tuple(out.shape) == (N, C, 2 * H, 2 * W)
     check(lib().dm_upsample2x_bilinear_fwd(_p(x), N * C, H, W, 1 if align_corners else 0, 1 if relu else 0,
                                            _p(out), _stream()), 'dm_upsample2x_bilinear_fwd')
     return out
@@ -841,6 +851,13 @@ def clip_scale_(x, sumsq_total, max_norm):
     _chk(x, 'x')
     _chk(sumsq_total, 'sumsq')
     check(lib().dm_clip_scale(_p(x), x.numel(), _p(sumsq_total), float(max_norm), _stream()), 'dm_clip_scale')
+    return x
+
+
+def scale_(x, factor):
+    """x *= factor (x: a contiguous run of fp32, e.g. a slice of a flat gradient buffer)."""
+    _chk(x, 'x')
+    check(lib().dm_scale(_p(x), x.numel(), float(factor), _stream()), 'dm_scale')
     return x
 
 

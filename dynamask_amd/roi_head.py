@@ -192,21 +192,22 @@ class DynaMaskRoIHead(nn.Module):
             bounds = [0] + [round(f * n) for f in split]
         else:
             bounds = [round(i * n / n_streams) for i in range(n_streams + 1)]
-        parts = []
+        # every chunk writes its rows of the logit tensors in place (allocated here, on the caller's stream, before
+        # the fork): no concatenation after the join
+        sizes = self.mask_head.pred_sizes(last_stage)
+        ips = [torch.empty((n, 1, s_, s_), device=rois.device, dtype=torch.float32) for s_ in sizes]
+        dps = [torch.empty((n, 1, s_, s_), device=rois.device, dtype=torch.float32) for s_ in sizes]
         for st, lo, hi in zip(streams, bounds[:-1], bounds[1:]):
+            if hi <= lo:
+                continue
             st.wait_stream(cur)
             with torch.cuda.stream(st), ops.overlapped_streams():
                 r, l = rois[lo:hi], roi_labels[lo:hi]
                 ins = self.mask_roi_extractor(x[:self.mask_roi_extractor.num_inputs], r)
-                parts.append(self.mask_head(ins, x, r, l, last_stage=last_stage, sems=sems))
+                self.mask_head(ins, x, r, l, last_stage=last_stage, sems=sems,
+                               pred_out=[(a[lo:hi], b[lo:hi]) for a, b in zip(ips, dps)])
         for st in streams:
             cur.wait_stream(st)
-        n_out = len(parts[0][0])
-        ips = [torch.cat([p[0][i] for p in parts]) for i in range(n_out)]
-        dps = [torch.cat([p[1][i] for p in parts]) for i in range(n_out)]
-        for p in parts:
-            for t in p[0] + p[1]:
-                t.record_stream(cur)
         return dict(stage_instance_preds=ips, stage_detail_preds=dps)
 
     def _side_streams(self, k, device):

@@ -469,6 +469,9 @@ int dm_l1_loss_fwd_bwd(const float* bbox_pred, const int64_t* labels, const floa
 long long dm_sumsq_scratch_floats(void);
 int dm_sumsq(const float* x, long long count, float* scratch, float* out, dm_stream_t stream);
 int dm_clip_scale(float* x, long long count, const float* sumsq, float max_norm, dm_stream_t stream);
+/* x *= factor: a parameter group's gradient scale (the reference's optional OptimizerHook_ multiplies the
+ * gradients of roi_head.mask_predictor by 0.05 between clipping and the step, OptimizerHook.py:27-29). */
+int dm_scale(float* x, long long count, float factor, dm_stream_t stream);
 
 #ifdef __cplusplus
 }

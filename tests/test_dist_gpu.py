@@ -124,3 +124,21 @@ def test_clip_grad_norm_on_the_flat_group_matches_torch(rccl_world1):
         coef = min(1.0, max_norm / (norm + 1e-6))
         torch.testing.assert_close(float(total.sqrt()), norm, rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(grp.flat_grad, gref * coef, rtol=1e-5, atol=1e-7)
+
+
+def test_scale_grads_of_a_parameter_subset(rccl_world1):
+    """The reference's optional OptimizerHook_ (OptimizerHook.py:27-29) multiplies the gradients of
+    roi_head.mask_predictor by 0.05 between clipping and the step: FlatParamGroup.scale_grads_ on the device,
+    adjacent parameters as one run, the other parameters untouched."""
+    from dynamask_amd.dist import FlatParamGroup
+    dev = rccl_world1
+    torch.manual_seed(3)
+    net = nn.Sequential(nn.Linear(16, 24), nn.Linear(24, 8), nn.Linear(8, 4)).to(dev)
+    grp = FlatParamGroup(list(net.parameters()))
+    net(torch.randn(5, 16, device=dev)).square().sum().backward()
+    before = [p.grad.clone() for p in net.parameters()]
+    sub = list(net[0].parameters()) + [net[2].bias]
+    grp.scale_grads_(sub, 0.05)
+    for p, b in zip(net.parameters(), before):
+        exp = b * 0.05 if any(p is q for q in sub) else b
+        assert torch.equal(p.grad, exp)
