@@ -18,6 +18,8 @@ import torch
 
 from . import ops
 
+# maps of at least this many pixels keep the DCN column matrix from the forward for the weight gradient (56 x 56)
+_KEEP_COL_MIN_PIXELS = int(os.environ.get('DM_TRAIN_KEEP_COL_MIN_PIXELS', '1024'))
 _SIDE_STREAMS = {'leaf': 0, 'selector': 1, 'bbox': 1, 'coord': 2}      # slots of the shared pool (streams.py)
 
 
@@ -173,10 +175,11 @@ class MaskHeadFn(torch.autograd.Function):
             dcn = stage.fuse_conv[1]
             off = dcn.conv_offset.run(f1)
             col = None
-            if s * s >= 512:
-                # training keeps the deformable column matrix: the weight gradient needs it anyway, and on the large
-                # maps im2col + a 1x1 GEMM over it (0.61 + 0.68 ms at 56x56, 256 RoIs) beat the fused gather kernel
-                # plus the backward's own im2col (1.15 + 0.61 ms).  1.85 GB at 56x56: HBM is there to be used.
+            if s * s >= _KEEP_COL_MIN_PIXELS:
+                # 56 x 56: training keeps the deformable column matrix -- the weight gradient needs it anyway, and
+                # im2col + a 1x1 GEMM over it (0.61 + 0.68 ms, 256 RoIs) cost the chain less than the fused kernel
+                # (0.76 ms) plus an im2col in the backward (0.61 ms, beside the chain on the leaf stream): 23.45 vs
+                # 23.5 ms per step, and 23.75 with the 28 x 28 stage kept too.  1.85 GB live until the backward.
                 col = ops.deform_im2col(f1, off, dcn.deform_groups)
                 f2 = ops.conv2d([col], dcn._pk.get('w_cm', dcn.weight, _pack_dcn_colmajor), None, dcn.out_channels, 1, relu=True)
             else:
