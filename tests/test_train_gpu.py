@@ -254,3 +254,45 @@ def test_side_streams_come_from_one_shared_pool():
     used.add(grp._stream.cuda_stream)
     assert used <= pool
     assert torch.cuda.default_stream(dev).cuda_stream not in pool
+
+
+def test_training_step_on_side_streams_matches_the_single_stream_step(monkeypatch):
+    """The step overlaps its branches on three side streams (leaf work, selector, coordinate gradient).  Two steps at
+    the benchmark's size (2 x 128 RoIs on the 800 x 1333 pyramid) with and without them must give the same parameters
+    up to the last-bit noise of the atomically accumulated weight gradients -- a missing stream dependency or a tensor
+    recycled under a side stream shows up as a gross difference."""
+    from dynamask_amd import synth, registry, roi_head, mask_heads, roi_extractors, losses  # noqa: F401
+    from dynamask_amd.dist import FlatParamGroup, mask_path_parameters
+    dev = torch.device('cuda')
+    B, per, H, W = 2, 128, 800, 1333
+    feats = [f.to(dev) for f in synth.make_fpn(B, H, W, 256, seed=10)]
+    rois = synth.make_rois(B, per, H, W, seed=11).to(dev)
+    labels = synth.make_labels(B * per, seed=12).to(dev)
+    targets = [t.to(dev) for t in synth.make_targets(B * per, seed=13)]
+    noise = synth.make_gumbel_noise(B * per, seed=14).to(dev)
+
+    def run(side):
+        monkeypatch.setenv('DM_TRAIN_SIDE_STREAM', '1' if side else '0')
+        m = registry.build_head(dict(type='DynaMaskRoIHead',
+                                     mask_roi_extractor=dict(type='SingleRoIExtractor', **gi.MASK_ROI_EXTRACTOR_CFG),
+                                     mask_head=dict(type='DynaMaskHead', **gi.MASK_HEAD_CFG)))
+        m.load_state_dict({**synth.init_dynamask_head_state(seed=5), **synth.init_mask_pre_state(seed=6)}, strict=True)
+        m = m.to(dev).train()
+        grp = FlatParamGroup(mask_path_parameters(m))
+        out = []
+        for _ in range(2):
+            grp.zero_grad()
+            res = m._mask_forward_train(feats, rois, labels, targets, noise=noise)
+            res['loss_mask']['loss_masks'].backward()
+            out.append((float(res['loss_mask']['loss_masks'].detach()), grp.flat_grad.clone()))
+            grp.all_reduce_async()
+            grp.sgd_step(lr=0.02, momentum=0.9, weight_decay=1e-4)
+        torch.cuda.synchronize()
+        return out, grp.flat_param.clone()
+    (a0, a1), pa = run(True)
+    (b0, b1), pb = run(False)
+    assert abs(a0[0] - b0[0]) <= 1e-6 * abs(b0[0])
+    scale = float(b0[1].abs().max())
+    assert float((a0[1] - b0[1]).abs().max()) <= 2e-5 * scale, 'first-step gradients differ'
+    assert abs(a1[0] - b1[0]) <= 1e-5 * abs(b1[0])
+    torch.testing.assert_close(pa, pb, atol=2e-6, rtol=1e-4)
