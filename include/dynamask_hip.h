@@ -10,9 +10,12 @@
  *     stream) on the CURRENT device and the call returns without synchronising.
  *     What the library does keep, per device and only as a cache: the device's
  *     compute-unit count and "this kernel's dynamic-LDS limit has been raised"
- *     flags (hipFuncSetAttribute once per device).  Four tuning knobs are read
- *     from the environment on first use and never change results, only tile /
- *     split choices: DM_CONV_TAIL, DM_DCN_TAIL, DM_WGRAD_WGS, DM_FC_WGS.
+ *     flags (hipFuncSetAttribute once per device).  A few knobs are read from
+ *     the environment on first use.  Tuning knobs that never change results,
+ *     only tile / split choices: DM_CONV_TAIL, DM_DCN_TAIL, DM_WGRAD_WGS,
+ *     DM_FC_WGS.  A/B switches that select an older kernel for the same
+ *     operation (same mathematics; sums may differ in the last bits):
+ *     DM_WGRAD_NARROW_OFF, DM_DCN_BAND_OFF, DM_IM2COL_V1.
  *     Calls from several host threads are safe (a race only repeats an
  *     idempotent attribute call);
  *   - LDS scatter-accumulators (dm_deform_col2im_coord, dm_point_sample_bwd) are
