@@ -12,8 +12,8 @@
  *     compute-unit count and "this kernel's dynamic-LDS limit has been raised"
  *     flags (hipFuncSetAttribute once per device).  A few knobs are read from
  *     the environment on first use.  Tuning knobs that never change results,
- *     only tile / split choices: DM_CONV_TAIL, DM_DCN_TAIL, DM_WGRAD_WGS,
- *     DM_FC_WGS.  A/B switches that select an older kernel for the same
+ *     only tile / split choices: DM_CONV_TAIL, DM_DCN_TAIL, DM_WGRAD_WGS.
+ *     A/B switches that select an older kernel for the same
  *     operation (same mathematics; sums may differ in the last bits):
  *     DM_WGRAD_NARROW_OFF, DM_DCN_BAND_OFF, DM_IM2COL_V1.
  *     Calls from several host threads are safe (a race only repeats an
