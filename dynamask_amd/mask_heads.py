@@ -213,6 +213,22 @@ class DynaMaskHead(nn.Module):
         n = len(self.stages) if last_stage is None else min(last_stage, len(self.stages))
         return [self.stages[i].semantic_map(semantic_feats[-i - 3]) for i in range(n)]
 
+    def prepack(self, fused_dcn=None):
+        """Refresh the kernel-layout weights of everything ``forward`` launches (except the semantic 1x1 convs, which
+        ``semantic_maps`` owns) on the CURRENT stream.  The caches are filled by whoever asks first; a caller that is
+        about to fork RoI chunks onto several streams calls this first, so that no stream reads a pack another
+        stream is still writing.  ``fused_dcn``: per stage, whether the fused DCN kernel's layout is the one needed
+        (default: all)."""
+        for conv in self.instance_convs:
+            conv.conv.packed([conv.conv.in_channels])
+        for i, stage in enumerate(self.stages):
+            c, dcn = stage.instance_in_channel, stage.fuse_conv[1]
+            stage.fuse_conv[0].packed([c, stage.semantic_transform_in.out_channels, 2])
+            dcn.conv_offset.packed([c])
+            if fused_dcn is None or fused_dcn[i]:
+                dcn._pk.get('w', dcn.weight, ops.pack_conv_weight)
+            stage.fuse_transform_out.packed([dcn.out_channels])
+
     def pred_sizes(self, last_stage=None):
         """Spatial size of every (instance, detail) logit pair ``forward`` returns, in order."""
         n = len(self.stages) if last_stage is None else min(last_stage, len(self.stages))

@@ -309,14 +309,18 @@ def conv2d(srcs, w_packed, bias, cout, ksize, relu=False, out=None, out_ch_offse
     return out
 
 
-def deform_conv(x, offset, w_packed, cout, deform_groups, relu=False):
+def deform_conv(x, offset, w_packed, cout, deform_groups, relu=False, out=None):
     _chk(x, 'x')
     _chk(offset, 'offset')
     _chk(w_packed, 'w_packed')
     NB, C, H, W = x.shape
     assert offset.shape == (NB, deform_groups * 18, H, W)
     assert w_packed.numel() == packed_floats(cout, 3, [C])
-    out = torch.empty((NB, cout, H, W), device=x.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((NB, cout, H, W), device=x.device, dtype=torch.float32)
+    else:
+        _chk(out, 'out')
+        assert tuple(out.shape) == (NB, cout, H, W)
     check(lib().dm_deform_conv_fwd(_p(x), _p(offset), NB, C, H, W, _p(w_packed), cout, deform_groups,
                                    (1 if relu else 0) | (8 if _overlapped else 0), _p(out), _stream()), 'dm_deform_conv_fwd')
     return out
@@ -603,11 +607,16 @@ def class_logits_backward(x, w_inst, w_det, labels, g_inst, g_det, grad_x, accum
     return grad_x
 
 
-def deform_im2col(x, offset, deform_groups):
+def deform_im2col(x, offset, deform_groups, out=None):
     _chk(x, 'x')
     _chk(offset, 'offset')
     NB, C, H, W = x.shape
-    col = torch.empty((NB, 9 * C, H, W), device=x.device, dtype=torch.float32)
+    if out is None:
+        col = torch.empty((NB, 9 * C, H, W), device=x.device, dtype=torch.float32)
+    else:
+        col = out
+        _chk(col, 'out')
+        assert tuple(col.shape) == (NB, 9 * C, H, W)
     check(lib().dm_deform_im2col(_p(x), _p(offset), NB, C, H, W, deform_groups, _p(col), _stream()), 'dm_deform_im2col')
     return col
 

@@ -187,6 +187,7 @@ class DynaMaskRoIHead(nn.Module):
         cur = torch.cuda.current_stream()
         streams = self._side_streams(n_streams, rois.device)
         sems = self.mask_head.semantic_maps(x, last_stage)
+        self.mask_head.prepack()                 # packs are cached by whoever asks first: before the fork, on this stream
         split = getattr(self, 'stream_split', None)      # optional cumulative fractions, e.g. (0.4, 1.0)
         if split is not None and len(split) == n_streams:
             bounds = [0] + [round(f * n) for f in split]

@@ -20,6 +20,8 @@ from . import ops
 
 # maps of at least this many pixels keep the DCN column matrix from the forward for the weight gradient (56 x 56)
 _KEEP_COL_MIN_PIXELS = int(os.environ.get('DM_TRAIN_KEEP_COL_MIN_PIXELS', '1024'))
+# the training forward splits the RoIs in two halves on two streams from this many RoIs on
+_FWD_SPLIT_MIN_ROIS = int(os.environ.get('DM_TRAIN_FWD_SPLIT_MIN_ROIS', '128'))
 _SIDE_STREAMS = {'leaf': 0, 'selector': 1, 'bbox': 1, 'coord': 2}      # slots of the shared pool (streams.py)
 
 
@@ -151,61 +153,113 @@ class MaskHeadFn(torch.autograd.Function):
                 sems.append(sem)
                 isfs.append(ops.point_sample(sem, rois, stage.out_size, stage.spatial_scale))
         sw.run(semantic_branches)
-        conv_in = []
+        # Everything below is per RoI: the buffers are allocated for the whole batch (the backward sees whole
+        # tensors) and filled by rows -- two halves on two streams when the batch is large enough, so that the
+        # memory-bound kernels of one half (logit gathers, deformable im2col, upsampling) run beside the GEMMs of the
+        # other.  (The backward is not split: it already shares the GPU between the chain and its leaves, and halving
+        # its launches as well was measured slower.)
+        dev = x.device
+        n = x.shape[0]
+
+        def buf(*shape):
+            return torch.empty(shape, device=dev, dtype=torch.float32)
+        conv_in = [x]
         for conv in head.instance_convs:
-            conv_in.append(x)
-            x = conv(x)
-        sw.join(*sems, *isfs)
-        saved['conv_in'] = conv_in
+            conv_in.append(buf(n, conv.conv.out_channels, x.shape[2], x.shape[3]))
+        n_stages = len(head.stages)
+        stbuf = []
+        xin = conv_in[-1]
+        for idx, stage in enumerate(head.stages):
+            up_flag = head.pre_upsample_last_stage or idx < n_stages - 1
+            c, s, co = stage.instance_in_channel, stage.out_size, stage.instance_out_channel
+            dcn = stage.fuse_conv[1]
+            st = dict(xin=xin, tail=buf(n, co, s, s), f1=buf(n, c, s, s), off=buf(n, dcn.conv_offset.out_channels, s, s),
+                      f2=buf(n, dcn.out_channels, s, s), ip=buf(n, 1, s, s), dp=buf(n, 1, s, s),
+                      col=buf(n, 9 * c, s, s) if s * s >= _KEEP_COL_MIN_PIXELS else None,
+                      up=buf(n, co, 2 * s, 2 * s) if up_flag else None, feat_idx=len(feats) - idx - 3)
+            stbuf.append(st)
+            xin = st['up'] if up_flag else st['tail']
+        x_last = xin
+        S = x_last.shape[-1]
+        fin_ip, fin_dp = buf(n, 1, S, S), buf(n, 1, S, S)
+        fin_up = None if head.pre_upsample_last_stage else (buf(n, 1, 2 * S, 2 * S), buf(n, 1, 2 * S, 2 * S))
+        lab_last = labels.clamp(max=0) if head.stage_num_classes[-1] == 1 else labels
+
+        def convs(lo, hi):
+            for i, conv in enumerate(head.instance_convs):
+                conv.conv.run([conv_in[i][lo:hi]], relu=True, out=conv_in[i + 1][lo:hi])
+
+        def stages(lo, hi):
+            r, lab = rois[lo:hi], labels[lo:hi]
+            for idx, stage in enumerate(head.stages):
+                st = stbuf[idx]
+                c, s, co, nc = stage.instance_in_channel, stage.out_size, stage.instance_out_channel, stage.num_classes
+                x_, tail = st['xin'][lo:hi], st['tail'][lo:hi]
+                ops.class_logits(x_, stage.instance_logits.weight.detach().view(nc, c), stage.instance_logits.bias.detach(),
+                                 stage.detail_logits.weight.detach().view(nc, c), stage.detail_logits.bias.detach(), lab,
+                                 sig_out=tail, sig_ch_offset=co - 2, out=(st['ip'][lo:hi], st['dp'][lo:hi]))
+                f1 = stage.fuse_conv[0].run([x_, isfs[idx][lo:hi], tail[:, co - 2:]], relu=True, out=st['f1'][lo:hi])
+                dcn = stage.fuse_conv[1]
+                off = dcn.conv_offset.run(f1, out=st['off'][lo:hi])
+                if st['col'] is not None:
+                    # 56 x 56: training keeps the deformable column matrix -- the weight gradient needs it anyway, and
+                    # im2col + a 1x1 GEMM over it (0.61 + 0.68 ms, 256 RoIs) cost the chain less than the fused kernel
+                    # (0.76 ms) plus an im2col in the backward (0.61 ms, beside the chain on the leaf stream): 23.45 vs
+                    # 23.5 ms per step, and 23.75 with the 28 x 28 stage kept too.  1.85 GB live until the backward.
+                    col = ops.deform_im2col(f1, off, dcn.deform_groups, out=st['col'][lo:hi])
+                    f2 = ops.conv2d([col], dcn._pk.get('w_cm', dcn.weight, _pack_dcn_colmajor), None, dcn.out_channels, 1,
+                                    relu=True, out=st['f2'][lo:hi])
+                else:
+                    f2 = ops.deform_conv(f1, off, dcn._pk.get('w', dcn.weight, ops.pack_conv_weight), dcn.out_channels,
+                                         dcn.deform_groups, relu=True, out=st['f2'][lo:hi])
+                stage.fuse_transform_out.run(f2, relu=True, out=tail, out_ch_offset=0)
+                if st['up'] is not None:
+                    ops.upsample2x(tail, align_corners=False, relu=True, out=st['up'][lo:hi])
+            nc = head.stage_num_classes[-1]
+            c = head.final_instance_logits.in_channels
+            ops.class_logits(x_last[lo:hi], head.final_instance_logits.weight.detach().view(nc, c),
+                             head.final_instance_logits.bias.detach(), head.final_detail_logits.weight.detach().view(nc, c),
+                             head.final_detail_logits.bias.detach(), lab_last[lo:hi], out=(fin_ip[lo:hi], fin_dp[lo:hi]))
+            if fin_up is not None:
+                ops.upsample2x(fin_ip[lo:hi], align_corners=True, out=fin_up[0][lo:hi])
+                ops.upsample2x(fin_dp[lo:hi], align_corners=True, out=fin_up[1][lo:hi])
+
+        second = side_stream(dev, 'coord') if n >= _FWD_SPLIT_MIN_ROIS else None       # idle during the forward
+        if second is not None and sw.enabled:
+            main = torch.cuda.current_stream(dev)
+            h = (n + 1) // 2
+            # kernel-layout weights are cached per module and refreshed after every optimizer step by whoever asks
+            # first: refresh them here, on the main stream, before the fork (packed by one stream and read by the
+            # other without a dependency would be a race)
+            head.prepack(fused_dcn=[st['col'] is None for st in stbuf])
+            for stage, st in zip(head.stages, stbuf):
+                if st['col'] is not None:
+                    stage.fuse_conv[1]._pk.get('w_cm', stage.fuse_conv[1].weight, _pack_dcn_colmajor)
+            second.wait_stream(main)
+            with torch.cuda.stream(second):
+                convs(h, n)
+                second.wait_stream(sw.side)         # the semantic branches
+                stages(h, n)
+            convs(0, h)
+            sw.join(*sems, *isfs)
+            stages(0, h)
+            main.wait_stream(second)
+        else:
+            convs(0, n)
+            sw.join(*sems, *isfs)
+            stages(0, n)
+        saved['conv_in'] = conv_in[:-1]
         saved['stages'] = []
         ips, dps = [], []
-        for idx, stage in enumerate(head.stages):
-            up_flag = head.pre_upsample_last_stage or idx < len(head.stages) - 1
-            st = {}
-            n, c, s, co = x.shape[0], stage.instance_in_channel, stage.out_size, stage.instance_out_channel
-            feat = feats[len(feats) - idx - 3]
-            st['feat_idx'] = len(feats) - idx - 3
-            sem, isf = sems[idx], isfs[idx]
-            tail = torch.empty((n, co, s, s), device=x.device, dtype=torch.float32)
-            nc = stage.num_classes
-            ip, dp = ops.class_logits(x, stage.instance_logits.weight.detach().view(nc, c),
-                                      stage.instance_logits.bias.detach(), stage.detail_logits.weight.detach().view(nc, c),
-                                      stage.detail_logits.bias.detach(), labels, sig_out=tail, sig_ch_offset=co - 2)
-            f1 = stage.fuse_conv[0].run([x, isf, tail[:, co - 2:]], relu=True)
-            dcn = stage.fuse_conv[1]
-            off = dcn.conv_offset.run(f1)
-            col = None
-            if s * s >= _KEEP_COL_MIN_PIXELS:
-                # 56 x 56: training keeps the deformable column matrix -- the weight gradient needs it anyway, and
-                # im2col + a 1x1 GEMM over it (0.61 + 0.68 ms, 256 RoIs) cost the chain less than the fused kernel
-                # (0.76 ms) plus an im2col in the backward (0.61 ms, beside the chain on the leaf stream): 23.45 vs
-                # 23.5 ms per step, and 23.75 with the 28 x 28 stage kept too.  1.85 GB live until the backward.
-                col = ops.deform_im2col(f1, off, dcn.deform_groups)
-                f2 = ops.conv2d([col], dcn._pk.get('w_cm', dcn.weight, _pack_dcn_colmajor), None, dcn.out_channels, 1, relu=True)
-            else:
-                f2 = ops.deform_conv(f1, off, dcn._pk.get('w', dcn.weight, ops.pack_conv_weight), dcn.out_channels,
-                                     dcn.deform_groups, relu=True)
-            stage.fuse_transform_out.run(f2, relu=True, out=tail, out_ch_offset=0)
-            up = ops.upsample2x(tail, align_corners=False, relu=True) if up_flag else None
-            st.update(xin=x, sem=sem, isf=isf, tail=tail, f1=f1, off=off, f2=f2, up=up, col=col)
-            saved['stages'].append(st)
-            ips.append(ip)
-            dps.append(dp)
-            x = up if up_flag else tail
-        lab_last = labels.clamp(max=0) if head.stage_num_classes[-1] == 1 else labels
-        nc = head.stage_num_classes[-1]
-        c = head.final_instance_logits.in_channels
-        ip, dp = ops.class_logits(x, head.final_instance_logits.weight.detach().view(nc, c),
-                                  head.final_instance_logits.bias.detach(),
-                                  head.final_detail_logits.weight.detach().view(nc, c),
-                                  head.final_detail_logits.bias.detach(), lab_last)
-        saved['x_last'] = x
+        for idx, st in enumerate(stbuf):
+            saved['stages'].append(dict(xin=st['xin'], sem=sems[idx], isf=isfs[idx], tail=st['tail'], f1=st['f1'], off=st['off'],
+                                        f2=st['f2'], up=st['up'], col=st['col'], feat_idx=st['feat_idx']))
+            ips.append(st['ip'])
+            dps.append(st['dp'])
+        saved['x_last'] = x_last
         saved['lab_last'] = lab_last
-        if not head.pre_upsample_last_stage:
-            ip = ops.upsample2x(ip, align_corners=True)
-            dp = ops.upsample2x(dp, align_corners=True)
-        ips.append(ip)
-        dps.append(dp)
+        ips.append(fin_ip if fin_up is None else fin_up[0])
+        dps.append(fin_dp if fin_up is None else fin_up[1])
         ctx.head, ctx.saved, ctx.feats, ctx.rois, ctx.labels = head, saved, feats, rois, labels
         ctx.n_feats = n_feats
         return (*ips, *dps)
