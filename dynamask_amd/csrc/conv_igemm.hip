@@ -48,6 +48,7 @@ struct ConvArgs {
   int MT;         // number of cout tiles
   int q_begin = 0;  // first flat pixel of this launch (Q is its end): a launch may cover a pixel range
   int shuffle;    // deconv 2x2/s2 epilogue: packed cout = phase*shuffle + co, stored at (2y+dy, 2x+dx)
+  const float* mask = nullptr;   // same layout as out: outputs whose mask value is not > 0 are stored as 0 (a ReLU adjoint)
 };
 
 // CK input channels per chunk (multiple of 8); MAXPOS = plane positions per thread (3x3)
@@ -390,7 +391,8 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
 #pragma unroll
         for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(bias_r[i][r]));
     }
-    auto store_all = [&](auto acc_mode, auto nt_mode) {
+    const ptrdiff_t mask_off = a.mask ? a.mask - a.out : 0;
+    auto store_all = [&](auto acc_mode, auto nt_mode, auto mask_mode) {
 #pragma unroll
       for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -406,6 +408,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
                 float v = acc[i][j][r] + b;
                 if (decltype(acc_mode)::value) v += *op;          // accumulate into the destination (gradient sums)
                 if (relu) v = fmaxf(v, 0.f);
+                if (decltype(mask_mode)::value) v = (op[mask_off] > 0.f) ? v : 0.f;   // the producer's ReLU, looking backward
                 if (decltype(nt_mode)::value) __builtin_nontemporal_store(v, op);   // output larger than the Infinity Cache: stream it
                 else *op = v;
               }
@@ -416,9 +419,12 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
     };
     using T = std::true_type;
     using F = std::false_type;
-    if (a.relu & 2) store_all(T{}, F{});
-    else if (a.relu & 4) store_all(F{}, T{});
-    else store_all(F{}, F{});
+    if (a.mask) {
+      if (a.relu & 2) store_all(T{}, F{}, T{});
+      else store_all(F{}, F{}, T{});
+    } else if (a.relu & 2) store_all(T{}, F{}, F{});
+    else if (a.relu & 4) store_all(F{}, T{}, F{});
+    else store_all(F{}, F{}, F{});
   } else {
     // deconv 2x2/s2: packed cout = phase * shuffle + oc, stored at (2y+dy, 2x+dx)
     int sy[WN], sx[WN];
@@ -462,6 +468,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
           float* op = a.out + ((size_t)col_n[j] * a.out_ch_total + a.out_ch_offset + co) * HW + col_p[j];
           if (a.relu & 2) v += *op;
           if (a.relu & 1) v = fmaxf(v, 0.f);
+          if (a.mask && !(a.mask[op - a.out] > 0.f)) v = 0.f;
           *op = v;
         }
       }
@@ -593,10 +600,32 @@ extern "C" int dm_conv_pack_weight(const float* w_oihw, int Cout, int Cin, int k
   return run_pack(p, (hipStream_t)stream);
 }
 
+static int conv2d_launch(const float* const* srcs, const int* src_channels, const long long* src_batch_strides,
+                         int num_srcs, int NB, int H, int W,
+                         const float* w_packed, const float* bias, int Cout, int ksize, int relu, float* out,
+                         int out_ch_total, int out_ch_offset, const float* mask, dm_stream_t stream);
+
 extern "C" int dm_conv2d_fwd(const float* const* srcs, const int* src_channels, const long long* src_batch_strides,
                              int num_srcs, int NB, int H, int W,
                              const float* w_packed, const float* bias, int Cout, int ksize, int relu, float* out,
                              int out_ch_total, int out_ch_offset, dm_stream_t stream) {
+  return conv2d_launch(srcs, src_channels, src_batch_strides, num_srcs, NB, H, W, w_packed, bias, Cout, ksize, relu, out,
+                       out_ch_total, out_ch_offset, nullptr, stream);
+}
+
+extern "C" int dm_conv2d_fwd_masked(const float* const* srcs, const int* src_channels, const long long* src_batch_strides,
+                                    int num_srcs, int NB, int H, int W,
+                                    const float* w_packed, const float* bias, int Cout, int ksize, int relu, float* out,
+                                    int out_ch_total, int out_ch_offset, const float* mask, dm_stream_t stream) {
+  if (!mask) return DM_ERR_INVALID_ARG;
+  return conv2d_launch(srcs, src_channels, src_batch_strides, num_srcs, NB, H, W, w_packed, bias, Cout, ksize, relu, out,
+                       out_ch_total, out_ch_offset, mask, stream);
+}
+
+static int conv2d_launch(const float* const* srcs, const int* src_channels, const long long* src_batch_strides,
+                         int num_srcs, int NB, int H, int W,
+                         const float* w_packed, const float* bias, int Cout, int ksize, int relu, float* out,
+                         int out_ch_total, int out_ch_offset, const float* mask, dm_stream_t stream) {
   if (!srcs || !src_channels || num_srcs < 1 || num_srcs > DM_MAX_SOURCES || !w_packed || !out) return DM_ERR_INVALID_ARG;
   if (NB < 0 || H <= 0 || W <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3)) return DM_ERR_INVALID_ARG;
   if (out_ch_offset < 0 || out_ch_offset + Cout > out_ch_total) return DM_ERR_INVALID_ARG;
@@ -620,6 +649,7 @@ extern "C" int dm_conv2d_fwd(const float* const* srcs, const int* src_channels, 
   a.relu = relu & 3; a.out = out; a.out_ch_total = out_ch_total; a.out_ch_offset = out_ch_offset;
   a.shuffle = 0;
   a.q_begin = 0;
+  a.mask = mask;
   // outputs that cannot stay in the 256 MB Infinity Cache next to their consumer's other traffic are
   // written with nontemporal stores (measured: -10 % on the 1.85 GB column-gradient GEMM, neutral
   // below); accumulating launches read the destination and keep the default policy

@@ -282,8 +282,9 @@ class overlapped_streams:
         _overlapped -= 1
 
 
-def conv2d(srcs, w_packed, bias, cout, ksize, relu=False, out=None, out_ch_offset=0, accumulate=False):
-    """Fused concat(srcs) -> conv(ksize, same) -> +bias -> ReLU."""
+def conv2d(srcs, w_packed, bias, cout, ksize, relu=False, out=None, out_ch_offset=0, accumulate=False, mask=None):
+    """Fused concat(srcs) -> conv(ksize, same) -> +bias -> ReLU.  ``mask`` (same shape as ``out``): outputs where it
+    is not > 0 are stored as 0 -- the ReLU adjoint of a data gradient, fused into the epilogue."""
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
     srcs = [_chk_src(s) for s in srcs]
@@ -301,10 +302,17 @@ def conv2d(srcs, w_packed, bias, cout, ksize, relu=False, out=None, out_ch_offse
         _chk(out, 'out')
         assert out.shape[0] == NB and out.shape[2] == H and out.shape[3] == W
     strides = (ctypes.c_longlong * len(srcs))(*[int(s.stride(0)) for s in srcs])
+    flags = (1 if relu else 0) | (2 if accumulate else 0) | (8 if _overlapped else 0)
+    if mask is not None:
+        _chk(mask, 'mask')
+        assert mask.shape == out.shape
+        rc = lib().dm_conv2d_fwd_masked(_ptr_array(srcs), _int_array([s.shape[1] for s in srcs]), strides, len(srcs), NB, H, W,
+                                        _p(w_packed), _p(bias), cout, ksize, flags, _p(out), out.shape[1], out_ch_offset,
+                                        _p(mask), _stream())
+        check(rc, 'dm_conv2d_fwd_masked')
+        return out
     rc = lib().dm_conv2d_fwd(_ptr_array(srcs), _int_array([s.shape[1] for s in srcs]), strides, len(srcs), NB, H, W,
-                             _p(w_packed), _p(bias), cout, ksize,
-                             (1 if relu else 0) | (2 if accumulate else 0) | (8 if _overlapped else 0), _p(out), out.shape[1],
-                             out_ch_offset, _stream())
+                             _p(w_packed), _p(bias), cout, ksize, flags, _p(out), out.shape[1], out_ch_offset, _stream())
     check(rc, 'dm_conv2d_fwd')
     return out
 

@@ -305,12 +305,15 @@ class MaskHeadFn(torch.autograd.Function):
                 outs.append(t.view(shape))
             return outs, keep
 
-        def data_grad(conv, dy, lo, hi, ks, out=None, accumulate=False):
-            """d/d(input channels lo:hi) of a conv: forward kernel, transposed+rotated weights."""
+        def data_grad(conv, dy, lo, hi, ks, out=None, accumulate=False, mask=None):
+            """d/d(input channels lo:hi) of a conv: forward kernel, transposed+rotated weights.  ``mask``: the ReLU
+            output this gradient flows into -- its adjoint is applied in the conv's epilogue."""
             w = conv.weight
             wq = conv._pk.get(('flip', lo, hi), w, lambda t: ops.pack_conv_weight(t[:, lo:hi].contiguous(),
                                                                                    transpose_flip=True))
-            return ops.conv2d(dy, wq, None, hi - lo, ks, out=out, accumulate=accumulate)
+            if out is None and mask is not None:
+                out = torch.empty_like(mask)
+            return ops.conv2d(dy, wq, None, hi - lo, ks, out=out, accumulate=accumulate, mask=mask)
 
         # ---------------- final logits + x2 (align_corners=True) upsample
         x_last = sv['x_last']
@@ -345,8 +348,7 @@ class MaskHeadFn(torch.autograd.Function):
             ops.relu_backward_(g_tail, tail)
             dy = g_tail[:, :co - 2]
             sw.run(lambda: conv_params_bwd(stage.fuse_transform_out, dy, f2, 1), g_tail)
-            g_f2 = data_grad(stage.fuse_transform_out, dy, 0, c, 1)
-            ops.relu_backward_(g_f2, f2)
+            g_f2 = data_grad(stage.fuse_transform_out, dy, 0, c, 1, mask=f2)
             dcn = stage.fuse_conv[1]
 
             col = st.pop('col', None)          # allocated by the forward on the main stream: kept alive until the join
@@ -359,8 +361,7 @@ class MaskHeadFn(torch.autograd.Function):
             g_f1, g_off = ops.deform_conv_backward_data(f1, off, dcn.weight.detach(), g_f2, dcn.deform_groups,
                                                         side=side_stream(dev, 'coord'))
             sw.run(lambda: conv_params_bwd(dcn.conv_offset, g_off, f1, 3), g_off)
-            data_grad(dcn.conv_offset, g_off, 0, c, 3, out=g_f1, accumulate=True)
-            ops.relu_backward_(g_f1, f1)
+            data_grad(dcn.conv_offset, g_off, 0, c, 3, out=g_f1, accumulate=True, mask=f1)
             f0 = stage.fuse_conv[0]
             sw.run(lambda: conv_params_bwd(f0, g_f1, [xin, isf, tail[:, co - 2:]], 1), g_f1)
             g_xin = data_grad(f0, g_f1, 0, c, 1)
@@ -397,9 +398,11 @@ class MaskHeadFn(torch.autograd.Function):
             conv = head.instance_convs[i].conv
             x_in = sv['conv_in'][i]
             y = sv['conv_in'][i + 1] if i + 1 < len(sv['conv_in']) else sv['stages'][0]['xin']
-            ops.relu_backward_(g_x, y)
+            if i == len(head.instance_convs) - 1:
+                ops.relu_backward_(g_x, y)          # (the earlier convs' masks ride in the data gradient below)
             sw.run(lambda conv=conv, g_x=g_x, x_in=x_in: conv_params_bwd(conv, g_x, x_in, conv.kernel_size), g_x)
-            g_x = data_grad(conv, g_x, 0, conv.in_channels, conv.kernel_size)
+            # x_in of conv i > 0 is the ReLU output of conv i - 1: its adjoint is fused into this data gradient
+            g_x = data_grad(conv, g_x, 0, conv.in_channels, conv.kernel_size, mask=x_in if i > 0 else None)
 
         sw.join(*g_feats, *pgrad.values())
         params = list(head.parameters())

@@ -48,7 +48,7 @@ extern "C" {
 typedef void* dm_stream_t; /* hipStream_t */
 
 const char* dm_error_string(int code);
-/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_upsample2x_bilinear_bwd overwrites). */
+/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_upsample2x_bilinear_bwd overwrites). */
 int dm_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -117,6 +117,13 @@ int dm_conv2d_fwd(const float* const* srcs, const int* src_channels, const long 
                   int num_srcs, int NB, int H, int W,
                   const float* w_packed, const float* bias, int Cout, int ksize, int relu, float* out,
                   int out_ch_total, int out_ch_offset, dm_stream_t stream);
+/* dm_conv2d_fwd whose epilogue also applies a ReLU adjoint: outputs where `mask` (same layout, channel count and
+ * channel offset as `out`) is not > 0 are stored as 0.  Used for data gradients: the mask is the activation the
+ * gradient flows into, so the separate mask pass (read gradient + activation, write gradient) disappears. */
+int dm_conv2d_fwd_masked(const float* const* srcs, const int* src_channels, const long long* src_batch_strides,
+                         int num_srcs, int NB, int H, int W, const float* w_packed, const float* bias, int Cout,
+                         int ksize, int relu, float* out, int out_ch_total, int out_ch_offset, const float* mask,
+                         dm_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * K4  SimpleRoIAlign / point_sample forward (grid_sample bilinear, zero

@@ -182,3 +182,20 @@ def test_fixed_point_scatter_accumulators_propagate_non_finite_gradients(ops):
     assert torch.isnan(gf[b, 3]).any()
     others = [c for c in range(8) if c != 3]
     assert torch.isfinite(gf[:, others]).all()
+
+
+@pytest.mark.parametrize('N,Cin,Cout,S,ks,acc', [(6, 64, 64, 56, 1, False), (5, 36, 128, 28, 3, True), (9, 256, 256, 14, 3, False),
+                                                 (3, 30, 64, 56, 1, False), (40, 256, 256, 14, 3, False)])
+def test_conv_with_fused_relu_adjoint_mask(ops, N, Cin, Cout, S, ks, acc):
+    """dm_conv2d_fwd_masked = dm_conv2d_fwd followed by the ReLU mask pass, same bits (every tile shape, with and
+    without accumulation, incl. the split last-round launch at 40 RoIs)."""
+    x = torch.randn(N, Cin, S, S, generator=_g(95)).cuda()
+    w = (torch.randn(Cout, Cin, ks, ks, generator=_g(96)) / (Cin * ks * ks) ** 0.5).cuda()
+    y = torch.randn(N, Cout, S, S, generator=_g(97)).clamp(min=0).cuda()          # a ReLU output: half zeros
+    base = torch.randn(N, Cout, S, S, generator=_g(98)).cuda()
+    wq = ops.pack_conv_weight(w)
+    ref = ops.conv2d(x, wq, None, Cout, ks, out=base.clone() if acc else None, accumulate=acc)
+    ops.relu_backward_(ref, y)
+    got = ops.conv2d(x, wq, None, Cout, ks, out=base.clone() if acc else None, accumulate=acc,
+                     mask=y if acc else y)
+    assert torch.equal(got, ref)
