@@ -673,14 +673,21 @@ def dcn_weight_permute(src, cout, c, to_colmajor, dst=None, accumulate=False):
     return dst
 
 
-def deform_conv_backward_data(x, offset, weight, grad_out, deform_groups, side=None):
+def pack_dcn_colgrad_weight(weight):
+    """DCN weight [Cout, C, 3, 3] packed for the column-gradient GEMM W^T . dY (a 1x1 conv Cout -> 9C)."""
+    cout, c = weight.shape[0], weight.shape[1]
+    return pack_conv_weight(dcn_weight_permute(weight.contiguous(), cout, c, True))        # [(tap,ci)][co]
+
+
+def deform_conv_backward_data(x, offset, weight, grad_out, deform_groups, side=None, w_colgrad=None):
     """(grad_x, grad_offset) of DCNv1 3x3: column gradient = W^T . dY as a 1x1 conv, then the coordinate
-    gradient and col2im over it.  ``side``: a second stream -- the coordinate gradient (bound by its gathers) then
+    gradient and col2im over it.  ``w_colgrad``: ``pack_dcn_colgrad_weight(weight)`` if the caller caches it.
+    ``side``: a second stream -- the coordinate gradient (bound by its gathers) then
     runs there, beside col2im (bound by LDS atomics) on the caller's stream; both only read the column gradient."""
     NB, C, H, W = x.shape
-    cout = weight.shape[0]
-    wt = dcn_weight_permute(weight.contiguous(), cout, C, True)                # [(tap,ci)][co]
-    colgrad = conv2d(grad_out, pack_conv_weight(wt), None, 9 * C, 1)           # W^T . dY
+    if w_colgrad is None:
+        w_colgrad = pack_dcn_colgrad_weight(weight)
+    colgrad = conv2d(grad_out, w_colgrad, None, 9 * C, 1)                      # W^T . dY
     if side is None:
         return deform_col2im_coord(colgrad, x, offset, deform_groups)
     main = torch.cuda.current_stream(x.device)

@@ -111,6 +111,25 @@ def _pack_dcn_colmajor(w):
     return ops.pack_conv_weight(ops.dcn_weight_permute(w.detach().contiguous(), cout, c, True), transpose_flip=True)
 
 
+def _flip_pack(conv, lo, hi):
+    """Packed weights of d/d(input channels lo:hi) of ``conv`` (forward kernel, transposed + rotated)."""
+    return conv._pk.get(('flip', lo, hi), conv.weight,
+                        lambda t: ops.pack_conv_weight(t[:, lo:hi].contiguous(), transpose_flip=True))
+
+
+def _prepack_backward(head, feats):
+    for i, cm in enumerate(head.instance_convs):
+        _flip_pack(cm.conv, 0, cm.conv.in_channels)
+    for idx, stage in enumerate(head.stages):
+        c, dcn = stage.instance_in_channel, stage.fuse_conv[1]
+        _flip_pack(stage.fuse_transform_out, 0, c)
+        _flip_pack(dcn.conv_offset, 0, c)
+        for lo, hi in ((0, c), (c, 2 * c), (2 * c, 2 * c + 2)):
+            _flip_pack(stage.fuse_conv[0], lo, hi)
+        _flip_pack(stage.semantic_transform_in, 0, feats[len(feats) - idx - 3].shape[1])
+        dcn._pk.get('colgrad', dcn.weight, ops.pack_dcn_colgrad_weight)
+
+
 def _direct(p):
     """The tensor a parameter's gradient may be accumulated into IN PLACE, or None.
 
@@ -152,6 +171,9 @@ class MaskHeadFn(torch.autograd.Function):
                 sem = stage.semantic_transform_in.run(feats[len(feats) - idx - 3], relu=True)
                 sems.append(sem)
                 isfs.append(ops.point_sample(sem, rois, stage.out_size, stage.spatial_scale))
+            # the backward's kernel-layout weights (transposed / rotated packs of every data gradient, the DCN
+            # column-gradient GEMM's) are refreshed here, beside the forward, instead of on the backward's chain
+            _prepack_backward(head, feats)
         sw.run(semantic_branches)
         # Everything below is per RoI: the buffers are allocated for the whole batch (the backward sees whole
         # tensors) and filled by rows -- two halves on two streams when the batch is large enough, so that the
@@ -308,9 +330,7 @@ class MaskHeadFn(torch.autograd.Function):
         def data_grad(conv, dy, lo, hi, ks, out=None, accumulate=False, mask=None):
             """d/d(input channels lo:hi) of a conv: forward kernel, transposed+rotated weights.  ``mask``: the ReLU
             output this gradient flows into -- its adjoint is applied in the conv's epilogue."""
-            w = conv.weight
-            wq = conv._pk.get(('flip', lo, hi), w, lambda t: ops.pack_conv_weight(t[:, lo:hi].contiguous(),
-                                                                                   transpose_flip=True))
+            wq = _flip_pack(conv, lo, hi)
             if out is None and mask is not None:
                 out = torch.empty_like(mask)
             return ops.conv2d(dy, wq, None, hi - lo, ks, out=out, accumulate=accumulate, mask=mask)
@@ -359,7 +379,8 @@ class MaskHeadFn(torch.autograd.Function):
                     pgrad[dcn.weight] = gw_dcn
             sw.run(dcn_weight_grad, g_f2, col)
             g_f1, g_off = ops.deform_conv_backward_data(f1, off, dcn.weight.detach(), g_f2, dcn.deform_groups,
-                                                        side=side_stream(dev, 'coord'))
+                                                        side=side_stream(dev, 'coord'),
+                                                        w_colgrad=dcn._pk.get('colgrad', dcn.weight, ops.pack_dcn_colgrad_weight))
             sw.run(lambda: conv_params_bwd(dcn.conv_offset, g_off, f1, 3), g_off)
             data_grad(dcn.conv_offset, g_off, 0, c, 3, out=g_f1, accumulate=True, mask=f1)
             f0 = stage.fuse_conv[0]

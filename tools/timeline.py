@@ -56,3 +56,11 @@ print(f'union busy {union / 1e6:.3f} ms, idle {(t1 - t0 - union) / 1e6:.3f} ms, 
 print('running alone (ms) | overlapped (ms)')
 for n, v in sorted(alone.items(), key=lambda kv: -kv[1])[:28]:
     print(f'{v:7.3f} | {shared.get(n, 0.0):7.3f}  {n}')
+
+# per queue: the kernel families that keep it busy (queue 1 is the chain of the step)
+per = collections.defaultdict(lambda: collections.defaultdict(float))
+for s_, e_, n_, q_ in step:
+    per[q_][short(n_)] += (e_ - s_) / 1e6
+for q_ in sorted(per):
+    top = sorted(per[q_].items(), key=lambda kv: -kv[1])[:14]
+    print(f'queue {q_}: ' + ', '.join(f'{n_} {v:.2f}' for n_, v in top))
