@@ -48,6 +48,11 @@ if os.environ.get('TP_WINDOWS'):
     import contextlib
     hint = ops.overlapped_streams() if os.environ.get('TP_OVERLAPPED') else contextlib.nullcontext()
     hint.__enter__()
+    if os.environ.get('TP_HIGH_PRIO'):       # the whole step on a high-priority stream (the side streams keep the default)
+        print('priority range', torch.cuda.Stream.priority_range(), flush=True)
+        hp = torch.cuda.Stream(priority=int(os.environ['TP_HIGH_PRIO']))
+        hp.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(hp)
     for w in range(int(os.environ['TP_WINDOWS'])):
         torch.cuda.synchronize()
         a0 = stats(); g0 = gc.get_count()
