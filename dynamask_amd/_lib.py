@@ -59,6 +59,7 @@ SIGNATURES = {
     'dm_fc_fwd': ([_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp], _c_int),
     'dm_sgd_momentum_step': ([_vp, _vp, _vp, ctypes.c_longlong, _c_float, _c_float, _c_float, _c_float, _c_int, _vp], _c_int),
     'dm_mask_target_rois': ([_vp, _vp, _c_int, _c_float, _c_float, _vp, _vp], _c_int),
+    'dm_polygon_mask_targets': ([_vp, _vp, _vp, _c_int, _vp, _vp, _c_int, _c_int, _vp, _vp], _c_int),
     'dm_threshold_ge': ([_vp, ctypes.c_longlong, _c_float, _vp, _vp], _c_int),
     'dm_paste_masks': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _vp, _vp], _c_int),
     'dm_detail_target': ([_vp, _c_int, _c_int, _c_float, _c_float, _vp, _vp, _vp], _c_int),

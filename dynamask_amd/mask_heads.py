@@ -351,6 +351,16 @@ class DynaMaskHead(nn.Module):
                 for i, size in enumerate(self.stage_sup_size):
                     per_stage[i].append(boxes.new_zeros((0, size, size)))
                 continue
+            if hasattr(masks, 'masks') and isinstance(masks.masks, (list, tuple)):
+                # a PolygonMasks-like holder (list over objects of lists of vertex arrays; .height / .width): the
+                # polygons go to the device once and every size is rasterised there (structures.py:469-503, 583-599)
+                packed = ops.pack_polygons(masks.masks, boxes.device)
+                b = boxes[:, :4].contiguous().float().clone()
+                b[:, 0::2].clamp_(0, float(masks.width))
+                b[:, 1::2].clamp_(0, float(masks.height))
+                for i, size in enumerate(self.stage_sup_size):
+                    per_stage[i].append(ops.polygon_mask_targets(packed, b, inds.long().contiguous(), size))
+                continue
             if hasattr(masks, 'masks'):           # a BitmapMasks-like holder of a numpy array
                 masks = torch.from_numpy(masks.masks).to(boxes.device)
             m = masks.to(torch.float32).contiguous()[:, None]

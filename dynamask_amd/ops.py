@@ -757,6 +757,39 @@ def mask_target_rois(boxes, gt_inds, max_w, max_h):
     return rois
 
 
+def pack_polygons(masks, device):
+    """``PolygonMasks.masks`` (list over objects of lists of float arrays x0, y0, x1, y1, ...) -> the three device
+    arrays of ``polygon_mask_targets``: vertices [V, 2] float64, first vertex of each polygon [P + 1] int32, first
+    polygon of each object [G + 1] int32.  One upload per image."""
+    import numpy as np
+    verts, poly_start, inst_start = [], [0], [0]
+    for obj in masks:
+        for p in obj:
+            p = np.asarray(p, dtype=np.float64).reshape(-1)
+            assert p.size % 2 == 0, 'a polygon is a flat (x, y) list'
+            verts.append(p.reshape(-1, 2))
+            poly_start.append(poly_start[-1] + p.size // 2)
+        inst_start.append(len(poly_start) - 1)
+    v = np.concatenate(verts, 0) if verts else np.zeros((0, 2), np.float64)
+    return (torch.from_numpy(np.ascontiguousarray(v)).to(device), torch.tensor(poly_start, dtype=torch.int32, device=device),
+            torch.tensor(inst_start, dtype=torch.int32, device=device))
+
+
+def polygon_mask_targets(packed, boxes, gt_inds, size):
+    """[N, size, size] 0 / 1 targets of the objects ``gt_inds`` in the frames of ``boxes`` (clipped to the image)."""
+    verts, poly_start, inst_start = packed
+    _chk(verts, 'verts', torch.float64)
+    _chk(poly_start, 'poly_start', torch.int32)
+    _chk(inst_start, 'inst_start', torch.int32)
+    _chk(boxes, 'boxes')
+    _chk(gt_inds, 'gt_inds', torch.int64)
+    N = boxes.shape[0]
+    out = torch.empty((N, size, size), device=boxes.device, dtype=torch.float32)
+    check(lib().dm_polygon_mask_targets(_p(verts), _p(poly_start), _p(inst_start), inst_start.numel() - 1, _p(boxes), _p(gt_inds),
+                                        N, size, _p(out), _stream()), 'dm_polygon_mask_targets')
+    return out
+
+
 def threshold_ge(x, thr):
     _chk(x, 'x')
     out = torch.empty_like(x)

@@ -48,7 +48,7 @@ extern "C" {
 typedef void* dm_stream_t; /* hipStream_t */
 
 const char* dm_error_string(int code);
-/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_upsample2x_bilinear_bwd overwrites). */
+/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_upsample2x_bilinear_bwd overwrites). */
 int dm_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -287,6 +287,16 @@ int dm_class_balance_fwd_bwd(const float* mask_labels, int N, int K, float* loss
 int dm_mask_target_rois(const float* boxes, const int64_t* gt_inds, int N, float max_w, float max_h, float* rois,
                         dm_stream_t stream);
 int dm_threshold_ge(const float* x, long long count, float thr, float* out, dm_stream_t stream);
+
+/* Mask targets from POLYGON annotations: out[n] = S x S bitmap (0 / 1) of object inds[n] in the frame of boxes[n].
+ * replaces: PolygonMasks.crop_and_resize + to_ndarray -> polygon_to_bitmap -> pycocotools frPyObjects / merge / decode
+ * (core/mask/structures.py:469-503, 544-552, 583-599) as DynaMaskHead.get_targets calls them per image and size
+ * (mask_heads/dynamask_head.py:248-262), bit-identical to cocoapi's rleFrPoly arithmetic.
+ * verts: [V][2] float64 (x, y) of all polygons of the image; poly_start: [P + 1] first vertex of each polygon;
+ * inst_start: [num_objects + 1] first polygon of each object; boxes: [N][4] float32 already clipped to the image;
+ * inds: [N]; S <= 256.  One workgroup per RoI. */
+int dm_polygon_mask_targets(const double* verts, const int* poly_start, const int* inst_start, int num_objects,
+                            const float* boxes, const int64_t* inds, int N, int S, float* out, dm_stream_t stream);
 
 /* K18  paste N masks [N, mask_h, mask_w] into their boxes on an [img_h, img_w] canvas
  * and binarise: out[n, y, x] = (grid_sample(mask_n) >= threshold) as uint8.

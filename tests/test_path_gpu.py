@@ -530,3 +530,63 @@ def test_fcn_mask_head_backward_matches_oracle_autograd(up):
     for k, p in head.named_parameters():
         assert p.grad is not None, k
         scaled(p.grad, sdo[k].grad, k)
+
+
+class _FakePolygonMasks:
+    """The part of mmdet's PolygonMasks get_targets touches: .masks (list over objects of lists of arrays), size."""
+
+    def __init__(self, masks, height, width):
+        self.masks, self.height, self.width = masks, height, width
+
+
+def test_polygon_mask_targets_match_the_oracle_and_the_reference_known_answers(golden_dir):
+    """DynaMaskHead.get_targets with polygon annotations (dynamask_head.py:248-262 -> structures.py:469-503, 583-599 ->
+    pycocotools): the device rasteriser against oracle/ref_poly.py (the restated rleFrPoly, pinned by the reference's
+    own test bitmaps) -- bit-exact, every supervision size, polygons that reach far outside their boxes, several
+    parts per object, degenerate edges, boxes beyond the image -- and against those bitmaps directly."""
+    from dynamask_amd import ops
+    from oracle import ref_poly as rp
+    g = np.load(os.path.join(golden_dir, 'g12_polygon_truth.npz'))
+    dev = torch.device('cuda')
+    # (a) the reference's known answers: crop_and_resize with the box = the canvas is resize
+    for polys, hw, size, truth in (([g['poly1']], 5, 10, g['truth1']), ([g['poly2a'], g['poly2b']], 3, 6, g['truth2'])):
+        packed = ops.pack_polygons([polys], dev)
+        box = torch.tensor([[0., 0., hw, hw]], device=dev)
+        t = ops.polygon_mask_targets(packed, box, torch.zeros(1, dtype=torch.long, device=dev), size)
+        assert np.array_equal(t[0].cpu().numpy().astype(np.uint8), truth)
+    # (b) random scenes against the oracle
+    rng = np.random.default_rng(7)
+    H, W = 96, 128
+    objs = []
+    for o in range(9):
+        parts = []
+        for _ in range(int(rng.integers(1, 4))):
+            k = int(rng.integers(3, 12))
+            cx, cy, r = rng.uniform(0, W), rng.uniform(0, H), rng.uniform(2, 60)
+            ang = np.sort(rng.uniform(0, 2 * np.pi, k))
+            rad = r * rng.uniform(0.4, 1.0, k)
+            p = np.stack([cx + rad * np.cos(ang), cy + rad * np.sin(ang)], 1).reshape(-1)
+            if o % 3 == 0:
+                p = np.round(p)                       # integer vertices: ties in every rounding
+            if o % 4 == 1 and k > 3:
+                p[2:4] = p[0:2]                       # duplicate vertex
+            parts.append(p)
+        objs.append(parts)
+    objs.append([])                                   # an object without polygons
+    masks = _FakePolygonMasks(objs, H, W)
+    n = 40
+    x1, y1 = rng.uniform(-10, W - 4, n), rng.uniform(-10, H - 4, n)
+    boxes = np.stack([x1, y1, x1 + rng.uniform(0.5, 90, n), y1 + rng.uniform(0.5, 90, n)], 1).astype(np.float32)
+    boxes[0] = [3, 4, 3.2, 4.1]                       # thinner than one pixel: width / height floor at 1
+    boxes[1] = [0, 0, W, H]
+    inds = rng.integers(0, len(objs), n)
+    head = type('H', (), {})()
+    from dynamask_amd.mask_heads import DynaMaskHead
+    head.stage_sup_size = [14, 28, 56, 112]
+    tgt = DynaMaskHead.get_targets(head, [torch.from_numpy(boxes).to(dev)], [torch.from_numpy(inds).to(dev)], [masks])
+    for size, t in zip(head.stage_sup_size, tgt):
+        ref = rp.polygon_mask_targets(objs, H, W, boxes, inds, size, events=rp.fr_poly_points_literal)
+        got = t.cpu().numpy()
+        assert got.shape == ref.shape
+        assert np.array_equal(got, ref), (size, int((got != ref).sum()))
+        assert 0.02 < ref.mean() < 0.9                # the scene is neither empty nor full
