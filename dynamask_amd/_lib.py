@@ -70,6 +70,7 @@ SIGNATURES = {
     'dm_pixel_unshuffle2x': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp], _c_int),
     'dm_bbox_overlaps': ([_vp, _c_int, _vp, _c_int, _c_int, _c_float, _vp, _vp], _c_int),
     'dm_max_iou_assign': ([_vp, _c_int, _c_int, _c_float, _c_float, _c_float, _c_float, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp], _c_int),
+    'dm_ignore_columns': ([_vp, _c_int, _c_int, _vp, _c_int, _c_int, _c_float, _vp], _c_int),
     'dm_bbox_encode': ([_vp, _vp, _c_int, _vp, _vp, _vp, _vp], _c_int),
     'dm_softmax_ce_fwd_bwd': ([_vp, _vp, _vp, _c_int, _c_int, _c_float, _vp, _vp, _vp, _vp, _vp], _c_int),
     'dm_l1_loss_fwd_bwd': ([_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_float, _vp, _vp, _vp, _vp], _c_int),

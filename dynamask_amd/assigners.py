@@ -86,10 +86,16 @@ class MaxIoUAssigner:
 
     def assign(self, bboxes, gt_bboxes, gt_bboxes_ignore=None, gt_labels=None):
         """max_iou_assigner.py:58-127."""
+        overlaps = self.iou_calculator(gt_bboxes, bboxes)
         if (self.ignore_iof_thr > 0 and gt_bboxes_ignore is not None and gt_bboxes_ignore.numel() > 0
                 and bboxes.numel() > 0):
-            raise NotImplementedError('ignore_iof_thr > 0 is not used by configs/dynamask (ignore_iof_thr=-1)')
-        overlaps = self.iou_calculator(gt_bboxes, bboxes)
+            # :107-118: candidates inside an ignore region (IoF over the candidate, or over the region) are taken out
+            if self.ignore_wrt_candidates:
+                iof = self.iou_calculator(bboxes, gt_bboxes_ignore, mode='iof')
+            else:
+                iof = self.iou_calculator(gt_bboxes_ignore, bboxes, mode='iof')
+            if overlaps.numel() > 0:
+                ops.ignore_columns_(overlaps, iof, self.ignore_iof_thr, boxes_major=self.ignore_wrt_candidates)
         return self.assign_wrt_overlaps(overlaps, gt_labels)
 
     def assign_wrt_overlaps(self, overlaps, gt_labels=None):

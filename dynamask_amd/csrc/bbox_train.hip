@@ -235,6 +235,17 @@ __global__ __launch_bounds__(256) void clip_scale_kernel(float* __restrict__ x, 
   if (i < n) x[i] *= coef;
 }
 
+// max_iou_assigner.py:107-118: overlaps[:, n] = -1 for every box n whose largest IoF with an ignore region is > thr
+__global__ __launch_bounds__(256) void ignore_columns_kernel(float* __restrict__ overlaps, int G, int N,
+                                                             const float* __restrict__ iof, int I, int boxes_major, float thr) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float m = -INFINITY;
+  for (int i = 0; i < I; ++i) m = fmaxf(m, boxes_major ? iof[(size_t)n * I + i] : iof[(size_t)i * N + n]);
+  if (m > thr)
+    for (int g = 0; g < G; ++g) overlaps[(size_t)g * N + n] = -1.f;
+}
+
 __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long long n, float factor) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) x[i] *= factor;
@@ -336,5 +347,15 @@ extern "C" int dm_scale(float* x, long long count, float factor, dm_stream_t str
   if (count < 0 || (count > 0 && !x)) return DM_ERR_INVALID_ARG;
   if (count == 0) return DM_OK;
   DM_LAUNCH(scale_kernel, dim3(dm_ceil_div(count, 256)), dim3(256), 0, (hipStream_t)stream, x, count, factor);
+  return dm_check_launch();
+}
+
+extern "C" int dm_ignore_columns(float* overlaps, int G, int N, const float* iof, int I, int boxes_major, float thr,
+                                 dm_stream_t stream) {
+  if (G < 0 || N < 0 || I < 0) return DM_ERR_INVALID_ARG;
+  if (G == 0 || N == 0 || I == 0) return DM_OK;
+  if (!overlaps || !iof) return DM_ERR_INVALID_ARG;
+  DM_LAUNCH(ignore_columns_kernel, dim3(dm_ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, overlaps, G, N, iof, I,
+            boxes_major, thr);
   return dm_check_launch();
 }

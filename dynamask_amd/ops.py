@@ -830,6 +830,19 @@ def bbox_overlaps(bboxes1, bboxes2, mode='iou', eps=1e-6):
     return out
 
 
+def ignore_columns_(overlaps, iof, thr, boxes_major=True):
+    """max_iou_assigner.py:107-118, in place: overlaps[:, n] = -1 where box n's largest IoF with an ignore region is
+    > thr.  ``iof``: [N, I] (boxes vs regions, ``boxes_major``) or [I, N] (regions vs boxes)."""
+    _chk(overlaps, 'overlaps')
+    _chk(iof, 'iof')
+    G, N = overlaps.shape
+    I = iof.shape[1] if boxes_major else iof.shape[0]
+    assert (iof.shape[0] if boxes_major else iof.shape[1]) == N
+    check(lib().dm_ignore_columns(_p(overlaps), G, N, _p(iof), I, 1 if boxes_major else 0, float(thr), _stream()),
+          'dm_ignore_columns')
+    return overlaps
+
+
 def max_iou_assign(overlaps, pos_iou_thr, neg_iou_thr, min_pos_iou=0.0, match_low_quality=True, gt_max_assign_all=True,
                    gt_labels=None):
     """max_iou_assigner.py:129-212 for non-empty inputs -> (gt_inds, max_overlaps, labels|None)."""

@@ -48,7 +48,7 @@ extern "C" {
 typedef void* dm_stream_t; /* hipStream_t */
 
 const char* dm_error_string(int code);
-/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_upsample2x_bilinear_bwd overwrites). */
+/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites). */
 int dm_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -454,6 +454,11 @@ int dm_bbox_overlaps(const float* bboxes1, int n1, const float* bboxes2, int n2,
 int dm_max_iou_assign(const float* overlaps, int num_gts, int num_bboxes, float pos_iou_thr, float neg_iou_lo,
                       float neg_iou_hi, float min_pos_iou, int match_low_quality, int gt_max_assign_all,
                       const int64_t* gt_labels, float* scratch, int64_t* gt_inds, float* max_overlaps, int64_t* labels,
+                      dm_stream_t stream);
+/* the gt_bboxes_ignore branch of MaxIoUAssigner.assign (max_iou_assigner.py:107-118): overlaps[:, n] = -1 where
+ * box n's largest IoF with an ignore region exceeds thr.  iof = dm_bbox_overlaps(mode_iof = 1) of (boxes, regions)
+ * [N][I] (boxes_major = 1, ignore_wrt_candidates) or of (regions, boxes) [I][N] (boxes_major = 0). */
+int dm_ignore_columns(float* overlaps, int G, int N, const float* iof, int I, int boxes_major, float thr,
                       dm_stream_t stream);
 
 /* bbox2delta (core/bbox/coder/delta_xywh_bbox_coder.py:74-116): proposals, gt [n,4] -> deltas [n,4]. */

@@ -507,6 +507,18 @@ def max_iou_assign(overlaps, pos_iou_thr, neg_iou_thr, min_pos_iou=0.0, match_lo
     return gt_inds, torch.tensor(col_max, dtype=torch.float32), labels
 
 
+def ignore_overlaps(overlaps, bboxes, gt_bboxes_ignore, ignore_iof_thr, ignore_wrt_candidates=True):
+    """MaxIoUAssigner.assign, the gt_bboxes_ignore branch -- core/bbox/assigners/max_iou_assigner.py:107-118:
+    columns of boxes lying in an ignore region (IoF over the box, or over the region) become -1."""
+    overlaps = overlaps.clone()
+    if ignore_wrt_candidates:
+        m = bbox_overlaps(bboxes, gt_bboxes_ignore, mode='iof').max(dim=1)[0]
+    else:
+        m = bbox_overlaps(gt_bboxes_ignore, bboxes, mode='iof').max(dim=0)[0]
+    overlaps[:, m > ignore_iof_thr] = -1
+    return overlaps
+
+
 def random_sample(gt_inds, labels, bboxes, gt_bboxes, gt_labels, num, pos_fraction, neg_pos_ub=-1, add_gt_as_proposals=True):
     """RandomSampler.sample -- core/bbox/samplers/base_sampler.py:35-101 + random_sampler.py:32-78 +
     SamplingResult (sampling_result.py:21-56).  Draws ``torch.randperm`` on the default CPU generator in

@@ -245,3 +245,16 @@ def test_forward_train_matches_reference(golden_dir):
     for i in range(4):
         if g[f'ft.grad_feat{i}'].size > 1:
             np.testing.assert_allclose(gi.feat_grad_slice(feats[i].grad).numpy(), g[f'ft.grad_feat{i}'], atol=1e-5, rtol=1e-4)
+
+
+def test_assigner_ignore_regions_match_reference_golden(golden_dir):
+    """g13: the reference's MaxIoUAssigner with gt_bboxes_ignore (max_iou_assigner.py:107-118), both IoF conventions."""
+    g = np.load(os.path.join(golden_dir, 'g13_assign_ignore.npz'))
+    b, gts, ign, lab = (torch.from_numpy(g[k]) for k in ('bboxes', 'gts', 'ign', 'labels'))
+    for name, wrt in (('cand', True), ('region', False)):
+        ov = ref_model.ignore_overlaps(ref_model.bbox_overlaps(gts, b), b, ign, 0.5, wrt)
+        gi_, mo, lb = ref_model.max_iou_assign(ov, 0.5, 0.5, 0.5, gt_labels=lab)
+        assert np.array_equal(gi_.numpy(), g[f'{name}_gt_inds'])
+        np.testing.assert_array_equal(mo.numpy(), g[f'{name}_max_overlaps'])
+        assert np.array_equal(lb.numpy(), g[f'{name}_labels'])
+    assert (g['cand_gt_inds'] == -1).sum() > 0 and (g['noign_gt_inds'] == -1).sum() == 0

@@ -296,3 +296,21 @@ def test_training_step_on_side_streams_matches_the_single_stream_step(monkeypatc
     assert float((a0[1] - b0[1]).abs().max()) <= 2e-5 * scale, 'first-step gradients differ'
     assert abs(a1[0] - b1[0]) <= 1e-5 * abs(b1[0])
     torch.testing.assert_close(pa, pb, atol=2e-6, rtol=1e-4)
+
+
+def test_assigner_ignore_regions_match_reference_golden(golden_dir):
+    """MaxIoUAssigner with gt_bboxes_ignore (max_iou_assigner.py:107-118) on the device against the reference's own
+    assigner (g13): indices and labels bit-exact, both IoF conventions; without regions nothing is ignored."""
+    from dynamask_amd.assigners import MaxIoUAssigner
+    g = np.load(os.path.join(golden_dir, 'g13_assign_ignore.npz'))
+    dev = torch.device('cuda')
+    b, gts, ign, lab = (torch.from_numpy(g[k]).to(dev) for k in ('bboxes', 'gts', 'ign', 'labels'))
+    for name, wrt in (('cand', True), ('region', False)):
+        asg = MaxIoUAssigner(pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5, ignore_iof_thr=0.5, ignore_wrt_candidates=wrt)
+        ar = asg.assign(b, gts, ign, lab)
+        assert np.array_equal(ar.gt_inds.cpu().numpy(), g[f'{name}_gt_inds'])
+        np.testing.assert_array_equal(ar.max_overlaps.cpu().numpy(), g[f'{name}_max_overlaps'])
+        assert np.array_equal(ar.labels.cpu().numpy(), g[f'{name}_labels'])
+    asg = MaxIoUAssigner(pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5, ignore_iof_thr=0.5)
+    assert np.array_equal(asg.assign(b, gts, None, lab).gt_inds.cpu().numpy(), g['noign_gt_inds'])
+    assert np.array_equal(asg.assign(b, gts, ign[:0], lab).gt_inds.cpu().numpy(), g['noign_gt_inds'])
