@@ -793,6 +793,7 @@ __global__ __launch_bounds__(256, 2) void deform_conv_band_kernel(DcnArgs a, int
 template <int WM, int WGM, int XR>
 int launch_dcn_band(DcnArgs& a, hipStream_t st) {
   const int BR = 16;
+  if (8 * BR * a.W / 4 > XR * 256 || a.H < BR) return DM_ERR_UNSUPPORTED;      // the staging registers must cover the band planes
   const int tiles = dm_ceil_div(a.HW, (4 / WGM) * 32);
   const size_t lds_bytes = 16 * (size_t)(9 * 2 * WM * WGM * 32) + 4 * (size_t)8 * BR * a.W;
   DM_LAUNCH((deform_conv_band_kernel<WM, WGM, XR>), dim3((unsigned)(a.NB * tiles)), dim3(256), lds_bytes, st, a, tiles, BR);
@@ -841,11 +842,12 @@ extern "C" int dm_deform_conv_fwd(const float* x, const float* offset, int NB, i
   // (14 x 14, 8 RoIs: 0.208 -> 0.108 ms, 32 RoIs: 0.213 -> 0.168 ms; from 64 RoIs on the big tiles win).
   // Same products in the same order in every variant: results do not depend on the choice.
   {
-    // large maps: gather in the consuming wave from an LDS band of 16 rows (BR * W / 4 <= 256 lanes copy the band).
+    // large maps: gather in the consuming wave from an LDS band of 16 rows (the 8 band planes of a chunk must fit the
+    // 7 float4 per thread of the widest staging build: W <= 56).
     // Every launch size of an eligible shape takes this kernel (rows must not depend on the batch).
     static const bool band_off = getenv("DM_DCN_BAND_OFF") != nullptr;      // A/B switch
     const int max_rows = (W - 1 + 128 + W - 1) / W;                         // rows a 128-pixel tile can span
-    if (!band_off && H >= 16 && (W & 3) == 0 && 16 * W / 4 <= 256 && (16 - max_rows) / 2 >= DCN_NEAR_ROWS && a.HW > 256 &&
+    if (!band_off && H >= 16 && (W & 3) == 0 && 8 * 16 * W / 4 <= 7 * 256 && (16 - max_rows) / 2 >= DCN_NEAR_ROWS && a.HW > 256 &&
         a.HW < 65536 && (a.CoutP == 64 || a.CoutP == 128) && Cout > 32) {
       const bool narrow = 8 * 16 * W / 4 <= 4 * 256;                        // band planes fit 4 float4 per thread
       // a handful of RoIs (real inference): the launch is bound by the time of one workgroup -- one cout tile per

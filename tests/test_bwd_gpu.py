@@ -199,3 +199,24 @@ def test_conv_with_fused_relu_adjoint_mask(ops, N, Cin, Cout, S, ks, acc):
     got = ops.conv2d(x, wq, None, Cout, ks, out=base.clone() if acc else None, accumulate=acc,
                      mask=y if acc else y)
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize('N,Cs,Cout,H,W', [(1, 32, 36, 8, 8), (3, 40, 16, 20, 12), (2, 64, 33, 9, 56), (5, 8, 5, 30, 64), (4, 96, 32, 14, 14)])
+def test_narrow_wgrad_kernel_odd_shapes(ops, N, Cs, Cout, H, W):
+    """conv_wgrad3_narrow_kernel away from the training shapes: one image, channel counts that are not multiples
+    of 32 (a partly empty channel group), couts at 5 / 16 / 32 / 33 / 36 (with and without the 4-row tail), maps
+    whose last row band is short, the narrowest and widest maps it takes."""
+    x = torch.randn(N, Cs, H, W, generator=_g(85))
+    gy = torch.randn(N, Cout, H, W, generator=_g(86))
+    xd, gyd = x.double(), gy.double()
+    ref64 = torch.nn.grad.conv2d_weight(xd, (Cout, Cs, 3, 3), gyd, padding=1)
+    mag64 = torch.nn.grad.conv2d_weight(xd.abs(), (Cout, Cs, 3, 3), gyd.abs(), padding=1)
+    n_cond = _close_sum(ops.conv2d_wgrad(_dev(gy), [_dev(x)], 3), ref64, mag64, 'narrow wgrad')
+    assert n_cond <= 0.001 * ref64.numel() + 1
+    # accumulation into an existing buffer at a column offset (concatenated sources)
+    x2 = torch.randn(N, 8, H, W, generator=_g(87))
+    dw = torch.zeros(Cout, Cs + 8, 3, 3).cuda()
+    ops.conv2d_wgrad(_dev(gy), [_dev(x), _dev(x2)], 3, dw=dw)
+    ref2 = torch.nn.grad.conv2d_weight(torch.cat([x, x2], 1).double(), (Cout, Cs + 8, 3, 3), gyd, padding=1)
+    mag2 = torch.nn.grad.conv2d_weight(torch.cat([x, x2], 1).double().abs(), (Cout, Cs + 8, 3, 3), gyd.abs(), padding=1)
+    _close_sum(dw, ref2, mag2, 'narrow wgrad, two sources')

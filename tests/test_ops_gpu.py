@@ -507,3 +507,18 @@ def test_fc_rows_do_not_depend_on_batch_size_and_match_torch(ops):
         ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
         ref = ref.relu() if relu else ref
         _close(full, ref.float(), atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize('N,C,Cout,H,W', [(2, 16, 64, 16, 64), (3, 48, 128, 40, 28), (2, 64, 64, 33, 32), (1, 32, 128, 17, 60),
+                                          (70, 16, 64, 24, 28)])
+def test_deform_conv_band_kernel_odd_shapes(ops, N, C, Cout, H, W):
+    """Shapes that take the 28x28 / 56x56 kernel but are neither: the minimum height (band = whole map), the widest
+    map, non-square maps whose tiles start mid-row, C != Cout, 8 channels per deformable group, and a batch large
+    enough for the many-RoI build (70 x 24 x 28) next to the few-RoI one."""
+    x = torch.randn(N, C, H, W, generator=_g(80))
+    w = torch.randn(Cout, C, 3, 3, generator=_g(81)) / (9 * C) ** 0.5
+    off = torch.randn(N, 36, H, W, generator=_g(82)) * 2.5
+    off[0, :, 0, :] = 9.0                       # first row looks 9 rows / columns away: the slow pass
+    ref = F.relu(ref_ops.deform_conv2d(x, off, w, 1, 1, 1, 2))
+    out = ops.deform_conv(_dev(x), _dev(off), ops.pack_conv_weight(_dev(w)), Cout, 2, relu=True)
+    _close(out, ref)
