@@ -220,3 +220,40 @@ def test_narrow_wgrad_kernel_odd_shapes(ops, N, Cs, Cout, H, W):
     ref2 = torch.nn.grad.conv2d_weight(torch.cat([x, x2], 1).double(), (Cout, Cs + 8, 3, 3), gyd, padding=1)
     mag2 = torch.nn.grad.conv2d_weight(torch.cat([x, x2], 1).double().abs(), (Cout, Cs + 8, 3, 3), gyd.abs(), padding=1)
     _close_sum(dw, ref2, mag2, 'narrow wgrad, two sources')
+
+
+@pytest.mark.parametrize('N,C,H,W', [(3, 5, 10, 6), (2, 7, 7, 9), (4, 16, 28, 28), (1, 3, 12, 20), (2, 2, 56, 56)])
+def test_bn_relu_maxpool_forward_and_backward_odd_shapes(ops, N, C, H, W):
+    """MaskPre's BatchNorm(train) -> ReLU -> MaxPool(3, 2, 1) block by itself, away from the 56 / 28 maps of the
+    golden: non-square maps, odd sizes (the plane-in-LDS backward needs H * W % 4 == 0; 7 x 9 takes the other
+    one), few channels.  Against autograd of the same block (forward 1e-5, gradients at the 1e-4 gate)."""
+    x = torch.randn(N, C, H, W, generator=_g(110)) * 1.5 + 0.3
+    gamma = torch.rand(C, generator=_g(111)) + 0.5
+    beta = torch.randn(C, generator=_g(112)) * 0.2
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y = F.max_pool2d(F.relu(F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5)), 3, 2, 1)
+    go = torch.randn(y.shape, generator=_g(113))
+    y.backward(go)
+    xd = _dev(x)
+    mean, var = ops.bn_stats(xd)
+    out = ops.bn_relu_maxpool(xd, mean, var, _dev(gamma), _dev(beta), 1e-5)
+    _close(out, y, atol=1e-5, rtol=1e-5)
+    gx, gg, gb = ops.bn_relu_maxpool_backward(xd, mean, var, _dev(gamma), _dev(beta), _dev(go), 1e-5)
+    _close(gx, xr.grad)
+    _close(gg, gr.grad)
+    _close(gb, br.grad)
+
+
+@pytest.mark.parametrize('N,C,H,W', [(2, 16, 10, 6), (1, 32, 20, 12), (3, 16, 7, 9)])
+def test_deform_conv_backward_non_square(ops, N, C, H, W):
+    x = torch.randn(N, C, H, W, generator=_g(120), requires_grad=True)
+    w = (torch.randn(C, C, 3, 3, generator=_g(121)) / (9 * C) ** 0.5).requires_grad_(True)
+    off = (torch.randn(N, 36, H, W, generator=_g(122)) * 1.5).requires_grad_(True)
+    y = ref_ops.deform_conv2d(x, off, w, 1, 1, 1, 2)
+    go = torch.randn(y.shape, generator=_g(123))
+    y.backward(go)
+    gx, goff, gw = ops.deform_conv_backward(_dev(x), _dev(off), _dev(w), _dev(go), 2)
+    _close(gx, x.grad)
+    _close(goff, off.grad)
+    _close(gw, w.grad)

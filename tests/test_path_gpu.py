@@ -590,3 +590,20 @@ def test_polygon_mask_targets_match_the_oracle_and_the_reference_known_answers(g
         assert got.shape == ref.shape
         assert np.array_equal(got, ref), (size, int((got != ref).sum()))
         assert 0.02 < ref.mean() < 0.9                # the scene is neither empty nor full
+
+
+@pytest.mark.parametrize('size', [5, 33, 256])
+def test_polygon_mask_targets_other_sizes(size):
+    """dm_polygon_mask_targets at sizes the head does not use (odd, tiny, the largest it accepts)."""
+    from dynamask_amd import ops
+    from oracle import ref_poly as rp
+    dev = torch.device('cuda')
+    objs = [[np.array([3.0, 2.0, 30.5, 4.0, 41.0, 25.0, 22.0, 38.5, 5.0, 21.0])],
+            [np.array([10.0, 10.0, 20.0, 10.0, 20.0, 20.0, 10.0, 20.0]), np.array([15.0, 15.0, 44.0, 18.0, 30.0, 44.0])]]
+    boxes = np.array([[0, 0, 48, 40], [8, 8, 24, 24], [12.5, 9.25, 47.0, 39.5]], np.float32)
+    inds = np.array([0, 1, 1])
+    got = ops.polygon_mask_targets(ops.pack_polygons(objs, dev), torch.from_numpy(boxes).to(dev),
+                                   torch.from_numpy(inds).to(dev), size).cpu().numpy()
+    ref = rp.polygon_mask_targets(objs, 40, 48, boxes, inds, size, events=rp.fr_poly_events)
+    assert np.array_equal(got, ref)
+    assert 0.05 < ref.mean() < 0.95
