@@ -160,3 +160,19 @@ def test_deform_conv_integer_shifts_at_every_border():
         shifted = torch.roll(xs, shifts=(-dh, -dw), dims=(2, 3))           # sample (h + dh, w + dw)
         exp = F.conv2d(shifted, w, padding=1)[:, :, pad:pad + 9, pad:pad + 11]
         assert torch.allclose(out, exp, atol=1e-5), (dh, dw)
+
+
+def test_oracle_assigner_on_the_reference_tests_known_answers():
+    """/root/reference/tests/test_assigner.py:14-82 (inputs and expected assignments as data): plain, with an ignore
+    region (IoF over the region), without ground truth."""
+    import torch
+    from oracle import ref_model
+    bb = torch.tensor([[0, 0, 10, 10], [10, 10, 20, 20], [5, 5, 15, 15], [32, 32, 38, 42]], dtype=torch.float32)
+    gt = torch.tensor([[0, 0, 10, 9], [0, 10, 10, 19]], dtype=torch.float32)
+    gi_, _, lab = ref_model.max_iou_assign(ref_model.bbox_overlaps(gt, bb), 0.5, 0.5, gt_labels=torch.tensor([2, 3]))
+    assert gi_.tolist() == [1, 0, 2, 0] and lab.tolist() == [2, -1, 3, -1]
+    bb2 = bb.clone()
+    bb2[3] = torch.tensor([30., 32., 40., 42.])
+    ov = ref_model.ignore_overlaps(ref_model.bbox_overlaps(gt, bb2), bb2, torch.tensor([[30., 30., 40., 40.]]), 0.5, False)
+    assert ref_model.max_iou_assign(ov, 0.5, 0.5)[0].tolist() == [1, 0, 2, -1]
+    assert ref_model.max_iou_assign(torch.zeros(0, 4), 0.5, 0.5)[0].tolist() == [0, 0, 0, 0]
