@@ -172,8 +172,14 @@ class CrossEntropyLoss(nn.Module):
         if self.use_mask:
             raise NotImplementedError('CrossEntropyLoss(use_mask=True) is broken in the reference fork (SURVEY Q5); '
                                       'only FCNMaskHead.forward is on the path')
-        if self.use_sigmoid or self.class_weight is not None:
-            raise NotImplementedError('the RoI head uses the softmax form without class weights')
+        if self.use_sigmoid:
+            raise NotImplementedError('use_sigmoid=True is the RPN\'s form; the RoI head uses the softmax form')
+        if self.class_weight is not None:
+            # F.cross_entropy(..., weight=class_weight, reduction='none') scales sample i by class_weight[label_i]
+            # (cross_entropy_loss.py:9-38): a gather, handed to the kernel as the per-sample weight
+            if weight is not None:
+                raise NotImplementedError('class_weight together with per-sample weights is not used by the RoI head')
+            weight = cls_score.new_tensor(self.class_weight)[label.long()].contiguous()
         assert reduction_override in (None, 'none', 'mean', 'sum')
         reduction = reduction_override if reduction_override else self.reduction
         n = cls_score.shape[0]

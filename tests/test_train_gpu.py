@@ -314,3 +314,23 @@ def test_assigner_ignore_regions_match_reference_golden(golden_dir):
     asg = MaxIoUAssigner(pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5, ignore_iof_thr=0.5)
     assert np.array_equal(asg.assign(b, gts, None, lab).gt_inds.cpu().numpy(), g['noign_gt_inds'])
     assert np.array_equal(asg.assign(b, gts, ign[:0], lab).gt_inds.cpu().numpy(), g['noign_gt_inds'])
+
+
+def test_ce_loss_and_accuracy_known_answers_of_the_reference_tests():
+    """/root/reference/tests/test_models/test_losses.py:7-50 (inputs and expected values as data): CrossEntropyLoss
+    with and without class weights, use_mask + use_sigmoid refused, top-1 accuracy incl. the empty prediction."""
+    from dynamask_amd import registry, losses
+    dev = torch.device('cuda')
+    with pytest.raises(AssertionError):
+        registry.build_loss(dict(type='CrossEntropyLoss', use_mask=True, use_sigmoid=True, loss_weight=1.0))
+    fake_pred = torch.tensor([[100., -100.]], device=dev)
+    fake_label = torch.tensor([1], device=dev)
+    loss_cls = registry.build_loss(dict(type='CrossEntropyLoss', use_sigmoid=False, class_weight=[0.8, 0.2], loss_weight=1.0))
+    assert torch.allclose(loss_cls(fake_pred, fake_label).cpu(), torch.tensor(40.))
+    loss_cls = registry.build_loss(dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0))
+    assert torch.allclose(loss_cls(fake_pred, fake_label).cpu(), torch.tensor(200.))
+    assert losses.accuracy(torch.empty(0, 4, device=dev), torch.empty(0, device=dev)).item() == 0
+    pred = torch.tensor([[0.2, 0.3, 0.6, 0.5], [0.1, 0.1, 0.2, 0.6], [0.9, 0.0, 0.0, 0.1], [0.4, 0.7, 0.1, 0.1],
+                         [0.0, 0.0, 0.99, 0]], device=dev)
+    assert losses.accuracy(pred, torch.tensor([2, 3, 0, 1, 2], device=dev)).item() == 100
+    assert losses.accuracy(pred, torch.tensor([2, 3, 0, 0, 1], device=dev)).item() == 60
