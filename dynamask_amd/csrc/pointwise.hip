@@ -319,18 +319,23 @@ __global__ void gumbel_kernel(const float* __restrict__ logits, const float* __r
 }
 
 // ------------------------------------------------------------------ K13
+// grid = (N, row bands): a workgroup stages its band of the mask plus 3 halo rows (the stride-2 Laplacian of pixel
+// (y, x) is taken at row 2 * floor(y * S2 / S), within [y - 2, y]) -- one workgroup per RoI left three quarters of
+// the chip idle at 256 RoIs.
 __global__ __launch_bounds__(256) void detail_target_kernel(const float* __restrict__ masks, int N, int S, float f0,
-                                                            float f1, const float* __restrict__ fuse_dev,
+                                                            float f1, const float* __restrict__ fuse_dev, int band_rows,
                                                             float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if (fuse_dev) {          // the fuse kernel is a weight-decayed parameter: read its current value on the device
     f0 = fuse_dev[0];
     f1 = fuse_dev[1];
   }
-  float* m = lds;  // [S*S]
+  float* m = lds;  // rows [r_lo, r_hi) of the mask
   const int r = blockIdx.x;
+  const int y_begin = blockIdx.y * band_rows, y_end = min(y_begin + band_rows, S);
+  const int r_lo = max(y_begin - 3, 0), r_hi = min(y_end + 3, S);
   const float* src = masks + (size_t)r * S * S;
-  for (int i = threadIdx.x; i < S * S; i += blockDim.x) m[i] = src[i];
+  for (int i = r_lo * S + threadIdx.x; i < r_hi * S; i += blockDim.x) m[i - r_lo * S] = src[i];
   __syncthreads();
   auto lap = [&](int y, int x) -> float {
     float acc = 0.f;
@@ -339,12 +344,12 @@ __global__ __launch_bounds__(256) void detail_target_kernel(const float* __restr
 #pragma unroll
       for (int dx = -1; dx <= 1; ++dx) {
         const int yy = y + dy, xx = x + dx;
-        if (yy >= 0 && yy < S && xx >= 0 && xx < S) acc += ((dy == 0 && dx == 0) ? 8.f : -1.f) * m[yy * S + xx];
+        if (yy >= 0 && yy < S && xx >= 0 && xx < S) acc += ((dy == 0 && dx == 0) ? 8.f : -1.f) * m[(yy - r_lo) * S + xx];
       }
     return fmaxf(acc, 0.f);
   };
   const int S2 = (S - 1) / 2 + 1;  // stride-2 conv output size (pad 1, k 3)
-  for (int i = threadIdx.x; i < S * S; i += blockDim.x) {
+  for (int i = y_begin * S + threadIdx.x; i < y_end * S; i += blockDim.x) {
     const int y = i / S, x = i - y * S;
     const float b1 = lap(y, x) > 0.1f ? 1.f : 0.f;
     // F.interpolate(nearest): src = floor(dst * in/out)
@@ -502,8 +507,13 @@ extern "C" int dm_detail_target(const float* masks, int N, int S, float fuse0, f
   if (!masks || !out || N < 0 || S <= 0) return DM_ERR_INVALID_ARG;
   if ((size_t)S * S * sizeof(float) > 64 * 1024) return DM_ERR_UNSUPPORTED;
   if (N == 0) return DM_OK;
-  DM_LAUNCH(detail_target_kernel, dim3(N), dim3(256), S * S * sizeof(float), (hipStream_t)stream, masks, N, S,
-                     fuse0, fuse1, fuse_dev, out);
+  // bands of rows so that a few hundred RoIs still give every CU several workgroups
+  int bands = 1;
+  while (bands < 8 && (long long)N * bands < 4LL * dm_num_cus() && dm_ceil_div(S, bands * 2) >= 8) bands *= 2;
+  const int band_rows = dm_ceil_div(S, bands);
+  bands = dm_ceil_div(S, band_rows);
+  DM_LAUNCH(detail_target_kernel, dim3(N, bands), dim3(256), (size_t)(band_rows + 6) * S * sizeof(float), (hipStream_t)stream,
+            masks, N, S, fuse0, fuse1, fuse_dev, band_rows, out);
   return dm_check_launch();
 }
 
@@ -513,7 +523,10 @@ extern "C" int dm_mask_loss_fwd_bwd(const float* inst_pred, const float* det_pre
   if (!inst_pred || !det_pred || !inst_tgt || !det_tgt || !weight || !sums || N < 0 || HW <= 0)
     return DM_ERR_INVALID_ARG;
   if (N == 0) return DM_OK;
-  const int pb = min(dm_ceil_div(HW, 256), 8);
+  // every workgroup ends in two float atomics on the SAME two addresses, which the memory side serialises (about
+  // 10 ns each: 8 x 256 workgroups cost 40 us for 13 MB of logits): as few workgroups per RoI as still fill the chip
+  int pb = min(dm_ceil_div(HW, 256), 8);
+  while (pb > 1 && (long long)N * (pb / 2) >= dm_num_cus()) pb /= 2;
   DM_LAUNCH(mask_loss_kernel, dim3(pb, N), dim3(256), 0, (hipStream_t)stream, inst_pred, det_pred, inst_tgt,
                      det_tgt, weight, N, HW, sums, per_roi_det, grad_inst, grad_det);
   return dm_check_launch();
