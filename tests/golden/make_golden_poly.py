@@ -52,3 +52,42 @@ np.savez_compressed(out, poly1=poly1, truth1=truth1.astype(np.uint8), poly2a=pol
                     truth2=truth2.astype(np.uint8), truth_rescale=truth_rescale.astype(np.uint8),
                     poly_crop=poly_crop, crop_bbox=np.array([0, 0, 3, 4], dtype=np.float64), truth_crop=truth_crop.astype(np.uint8))
 print('wrote', out, truth1.shape, truth2.shape, truth_rescale.shape, truth_crop.shape)
+
+
+def vertex_transform_golden():
+    """Second fixture: the vertex arithmetic of ``PolygonMasks.crop_and_resize`` (structures.py:469-503) from the
+    REFERENCE's own class, run here (that method is pure numpy; only ``to_ndarray`` needs pycocotools).  Pins the
+    dtypes of the oracle's ``crop_and_resize_polygons`` (float32 box / scale arithmetic, float64 vertices)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import make_golden_train as mgt
+    st = mgt.load_train_reference()['structures']
+    rng = np.random.default_rng(41)
+    masks = []
+    for _ in range(5):
+        parts = []
+        for _ in range(int(rng.integers(1, 3))):
+            k = int(rng.integers(3, 8))
+            parts.append(rng.uniform(0, 90, 2 * k))
+        masks.append(parts)
+    pm = st.PolygonMasks(masks, 80, 100)
+    n = 12
+    x1, y1 = rng.uniform(0, 80, n), rng.uniform(0, 60, n)
+    boxes = np.stack([x1, y1, x1 + rng.uniform(0.05, 40, n), y1 + rng.uniform(0.05, 40, n)], 1).astype(np.float32)
+    inds = rng.integers(0, 5, n)
+    out = {'boxes': boxes, 'inds': inds, 'n_obj': np.array(len(masks))}
+    for i, parts in enumerate(masks):
+        out[f'obj{i}_parts'] = np.array(len(parts))
+        for j, p in enumerate(parts):
+            out[f'obj{i}_{j}'] = p
+    for size in (14, 112):
+        res = pm.crop_and_resize(boxes, (size, size), inds)
+        for i, parts in enumerate(res.masks):
+            for j, p in enumerate(parts):
+                out[f's{size}_roi{i}_{j}'] = np.asarray(p)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'g12b_polygon_vertices.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, len(out), 'arrays')
+
+
+vertex_transform_golden()

@@ -57,3 +57,16 @@ def test_closed_form_equals_the_literal_edge_walk():
         b = sorted(rp.fr_poly_events(xy, h, w))
         assert a == b, (it, h, w, xy.tolist())
         assert np.array_equal(rp.rle_decode(rp.rle_from_points(a, h, w), h, w), rp.mask_from_points(b, h, w))
+
+
+def test_vertex_transform_matches_the_reference_class():
+    """g12b: PolygonMasks.crop_and_resize of the reference itself (pure numpy) on random polygons and float32 boxes --
+    the oracle's shifted / scaled vertices are the same float64 bits (boxes thinner than one pixel included)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'g12b_polygon_vertices.npz'))
+    masks = [[g[f'obj{i}_{j}'] for j in range(int(g[f'obj{i}_parts']))] for i in range(int(g['n_obj']))]
+    for size in (14, 112):
+        res = rp.crop_and_resize_polygons(masks, g['boxes'], (size, size), g['inds'])
+        for i, parts in enumerate(res):
+            for j, p in enumerate(parts):
+                ref = g[f's{size}_roi{i}_{j}']
+                assert p.dtype == np.float64 and np.array_equal(p, ref), (size, i, j)
