@@ -63,3 +63,16 @@ def test_max_iou_assigner_with_empty_boxes_and_gt(Assigner):
     self = Assigner(pos_iou_thr=0.5, neg_iou_thr=0.5)
     r = self.assign(torch.empty((0, 4)).cuda(), torch.empty((0, 4)).cuda())
     assert len(r.gt_inds) == 0
+
+
+def test_bbox_overlaps_docstring_examples():
+    """iou2d_calculator.py:55-79 (the reference's docstring: inputs and printed values as data), incl. empty inputs."""
+    from dynamask_amd.assigners import BboxOverlaps2D
+    iou = BboxOverlaps2D()
+    b1 = _t([[0, 0, 10, 10], [10, 10, 20, 20], [32, 32, 38, 42]])
+    b2 = _t([[0, 0, 10, 20], [0, 10, 10, 19], [10, 10, 20, 20]])
+    torch.testing.assert_close(iou(b1, b2).cpu(), torch.tensor([[0.5, 0., 0.], [0., 0., 1.], [0., 0., 0.]]), atol=1e-4, rtol=0)
+    empty, nonempty = torch.empty((0, 4)).cuda(), _t([[0, 0, 10, 9]])
+    assert tuple(iou(empty, nonempty).shape) == (0, 1)
+    assert tuple(iou(nonempty, empty).shape) == (1, 0)
+    assert tuple(iou(empty, empty).shape) == (0, 0)

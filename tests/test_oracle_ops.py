@@ -176,3 +176,13 @@ def test_oracle_assigner_on_the_reference_tests_known_answers():
     ov = ref_model.ignore_overlaps(ref_model.bbox_overlaps(gt, bb2), bb2, torch.tensor([[30., 30., 40., 40.]]), 0.5, False)
     assert ref_model.max_iou_assign(ov, 0.5, 0.5)[0].tolist() == [1, 0, 2, -1]
     assert ref_model.max_iou_assign(torch.zeros(0, 4), 0.5, 0.5)[0].tolist() == [0, 0, 0, 0]
+
+
+def test_oracle_bbox_overlaps_docstring_example():
+    """iou2d_calculator.py:55-71."""
+    import torch
+    from oracle import ref_model
+    b1 = torch.tensor([[0, 0, 10, 10], [10, 10, 20, 20], [32, 32, 38, 42]], dtype=torch.float32)
+    b2 = torch.tensor([[0, 0, 10, 20], [0, 10, 10, 19], [10, 10, 20, 20]], dtype=torch.float32)
+    torch.testing.assert_close(ref_model.bbox_overlaps(b1, b2), torch.tensor([[0.5, 0., 0.], [0., 0., 1.], [0., 0., 0.]]),
+                               atol=1e-4, rtol=0)
