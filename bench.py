@@ -173,10 +173,26 @@ def cpu_baseline(sd, feats, rois, labels, sample, reps=2):
     return dt, n_threads, out
 
 
-def train_step_bench(head, dev, rank, world, steps=4, warmup=4):
+def _max_over_ranks(x, world):
+    """Max of a host float over the ranks (default group = gloo at N > 1: a CPU tensor)."""
+    if world == 1:
+        return x
+    import torch.distributed as dist
+    t = torch.tensor([x], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def train_step_bench(head, dev, rank, world, steps=4, warmup=4, rehearsal=False):
     """BASELINE configs[2]/[3]: training step of the mask path, 2 images/GPU x 128
     positive RoIs, dynamic 14/28/56/112 selection + BCE backward + RCCL all-reduce of
-    the flat mask-head gradient + fused SGD.  Returns ms per step (max over ranks)."""
+    the flat mask-head gradient + fused SGD.  Returns ms per step (max over ranks).
+
+    The RCCL communicator exists only inside this function: at N > 1 the default process group
+    is gloo (host barriers and the max over ranks) and the data-path collective gets an `nccl`
+    subgroup that is destroyed again before the function returns, so that the headline leg runs
+    without an idle communicator in the process at every N (its watchdog thread costs eager
+    multi-stream launch sequences ~10 %)."""
     from dynamask_amd import synth
     from dynamask_amd.dist import FlatParamGroup, mask_path_parameters
     import torch.distributed as dist
@@ -187,7 +203,10 @@ def train_step_bench(head, dev, rank, world, steps=4, warmup=4):
     targets = [t.to(dev) for t in synth.make_targets(B * per, seed=13 + 1000 * rank)]
     noise = synth.make_gumbel_noise(B * per, seed=14 + 1000 * rank).to(dev)
     head.train()
-    grp = FlatParamGroup(mask_path_parameters(head))
+    sub = None
+    if world > 1 and not rehearsal:
+        sub = dist.new_group(backend='nccl', device_id=dev)
+    grp = FlatParamGroup(mask_path_parameters(head), process_group=sub)
     saved = grp.flat_param.clone()          # the SGD steps below must not leak into later legs
 
     def step():
@@ -218,12 +237,7 @@ def train_step_bench(head, dev, rank, world, steps=4, warmup=4):
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
-        w = time.perf_counter() - t0
-        if world > 1:
-            import torch.distributed as dist
-            t = torch.tensor([w], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            w = float(t.item())
+        w = _max_over_ranks(time.perf_counter() - t0, world)
         return w, r
     # median of three windows of `steps` steps: a caching-allocator growth (hipMalloc) inside one
     # window otherwise shows up as a 20-30 % outlier of this secondary figure
@@ -260,19 +274,20 @@ def train_step_bench(head, dev, rank, world, steps=4, warmup=4):
         for _ in range(5):
             grp.all_reduce_async(force=True); grp.wait()
         torch.cuda.synchronize()
-        comm_ms = (time.perf_counter() - t0) / 5 * 1e3
-        t = torch.tensor([comm_ms], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        comm_ms = float(t.item())
+        comm_ms = _max_over_ranks((time.perf_counter() - t0) / 5 * 1e3, world)
     from dynamask_amd import ops
     grp.flat_param.copy_(saved)
     ops.WEIGHT_EPOCH[0] += 1                # packed-weight caches follow the restored parameters
     head.eval()
-    collective = (f'{dist.get_backend()} all-reduce over {world} rank(s), executed' if dist.is_initialized()
+    collective = (f'{dist.get_backend(sub)} all-reduce over {world} rank(s), executed' if dist.is_initialized()
                   else 'none (no process group)')
     if own_group:
         torch.cuda.synchronize()
         dist.destroy_process_group()
+    if sub is not None:
+        torch.cuda.synchronize()
+        dist.barrier()
+        dist.destroy_process_group(sub)
     return dt / steps * 1e3, float(res['loss_mask']['loss_masks'].detach()), grp.numel, B, comm_ms, collective, forced_ms
 
 
@@ -327,6 +342,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--leg', choices=('infer', 'train'), default='infer',
+                    help="which leg is the headline `value`: 'infer' = BASELINE configs[1] (default); 'train' = the "
+                         "configs[2]/[3] training step, timed over exactly --steps steps (the other leg's figures stay "
+                         "top-level keys of the same line)")
     ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of a HIP graph replay')
     ap.add_argument('--end-to-end', action='store_true', help='also time a stock MIOpen ResNet-50-FPN + the mask path (context)')
     ap.add_argument('--cpu-sample', type=int, default=512, help='RoIs of the batch timed on the host cores (0 = skip)')
@@ -374,13 +393,11 @@ def main():
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     if world > 1:
-        if rehearsal:
-            dist.init_process_group('gloo')
-        else:
-            dist.init_process_group('nccl', device_id=dev)
-    # (world size 1: the training leg makes its own one-rank RCCL communicator and tears it down again --
-    # see train_step_bench; an idle communicator's watchdog thread slows eager multi-stream launch
-    # sequences by ~10 %, measured on full_head_112_ms: 10.0 -> 11.45 ms)
+        # default group = gloo: host-side barriers and the max over ranks.  The RCCL communicator of the data-path
+        # collective lives only inside the training leg (train_step_bench) at every N, so that each rank's headline
+        # leg runs in the same process state as the N = 1 bench (an idle communicator's watchdog thread slows eager
+        # multi-stream launch sequences by ~10 %, measured on full_head_112_ms: 10.0 -> 11.45 ms).
+        dist.init_process_group('gloo')
 
     head, sd = build_head(dev)
     feats_c, rois_c, labels_c = make_inputs(rank, dev)
@@ -392,7 +409,9 @@ def main():
     # HIP-graph capture of the headline leg below brings streams of its own that end up sharing queues with them
     # (measured: 23.6 ms per step before the capture, 24.3 ms after it).  The headline leg is not affected by the
     # order (the training leg leaves nothing behind but cached allocator memory).
-    train_ms, train_loss, n_flat, train_b, comm_ms, collective, forced_ms = train_step_bench(head, dev, rank, world)
+    t_steps, t_warm = (args.steps, args.warmup) if args.leg == 'train' else (4, 4)
+    train_ms, train_loss, n_flat, train_b, comm_ms, collective, forced_ms = train_step_bench(
+        head, dev, rank, world, steps=t_steps, warmup=t_warm, rehearsal=rehearsal)
 
     def step():
         with torch.no_grad():
@@ -401,7 +420,6 @@ def main():
 
     def barrier():
         if world > 1:
-            import torch.distributed as dist
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -439,12 +457,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
-        w = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([w], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            w = float(t.item())
-        return w
+        return _max_over_ranks(time.perf_counter() - t0, world)
     # three such windows, the median is reported (one window of 20 graph replays is 80 ms: a single
     # sample of that length is at the mercy of the clock ramp)
     windows = sorted(timed_window() for _ in range(3))
@@ -464,7 +477,27 @@ def main():
                    'timing': f'median of 3 windows of {args.steps} steps; windows ms/step = '
                              + ', '.join(f'{w / args.steps * 1e3:.3f}' for w in windows)},
     }
-
+    # The training step (BASELINE configs[2] at N = 1, configs[3] at N = 8) is the unit of the north star's scaling
+    # curve: its figures are TOP-LEVEL keys of the line at every N, whichever leg is the headline.
+    result.update({
+        'train_ms_per_step': train_ms, 'train_img_per_s': world * train_b / (train_ms * 1e-3),
+        'train_imgs_per_gpu': train_b, 'train_steps_timed': t_steps,
+        'allreduce_alone_ms': comm_ms, 'collective': collective,
+        'infer_ms_per_roi_batch': ms_per_step, 'infer_img_per_s': value,
+    })
+    if args.leg == 'train':
+        result.update({
+            'metric': 'img/s (DynaMask mask-path training step: 2 img/GPU x 128 positive RoIs, fwd + loss + bwd + '
+                      'flat-gradient all-reduce + fused SGD; ms_per_step = ms per training step)',
+            'value': result['train_img_per_s'], 'ms_per_step': train_ms,
+        })
+        result['config'] = {
+            'workload': ('BASELINE configs[2]: DynaMask R-50-FPN training step, 1xMI355X' if world == 1 else
+                         f'BASELINE configs[3]: DynaMask R-50-FPN training, {world}xMI355X, 2 img/GPU, RCCL grad all-reduce') +
+                        ', dynamic 14/28/56/112 resolution selection + BCE backward (mask path: RoIAlign14 + RoIAlign56 + '
+                        'MaskPre + ST-Gumbel + DynaMaskHead + loss + backward)',
+            'imgs_per_gpu': train_b, 'pos_rois_per_img': 128, 'parallelism': f'images sharded x{world}, {collective}',
+            'launch': 'eager (four streams)', 'timing': f'median of 3 windows of {t_steps} steps'}
 
     if rank == 0:
         from dynamask_amd import ops
@@ -497,6 +530,10 @@ def main():
                 t = json.load(open(pmc))
                 result['roofline']['traffic'] = t.get('conv3x3_bytes_per_launch')
                 result['roofline_roialign']['traffic'] = t.get('roialign_bytes_per_launch')
+                src = ('profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of '
+                       'tools/collect_profiles.sh (' + str(t.get('collected', 'date n/a')) + '), not measured in this run')
+                result['roofline']['traffic_source'] = src
+                result['roofline_roialign']['traffic_source'] = src
             except Exception:
                 pass
         # ---- other exits, for context (not the headline) ----

@@ -4,7 +4,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DYNAMASK_HIP_LIB') or os.path.join(_HERE, 'libdynamask_hip.so')      # override: kernel experiments
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -70,6 +70,8 @@ SIGNATURES = {
     'dm_pixel_unshuffle2x': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp], _c_int),
     'dm_bbox_overlaps': ([_vp, _c_int, _vp, _c_int, _c_int, _c_float, _vp, _vp], _c_int),
     'dm_max_iou_assign': ([_vp, _c_int, _c_int, _c_float, _c_float, _c_float, _c_float, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp], _c_int),
+    'dm_random_sample': ([_vp, _vp, _c_int, _c_int, _vp, _c_int, _vp, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_double, _vp,
+                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _c_int),
     'dm_ignore_columns': ([_vp, _c_int, _c_int, _vp, _c_int, _c_int, _c_float, _vp], _c_int),
     'dm_bbox_encode': ([_vp, _vp, _c_int, _vp, _vp, _vp, _vp], _c_int),
     'dm_softmax_ce_fwd_bwd': ([_vp, _vp, _vp, _c_int, _c_int, _c_float, _vp, _vp, _vp, _vp, _vp], _c_int),

@@ -7,8 +7,9 @@ Mirrors, under the reference's registry names and kwargs:
 (assigners/assign_result.py), ``RandomSampler`` / ``BaseSampler``
 (samplers/random_sampler.py:7-78, base_sampler.py:8-101) and ``SamplingResult``
 (samplers/sampling_result.py:6-56).  The IoU matrix and the assignment run in
-``dm_bbox_overlaps`` / ``dm_max_iou_assign``; the sampler only permutes and gathers indices
-(torch index plumbing, as in the reference).
+``dm_bbox_overlaps`` / ``dm_max_iou_assign``; the sampling (quota arithmetic, the random subset, the
+ordered compaction and every gather of ``SamplingResult``) is one launch of ``dm_random_sample``: each
+candidate carries a random key and a class over its quota keeps the smallest keys.
 """
 import torch
 
@@ -115,24 +116,20 @@ class MaxIoUAssigner:
 
 
 class SamplingResult:
-    """sampling_result.py:21-56."""
+    """What the heads read from a sampled image (the fields of sampling_result.py:21-56): views of
+    the fixed-capacity buffers ``dm_random_sample`` filled, cut to the kept counts."""
 
-    def __init__(self, pos_inds, neg_inds, bboxes, gt_bboxes, assign_result, gt_flags):
-        self.pos_inds = pos_inds
-        self.neg_inds = neg_inds
-        self.pos_bboxes = bboxes[pos_inds]
-        self.neg_bboxes = bboxes[neg_inds]
-        self.pos_is_gt = gt_flags[pos_inds]
-        self.num_gts = gt_bboxes.shape[0]
-        self.pos_assigned_gt_inds = assign_result.gt_inds[pos_inds] - 1
-        if gt_bboxes.numel() == 0:
-            assert self.pos_assigned_gt_inds.numel() == 0
-            self.pos_gt_bboxes = torch.empty_like(gt_bboxes).view(-1, 4)
-        else:
-            if len(gt_bboxes.shape) < 2:
-                gt_bboxes = gt_bboxes.view(-1, 4)
-            self.pos_gt_bboxes = gt_bboxes[self.pos_assigned_gt_inds, :]
-        self.pos_gt_labels = assign_result.labels[pos_inds] if assign_result.labels is not None else None
+    __slots__ = ('pos_inds', 'neg_inds', 'pos_bboxes', 'neg_bboxes', 'pos_is_gt', 'num_gts', 'pos_assigned_gt_inds',
+                 'pos_gt_bboxes', 'pos_gt_labels')
+
+    def __init__(self, buffers, n_pos, n_neg, num_gts):
+        for name in ('pos_inds', 'pos_bboxes', 'pos_is_gt', 'pos_assigned_gt_inds', 'pos_gt_bboxes'):
+            setattr(self, name, buffers[name][:n_pos])
+        for name in ('neg_inds', 'neg_bboxes'):
+            setattr(self, name, buffers[name][:n_neg])
+        lab = buffers['pos_gt_labels']
+        self.pos_gt_labels = None if lab is None else lab[:n_pos]
+        self.num_gts = num_gts
 
     @property
     def bboxes(self):
@@ -141,66 +138,66 @@ class SamplingResult:
 
 @BBOX_SAMPLERS.register_module()
 class RandomSampler:
-    """random_sampler.py + base_sampler.py.  ``cpu_rng=True`` draws the permutations on torch's
-    CPU generator and copies the indices to the device (reproducible against a CPU run of the
-    reference with the same seed; the reference draws on the boxes' device)."""
+    """``RandomSampler(num, pos_fraction, neg_pos_ub=-1, add_gt_as_proposals=True)`` of the reference's config
+    (random_sampler.py:7-30, base_sampler.py:11-22); ``sample`` has the signature of base_sampler.py:35-40.
+
+    The random subset is drawn as a selection by key on the device.  By default the keys are one
+    ``torch.rand`` tensor over the candidates (no host round trip before the launch).  ``cpu_rng=True`` is the
+    test hook: the keys are the inverse of ``torch.randperm(class size)`` drawn on torch's CPU generator --
+    once per class that exceeds its quota, positives first, exactly the draws a CPU run of the reference makes --
+    so that the kept indices equal the reference's under the same seed (golden g11)."""
 
     def __init__(self, num, pos_fraction, neg_pos_ub=-1, add_gt_as_proposals=True, cpu_rng=False, **kwargs):
-        self.num = num
+        self.num = int(num)
         self.pos_fraction = pos_fraction
         self.neg_pos_ub = neg_pos_ub
         self.add_gt_as_proposals = add_gt_as_proposals
         self.cpu_rng = cpu_rng
-        self.pos_sampler = self
-        self.neg_sampler = self
 
-    def random_choice(self, gallery, num):
-        assert len(gallery) >= num
-        if self.cpu_rng:
-            perm = torch.randperm(gallery.numel())[:num].to(gallery.device)
-        else:
-            perm = torch.randperm(gallery.numel(), device=gallery.device)[:num]
-        return gallery[perm]
+    def _quota_neg(self, kept_pos):
+        q = self.num - kept_pos
+        if self.neg_pos_ub >= 0:
+            q = min(q, int(self.neg_pos_ub * max(1, kept_pos)))
+        return q
 
-    def _sample_pos(self, assign_result, num_expected, **kwargs):
-        pos_inds = torch.nonzero(assign_result.gt_inds > 0, as_tuple=False)
-        if pos_inds.numel() != 0:
-            pos_inds = pos_inds.squeeze(1)
-        if pos_inds.numel() <= num_expected:
-            return pos_inds
-        return self.random_choice(pos_inds, num_expected)
-
-    def _sample_neg(self, assign_result, num_expected, **kwargs):
-        neg_inds = torch.nonzero(assign_result.gt_inds == 0, as_tuple=False)
-        if neg_inds.numel() != 0:
-            neg_inds = neg_inds.squeeze(1)
-        if len(neg_inds) <= num_expected:
-            return neg_inds
-        return self.random_choice(neg_inds, num_expected)
+    def _reference_order_keys(self, gt_inds, quota_pos):
+        """Test hook (one host sync): per class, key[r] = position of the class's r-th member in the permutation
+        the reference would draw; a class within its quota draws nothing."""
+        dev = gt_inds.device
+        n_pos, n_neg = torch.stack([(gt_inds > 0).sum(), (gt_inds == 0).sum()]).tolist()
+        keys = []
+        for size, quota in ((n_pos, quota_pos), (n_neg, self._quota_neg(min(n_pos, quota_pos)))):
+            k = torch.zeros(max(size, 1), dtype=torch.float32)
+            if size > quota:
+                k[torch.randperm(size)] = torch.arange(size, dtype=torch.float32)
+            keys.append(k.to(dev))
+        return keys
 
     def sample(self, assign_result, bboxes, gt_bboxes, gt_labels=None, **kwargs):
-        """base_sampler.py:35-101."""
-        if len(bboxes.shape) < 2:
-            bboxes = bboxes[None, :]
-        bboxes = bboxes[:, :4]
-        gt_flags = bboxes.new_zeros((bboxes.shape[0],), dtype=torch.uint8)
+        boxes = bboxes.reshape(-1, bboxes.shape[-1])[:, :4]
+        n_prepended = 0
         if self.add_gt_as_proposals and len(gt_bboxes) > 0:
             if gt_labels is None:
                 raise ValueError('gt_labels must be given when add_gt_as_proposals is True')
-            bboxes = torch.cat([gt_bboxes, bboxes], dim=0)
-            assign_result.add_gt_(gt_labels)
-            gt_ones = bboxes.new_ones(gt_bboxes.shape[0], dtype=torch.uint8)
-            gt_flags = torch.cat([gt_ones, gt_flags])
-        num_expected_pos = int(self.num * self.pos_fraction)
-        pos_inds = self.pos_sampler._sample_pos(assign_result, num_expected_pos, bboxes=bboxes, **kwargs)
-        pos_inds = pos_inds.unique()
-        num_sampled_pos = pos_inds.numel()
-        num_expected_neg = self.num - num_sampled_pos
-        if self.neg_pos_ub >= 0:
-            _pos = max(1, num_sampled_pos)
-            neg_upper_bound = int(self.neg_pos_ub * _pos)
-            if num_expected_neg > neg_upper_bound:
-                num_expected_neg = neg_upper_bound
-        neg_inds = self.neg_sampler._sample_neg(assign_result, num_expected_neg, bboxes=bboxes, **kwargs)
-        neg_inds = neg_inds.unique()
-        return SamplingResult(pos_inds, neg_inds, bboxes, gt_bboxes, assign_result, gt_flags)
+            assign_result.add_gt_(gt_labels)          # base_sampler.py:78: the caller's AssignResult grows too
+            n_prepended = gt_bboxes.shape[0]
+            boxes = torch.cat([gt_bboxes, boxes], dim=0)
+        boxes = boxes.float().contiguous()
+        gt_inds = assign_result.gt_inds.contiguous()
+        quota_pos = int(self.num * self.pos_fraction)
+        if gt_inds.numel() == 0:
+            empty = dict(pos_inds=gt_inds.new_zeros((0,)), neg_inds=gt_inds.new_zeros((0,)),
+                         pos_bboxes=boxes.new_zeros((0, 4)), neg_bboxes=boxes.new_zeros((0, 4)),
+                         pos_gt_bboxes=boxes.new_zeros((0, 4)), pos_assigned_gt_inds=gt_inds.new_zeros((0,)),
+                         pos_gt_labels=None if assign_result.labels is None else gt_inds.new_zeros((0,)),
+                         pos_is_gt=boxes.new_zeros((0,), dtype=torch.uint8))
+            return SamplingResult(empty, 0, 0, gt_bboxes.shape[0])
+        if self.cpu_rng:
+            pos_keys, neg_keys = self._reference_order_keys(gt_inds, quota_pos)
+        else:
+            pos_keys = neg_keys = torch.rand(gt_inds.shape[0], device=gt_inds.device)
+        labels = None if assign_result.labels is None else assign_result.labels.contiguous()
+        buffers = ops.random_sample(gt_inds, boxes, n_prepended, gt_bboxes.float().reshape(-1, 4).contiguous(), labels,
+                                    pos_keys, neg_keys, self.cpu_rng, self.num, quota_pos, float(self.neg_pos_ub))
+        n_pos, n_neg = buffers['counts'][:2].tolist()          # the one host sync: the heads' tensors are sized by it
+        return SamplingResult(buffers, n_pos, n_neg, gt_bboxes.shape[0])

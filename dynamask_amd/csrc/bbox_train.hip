@@ -284,6 +284,170 @@ extern "C" int dm_max_iou_assign(const float* overlaps, int num_gts, int num_bbo
   return dm_check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------
+// K29  RoI sampling (what BaseSampler.sample + RandomSampler + SamplingResult produce,
+//      core/bbox/samplers/base_sampler.py:35-101, random_sampler.py:31-75, sampling_result.py:21-49),
+//      formulated as a selection by key: every candidate box carries a random key; a class
+//      (positives: gt_inds > 0, negatives: gt_inds == 0) larger than its quota keeps the quota's
+//      smallest keys (ties: lower box index), a smaller one is kept whole; the kept boxes leave in
+//      ascending index order (the reference's `.unique()`), positives with their gt box / label /
+//      flag gathered alongside.  One workgroup: M is a few thousand boxes, the work is compares.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct SampleArgs {
+  const int64_t* gt_inds; const float* bboxes; const float* gt_bboxes; const int64_t* labels;
+  const float* pos_keys; const float* neg_keys;
+  int M, n_prepended, num, quota_pos, keys_by_class_rank;
+  double neg_pos_ub;
+  int* crank; float* ekey; int* keep;            // scratch, M each
+  int64_t* pos_inds; int64_t* neg_inds; int32_t* counts;
+  float* pos_bboxes; float* neg_bboxes; float* pos_gt_bboxes;
+  int64_t* pos_assigned_gt_inds; int64_t* pos_gt_labels; uint8_t* pos_is_gt;
+};
+
+constexpr int SMP_T = 1024;
+
+// exclusive scan of (a, b) over the workgroup; returns the totals through ta / tb
+__device__ __forceinline__ void block_scan2(int a, int b, int& ea, int& eb, int& ta, int& tb, int (*part)[2]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int ia = a, ib = b;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int ua = __shfl_up(ia, d), ub = __shfl_up(ib, d);
+    if (lane >= d) { ia += ua; ib += ub; }
+  }
+  if (lane == 63) { part[wave][0] = ia; part[wave][1] = ib; }
+  __syncthreads();
+  int oa = 0, ob = 0, sa = 0, sb = 0;
+  for (int w = 0; w < SMP_T / 64; ++w) {
+    if (w == wave) { oa = sa; ob = sb; }
+    sa += part[w][0]; sb += part[w][1];
+  }
+  ea = oa + ia - a; eb = ob + ib - b; ta = sa; tb = sb;
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(SMP_T) void random_sample_kernel(SampleArgs a) {
+  __shared__ int part[SMP_T / 64][2];
+  __shared__ float tkey[SMP_T];
+  __shared__ signed char tcls[SMP_T];
+  const int t = threadIdx.x;
+  // (1) class ranks in index order, class sizes
+  int n_pos = 0, n_neg = 0;
+  for (int base = 0; base < a.M; base += SMP_T) {
+    const int i = base + t;
+    const int64_t g = i < a.M ? a.gt_inds[i] : -1;
+    int ep, en, tp, tn;
+    block_scan2(g > 0, g == 0, ep, en, tp, tn, part);
+    if (i < a.M) {
+      const int r = g > 0 ? n_pos + ep : n_neg + en;
+      a.crank[i] = r;
+      float k = 0.f;
+      if (g > 0) k = a.pos_keys[a.keys_by_class_rank ? r : i];
+      else if (g == 0) k = a.neg_keys[a.keys_by_class_rank ? r : i];
+      a.ekey[i] = k;
+    }
+    n_pos += tp; n_neg += tn;
+  }
+  // (2) quotas
+  const int k_pos = min(n_pos, a.quota_pos);
+  int quota_neg = a.num - k_pos;
+  if (a.neg_pos_ub >= 0.0) {
+    const int ub = (int)(a.neg_pos_ub * (double)max(1, k_pos));
+    quota_neg = min(quota_neg, ub);
+  }
+  const int k_neg = min(n_neg, max(quota_neg, 0));
+  __syncthreads();          // crank / ekey of every box are visible to the workgroup below
+  // (3) a class over its quota keeps the boxes whose key rank is below the quota
+  for (int base = 0; base < a.M; base += SMP_T) {
+    const int i = base + t;
+    const int64_t g = i < a.M ? a.gt_inds[i] : -1;
+    const int cls = g > 0 ? 1 : (g == 0 ? 0 : -1);
+    const bool contested = cls == 1 ? n_pos > k_pos : (cls == 0 ? n_neg > k_neg : false);
+    const float key = i < a.M ? a.ekey[i] : 0.f;
+    int below = 0;
+    const bool any = __syncthreads_or(contested);
+    if (any) {
+      for (int jb = 0; jb < a.M; jb += SMP_T) {
+        const int j = jb + t;
+        if (j < a.M) {
+          const int64_t gj = a.gt_inds[j];
+          tkey[t] = a.ekey[j];
+          tcls[t] = gj > 0 ? 1 : (gj == 0 ? 0 : -1);
+        } else {
+          tcls[t] = -2;
+        }
+        __syncthreads();
+        if (contested) {
+          const int lim = min(SMP_T, a.M - jb);
+          for (int u = 0; u < lim; ++u) {
+            const float ku = tkey[u];
+            below += (tcls[u] == cls) & ((ku < key) | ((ku == key) & (jb + u < i)));
+          }
+        }
+        __syncthreads();
+      }
+    }
+    if (i < a.M) a.keep[i] = cls < 0 ? 0 : (contested ? below < (cls == 1 ? k_pos : k_neg) : 1);
+  }
+  __syncthreads();
+  // (4) kept boxes leave in index order
+  int o_pos = 0, o_neg = 0;
+  for (int base = 0; base < a.M; base += SMP_T) {
+    const int i = base + t;
+    const int64_t g = i < a.M ? a.gt_inds[i] : -1;
+    const int kp = i < a.M ? a.keep[i] : 0;
+    int ep, en, tp, tn;
+    block_scan2(kp && g > 0, kp && g == 0, ep, en, tp, tn, part);
+    if (kp && g > 0) {
+      const int o = o_pos + ep;
+      a.pos_inds[o] = i;
+      a.pos_assigned_gt_inds[o] = g - 1;
+      a.pos_is_gt[o] = i < a.n_prepended;
+      if (a.pos_gt_labels) a.pos_gt_labels[o] = a.labels[i];
+      for (int c = 0; c < 4; ++c) {
+        a.pos_bboxes[4 * o + c] = a.bboxes[4 * (size_t)i + c];
+        a.pos_gt_bboxes[4 * o + c] = a.gt_bboxes[4 * (size_t)(g - 1) + c];
+      }
+    } else if (kp && g == 0) {
+      const int o = o_neg + en;
+      a.neg_inds[o] = i;
+      for (int c = 0; c < 4; ++c) a.neg_bboxes[4 * o + c] = a.bboxes[4 * (size_t)i + c];
+    }
+    o_pos += tp; o_neg += tn;
+  }
+  if (t == 0) { a.counts[0] = o_pos; a.counts[1] = o_neg; a.counts[2] = n_pos; a.counts[3] = n_neg; }
+}
+
+}  // namespace
+
+extern "C" int dm_random_sample(const int64_t* gt_inds, const float* bboxes, int M, int n_prepended,
+                                const float* gt_bboxes, int num_gts, const int64_t* labels, const float* pos_keys,
+                                const float* neg_keys, int keys_by_class_rank, int num, int quota_pos, double neg_pos_ub,
+                                int32_t* scratch, int64_t* pos_inds, int64_t* neg_inds, int32_t* counts,
+                                float* pos_bboxes, float* neg_bboxes, float* pos_gt_bboxes,
+                                int64_t* pos_assigned_gt_inds, int64_t* pos_gt_labels, uint8_t* pos_is_gt,
+                                dm_stream_t stream) {
+  if (M <= 0 || num <= 0 || quota_pos < 0 || quota_pos > num || n_prepended < 0 || n_prepended > M || num_gts < 0)
+    return DM_ERR_INVALID_ARG;
+  if (!gt_inds || !bboxes || !pos_keys || !neg_keys || !scratch || !pos_inds || !neg_inds || !counts || !pos_bboxes ||
+      !neg_bboxes || !pos_gt_bboxes || !pos_assigned_gt_inds || !pos_is_gt || (pos_gt_labels && !labels) ||
+      (num_gts > 0 && !gt_bboxes))
+    return DM_ERR_INVALID_ARG;
+  SampleArgs a;
+  a.gt_inds = gt_inds; a.bboxes = bboxes; a.gt_bboxes = gt_bboxes; a.labels = labels;
+  a.pos_keys = pos_keys; a.neg_keys = neg_keys;
+  a.M = M; a.n_prepended = n_prepended; a.num = num; a.quota_pos = quota_pos; a.keys_by_class_rank = keys_by_class_rank;
+  a.neg_pos_ub = neg_pos_ub;
+  a.crank = scratch; a.ekey = reinterpret_cast<float*>(scratch + M); a.keep = scratch + 2 * (size_t)M;
+  a.pos_inds = pos_inds; a.neg_inds = neg_inds; a.counts = counts;
+  a.pos_bboxes = pos_bboxes; a.neg_bboxes = neg_bboxes; a.pos_gt_bboxes = pos_gt_bboxes;
+  a.pos_assigned_gt_inds = pos_assigned_gt_inds; a.pos_gt_labels = pos_gt_labels; a.pos_is_gt = pos_is_gt;
+  DM_LAUNCH(random_sample_kernel, dim3(1), dim3(SMP_T), 0, (hipStream_t)stream, a);
+  return dm_check_launch();
+}
+
 extern "C" int dm_bbox_encode(const float* proposals, const float* gt, int n, const float* means, const float* stds,
                               float* deltas, dm_stream_t stream) {
   if (n < 0) return DM_ERR_INVALID_ARG;

@@ -863,6 +863,43 @@ def max_iou_assign(overlaps, pos_iou_thr, neg_iou_thr, min_pos_iou=0.0, match_lo
     return gt_inds, max_ov, labels
 
 
+def random_sample(gt_inds, bboxes, n_prepended, gt_bboxes, labels, pos_keys, neg_keys, keys_by_class_rank, num, quota_pos,
+                  neg_pos_ub=-1.0):
+    """dm_random_sample: key-ranked RoI sampling -> dict of [num]-row device buffers + ``counts`` [4] int32
+    (positives kept, negatives kept, positive candidates, negative candidates).  No host sync."""
+    _chk(gt_inds, 'gt_inds', torch.int64)
+    _chk(bboxes, 'bboxes')
+    _chk(pos_keys, 'pos_keys')
+    _chk(neg_keys, 'neg_keys')
+    M = gt_inds.shape[0]
+    assert bboxes.shape == (M, 4)
+    if not keys_by_class_rank:
+        assert pos_keys.numel() >= M and neg_keys.numel() >= M
+    G = int(gt_bboxes.shape[0])
+    if G:
+        _chk(gt_bboxes, 'gt_bboxes')
+    if labels is not None:
+        _chk(labels, 'labels', torch.int64)
+        assert labels.shape[0] == M
+    dev = gt_inds.device
+    i64 = dict(device=dev, dtype=torch.int64)
+    f32 = dict(device=dev, dtype=torch.float32)
+    out = dict(pos_inds=torch.empty((num,), **i64), neg_inds=torch.empty((num,), **i64),
+               counts=torch.empty((4,), device=dev, dtype=torch.int32),
+               pos_bboxes=torch.empty((num, 4), **f32), neg_bboxes=torch.empty((num, 4), **f32),
+               pos_gt_bboxes=torch.empty((num, 4), **f32), pos_assigned_gt_inds=torch.empty((num,), **i64),
+               pos_gt_labels=torch.empty((num,), **i64) if labels is not None else None,
+               pos_is_gt=torch.empty((num,), device=dev, dtype=torch.uint8))
+    scratch = torch.empty((3 * M,), device=dev, dtype=torch.int32)
+    check(lib().dm_random_sample(_p(gt_inds), _p(bboxes), M, int(n_prepended), _p(gt_bboxes) if G else _p(None), G,
+                                 _p(labels), _p(pos_keys), _p(neg_keys), 1 if keys_by_class_rank else 0, int(num),
+                                 int(quota_pos), float(neg_pos_ub), _p(scratch), _p(out['pos_inds']), _p(out['neg_inds']),
+                                 _p(out['counts']), _p(out['pos_bboxes']), _p(out['neg_bboxes']), _p(out['pos_gt_bboxes']),
+                                 _p(out['pos_assigned_gt_inds']), _p(out['pos_gt_labels']), _p(out['pos_is_gt']),
+                                 _stream()), 'dm_random_sample')
+    return out
+
+
 def bbox_encode(proposals, gt, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.)):
     """bbox2delta, delta_xywh_bbox_coder.py:74-116."""
     _chk(proposals, 'proposals')

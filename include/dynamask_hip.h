@@ -48,7 +48,7 @@ extern "C" {
 typedef void* dm_stream_t; /* hipStream_t */
 
 const char* dm_error_string(int code);
-/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites). */
+/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, deterministic weight gradients (dm_conv2d_wgrad flag bit 2 + scratch)). */
 int dm_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -455,6 +455,29 @@ int dm_max_iou_assign(const float* overlaps, int num_gts, int num_bboxes, float 
                       float neg_iou_hi, float min_pos_iou, int match_low_quality, int gt_max_assign_all,
                       const int64_t* gt_labels, float* scratch, int64_t* gt_inds, float* max_overlaps, int64_t* labels,
                       dm_stream_t stream);
+
+/* RoI sampling: BaseSampler.sample + RandomSampler._sample_pos / _sample_neg + SamplingResult
+ * (core/bbox/samplers/base_sampler.py:35-101, random_sampler.py:31-75, sampling_result.py:21-49),
+ * stated as a selection by key.  Candidate boxes bboxes [M,4] (the n_prepended ground-truth boxes first
+ * when the sampler adds them as proposals) with AssignResult.gt_inds [M] (i+1 = gt i, 0 negative,
+ * -1 ignored) and optional labels [M].  quota_pos = int(num * pos_fraction) positives at most, then
+ * num - (positives kept) negatives at most, further limited to int(neg_pos_ub * max(1, positives kept))
+ * when neg_pos_ub >= 0.  A class within its quota is kept whole; a larger one keeps the boxes with
+ * the quota's smallest keys (ties: lower index) -- a uniformly random subset when the keys are
+ * i.i.d. noise.  keys_by_class_rank = 0: pos_keys / neg_keys are [M], indexed by box (both may be the
+ * same noise tensor); 1: pos_keys[r] / neg_keys[r] belong to the r-th positive / negative in index
+ * order (the inverse of the reference's torch.randperm(count) reproduces its choice: test hook).
+ * Keys must be finite.  Kept boxes leave in ascending index order (the reference's .unique()).
+ * Outputs have capacity `num` rows; counts[4] = (positives kept, negatives kept, positive candidates,
+ * negative candidates).  pos_gt_bboxes[o] = gt_bboxes[gt_inds - 1], pos_assigned_gt_inds = gt_inds - 1,
+ * pos_is_gt[o] = index < n_prepended, pos_gt_labels (NULL with labels NULL) = labels[index].
+ * scratch: 3 * M int32.  One workgroup; O(M^2 / 1024) compares per thread when a class is over quota. */
+int dm_random_sample(const int64_t* gt_inds, const float* bboxes, int M, int n_prepended, const float* gt_bboxes,
+                     int num_gts, const int64_t* labels, const float* pos_keys, const float* neg_keys,
+                     int keys_by_class_rank, int num, int quota_pos, double neg_pos_ub, int32_t* scratch,
+                     int64_t* pos_inds, int64_t* neg_inds, int32_t* counts, float* pos_bboxes, float* neg_bboxes,
+                     float* pos_gt_bboxes, int64_t* pos_assigned_gt_inds, int64_t* pos_gt_labels, uint8_t* pos_is_gt,
+                     dm_stream_t stream);
 /* the gt_bboxes_ignore branch of MaxIoUAssigner.assign (max_iou_assigner.py:107-118): overlaps[:, n] = -1 where
  * box n's largest IoF with an ignore region exceeds thr.  iof = dm_bbox_overlaps(mode_iof = 1) of (boxes, regions)
  * [N][I] (boxes_major = 1, ignore_wrt_candidates) or of (regions, boxes) [I][N] (boxes_major = 0). */
