@@ -35,6 +35,7 @@ SIGNATURES = {
     'dm_bn_stats': ([_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_float, _vp, _vp], _c_int),
     'dm_bn_scratch_floats': ([_c_int], ctypes.c_longlong),
     'dm_bn_relu_maxpool_fwd': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_float, _vp, _vp], _c_int),
+    'dm_bn_relu_maxpool_argmax': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_float, _vp, _vp], _c_int),
     'dm_relu_bwd': ([_vp, _vp, ctypes.c_longlong, _vp], _c_int),
     'dm_sigmoid_bwd': ([_vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _c_int, _c_int, _vp, _c_int, _vp], _c_int),
     'dm_channel_sum': ([_vp, ctypes.c_longlong, _c_int, _c_int, _c_int, _vp, _c_int, _vp], _c_int),

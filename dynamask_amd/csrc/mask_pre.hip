@@ -188,6 +188,57 @@ extern "C" int dm_bn_relu_maxpool_fwd(const float* x, int NB, int C, int H, int 
   return dm_check_launch();
 }
 
+// Which tap each pooled output took: the plane index (y * W + x) of the window's first maximum of z = relu(bn(x)),
+// found with the expression and scan order of the backward kernels below.  Diagnostic: a test compares the
+// choices with the reference's max_pool2d(return_indices=True) and counts the windows (fp32 ties) that differ.
+namespace {
+__global__ __launch_bounds__(256) void maxpool_argmax_kernel(const float* __restrict__ x, int NB, int C, int H, int W,
+                                                             const float* __restrict__ mean, const float* __restrict__ var,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float eps, int32_t* __restrict__ arg, int OH, int OW) {
+  const size_t total = (size_t)NB * C * OH * OW;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(idx % OW);
+    const int oy = (int)((idx / OW) % OH);
+    const int c = (int)((idx / ((size_t)OW * OH)) % C);
+    const size_t n = idx / ((size_t)OW * OH * C);
+    const float invstd = 1.0f / sqrtf(var[c] + eps);
+    const float g = gamma[c], b = beta[c], m = mean[c];
+    const float* p = x + (n * C + c) * (size_t)H * W;
+    float best = -INFINITY;
+    int bi = -1;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int y = 2 * oy - 1 + dy;
+      if (y < 0 || y >= H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int xx = 2 * ox - 1 + dx;
+        if (xx < 0 || xx >= W) continue;
+        const float v = fmaxf((p[y * W + xx] - m) * invstd * g + b, 0.f);
+        if (v > best) {
+          best = v;
+          bi = y * W + xx;
+        }
+      }
+    }
+    arg[idx] = bi;
+  }
+}
+}  // namespace
+
+extern "C" int dm_bn_relu_maxpool_argmax(const float* x, int NB, int C, int H, int W, const float* mean, const float* var,
+                                         const float* gamma, const float* beta, float eps, int32_t* argmax,
+                                         dm_stream_t stream) {
+  if (!x || !mean || !var || !gamma || !beta || !argmax || NB <= 0 || C <= 0 || H <= 0 || W <= 0) return DM_ERR_INVALID_ARG;
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const size_t total = (size_t)NB * C * OH * OW;
+  const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+  DM_LAUNCH(maxpool_argmax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, NB, C, H, W, mean, var, gamma, beta,
+            eps, argmax, OH, OW);
+  return dm_check_launch();
+}
+
 // ---------------------------------------------------------------------------
 // MaskPre backward pieces: max_pool2d(3,2,1) o ReLU o BatchNorm(train).
 namespace {

@@ -525,6 +525,17 @@ def bn_relu_maxpool(x, mean, var, gamma, beta, eps=1e-5):
     return out
 
 
+def bn_relu_maxpool_argmax(x, mean, var, gamma, beta, eps=1e-5):
+    """Plane index of the tap each pooled output took (diagnostic; = max_pool2d(return_indices=True))."""
+    for t, n in ((x, 'x'), (mean, 'mean'), (var, 'var'), (gamma, 'gamma'), (beta, 'beta')):
+        _chk(t, n)
+    NB, C, H, W = x.shape
+    arg = torch.empty((NB, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), device=x.device, dtype=torch.int32)
+    check(lib().dm_bn_relu_maxpool_argmax(_p(x), NB, C, H, W, _p(mean), _p(var), _p(gamma), _p(beta), eps, _p(arg),
+                                          _stream()), 'dm_bn_relu_maxpool_argmax')
+    return arg
+
+
 # ------------------------------------------------------------------- backward ops
 def relu_backward_(grad, out):
     _chk(grad, 'grad')

@@ -254,6 +254,11 @@ int dm_bn_stats(const float* x, int NB, int C, int HW, float* mean, float* var, 
 long long dm_bn_scratch_floats(int C);
 int dm_bn_relu_maxpool_fwd(const float* x, int NB, int C, int H, int W, const float* mean, const float* var,
                            const float* gamma, const float* beta, float eps, float* out, dm_stream_t stream);
+/* diagnostic: argmax [NB, C, OH, OW] int32 = plane index (y * W + x) of the tap each pooled output took (first
+ * maximum in scan order, the choice dm_bn_relu_maxpool_bwd routes the gradient to) -- what
+ * F.max_pool2d(..., return_indices=True) returns in the reference (roi_heads/base_roi_head.py:16,19). */
+int dm_bn_relu_maxpool_argmax(const float* x, int NB, int C, int H, int W, const float* mean, const float* var,
+                              const float* gamma, const float* beta, float eps, int32_t* argmax, dm_stream_t stream);
 
 /* backward of dm_bn_relu_maxpool_fwd with train-mode statistics (mean/var as
  * returned by dm_bn_stats): grad_x [NB,C,H,W] (overwritten), grad_gamma/grad_beta [C]. */

@@ -110,7 +110,21 @@ def fcn_mask_head_forward(sd, x, pre='', num_convs=4, upsample='deconv', scale=2
 
 
 # ------------------------------------------------- resolution predictor/selector
-def mask_pre(sd, x, pre='mask_predictor.', training=True, eps=1e-5):
+def _pool(z, choice, record, name):
+    """max_pool2d(3, 2, 1).  ``choice[name]`` (plane indices [N, C, OH, OW]) replaces the arg-max by a given
+    choice of tap per window (a test hands over the device kernel's choices: where two taps of a window are equal
+    to the last fp32 bit, which one receives the gradient is not defined by the mathematics); ``record[name]``
+    receives (z, own arg-max)."""
+    out, idx = F.max_pool2d(z, stride=2, kernel_size=3, padding=1, return_indices=True)
+    if record is not None:
+        record[name] = (z.detach(), idx)
+    if choice is not None and name in choice:
+        N, C = z.shape[:2]
+        out = z.flatten(2).gather(2, choice[name].long().flatten(2)).view_as(out)
+    return out
+
+
+def mask_pre(sd, x, pre='mask_predictor.', training=True, eps=1e-5, pool_choice=None, pool_record=None):
     """MaskPre.forward -- roi_heads/base_roi_head.py:10-27 (BatchNorm in train
     mode uses the batch statistics of this rank's RoIs: Quirk Q4)."""
     def bn(t, name):
@@ -120,9 +134,9 @@ def mask_pre(sd, x, pre='mask_predictor.', training=True, eps=1e-5):
         return F.batch_norm(t, sd[pre + name + '.running_mean'], sd[pre + name + '.running_var'],
                             sd[pre + name + '.weight'], sd[pre + name + '.bias'], False, 0.1, eps)
     x = F.conv2d(x, sd[pre + 'conv1.weight'], sd[pre + 'conv1.bias'])
-    x = F.max_pool2d(F.relu(bn(x, 'bn1')), stride=2, kernel_size=3, padding=1)
+    x = _pool(F.relu(bn(x, 'bn1')), pool_choice, pool_record, 'pool1')
     x = F.conv2d(x, sd[pre + 'conv2.weight'], sd[pre + 'conv2.bias'], padding=1)
-    x = F.max_pool2d(F.relu(bn(x, 'bn2')), stride=2, kernel_size=3, padding=1)
+    x = _pool(F.relu(bn(x, 'bn2')), pool_choice, pool_record, 'pool2')
     x = x.reshape(x.size(0), 3136)
     x = F.relu(F.linear(x, sd[pre + 'fc1.weight'], sd[pre + 'fc1.bias']))
     return F.linear(x, sd[pre + 'fc2.weight'], sd[pre + 'fc2.bias'])
@@ -248,13 +262,13 @@ def dynamic_exit_logits(stage_instance_preds, exits, merge=True):
     return out
 
 
-def mask_forward_train(sd, fpn_feats, rois, roi_labels, stage_targets, U, **kw):
+def mask_forward_train(sd, fpn_feats, rois, roi_labels, stage_targets, U, pool_choice=None, pool_record=None, **kw):
     """DynaMaskRoIHead._mask_forward_train minus target generation --
     roi_heads/dynamask_roi_head.py:48-73.  Returns (loss_masks, mask_labels,
     selector index, predictor logits)."""
     ips, dps = mask_forward(sd, fpn_feats, rois, roi_labels, **kw)
     sem = ref_ops.single_roi_extractor([fpn_feats[0].detach()], rois, 56, (4,))
-    logits = mask_pre(sd, sem, training=True)
+    logits = mask_pre(sd, sem, training=True, pool_choice=pool_choice, pool_record=pool_record)
     mask_labels, ind = gumbel_select(logits, U, 0.5)
     fk = sd.get('mask_head.loss_func.detail_target.fuse_kernel')
     loss = dyna_loss(ips, dps, stage_targets, mask_labels, fuse_kernel=fk)

@@ -9,6 +9,7 @@ import torch
 
 import golden_inputs as gi
 from oracle import ref_model, ref_ops
+from tolerances import assert_grad_close
 
 pytestmark = pytest.mark.gpu
 TOL = dict(atol=1e-4, rtol=1e-4)
@@ -142,11 +143,11 @@ def test_dyna_loss_and_grads_match_reference_golden(golden_dir):
     loss = out['loss_masks']
     loss.backward()
     _close(loss, g['loss_masks'], atol=1e-4, rtol=1e-4)
-    _close(ml.grad, g['grad_mask_labels'], atol=1e-4, rtol=1e-4)
+    assert_grad_close(ml.grad, g['grad_mask_labels'], 'mask_labels')
     for i in range(4):
-        _close(dps[i].grad, g[f'grad_dp{i}'], atol=1e-4, rtol=1e-4)
-        gip = ips[i].grad if ips[i].grad is not None else torch.zeros_like(ips[i])
-        _close(gip, g[f'grad_ip{i}'], atol=1e-4, rtol=1e-4)
+        # Quirk Q2 / start_stage: only the last stage's instance BCE and the first three detail BCEs reach the loss
+        assert_grad_close(dps[i].grad, g[f'grad_dp{i}'], f'dp{i}', zero=(i == 3))
+        assert_grad_close(ips[i].grad, g[f'grad_ip{i}'], f'ip{i}', zero=(i < 3))
 
 
 def test_mask_forward_train_loss_vs_oracle():
@@ -180,14 +181,14 @@ def test_training_slice_grads_match_reference_golden(golden_dir):
                                  [_dev(t) for t in gi.head_targets(n)], ml)['loss_masks']
     loss.backward()
     _close(loss, g['loss'])
-    _close(ml.grad, g['grad_mask_labels'], atol=1e-4, rtol=1e-4)
+    assert_grad_close(ml.grad, g['grad_mask_labels'], 'mask_labels')
     named = dict(m.mask_head.named_parameters())
     for k in gi.GRAD_KEYS:
         assert named[k].grad is not None, k
-        _close(gi.grad_slice(named[k].grad), g['grad.' + k], atol=1e-4, rtol=1e-4)
+        assert_grad_close(gi.grad_slice(named[k].grad), g['grad.' + k], k)
     for i in range(4):
         assert feats[i].grad is not None, i
-        _close(gi.feat_grad_slice(feats[i].grad), g[f'grad_feat{i}'], atol=1e-4, rtol=1e-4)
+        assert_grad_close(gi.feat_grad_slice(feats[i].grad), g[f'grad_feat{i}'], f'feat{i}')
 
 
 def test_mask_pre_and_selector_backward_match_reference_golden(golden_dir):
@@ -200,10 +201,10 @@ def test_mask_pre_and_selector_backward_match_reference_golden(golden_dir):
     logits = train_path.MaskPreFn.apply(mp, x, *list(mp.parameters()))
     _close(logits, g2['logits_train'])
     logits.square().sum().backward()
-    _close(mp.fc2.weight.grad, g2['grad_fc2_w'], atol=1e-4, rtol=1e-4)
-    _close(mp.conv1.bias.grad, g2['grad_conv1_b'], atol=1e-4, rtol=1e-4)
-    _close(mp.bn1.weight.grad, g2['grad_bn1_w'], atol=1e-4, rtol=1e-4)
-    _close(mp.conv2.weight.grad, g2['grad_conv2_w'], atol=1e-4, rtol=1e-4)
+    assert_grad_close(mp.fc2.weight.grad, g2['grad_fc2_w'], 'fc2.weight')
+    assert_grad_close(mp.conv1.bias.grad, g2['grad_conv1_b'], 'conv1.bias', cancels=1e-5)   # train-mode BN removes it
+    assert_grad_close(mp.bn1.weight.grad, g2['grad_bn1_w'], 'bn1.weight')
+    assert_grad_close(mp.conv2.weight.grad, g2['grad_conv2_w'], 'conv2.weight')
     # straight-through selector gradient
     lg = _dev(gi.gumbel_logits()).requires_grad_(True)
     torch.manual_seed(gi.GUMBEL_SEED)
@@ -211,7 +212,7 @@ def test_mask_pre_and_selector_backward_match_reference_golden(golden_dir):
     hot, idx = train_path.GumbelSelectFn.apply(lg, _dev(U), 0.5)
     assert np.array_equal(idx.cpu().numpy().astype(np.int64), g3['index'])
     (hot * torch.arange(1, 5, dtype=torch.float32, device='cuda')).sum().backward()
-    _close(lg.grad, g3['grad_logits'], atol=1e-4, rtol=1e-4)
+    assert_grad_close(lg.grad, g3['grad_logits'], 'selector logits')
 
 
 def test_full_training_step_runs_and_updates_every_parameter():

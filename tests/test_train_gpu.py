@@ -10,6 +10,7 @@ import torch
 
 import golden_inputs as gi
 from oracle import ref_model
+from tolerances import assert_grad_close
 
 pytestmark = pytest.mark.gpu
 TOL = dict(atol=1e-4, rtol=1e-4)
@@ -128,10 +129,10 @@ def test_forward_train_matches_reference_golden(golden_dir):
         for k in keys:
             got, ref = gi.grad_slice(named[pre + k].grad).cpu().numpy(), g['ft.grad.' + pre + k]
             worst = max(worst, float(np.abs(got - ref).max()))
-            np.testing.assert_allclose(got, ref, err_msg=pre + k, **TOL)
+            assert_grad_close(got, ref, pre + k)
     for i in range(4):
         if g[f'ft.grad_feat{i}'].size > 1:
-            np.testing.assert_allclose(gi.feat_grad_slice(feats[i].grad).cpu().numpy(), g[f'ft.grad_feat{i}'], **TOL)
+            assert_grad_close(gi.feat_grad_slice(feats[i].grad), g[f'ft.grad_feat{i}'], f'feat{i}')
     print('forward_train: worst parameter-gradient abs error', worst)
 
 
