@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restric
 // per-channel sum over batch and pixels (bias gradient): grid = (C, splits), one
 // atomic per workgroup into out (zero-filled by the launcher unless accumulating)
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ g, long long bs, int NB, int C, int HW,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out, int fx) {
   __shared__ float red[4];
   const int c = blockIdx.x;
   float s = 0.f;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
   s = wsum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out + c, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) dm_acc_add(out, c, red[0] + red[1] + red[2] + red[3], fx != 0);
 }
 
 // ----------------------------------------------------------------- conv weight gradient
@@ -101,6 +101,7 @@ struct WgradArgs {
   float* dw;
   int ldw, coloff;
   int JT, MT, chunks_per_split, nsplit;
+  int fx;            // dw is a 64-bit fixed-point accumulator (dm_conv2d_wgrad_fx)
 };
 
 // dW[co][j] = sum_q dy[co][q] * xshift[j][q]  (j = (ci, tap), q = flat pixel): a GEMM
@@ -209,28 +210,44 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   }
   {
     // hoisted addresses: one base per column, one per-lane row offset (see conv_igemm.hip's epilogue)
-    float* pj[2];
+    size_t cj[2];
     bool j_ok[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int jg = j0 + (wave_n * 2 + j) * 32 + l31;
       j_ok[j] = jg < Jtot;
-      pj[j] = a.dw + a.coloff + jg;
+      cj[j] = (size_t)a.coloff + jg;
     }
     const int co_lane = m0 + wave_m * 64 + 4 * hi;
     const size_t off_lane = (size_t)co_lane * a.ldw;
+    if (!a.fx) {
 #pragma unroll
-    for (int i = 0; i < (TAIL ? 1 : 2); ++i)
+      for (int i = 0; i < (TAIL ? 1 : 2); ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int k = i * 32 + (r & 3) + 8 * (r >> 2);
-        if (co_lane + k < a.Cout) {
-          const size_t o = off_lane + (size_t)k * a.ldw;
+        for (int r = 0; r < 16; ++r) {
+          const int k = i * 32 + (r & 3) + 8 * (r >> 2);
+          if (co_lane + k < a.Cout) {
+            const size_t o = off_lane + (size_t)k * a.ldw;
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
-            if (j_ok[j]) atomicAdd(pj[j] + o, acc[i][j][r]);
+            for (int j = 0; j < 2; ++j)
+              if (j_ok[j]) atomicAdd(a.dw + cj[j] + o, acc[i][j][r]);
+          }
         }
-      }
+    } else {
+      unsigned long long* dwx = reinterpret_cast<unsigned long long*>(a.dw);
+#pragma unroll
+      for (int i = 0; i < (TAIL ? 1 : 2); ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k = i * 32 + (r & 3) + 8 * (r >> 2);
+          if (co_lane + k < a.Cout) {
+            const size_t o = off_lane + (size_t)k * a.ldw;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              if (j_ok[j]) atomicAdd(dwx + cj[j] + o, dm_to_fx(acc[i][j][r]));
+          }
+        }
+    }
   }
   if (TAIL) {
 #pragma unroll
@@ -240,7 +257,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       for (int i = 0; i < 4; ++i) {
         const float v = acct[j][i] + __shfl_xor(acct[j][i], 32, 64);      // the two k parities
         const int co = m0 + 32 + i;
-        if (hi == 0 && co < a.Cout && jg < Jtot) atomicAdd(a.dw + (size_t)co * a.ldw + a.coloff + jg, v);
+        if (hi == 0 && co < a.Cout && jg < Jtot) dm_acc_add(a.dw, (size_t)co * a.ldw + a.coloff + jg, v, a.fx != 0);
       }
     }
   }
@@ -266,6 +283,7 @@ struct WgradNarrowArgs {
   int ldw, coloff;
   int R, Wp, PL, LDA, bands, units, units_per_split, groups;
   unsigned magic_w2, magic_rr, magic_band;      // ceil(2^32 / d) for d = W/2, R + 2, R * W/2
+  int fx;
 };
 
 template <bool TAIL>
@@ -394,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3_narrow_kernel(WgradNarrowA
     const int co = i / (CG * 9), jj = i - co * (CG * 9);
     if (jj >= ncols) continue;
     const int cil = jj / 9, t = jj - cil * 9;
-    atomicAdd(a.dw + (size_t)co * a.ldw + a.coloff + (size_t)ci0 * 9 + jj, red[(t * MR + co) * 32 + cil]);
+    dm_acc_add(a.dw, (size_t)co * a.ldw + a.coloff + (size_t)ci0 * 9 + jj, red[(t * MR + co) * 32 + cil], a.fx != 0);
   }
 }
 
@@ -425,7 +443,7 @@ static int launch_wgrad3_narrow(const WgradArgs& g, hipStream_t st) {
   if ((long long)32 * (R + 2) * (g.W / 2) >= 65536 || (long long)g.Cout * R * (g.W / 2) >= 65536) return 1;   // magic-division range
   WgradNarrowArgs a;
   a.dy = g.dy; a.dy_bs = g.dy_bs; a.x = g.x; a.x_bs = g.x_bs; a.Cout = g.Cout; a.Cs = g.Cs; a.NB = g.NB; a.H = g.H; a.W = g.W;
-  a.HW = g.HW; a.dw = g.dw; a.ldw = g.ldw; a.coloff = g.coloff;
+  a.HW = g.HW; a.dw = g.dw; a.ldw = g.ldw; a.coloff = g.coloff; a.fx = g.fx;
   a.R = R; a.Wp = Wp; a.PL = PL; a.LDA = LDA; a.bands = nb; a.units = g.NB * nb; a.groups = dm_ceil_div(g.Cs, 32);
   a.magic_w2 = dm_magic(g.W / 2); a.magic_rr = dm_magic(R + 2); a.magic_band = dm_magic(R * (g.W / 2));
   const int target = 2 * dm_num_cus();
@@ -680,7 +698,7 @@ __device__ __forceinline__ void ps_coord(float lo, float hi, int i, int S, int s
 template <int CT>
 __global__ __launch_bounds__(256) void point_sample_bwd_kernel(const float* __restrict__ gout, int B, int C, int H, int W,
                                                                const float* __restrict__ rois, int N, int S, float scale,
-                                                               float* __restrict__ gfeat, int lds_elems) {
+                                                               float* __restrict__ gfeat, int lds_elems, int fixed) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long tile[];   // [CT][TH][TW] fixed point
   __shared__ int bad[CT];            // a NaN / Inf gradient cannot be represented in fixed point: it poisons its plane
   if (threadIdx.x < CT) bad[threadIdx.x] = 0;
@@ -707,7 +725,8 @@ __global__ __launch_bounds__(256) void point_sample_bwd_kernel(const float* __re
     __syncthreads();
   }
   const size_t plane = (size_t)H * W;
-  float* gf = gfeat + ((size_t)b * C + c0) * plane;
+  // fixed: gfeat is a 64-bit fixed-point map (dm_point_sample_bwd_fx); cell indices are the same, cells twice as wide
+  float* gf = gfeat + ((size_t)b * C + c0) * plane * (fixed ? 2 : 1);
   const int nch = min(CT, C - c0);
   for (int pos = threadIdx.x; pos < S * S; pos += blockDim.x) {
     const int iy = pos / S, ix = pos - iy * S;
@@ -743,11 +762,11 @@ __global__ __launch_bounds__(256) void point_sample_bwd_kernel(const float* __re
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
         if (c >= nch) break;
-        float* gc = gf + (size_t)c * plane;
-        if (okx0 && oky0) atomicAdd(gc + y0 * W + x0, gv[c] * w_nw);
-        if (okx1 && oky0) atomicAdd(gc + y0 * W + x1i, gv[c] * w_ne);
-        if (okx0 && oky1) atomicAdd(gc + y1i * W + x0, gv[c] * w_sw);
-        if (okx1 && oky1) atomicAdd(gc + y1i * W + x1i, gv[c] * w_se);
+        const size_t cb = (size_t)c * plane;
+        if (okx0 && oky0) dm_acc_add(gf, cb + y0 * W + x0, gv[c] * w_nw, fixed != 0);
+        if (okx1 && oky0) dm_acc_add(gf, cb + y0 * W + x1i, gv[c] * w_ne, fixed != 0);
+        if (okx0 && oky1) dm_acc_add(gf, cb + y1i * W + x0, gv[c] * w_sw, fixed != 0);
+        if (okx1 && oky1) dm_acc_add(gf, cb + y1i * W + x1i, gv[c] * w_se, fixed != 0);
       }
     }
   }
@@ -759,8 +778,13 @@ __global__ __launch_bounds__(256) void point_sample_bwd_kernel(const float* __re
       if (q != 0 || bad[c]) {
         const int rem = i - c * TH * TW;
         const int ty = rem / TW, tx = rem - ty * TW;
-        const float v = bad[c] ? __builtin_nanf("") : (float)((double)q * (1.0 / DM_FIX_SCALE));
-        atomicAdd(gf + (size_t)c * plane + (size_t)(fy0 + ty) * W + fx0 + tx, v);
+        const size_t cell = (size_t)c * plane + (size_t)(fy0 + ty) * W + fx0 + tx;
+        if (fixed) {      // the LDS sum is already exact in the same fixed-point format: hand it over as it is
+          atomicAdd(reinterpret_cast<unsigned long long*>(gf) + cell, bad[c] ? (unsigned long long)(1LL << 62) : (unsigned long long)q);
+        } else {
+          const float v = bad[c] ? __builtin_nanf("") : (float)((double)q * (1.0 / DM_FIX_SCALE));
+          atomicAdd(gf + cell, v);
+        }
       }
     }
   }
@@ -776,7 +800,7 @@ __global__ __launch_bounds__(256) void class_logits_bwd_kernel(const float* __re
                                                                const float* __restrict__ gi, const float* __restrict__ gd,
                                                                float* __restrict__ gx, int accumulate,
                                                                float* __restrict__ gwi, float* __restrict__ gbi,
-                                                               float* __restrict__ gwd, float* __restrict__ gbd) {
+                                                               float* __restrict__ gwd, float* __restrict__ gbd, int fx) {
   __shared__ float red[8];
   const int c = blockIdx.x, n = blockIdx.y;
   int lab = (int)labels[n];
@@ -805,8 +829,8 @@ __global__ __launch_bounds__(256) void class_logits_bwd_kernel(const float* __re
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(gwi + (size_t)lab * C + c, red[0] + red[1] + red[2] + red[3]);
-    atomicAdd(gwd + (size_t)lab * C + c, red[4] + red[5] + red[6] + red[7]);
+    dm_acc_add(gwi, (size_t)lab * C + c, red[0] + red[1] + red[2] + red[3], fx != 0);
+    dm_acc_add(gwd, (size_t)lab * C + c, red[4] + red[5] + red[6] + red[7], fx != 0);
   }
   if (c == 0) {   // bias gradient once per RoI
     __syncthreads();
@@ -818,8 +842,8 @@ __global__ __launch_bounds__(256) void class_logits_bwd_kernel(const float* __re
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-      atomicAdd(gbi + lab, red[0] + red[1] + red[2] + red[3]);
-      atomicAdd(gbd + lab, red[4] + red[5] + red[6] + red[7]);
+      dm_acc_add(gbi, lab, red[0] + red[1] + red[2] + red[3], fx != 0);
+      dm_acc_add(gbd, lab, red[4] + red[5] + red[6] + red[7], fx != 0);
     }
   }
 }
@@ -1173,19 +1197,52 @@ extern "C" int dm_channel_sum(const float* g, long long batch_stride, int NB, in
   const long long total = (long long)NB * HW;
   int splits = (int)min((long long)max(1, 2048 / C), (total + 1023) / 1024);
   splits = max(splits, 1);
-  DM_LAUNCH(channel_sum_kernel, dim3(C, splits), dim3(256), 0, st, g, batch_stride, NB, C, HW, out);
+  DM_LAUNCH(channel_sum_kernel, dim3(C, splits), dim3(256), 0, st, g, batch_stride, NB, C, HW, out, 0);
   return dm_check_launch();
 }
 
-extern "C" int dm_conv2d_wgrad(const float* dy, long long dy_batch_stride, int Cout, const float* x,
-                               long long x_batch_stride, int Cs, int NB, int H, int W, int ksize, float* dw, int ldw,
-                               int col_offset, dm_stream_t stream) {
+extern "C" int dm_channel_sum_fx(const float* g, long long batch_stride, int NB, int C, int HW, long long* out_fx,
+                                 dm_stream_t stream) {
+  if (!g || !out_fx || NB <= 0 || C <= 0 || HW <= 0) return DM_ERR_INVALID_ARG;
+  const long long total = (long long)NB * HW;
+  int splits = (int)min((long long)max(1, 2048 / C), (total + 1023) / 1024);
+  splits = max(splits, 1);
+  DM_LAUNCH(channel_sum_kernel, dim3(C, splits), dim3(256), 0, (hipStream_t)stream, g, batch_stride, NB, C, HW,
+            reinterpret_cast<float*>(out_fx), 1);
+  return dm_check_launch();
+}
+
+namespace {
+__global__ __launch_bounds__(256) void fx_to_float_kernel(long long* __restrict__ fx, long long n, float* __restrict__ out,
+                                                          int accumulate, int clear) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const long long q = fx[i];
+  const bool poisoned = q >= (1LL << 61) || q <= -(1LL << 61);
+  const float v = poisoned ? __builtin_nanf("") : (float)((double)q * (1.0 / DM_FX_ONE));
+  out[i] = accumulate ? out[i] + v : v;
+  if (clear) fx[i] = 0;
+}
+}  // namespace
+
+extern "C" int dm_fx_to_float(long long* fx, long long n, float* out, int accumulate, int clear, dm_stream_t stream) {
+  if (n < 0 || (n > 0 && (!fx || !out))) return DM_ERR_INVALID_ARG;
+  if (n == 0) return DM_OK;
+  DM_LAUNCH(fx_to_float_kernel, dim3((unsigned)dm_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, fx, n, out, accumulate,
+            clear);
+  return dm_check_launch();
+}
+
+static int conv2d_wgrad_impl(const float* dy, long long dy_batch_stride, int Cout, const float* x,
+                             long long x_batch_stride, int Cs, int NB, int H, int W, int ksize, float* dw, int ldw,
+                             int col_offset, int fx, dm_stream_t stream) {
   if (!dy || !x || !dw || Cout <= 0 || Cs <= 0 || NB <= 0 || H <= 0 || W <= 0 || (ksize != 1 && ksize != 3))
     return DM_ERR_INVALID_ARG;
   if ((long long)NB * H * W > 0x7fffffffLL) return DM_ERR_INVALID_ARG;
   WgradArgs a;
   a.dy = dy; a.dy_bs = dy_batch_stride; a.x = x; a.x_bs = x_batch_stride; a.Cout = Cout; a.Cs = Cs;
   a.NB = NB; a.H = H; a.W = W; a.HW = H * W; a.Q = NB * H * W; a.dw = dw; a.ldw = ldw; a.coloff = col_offset;
+  a.fx = fx;
   if (ksize == 3) {
     const int rc = launch_wgrad3_narrow(a, (hipStream_t)stream);
     if (rc < 0) return rc;
@@ -1194,6 +1251,19 @@ extern "C" int dm_conv2d_wgrad(const float* dy, long long dy_batch_stride, int C
     launch_wgrad<1>(a, (hipStream_t)stream);
   }
   return dm_check_launch();
+}
+
+extern "C" int dm_conv2d_wgrad(const float* dy, long long dy_batch_stride, int Cout, const float* x,
+                               long long x_batch_stride, int Cs, int NB, int H, int W, int ksize, float* dw, int ldw,
+                               int col_offset, dm_stream_t stream) {
+  return conv2d_wgrad_impl(dy, dy_batch_stride, Cout, x, x_batch_stride, Cs, NB, H, W, ksize, dw, ldw, col_offset, 0, stream);
+}
+
+extern "C" int dm_conv2d_wgrad_fx(const float* dy, long long dy_batch_stride, int Cout, const float* x,
+                                  long long x_batch_stride, int Cs, int NB, int H, int W, int ksize, long long* dw_fx,
+                                  int ldw, int col_offset, dm_stream_t stream) {
+  return conv2d_wgrad_impl(dy, dy_batch_stride, Cout, x, x_batch_stride, Cs, NB, H, W, ksize,
+                           reinterpret_cast<float*>(dw_fx), ldw, col_offset, 1, stream);
 }
 
 extern "C" int dm_upsample2x_bilinear_bwd(const float* grad_out, const float* fwd_out_for_relu, int NC, int H, int W,
@@ -1226,15 +1296,40 @@ extern "C" int dm_upsample2x_bilinear_bwd(const float* grad_out, const float* fw
   return dm_check_launch();
 }
 
-extern "C" int dm_point_sample_bwd(const float* grad_out, int B, int C, int H, int W, const float* rois, int N, int S,
-                                   float spatial_scale, float* grad_feat, dm_stream_t stream) {
+static int point_sample_bwd_impl(const float* grad_out, int B, int C, int H, int W, const float* rois, int N, int S,
+                                 float spatial_scale, float* grad_feat, int fx, dm_stream_t stream) {
   if (!grad_out || !rois || !grad_feat || B <= 0 || C <= 0 || H <= 0 || W <= 0 || N < 0 || S <= 0) return DM_ERR_INVALID_ARG;
   if (N == 0) return DM_OK;
   constexpr int CT = 4;
   const int lds_elems = 6144;                    // 48 KB of 64-bit accumulators
   DM_LAUNCH(point_sample_bwd_kernel<CT>, dim3((unsigned)dm_ceil_div(C, CT), (unsigned)N), dim3(256),
             (size_t)lds_elems * sizeof(unsigned long long), (hipStream_t)stream, grad_out, B, C, H, W, rois, N, S,
-            spatial_scale, grad_feat, lds_elems);
+            spatial_scale, grad_feat, lds_elems, fx);
+  return dm_check_launch();
+}
+
+extern "C" int dm_point_sample_bwd(const float* grad_out, int B, int C, int H, int W, const float* rois, int N, int S,
+                                   float spatial_scale, float* grad_feat, dm_stream_t stream) {
+  return point_sample_bwd_impl(grad_out, B, C, H, W, rois, N, S, spatial_scale, grad_feat, 0, stream);
+}
+
+extern "C" int dm_point_sample_bwd_fx(const float* grad_out, int B, int C, int H, int W, const float* rois, int N, int S,
+                                      float spatial_scale, long long* grad_feat_fx, dm_stream_t stream) {
+  return point_sample_bwd_impl(grad_out, B, C, H, W, rois, N, S, spatial_scale, reinterpret_cast<float*>(grad_feat_fx), 1,
+                               stream);
+}
+
+static int class_logits_bwd_impl(const float* x, int N, int C, int HW, const float* w_inst, const float* w_det,
+                                 int num_classes, const int64_t* labels, const float* grad_inst, const float* grad_det,
+                                 float* grad_x, int accumulate_x, float* grad_w_inst, float* grad_b_inst,
+                                 float* grad_w_det, float* grad_b_det, int fx, dm_stream_t stream) {
+  if (!x || !w_inst || !w_det || !labels || !grad_inst || !grad_det || !grad_x || !grad_w_inst || !grad_b_inst ||
+      !grad_w_det || !grad_b_det)
+    return DM_ERR_INVALID_ARG;
+  if (N < 0 || C <= 0 || HW <= 0 || num_classes <= 0) return DM_ERR_INVALID_ARG;
+  if (N == 0) return DM_OK;
+  DM_LAUNCH(class_logits_bwd_kernel, dim3(C, N), dim3(256), 0, (hipStream_t)stream, x, N, C, HW, w_inst, w_det, num_classes,
+            labels, grad_inst, grad_det, grad_x, accumulate_x, grad_w_inst, grad_b_inst, grad_w_det, grad_b_det, fx);
   return dm_check_launch();
 }
 
@@ -1242,14 +1337,18 @@ extern "C" int dm_class_logits_bwd(const float* x, int N, int C, int HW, const f
                                    int num_classes, const int64_t* labels, const float* grad_inst, const float* grad_det,
                                    float* grad_x, int accumulate_x, float* grad_w_inst, float* grad_b_inst,
                                    float* grad_w_det, float* grad_b_det, dm_stream_t stream) {
-  if (!x || !w_inst || !w_det || !labels || !grad_inst || !grad_det || !grad_x || !grad_w_inst || !grad_b_inst ||
-      !grad_w_det || !grad_b_det)
-    return DM_ERR_INVALID_ARG;
-  if (N < 0 || C <= 0 || HW <= 0 || num_classes <= 0) return DM_ERR_INVALID_ARG;
-  if (N == 0) return DM_OK;
-  DM_LAUNCH(class_logits_bwd_kernel, dim3(C, N), dim3(256), 0, (hipStream_t)stream, x, N, C, HW, w_inst, w_det, num_classes,
-            labels, grad_inst, grad_det, grad_x, accumulate_x, grad_w_inst, grad_b_inst, grad_w_det, grad_b_det);
-  return dm_check_launch();
+  return class_logits_bwd_impl(x, N, C, HW, w_inst, w_det, num_classes, labels, grad_inst, grad_det, grad_x, accumulate_x,
+                               grad_w_inst, grad_b_inst, grad_w_det, grad_b_det, 0, stream);
+}
+
+extern "C" int dm_class_logits_bwd_fx(const float* x, int N, int C, int HW, const float* w_inst, const float* w_det,
+                                      int num_classes, const int64_t* labels, const float* grad_inst,
+                                      const float* grad_det, float* grad_x, int accumulate_x, long long* grad_w_inst_fx,
+                                      long long* grad_b_inst_fx, long long* grad_w_det_fx, long long* grad_b_det_fx,
+                                      dm_stream_t stream) {
+  return class_logits_bwd_impl(x, N, C, HW, w_inst, w_det, num_classes, labels, grad_inst, grad_det, grad_x, accumulate_x,
+                               reinterpret_cast<float*>(grad_w_inst_fx), reinterpret_cast<float*>(grad_b_inst_fx),
+                               reinterpret_cast<float*>(grad_w_det_fx), reinterpret_cast<float*>(grad_b_det_fx), 1, stream);
 }
 
 extern "C" int dm_deform_im2col(const float* x, const float* offset, int NB, int C, int H, int W, int deform_groups,

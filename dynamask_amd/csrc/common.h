@@ -60,5 +60,20 @@ static inline int dm_ensure_lds_limit(const void* kernel, int bytes, bool* flags
   return DM_OK;
 }
 
+// ---- order-independent accumulation (deterministic mode; dynamask_hip.h "Deterministic accumulation") ----
+// The *_fx entry points add into 64-bit fixed-point cells (value * 2^36, two's complement through the u64 atomic)
+// instead of float cells: integer addition is associative, so the sum does not depend on the order in which
+// workgroups arrive.  A non-finite addend becomes 2^62 (dm_fx_to_float turns any |cell| >= 2^61 into NaN).
+#define DM_FX_ONE 68719476736.0 /* 2^36 */
+__device__ __forceinline__ unsigned long long dm_to_fx(float v) {
+  const long long q = __builtin_isfinite(v) ? __double2ll_rn((double)v * DM_FX_ONE) : (1LL << 62);
+  return (unsigned long long)q;
+}
+// accumulate v into cell idx of an accumulator that is float (fx = false) or 64-bit fixed point (fx = true)
+__device__ __forceinline__ void dm_acc_add(float* base, size_t idx, float v, bool fx) {
+  if (fx) atomicAdd(reinterpret_cast<unsigned long long*>(base) + idx, dm_to_fx(v));
+  else atomicAdd(base + idx, v);
+}
+
 typedef float dm_f32x16 __attribute__((ext_vector_type(16)));
 typedef float dm_f32x4 __attribute__((ext_vector_type(4)));

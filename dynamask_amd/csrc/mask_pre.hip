@@ -281,22 +281,22 @@ __global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(const float* __re
   }
 }
 
-// The same scatter with the plane staged in LDS (round 2).  The kernel above reads the 9 window taps of every
-// pooled output from global memory (recomputing BatchNorm's affine per tap), adds with global float atomics
-// into a zero-filled g_z and needs a memset of the whole tensor first: 0.59 ms per step.  Here a workgroup takes
-// one (image, channel) plane at a time: z = relu(bn(x)) is staged once with 16-byte loads, the pooled
-// gradients are scattered into an LDS gradient plane and the plane is written out whole (no memset, no global
-// atomics).  LDS float atomics are slow (0.38 per clock and CU) but there is only one per pooled output.
-// Needs H*W % 4 == 0 and 2 planes of H*W floats in LDS.
+// The same routing with the plane staged in LDS, in gather form (round 3; round 2 scattered with LDS float atomics).
+// A workgroup takes one (image, channel) plane at a time: z = relu(bn(x)) is staged once with 16-byte loads; every
+// pooled output records which tap it took (arg) and its gradient (val) in LDS; then every INPUT pixel adds the
+// gradients of the <= 4 windows that contain it and chose it, in a fixed order (window row, then column) -- no
+// atomics, no memset, and the sum has the same bits on every run.  The plane leaves as 16-byte stores.
+// Needs H*W % 4 == 0; LDS: H*W floats + OH*OW (int, float) pairs.
 __global__ __launch_bounds__(256) void maxpool_relu_bwd_lds_kernel(const float* __restrict__ x, int NB, int C, int H, int W,
                                                                    const float* __restrict__ mean, const float* __restrict__ var,
                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                    float eps, const float* __restrict__ gout,
                                                                    float* __restrict__ gz, int OH, int OW) {
-  extern __shared__ __attribute__((aligned(16))) float pl[];       // z plane [HW], then g_z plane [HW]
+  extern __shared__ __attribute__((aligned(16))) float pl[];       // z plane [HW], arg [OHW], val [OHW]
   const int HW = H * W, OHW = OH * OW;
   float* zp = pl;
-  float* gp = pl + HW;
+  int* argp = reinterpret_cast<int*>(pl + HW);
+  float* valp = pl + HW + OHW;
   for (int nc = blockIdx.x; nc < NB * C; nc += gridDim.x) {
     const int c = nc % C;
     const float invstd = 1.0f / sqrtf(var[c] + eps);
@@ -308,7 +308,6 @@ __global__ __launch_bounds__(256) void maxpool_relu_bwd_lds_kernel(const float* 
 #pragma unroll
       for (int e = 0; e < 4; ++e) z[e] = fmaxf((v[e] - m) * invstd * g + b, 0.f);      // the expression of the kernel above
       reinterpret_cast<dm_f32x4*>(zp)[i] = z;
-      reinterpret_cast<dm_f32x4*>(gp)[i] = dm_f32x4{0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
     for (int o = threadIdx.x; o < OHW; o += 256) {
@@ -330,11 +329,30 @@ __global__ __launch_bounds__(256) void maxpool_relu_bwd_lds_kernel(const float* 
           }
         }
       }
-      if (bi >= 0 && best > 0.f) atomicAdd(gp + bi, gout[(size_t)nc * OHW + o]);
+      argp[o] = best > 0.f ? bi : -1;          // a zero maximum passes no gradient (ReLU)
+      valp[o] = gout[(size_t)nc * OHW + o];
     }
     __syncthreads();
     dm_f32x4* o4 = reinterpret_cast<dm_f32x4*>(gz + (size_t)nc * HW);
-    for (int i = threadIdx.x; i < HW / 4; i += 256) o4[i] = reinterpret_cast<const dm_f32x4*>(gp)[i];
+    for (int i = threadIdx.x; i < HW / 4; i += 256) {
+      dm_f32x4 r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int p = 4 * i + e;
+        const int y = p / W, xx = p - y * W;
+        // windows containing (y, xx): rows (y - 1 + 1) / 2 .. (y + 1) / 2, i.e. one for even y, two for odd
+        const int oy0 = y >> 1, oy1 = min((y + 1) >> 1, OH - 1);
+        const int ox0 = xx >> 1, ox1 = min((xx + 1) >> 1, OW - 1);
+        float acc = 0.f;
+        for (int oy = oy0; oy <= oy1; ++oy)
+          for (int ox = ox0; ox <= ox1; ++ox) {
+            const int o = oy * OW + ox;
+            if (argp[o] == p) acc += valp[o];
+          }
+        r[e] = acc;
+      }
+      o4[i] = r;
+    }
     __syncthreads();
   }
 }
@@ -442,9 +460,10 @@ extern "C" int dm_bn_relu_maxpool_bwd(const float* x, int NB, int C, int H, int 
   const size_t total = (size_t)NB * C * OH * OW;
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if ((H * W) % 4 == 0 && (size_t)H * W * 8 <= 64 * 1024) {
+  const size_t plane_lds = ((size_t)H * W + 2 * (size_t)OH * OW) * 4;
+  if ((H * W) % 4 == 0 && plane_lds <= 64 * 1024) {
     const int blocks = min(NB * C, 16 * dm_num_cus());
-    DM_LAUNCH(maxpool_relu_bwd_lds_kernel, dim3(blocks), dim3(256), (size_t)H * W * 8, st, x, NB, C, H, W, mean, var, gamma, beta,
+    DM_LAUNCH(maxpool_relu_bwd_lds_kernel, dim3(blocks), dim3(256), plane_lds, st, x, NB, C, H, W, mean, var, gamma, beta,
               eps, grad_out, grad_x, OH, OW);
     rc = dm_check_launch();
   } else {

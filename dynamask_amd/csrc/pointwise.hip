@@ -362,12 +362,14 @@ __global__ __launch_bounds__(256) void detail_target_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------ K12
-// grid = (pixel blocks, N).  sums[0] += BCE-with-logits sum, sums[1] += weighted
-// eps-BCE sum; per_roi[n] += un-weighted eps-BCE sum of RoI n.
+// grid = (pixel blocks, N).  Each workgroup leaves its two partial sums in part[(n * gridDim.x + block) * 2 ..]:
+// BCE-with-logits, un-weighted eps-BCE.  mask_loss_finish_kernel adds them in a fixed order (round 3; round 2 added
+// with float atomics, whose order -- and with it the last bits of the loss and of d loss / d mask_labels -- changed
+// from run to run).
 __global__ __launch_bounds__(256) void mask_loss_kernel(const float* __restrict__ ip, const float* __restrict__ dp,
                                                         const float* __restrict__ it, const float* __restrict__ dt,
                                                         const float* __restrict__ weight, int N, int HW,
-                                                        float* __restrict__ sums, float* __restrict__ per_roi,
+                                                        float* __restrict__ part,
                                                         float* __restrict__ gi, float* __restrict__ gd) {
   __shared__ float red[16];
   const int n = blockIdx.y;
@@ -392,10 +394,36 @@ __global__ __launch_bounds__(256) void mask_loss_kernel(const float* __restrict_
   const float b = block_sum(s_bce, red);
   const float d = block_sum(s_det, red);
   if (threadIdx.x == 0) {
-    atomicAdd(&sums[0], b);
-    atomicAdd(&sums[1], w * d);
-    if (per_roi) atomicAdd(&per_roi[n], d);
+    part[((size_t)n * gridDim.x + blockIdx.x) * 2] = b;
+    part[((size_t)n * gridDim.x + blockIdx.x) * 2 + 1] = d;
   }
+}
+
+// one workgroup: per_roi[n] = its blocks' eps-BCE partials in block order; sums[0] += sum_n BCE, sums[1] += sum_n w*d,
+// RoIs dealt to the threads by stride and the threads' sums added by a fixed tree
+__global__ __launch_bounds__(256) void mask_loss_finish_kernel(const float* __restrict__ part, const float* __restrict__ weight,
+                                                               int N, int pb, float* __restrict__ sums,
+                                                               float* __restrict__ per_roi) {
+  __shared__ float sa[256], sb[256];
+  const int t = threadIdx.x;
+  float xa = 0.f, xb = 0.f;
+  for (int n = t; n < N; n += 256) {
+    float b = 0.f, d = 0.f;
+    for (int j = 0; j < pb; ++j) {
+      b += part[((size_t)n * pb + j) * 2];
+      d += part[((size_t)n * pb + j) * 2 + 1];
+    }
+    if (per_roi) per_roi[n] += d;
+    xa += b;
+    xb += weight[n] * d;
+  }
+  sa[t] = xa; sb[t] = xb;
+  __syncthreads();
+  for (int s2 = 128; s2 > 0; s2 >>= 1) {
+    if (t < s2) { sa[t] += sa[t + s2]; sb[t] += sb[t + s2]; }
+    __syncthreads();
+  }
+  if (t == 0) { sums[0] += sa[0]; sums[1] += sb[0]; }
 }
 
 // nearest x2 (nn.Upsample(scale_factor=2, mode='nearest'), FCNMaskHead upsample_cfg type 'nearest',
@@ -517,18 +545,24 @@ extern "C" int dm_detail_target(const float* masks, int N, int S, float fuse0, f
   return dm_check_launch();
 }
 
+extern "C" long long dm_mask_loss_scratch_floats(int N) { return N >= 0 ? (long long)N * 16 : -1; }
+
 extern "C" int dm_mask_loss_fwd_bwd(const float* inst_pred, const float* det_pred, const float* inst_tgt,
                                     const float* det_tgt, const float* weight, int N, int HW, float* sums,
-                                    float* per_roi_det, float* grad_inst, float* grad_det, dm_stream_t stream) {
-  if (!inst_pred || !det_pred || !inst_tgt || !det_tgt || !weight || !sums || N < 0 || HW <= 0)
+                                    float* per_roi_det, float* grad_inst, float* grad_det, float* scratch,
+                                    dm_stream_t stream) {
+  if (!inst_pred || !det_pred || !inst_tgt || !det_tgt || !weight || !sums || !scratch || N < 0 || HW <= 0)
     return DM_ERR_INVALID_ARG;
   if (N == 0) return DM_OK;
-  // every workgroup ends in two float atomics on the SAME two addresses, which the memory side serialises (about
-  // 10 ns each: 8 x 256 workgroups cost 40 us for 13 MB of logits): as few workgroups per RoI as still fill the chip
+  // as few workgroups per RoI as still fill the chip (at most 8: the scratch holds 8 pairs per RoI)
   int pb = min(dm_ceil_div(HW, 256), 8);
   while (pb > 1 && (long long)N * (pb / 2) >= dm_num_cus()) pb /= 2;
   DM_LAUNCH(mask_loss_kernel, dim3(pb, N), dim3(256), 0, (hipStream_t)stream, inst_pred, det_pred, inst_tgt,
-                     det_tgt, weight, N, HW, sums, per_roi_det, grad_inst, grad_det);
+                     det_tgt, weight, N, HW, scratch, grad_inst, grad_det);
+  int rc = dm_check_launch();
+  if (rc != DM_OK) return rc;
+  DM_LAUNCH(mask_loss_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, weight, N, pb, sums,
+            per_roi_det);
   return dm_check_launch();
 }
 

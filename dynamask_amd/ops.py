@@ -11,9 +11,25 @@ import torch
 from ._lib import check, lib
 
 
+import os
+
 # bumped whenever a kernel rewrites parameter memory behind torch's back (the fused
 # SGD step), so that packed-weight caches refresh
 WEIGHT_EPOCH = [0]
+
+# DM_DETERMINISTIC=1 (or setting this flag): every cross-workgroup accumulation of the training step goes through
+# the *_fx entry points (64-bit fixed-point cells, order-independent) and is converted once: two runs of a training
+# loop give bit-identical parameters.  Costs one zero-fill and one conversion per accumulated tensor.
+DETERMINISTIC = [os.environ.get('DM_DETERMINISTIC', '0') == '1']
+
+
+def _fx_like(t):
+    return torch.zeros(t.shape, device=t.device, dtype=torch.int64)
+
+
+def _fx_finish(fx, out, accumulate):
+    check(lib().dm_fx_to_float(_p(fx), fx.numel(), _p(out), 1 if accumulate else 0, 0, _stream()), 'dm_fx_to_float')
+    return out
 
 
 def _stream():
@@ -463,8 +479,9 @@ def mask_loss(inst_pred, det_pred, inst_tgt, det_tgt, weight, need_grad=True):
     per_roi = torch.zeros((N,), device=inst_pred.device, dtype=torch.float32)
     gi = torch.empty_like(inst_pred) if need_grad else None
     gd = torch.empty_like(det_pred) if need_grad else None
+    scratch = torch.empty((max(16 * N, 1),), device=inst_pred.device, dtype=torch.float32)
     check(lib().dm_mask_loss_fwd_bwd(_p(inst_pred), _p(det_pred), _p(inst_tgt), _p(det_tgt), _p(weight), N, HW,
-                                     _p(sums), _p(per_roi), _p(gi), _p(gd), _stream()), 'dm_mask_loss_fwd_bwd')
+                                     _p(sums), _p(per_roi), _p(gi), _p(gd), _p(scratch), _stream()), 'dm_mask_loss_fwd_bwd')
     return sums, per_roi, gi, gd
 
 
@@ -565,6 +582,10 @@ def channel_sum(g, out=None):
     acc = out is not None
     if out is None:
         out = torch.empty((C,), device=g.device, dtype=torch.float32)
+    if DETERMINISTIC[0]:
+        fx = _fx_like(out)
+        check(lib().dm_channel_sum_fx(_p(g), g.stride(0), NB, C, H * W, _p(fx), _stream()), 'dm_channel_sum_fx')
+        return _fx_finish(fx, out, acc)
     check(lib().dm_channel_sum(_p(g), g.stride(0), NB, C, H * W, _p(out), 1 if acc else 0, _stream()), 'dm_channel_sum')
     return out
 
@@ -577,16 +598,23 @@ def conv2d_wgrad(dy, srcs, ksize, dw=None):
     srcs = [_chk_src(s) for s in srcs]
     NB, Cout, H, W = dy.shape
     cin = sum(s.shape[1] for s in srcs)
+    det = DETERMINISTIC[0]
     if dw is None:
-        dw = torch.zeros((Cout, cin, ksize, ksize), device=dy.device, dtype=torch.float32)
+        dw = (torch.empty if det else torch.zeros)((Cout, cin, ksize, ksize), device=dy.device, dtype=torch.float32)
+        acc = False
     else:
         _chk(dw, 'dw')
         assert dw.shape == (Cout, cin, ksize, ksize)
+        acc = True
+    fx = _fx_like(dw) if det else None
+    fn = lib().dm_conv2d_wgrad_fx if det else lib().dm_conv2d_wgrad
     base = 0
     for s in srcs:
-        check(lib().dm_conv2d_wgrad(_p(dy), dy.stride(0), Cout, _p(s), s.stride(0), s.shape[1], NB, H, W, ksize, _p(dw),
-                                    cin * ksize * ksize, base * ksize * ksize, _stream()), 'dm_conv2d_wgrad')
+        check(fn(_p(dy), dy.stride(0), Cout, _p(s), s.stride(0), s.shape[1], NB, H, W, ksize, _p(fx if det else dw),
+                 cin * ksize * ksize, base * ksize * ksize, _stream()), 'dm_conv2d_wgrad')
         base += s.shape[1]
+    if det:
+        _fx_finish(fx, dw, acc)
     return dw
 
 
@@ -606,6 +634,14 @@ def point_sample_backward(grad_out, feat_shape, rois, spatial_scale, grad_feat=N
     _chk(rois, 'rois')
     B, C, H, W = feat_shape
     N, _, S, _ = grad_out.shape
+    if DETERMINISTIC[0]:
+        acc = grad_feat is not None
+        if grad_feat is None:
+            grad_feat = torch.empty(feat_shape, device=grad_out.device, dtype=torch.float32)
+        fx = _fx_like(grad_feat)
+        check(lib().dm_point_sample_bwd_fx(_p(grad_out), B, C, H, W, _p(rois), N, S, spatial_scale, _p(fx), _stream()),
+              'dm_point_sample_bwd_fx')
+        return _fx_finish(fx, grad_feat, acc)
     if grad_feat is None:
         grad_feat = torch.zeros(feat_shape, device=grad_out.device, dtype=torch.float32)
     check(lib().dm_point_sample_bwd(_p(grad_out), B, C, H, W, _p(rois), N, S, spatial_scale, _p(grad_feat), _stream()),
@@ -620,6 +656,15 @@ def class_logits_backward(x, w_inst, w_det, labels, g_inst, g_det, grad_x, accum
     _chk(labels, 'labels', torch.int64)
     N, C, H, W = x.shape
     nc = w_inst.shape[0]
+    if DETERMINISTIC[0]:
+        outs = (gw_inst, gb_inst, gw_det, gb_det)
+        fxs = [_fx_like(t) for t in outs]
+        check(lib().dm_class_logits_bwd_fx(_p(x), N, C, H * W, _p(w_inst), _p(w_det), nc, _p(labels), _p(g_inst), _p(g_det),
+                                           _p(grad_x), 1 if accumulate_x else 0, *[_p(f) for f in fxs], _stream()),
+              'dm_class_logits_bwd_fx')
+        for f, t in zip(fxs, outs):
+            _fx_finish(f, t, True)
+        return grad_x
     check(lib().dm_class_logits_bwd(_p(x), N, C, H * W, _p(w_inst), _p(w_det), nc, _p(labels), _p(g_inst), _p(g_det),
                                     _p(grad_x), 1 if accumulate_x else 0, _p(gw_inst), _p(gb_inst), _p(gw_det), _p(gb_det),
                                     _stream()), 'dm_class_logits_bwd')

@@ -48,7 +48,7 @@ extern "C" {
 typedef void* dm_stream_t; /* hipStream_t */
 
 const char* dm_error_string(int code);
-/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, deterministic weight gradients (dm_conv2d_wgrad flag bit 2 + scratch)). */
+/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch). */
 int dm_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -236,9 +236,12 @@ int dm_detail_target(const float* masks, int N, int S, float fuse0, float fuse1,
  * grad_inst / grad_det (optional): d sums[0]/d inst_pred, d(eps-BCE)/d det_pred
  *   scaled by weight[n]; the host applies the scalar normalisers.
  * ------------------------------------------------------------------------- */
+/* scratch: dm_mask_loss_scratch_floats(N) floats (per-workgroup partial sums, added in a fixed order: the loss and
+ * d loss / d weight have the same bits on every run). */
+long long dm_mask_loss_scratch_floats(int N);
 int dm_mask_loss_fwd_bwd(const float* inst_pred, const float* det_pred, const float* inst_tgt,
                          const float* det_tgt, const float* weight, int N, int HW, float* sums,
-                         float* per_roi_det, float* grad_inst, float* grad_det, dm_stream_t stream);
+                         float* per_roi_det, float* grad_inst, float* grad_det, float* scratch, dm_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * K9  resolution predictor MaskPre (roi_heads/base_roi_head.py:10-27): BatchNorm
@@ -525,6 +528,34 @@ int dm_clip_scale(float* x, long long count, const float* sumsq, float max_norm,
 /* x *= factor: a parameter group's gradient scale (the reference's optional OptimizerHook_ multiplies the
  * gradients of roi_head.mask_predictor by 0.05 between clipping and the step, OptimizerHook.py:27-29). */
 int dm_scale(float* x, long long count, float factor, dm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Deterministic accumulation (SURVEY 7 "hard parts": a deterministic mode for parity tests; the
+ * reference's weight gradient is a deterministic addmm_, mmdet/ops/dcn/src/deform_conv_cuda.cpp:460-465).
+ * The entry points above that accumulate across workgroups -- dm_conv2d_wgrad, dm_channel_sum,
+ * dm_class_logits_bwd (its four parameter gradients), dm_point_sample_bwd -- add with float atomics, so the
+ * last bits of their sums depend on the order in which workgroups arrive.  Each has an *_fx twin with the
+ * same arguments whose accumulation target is a buffer of 64-bit FIXED-POINT cells (value * 2^36, two's
+ * complement; same indexing as the float target, the caller zero-fills it): integer addition is associative,
+ * so the sum is exact in that format and identical on every run.  dm_fx_to_float converts
+ * (out[i] (+)= fx[i] * 2^-36, NaN for a cell that received a non-finite addend; `clear` re-zeroes fx).
+ * Range: |sum| < 3.3e7 per cell, resolution 1.5e-11 -- far outside what gradients of this path reach.
+ * Everything else in the training step is deterministic by construction (fixed-order partial sums, LDS
+ * fixed-point scatter, gather-form adjoints) except dm_roi_align_bwd (float atomics into the FPN-map
+ * gradients, as in the reference's RoIAlign backward).  The host switch is DM_DETERMINISTIC=1
+ * (dynamask_amd.ops.DETERMINISTIC).
+ * ------------------------------------------------------------------------------------------ */
+int dm_conv2d_wgrad_fx(const float* dy, long long dy_batch_stride, int Cout, const float* x, long long x_batch_stride,
+                       int Cs, int NB, int H, int W, int ksize, long long* dw_fx, int ldw, int col_offset,
+                       dm_stream_t stream);
+int dm_channel_sum_fx(const float* g, long long batch_stride, int NB, int C, int HW, long long* out_fx, dm_stream_t stream);
+int dm_class_logits_bwd_fx(const float* x, int N, int C, int HW, const float* w_inst, const float* w_det, int num_classes,
+                           const int64_t* labels, const float* grad_inst, const float* grad_det, float* grad_x,
+                           int accumulate_x, long long* grad_w_inst_fx, long long* grad_b_inst_fx,
+                           long long* grad_w_det_fx, long long* grad_b_det_fx, dm_stream_t stream);
+int dm_point_sample_bwd_fx(const float* grad_out, int B, int C, int H, int W, const float* rois, int N, int S,
+                           float spatial_scale, long long* grad_feat_fx, dm_stream_t stream);
+int dm_fx_to_float(long long* fx, long long n, float* out, int accumulate, int clear, dm_stream_t stream);
 
 #ifdef __cplusplus
 }

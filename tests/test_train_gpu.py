@@ -299,6 +299,54 @@ def test_training_step_on_side_streams_matches_the_single_stream_step(monkeypatc
     torch.testing.assert_close(pa, pb, atol=2e-6, rtol=1e-4)
 
 
+def test_deterministic_mode_gives_bit_identical_training_runs(monkeypatch):
+    """DM_DETERMINISTIC (ops.DETERMINISTIC): every cross-workgroup accumulation of the step goes through 64-bit
+    fixed-point cells, so two runs of a 2-step training loop at the benchmark's size -- and a third one without the
+    side streams -- end in torch.equal parameters, losses and gradients.  The default mode (float atomics) agrees with
+    it to the usual last-bit noise."""
+    from dynamask_amd import ops, synth, registry, roi_head, mask_heads, roi_extractors, losses  # noqa: F401
+    from dynamask_amd.dist import FlatParamGroup, mask_path_parameters
+    dev = torch.device('cuda')
+    B, per, H, W = 2, 128, 800, 1333
+    feats = [f.to(dev) for f in synth.make_fpn(B, H, W, 256, seed=10)]
+    rois = synth.make_rois(B, per, H, W, seed=11).to(dev)
+    labels = synth.make_labels(B * per, seed=12).to(dev)
+    targets = [t.to(dev) for t in synth.make_targets(B * per, seed=13)]
+    noise = synth.make_gumbel_noise(B * per, seed=14).to(dev)
+
+    def run(det, side=True):
+        monkeypatch.setenv('DM_TRAIN_SIDE_STREAM', '1' if side else '0')
+        monkeypatch.setitem(ops.DETERMINISTIC, 0, det)
+        m = registry.build_head(dict(type='DynaMaskRoIHead',
+                                     mask_roi_extractor=dict(type='SingleRoIExtractor', **gi.MASK_ROI_EXTRACTOR_CFG),
+                                     mask_head=dict(type='DynaMaskHead', **gi.MASK_HEAD_CFG)))
+        m.load_state_dict({**synth.init_dynamask_head_state(seed=5), **synth.init_mask_pre_state(seed=6)}, strict=True)
+        m = m.to(dev).train()
+        grp = FlatParamGroup(mask_path_parameters(m))
+        out = []
+        for _ in range(2):
+            grp.zero_grad()
+            res = m._mask_forward_train(feats, rois, labels, targets, noise=noise)
+            res['loss_mask']['loss_masks'].backward()
+            out.append((res['loss_mask']['loss_masks'].detach().clone(), grp.flat_grad.clone()))
+            grp.all_reduce_async()
+            grp.sgd_step(lr=0.02, momentum=0.9, weight_decay=1e-4)
+        torch.cuda.synchronize()
+        return out, grp.flat_param.clone()
+    a, pa = run(True)
+    b, pb = run(True)
+    c, pc = run(True, side=False)
+    for x, px, what in ((b, pb, 'second run'), (c, pc, 'run without side streams')):
+        for s in range(2):
+            assert torch.equal(a[s][0], x[s][0]), f'{what}: loss of step {s}'
+            assert torch.equal(a[s][1], x[s][1]), f'{what}: gradients of step {s}'
+        assert torch.equal(pa, px), f'{what}: parameters'
+    d, pd = run(False)
+    scale = float(a[0][1].abs().max())
+    assert float((a[0][1] - d[0][1]).abs().max()) <= 2e-5 * scale
+    torch.testing.assert_close(pa, pd, atol=2e-6, rtol=1e-4)
+
+
 def test_assigner_ignore_regions_match_reference_golden(golden_dir):
     """MaxIoUAssigner with gt_bboxes_ignore (max_iou_assigner.py:107-118) on the device against the reference's own
     assigner (g13): indices and labels bit-exact, both IoF conventions; without regions nothing is ignored."""
