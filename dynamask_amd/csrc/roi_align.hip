@@ -30,7 +30,30 @@ struct RoiArgs {
   int32_t* levels;
   int CT;              // channels per workgroup
   int lds_floats;      // forward: LDS budget of the footprint tile (0 = direct global path)
+  int order;           // forward tile / band kernels: 0 = workgroup b -> (RoI b / chunks, chunk b % chunks);
+                       // 1 = XCD-aware (see roi_unit)
 };
+
+// Which (RoI, channel chunk) a workgroup of the forward tile / band kernels takes.
+// Workgroups are dealt round-robin to the 8 XCDs (b % 8), each with its own 4 MB L2.  In the plain order the
+// chunks of one RoI sit side by side, so at any time every XCD is reading ALL the channels it owns of many RoIs:
+// with 32 channels per chunk that is 8 channel quads x 1.4 MB of pyramid per XCD, and the staging reads of the
+// RoIs that overlap (each map pixel is wanted by ~10 RoIs) miss the L2 and go out to the fabric again.  Order 1
+// gives XCD x the chunks c with c % 8 == x and walks them chunk-major (all RoIs of a chunk before the next chunk):
+// what an XCD reads at any time is one or two chunks' planes, which stay in its L2 across the RoIs, and no plane is
+// fetched by more than one XCD.  Placement (b % 8) is a speed assumption only; any mapping gives the same results.
+__device__ __forceinline__ void roi_unit(const RoiArgs& a, int chunks, int& k, int& chunk) {
+  const int b = blockIdx.x;
+  if (a.order == 1) {
+    const int x = b & 7, j = b >> 3;          // chunks % 8 == 0 (checked by the launcher)
+    const int lc = j / a.N;
+    k = j - lc * a.N;
+    chunk = lc * 8 + x;
+  } else {
+    k = b / chunks;
+    chunk = b - k * chunks;
+  }
+}
 
 // One sample coordinate along an axis -> (low index, high index, w_low, w_high).
 // mmcv bilinear_interpolate rules: c < -1 or c > size -> void sample; clamp to
@@ -592,8 +615,8 @@ __device__ __forceinline__ void roi_tile_fwd(const RoiArgs& a, const float* __re
 __global__ __launch_bounds__(256, 4) void roi_align_tile_kernel(RoiArgs a) {
   extern __shared__ __attribute__((aligned(16))) float4 lds4[];
   const int chunks = (a.C + a.CT - 1) / a.CT;
-  const int k = blockIdx.x / chunks;
-  const int chunk = blockIdx.x - k * chunks;
+  int k, chunk;
+  roi_unit(a, chunks, k, chunk);
   const int c0 = chunk * a.CT;
   const int c1 = min(c0 + a.CT, a.C);
   const float* r = a.rois + (size_t)k * 5;
@@ -828,8 +851,8 @@ __device__ __forceinline__ void roi_band_fwd(const RoiArgs& a, const float* __re
 __global__ __launch_bounds__(256, 4) void roi_align_band_kernel(RoiArgs a) {
   extern __shared__ __attribute__((aligned(16))) float4 lds4[];
   const int chunks = (a.C + a.CT - 1) / a.CT;
-  const int k = blockIdx.x / chunks;
-  const int chunk = blockIdx.x - k * chunks;
+  int k, chunk;
+  roi_unit(a, chunks, k, chunk);
   const int c0 = chunk * a.CT;
   const int c1 = min(c0 + a.CT, a.C);
   const float* r = a.rois + (size_t)k * 5;
@@ -915,6 +938,7 @@ int fill_args(RoiArgs& a, const int* H, const int* W, const float* spatial_scale
   // channels per workgroup: enough workgroups to fill 256 CUs several times over
   a.CT = (P * P >= 1024) ? 4 : 16;
   a.lds_floats = 0;
+  a.order = 0;
   a.out = nullptr; a.gout = nullptr; a.levels = nullptr;
   return DM_OK;
 }
@@ -942,7 +966,10 @@ extern "C" int dm_roi_align_fwd(const float* const* feats, const int* H, const i
     // 32 channels per workgroup (swept 16 .. 256 at 128 .. 2048 RoIs): more channels amortise the
     // per-workgroup setup, fewer shorten the chain of dependent staging batches of the large RoIs
     a.CT = 32;
-    const int chunks = dm_ceil_div(C, a.CT);
+    if (const char* e = getenv("DM_ROI_CT")) a.CT = max(4, atoi(e) & ~3);          // tuning knobs (experiments)
+    int chunks = dm_ceil_div(C, a.CT);
+    if (const char* e = getenv("DM_ROI_ORDER")) a.order = atoi(e);
+    if (chunks % 8 != 0) a.order = 0;
     DM_LAUNCH(roi_align_tile_kernel, dim3(N * chunks), dim3(256), (kTileFloats4 + 64) * sizeof(float4), (hipStream_t)stream, a);
     return dm_check_launch();
   }
@@ -953,7 +980,10 @@ extern "C" int dm_roi_align_fwd(const float* const* feats, const int* H, const i
     // bands of a large RoI are a long chain of dependent staging round trips, so the parallelism has to
     // come from the number of workgroups
     a.CT = 4;
+    if (const char* e = getenv("DM_ROI_BAND_CT")) a.CT = max(4, atoi(e) & ~3);
     const int chunks = dm_ceil_div(C, a.CT);
+    if (const char* e = getenv("DM_ROI_BAND_ORDER")) a.order = atoi(e);
+    if (chunks % 8 != 0) a.order = 0;
     DM_LAUNCH(roi_align_band_kernel, dim3(N * chunks), dim3(256), (kTileFloats4 + kBandTabFloats4) * sizeof(float4),
               (hipStream_t)stream, a);
     return dm_check_launch();

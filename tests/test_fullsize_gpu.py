@@ -202,7 +202,7 @@ def test_config2_training_step_at_full_size_matches_oracle():
     # differs from the oracle's own arg-max and checks that every such window is a genuine tie in the oracle's
     # activations (its two taps closer than the forward gate of 1e-4), (3) runs the oracle's backward with the device's
     # choices and compares these parameters at the same 1e-4 gate as all others.
-    flip_keys = ['mask_predictor.conv2.weight', 'mask_predictor.bn1.weight', 'mask_predictor.conv1.weight']
+    flip_keys = ['mask_predictor.conv2.weight', 'mask_predictor.bn1.weight']
     from dynamask_amd import ops as _ops
     choice = {}
     orig_pool = _ops.bn_relu_maxpool
@@ -229,7 +229,7 @@ def test_config2_training_step_at_full_size_matches_oracle():
                                                                      pool_choice=choice, pool_record=record)
     loss_ref.backward()
     # (2) windows whose tap differs from the oracle's own arg-max: few RoIs, and each a tie in the oracle's z
-    flipped_rois = set()
+    flipped_rois, flipped_windows, all_windows = set(), 0, 0
     for name in ('pool1', 'pool2'):
         z, own = record[name]
         dev_idx = choice[name].long()
@@ -244,9 +244,12 @@ def test_config2_training_step_at_full_size_matches_oracle():
         assert bool((gap <= 1e-4 + 1e-4 * b.abs()).all()), \
             f'{name}: a device choice is not among the window maxima (worst gap {float(gap.max()):.3e})'
         flipped_rois |= set(diff[:, 0].tolist())
+        flipped_windows += len(diff)
+        all_windows += own.numel()
         print(f'{name}: {len(diff)} of {own.numel()} windows take another tap (worst gap between the two taps '
               f'{float(gap.max()) if len(diff) else 0.0:.2e}), in {len(set(diff[:, 0].tolist()))} RoIs')
-    assert len(flipped_rois) <= 64, f'arg-max choices differ in {len(flipped_rois)} RoIs'
+    # measured: 59 of 26.5 M windows (2e-6), spread over 45 of the 256 RoIs (each RoI has 103 k windows)
+    assert flipped_windows <= 1e-5 * all_windows, f'{flipped_windows} windows take another tap ({len(flipped_rois)} RoIs)'
 
     # selector: indices bit-exact; report how decisive the choices were
     assert torch.equal(res['mask_index'].cpu().long(), ind_ref.long())

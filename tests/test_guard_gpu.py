@@ -192,7 +192,7 @@ def test_training_step_keeps_its_guard_bands(monkeypatch, H, W, per):
     from dynamask_amd.dist import FlatParamGroup, mask_path_parameters
     B = 2
     for det in (False, True):
-        monkeypatch.setitem(ops.DETERMINISTIC, 0, det)
+        monkeypatch.setattr(ops, 'DETERMINISTIC', [det])
         m = _full_head().train()
         with guarded(monkeypatch) as arena:
             feats = [_put(arena, f).requires_grad_(True) for f in synth.make_fpn(B, H, W, 256, seed=H + 1)]

@@ -316,7 +316,7 @@ def test_deterministic_mode_gives_bit_identical_training_runs(monkeypatch):
 
     def run(det, side=True):
         monkeypatch.setenv('DM_TRAIN_SIDE_STREAM', '1' if side else '0')
-        monkeypatch.setitem(ops.DETERMINISTIC, 0, det)
+        ops.DETERMINISTIC[0] = det
         m = registry.build_head(dict(type='DynaMaskRoIHead',
                                      mask_roi_extractor=dict(type='SingleRoIExtractor', **gi.MASK_ROI_EXTRACTOR_CFG),
                                      mask_head=dict(type='DynaMaskHead', **gi.MASK_HEAD_CFG)))
@@ -333,15 +333,18 @@ def test_deterministic_mode_gives_bit_identical_training_runs(monkeypatch):
             grp.sgd_step(lr=0.02, momentum=0.9, weight_decay=1e-4)
         torch.cuda.synchronize()
         return out, grp.flat_param.clone()
-    a, pa = run(True)
-    b, pb = run(True)
-    c, pc = run(True, side=False)
+    try:
+        a, pa = run(True)
+        b, pb = run(True)
+        c, pc = run(True, side=False)
+        d, pd = run(False)
+    finally:
+        ops.DETERMINISTIC[0] = False
     for x, px, what in ((b, pb, 'second run'), (c, pc, 'run without side streams')):
         for s in range(2):
             assert torch.equal(a[s][0], x[s][0]), f'{what}: loss of step {s}'
             assert torch.equal(a[s][1], x[s][1]), f'{what}: gradients of step {s}'
         assert torch.equal(pa, px), f'{what}: parameters'
-    d, pd = run(False)
     scale = float(a[0][1].abs().max())
     assert float((a[0][1] - d[0][1]).abs().max()) <= 2e-5 * scale
     torch.testing.assert_close(pa, pd, atol=2e-6, rtol=1e-4)
