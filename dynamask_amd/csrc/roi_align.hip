@@ -702,19 +702,20 @@ __global__ __launch_bounds__(256, 4) void roi_align_tile_kernel(RoiArgs a) {
 // RoIs wider than the buffer allows even for a one-row band take the direct global path.
 constexpr int kBandTabFloats4 = 2 * 64 * 8 / 4;      // stencil table for P <= 64
 
-template <int G>
+template <int G, int TB>
 __device__ __forceinline__ void roi_band_fwd(const RoiArgs& a, const float* __restrict__ fimg, int Hl, int Wl, float sh,
                                              float sw, float bh, float bw, int gh, int gw, float inv_count, int k,
                                              int c0, int c1, int fx0, int pitch, int xmax, int rows_per_band,
-                                             float4* __restrict__ lds) {
+                                             int pw0, int Cw, float4* __restrict__ lds) {
+  // pw0, Cw: the block of output columns this call produces (the whole width unless the RoI is too wide for a tile)
   constexpr int S = G + 1;
   constexpr int GG = G > 0 ? G : 1;
-  constexpr int IPT = (kTileFloats4 + 255) / 256;
+  constexpr int IPT = (TB + 255) / 256;
   const int tid = threadIdx.x;
   const int P = a.P, PP = P * P;
   const size_t plane = (size_t)Hl * Wl;
-  float* tab = reinterpret_cast<float*>(lds + kTileFloats4);     // [2][P][8]: {L, W0 .. WG}
-  if (G > 0) {
+  float* tab = reinterpret_cast<float*>(lds + TB);     // [2][P][8]: {L, W0 .. WG}
+  if (G > 0 && pw0 == 0) {                                        // (same table for every column block of the RoI)
     if (tid < 2 * P) {
       const bool xa = tid >= P;
       const int p = xa ? tid - P : tid;
@@ -739,8 +740,8 @@ __device__ __forceinline__ void roi_band_fwd(const RoiArgs& a, const float* __re
     const int ylast = min((int)fmaxf(fmaxf(yf, yl), 0.f), Hl - 1);
     const int FH = ylast + pad - fy0 + 1;
     const int ymax = min(ylast + 1, Hl - 1);
-    const int plane_px = FH * pitch;                       // <= kTileFloats4 by the choice of rows_per_band
-    const int NQ = min(kTileFloats4 / plane_px, (c1 - c0) >> 2);
+    const int plane_px = FH * pitch;                       // <= TB by the choice of rows_per_band
+    const int NQ = min(TB / plane_px, (c1 - c0) >> 2);
     const int NCB = NQ * 4;
     const unsigned m_plane = 0xFFFFFFFFu / (unsigned)plane_px + 1u;
     int voff[IPT];
@@ -778,9 +779,9 @@ __device__ __forceinline__ void roi_band_fwd(const RoiArgs& a, const float* __re
           if (tid + i * 256 < live) lds[tid + i * 256] = make_float4(pf[i][0], pf[i][1], pf[i][2], pf[i][3]);
       }
       __syncthreads();
-      for (int i = tid; i < R * P; i += 256) {
-        const int pr = i / P;
-        const int ph = ph0 + pr, pw = i - pr * P;
+      for (int i = tid; i < R * Cw; i += 256) {
+        const int pr = i / Cw;
+        const int ph = ph0 + pr, pw = pw0 + i - pr * Cw;
         float* o = a.out + ((size_t)k * a.C + cb) * PP + ph * P + pw;
         if (G > 0) {
           const float* ey = tab + ph * 8;
@@ -848,11 +849,35 @@ __device__ __forceinline__ void roi_band_fwd(const RoiArgs& a, const float* __re
   }
 }
 
-__global__ __launch_bounds__(256, 4) void roi_align_band_kernel(RoiArgs a) {
+// Column blocks and band height of a RoI.  (Also tried on top of it: taking the RoIs longest-first, every workgroup
+// ranking the RoIs by their number of staging rounds -- once the wide RoIs below stopped falling to the per-sample
+// path the tail was gone, and the ranking cost more than it saved: 237 vs 207 us at 128 RoIs.)
+template <int TB>
+__device__ __forceinline__ void band_plan(const RoiArgs& a, int P, float bh, float bw, int gh, int gw, int& ncb, int& Cwb,
+                                          int& R) {
+  const int G = max(gh, gw);
+  const bool merged = G <= 4 && bh <= (float)gh && bw <= (float)gw;
+  const int pad = merged ? G : 1;
+  const float abh = fmaxf(fabsf(bh), 1e-6f), abw = fmaxf(fabsf(bw), 1e-6f);
+  // fewest column blocks (of equal width, a multiple of 4 columns where P allows) whose tiles hold >= 2 output rows
+  ncb = 1; Cwb = P; R = 0;
+  for (int n = 1; n <= P; n *= 2) {
+    const int cw = ((P + n - 1) / n + 3) & ~3;
+    const int pitch = (int)floorf((float)cw * abw) + pad + 3;          // >= the tile pitch of any block of cw columns
+    const int fh_max = TB / pitch;
+    const int r = (int)fminf((float)P, floorf((float)(fh_max - pad - 2) / abh));
+    if (r > R) { R = r; ncb = (P + cw - 1) / cw; Cwb = cw; }
+    if (r >= min(P, 2) || cw <= 4) break;
+  }
+}
+
+template <int TB, int WPC>
+__global__ __launch_bounds__(256, WPC) void roi_align_band_kernel(RoiArgs a) {
   extern __shared__ __attribute__((aligned(16))) float4 lds4[];
   const int chunks = (a.C + a.CT - 1) / a.CT;
   int k, chunk;
   roi_unit(a, chunks, k, chunk);
+  const int P = a.P, PP = P * P;
   const int c0 = chunk * a.CT;
   const int c1 = min(c0 + a.CT, a.C);
   const float* r = a.rois + (size_t)k * 5;
@@ -875,7 +900,6 @@ __global__ __launch_bounds__(256, 4) void roi_align_band_kernel(RoiArgs a) {
   const float sw = x1 * sc - 0.5f, sh = y1 * sc - 0.5f;
   const float ew = x2 * sc - 0.5f, eh = y2 * sc - 0.5f;
   const float rw = ew - sw, rh = eh - sh;
-  const int P = a.P, PP = P * P;
   const float bh = rh / (float)P, bw = rw / (float)P;
   const int gh = a.sr > 0 ? a.sr : (int)ceilf(rh / (float)P);
   const int gw = a.sr > 0 ? a.sr : (int)ceilf(rw / (float)P);
@@ -886,37 +910,384 @@ __global__ __launch_bounds__(256, 4) void roi_align_band_kernel(RoiArgs a) {
     return;
   }
   {
-    const float xf = sw + 0.5f * bw / (float)gw;
-    const float xl = sw + (float)(P - 1) * bw + ((float)(gw - 1) + 0.5f) * bw / (float)gw;
     const int G = max(gh, gw);
     const bool merged = G <= 4 && bh <= (float)gh && bw <= (float)gw;
     const int pad = merged ? G : 1;
-    const int fx0 = min((int)fmaxf(fminf(xf, xl), 0.f), Wl - 1);
-    const int xlast = min((int)fmaxf(fmaxf(xf, xl), 0.f), Wl - 1);
-    const int pitch = xlast + pad - fx0 + 1;
-    const int xmax = min(xlast + 1, Wl - 1);
-    // rows of output per band: the band's tile has at most ceil(R * |bh|) + pad + 2 rows
-    const int fh_max = kTileFloats4 / pitch;
-    const float abh = fmaxf(fabsf(bh), 1e-6f);
-    int R = (int)fminf((float)P, floorf((float)(fh_max - pad - 2) / abh));
-    // prefer bands small enough for two channel quads per batch when that still leaves >= 4 rows
-    const int R2 = (int)fminf((float)P, floorf((float)(fh_max / 2 - pad - 2) / abh));
-    if (R2 >= 4) R = R2;
+    int ncb, Cwb, R;
+    band_plan<TB>(a, P, bh, bw, gh, gw, ncb, Cwb, R);
+    if (ncb == 1) {
+      // the whole width in one tile: as many rows per band as the tile holds.  (Round 2 halved the bands where that
+      // still left >= 4 rows, so that a batch could hold two channel quads; with one quad per workgroup that only
+      // doubled the dependent staging rounds: 207 -> 188 us at 128 RoIs without it.  DM_ROI_BAND_ORDER=3 brings it back.)
+      const float xf = sw + 0.5f * bw / (float)gw;
+      const float xl = sw + (float)(P - 1) * bw + ((float)(gw - 1) + 0.5f) * bw / (float)gw;
+      const int fx0 = min((int)fmaxf(fminf(xf, xl), 0.f), Wl - 1);
+      const int xlast = min((int)fmaxf(fmaxf(xf, xl), 0.f), Wl - 1);
+      const int pitch = xlast + pad - fx0 + 1;
+      const int fh_max = TB / pitch;
+      const float abh = fmaxf(fabsf(bh), 1e-6f);
+      R = (int)fminf((float)P, floorf((float)(fh_max - pad - 2) / abh));
+      const int R2 = (int)fminf((float)P, floorf((float)(fh_max / 2 - pad - 2) / abh));
+      if (R2 >= 4 && a.order == 3) R = R2;
+    }
     if (R >= 1) {
-#define DM_ROI_BAND(GG) roi_band_fwd<GG>(a, fimg, Hl, Wl, sh, sw, bh, bw, gh, gw, inv_count, k, c0, c1, fx0, pitch, xmax, R, lds4)
-      if (!merged) DM_ROI_BAND(0);
-      else if (G == 1) DM_ROI_BAND(1);
-      else if (G == 2) DM_ROI_BAND(2);
-      else if (G == 3) DM_ROI_BAND(3);
-      else DM_ROI_BAND(4);
+      for (int cb = 0; cb < ncb; ++cb) {
+        const int pw0 = cb * Cwb, Cw = min(Cwb, P - pw0);
+        const float xf = sw + (float)pw0 * bw + 0.5f * bw / (float)gw;
+        const float xl = sw + (float)(pw0 + Cw - 1) * bw + ((float)(gw - 1) + 0.5f) * bw / (float)gw;
+        const int fx0 = min((int)fmaxf(fminf(xf, xl), 0.f), Wl - 1);
+        const int xlast = min((int)fmaxf(fmaxf(xf, xl), 0.f), Wl - 1);
+        const int pitch = xlast + pad - fx0 + 1;
+        const int xmax = min(xlast + 1, Wl - 1);
+        if ((R * fmaxf(fabsf(bh), 1e-6f) + (float)(pad + 2)) * (float)pitch > (float)TB) { R = 0; break; }   // (bounds of band_plan: never)
+#define DM_ROI_BAND(GG) roi_band_fwd<GG, TB>(a, fimg, Hl, Wl, sh, sw, bh, bw, gh, gw, inv_count, k, c0, c1, fx0, pitch, xmax, R, pw0, Cw, lds4)
+        if (!merged) DM_ROI_BAND(0);
+        else if (G == 1) DM_ROI_BAND(1);
+        else if (G == 2) DM_ROI_BAND(2);
+        else if (G == 3) DM_ROI_BAND(3);
+        else DM_ROI_BAND(4);
 #undef DM_ROI_BAND
-      return;
+      }
+      if (R >= 1) return;
     }
   }
   for (int pos = threadIdx.x; pos < PP; pos += blockDim.x) {
     const int ph = pos / P;
     const int pw = pos - ph * P;
     roi_bin_generic<false>(a, fimg, nullptr, Hl, Wl, sh, sw, bh, bw, gh, gw, inv_count, ph, pw, k, c0, c1);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Forward kernel for larger output grids, round 3: the same LDS tile format, staging and merged stencils as the band
+// kernel, reorganised around UNITS of equal size.
+//
+// What the band kernel measured (tools/roi_exp.py, 128 RoIs on P2 -> [128,256,56,56], 411 MB written): 284 us =
+// 1.45 TB/s, and 378 us for twice the RoIs -- the launch ends in a long tail.  A workgroup there owns (RoI, channel
+// quad) and walks the RoI's bands one after the other, each a dependent global -> LDS round trip: a 100 x 100-pixel
+// footprint is 7 such trips, the widest RoIs (bins of 3.6 feature pixels, 5 x 5 merged stencils, footprints wider
+// than the buffer allows for even one output row) fell to the per-sample global path, and whichever workgroups got
+// those RoIs were still running when everything else had finished.
+//
+// Here the work is cut into units = (RoI, tile of output rows x columns, channel quad) whose footprint fills the
+// 32 KB staging buffer at most once -- wide RoIs are cut into column blocks as well, so every RoI goes through LDS --
+// and a fixed number of persistent workgroups (4 per CU) takes unit u = workgroup + i * workgroups.  Every
+// workgroup derives the unit table itself: the tile counts of all RoIs (a function of the RoI's geometry alone, so
+// every workgroup finds the same) and their prefix sums in LDS; a binary search maps a unit to its RoI.  Units are
+// numbered tile-major, channel quads innermost: the workgroups running at any moment write neighbouring pieces of
+// one output region (the chunk-major order, which would share staged planes through the L2, measured 40 % slower).
+// A thread owns 4 neighbouring output columns and stores 16 bytes per channel (sampling grids up to 2 x 2), or one
+// output bin where the 5 x 5 stencils of large RoIs make reading, not writing, the bulk of the work.
+// Same products in the same order as the band kernel: the two give the same bits.
+constexpr int kUnitMaxRois = 2047;      // prefix sums are 16-bit (at most 64 x 16 tiles per RoI)
+
+struct UnitGeom {
+  int Hl, Wl;
+  const float* fimg;
+  float sw, sh, bw, bh, inv_count;
+  int gh, gw, G, pad;
+  int mode;            // 0: zero fill, 1: LDS tiles, 2: per-sample global path (footprint beyond any tile)
+  int ncb, gpb, R, nb; // column blocks, 4-column groups per block, output rows per band, bands
+  int lvl;
+};
+
+__device__ __forceinline__ void unit_geom(const RoiArgs& a, int k, UnitGeom& g) {
+  const float* r = a.rois + (size_t)k * 5;
+  const int b = (int)r[0];
+  const float x1 = r[1], y1 = r[2], x2 = r[3], y2 = r[4];
+  g.lvl = (a.L > 1) ? roi_level(x1, y1, x2, y2, a.finest, a.L) : 0;
+  g.Hl = a.H[0];
+  g.Wl = a.W[0];
+  float sc = a.scale[0];
+  const float* flvl = a.feat[0];
+#pragma unroll
+  for (int l = 1; l < DM_MAX_LEVELS; ++l)
+    if (g.lvl == l) {
+      g.Hl = a.H[l];
+      g.Wl = a.W[l];
+      sc = a.scale[l];
+      flvl = a.feat[l];
+    }
+  g.sw = x1 * sc - 0.5f;
+  g.sh = y1 * sc - 0.5f;
+  const float rw = (x2 * sc - 0.5f) - g.sw, rh = (y2 * sc - 0.5f) - g.sh;
+  const int P = a.P;
+  g.bh = rh / (float)P;
+  g.bw = rw / (float)P;
+  g.gh = a.sr > 0 ? a.sr : (int)ceilf(rh / (float)P);
+  g.gw = a.sr > 0 ? a.sr : (int)ceilf(rw / (float)P);
+  g.inv_count = 1.0f / (float)max(g.gh * g.gw, 1);
+  const bool bad_batch = (b < 0 || b >= a.B);
+  g.fimg = flvl + (bad_batch ? 0 : (size_t)b * a.C * g.Hl * g.Wl);
+  g.ncb = 1; g.gpb = P >> 2; g.R = P; g.nb = 1; g.G = 0; g.pad = 1;
+  if (g.gh <= 0 || g.gw <= 0 || bad_batch) { g.mode = 0; return; }
+  const int Gm = max(g.gh, g.gw);
+  const bool merged = Gm <= 4 && g.bh <= (float)g.gh && g.bw <= (float)g.gw;
+  g.G = merged ? Gm : 0;
+  g.pad = merged ? Gm : 1;
+  const float abh = fmaxf(fabsf(g.bh), 1e-6f), abw = fmaxf(fabsf(g.bw), 1e-6f);
+  const int groups = P >> 2;
+  // fewest column blocks whose tiles still hold >= 4 output rows (or the whole height); else the tallest on offer
+  int best_R = 0, best_ncb = 1;
+  for (int ncb = 1; ncb <= groups; ncb = (ncb < 4 ? ncb * 2 : ncb + 3)) {
+    const int gpb = (groups + ncb - 1) / ncb;
+    const int pitch = (int)floorf((float)(4 * gpb) * abw) + g.pad + 3;       // >= the widest block's tile (see unit_tile)
+    const int fh_max = kTileFloats4 / pitch;
+    const int R = (int)fminf((float)P, floorf((float)(fh_max - g.pad - 2) / abh));
+    if (R > best_R) { best_R = R; best_ncb = ncb; }
+    if (R >= min(P, 4)) break;
+  }
+  if (best_R < 1) { g.mode = 2; return; }
+  g.mode = 1;
+  g.ncb = best_ncb;
+  g.gpb = (groups + best_ncb - 1) / best_ncb;
+  g.ncb = (groups + g.gpb - 1) / g.gpb;          // blocks that actually hold columns
+  g.R = best_R;
+  g.nb = (P + best_R - 1) / best_R;
+}
+
+// one entry of a unit's stencil table: {L, W0 .. WG} (rows carry the 1 / (gh * gw) of the average)
+template <int GG>
+__device__ __forceinline__ void unit_table_entry(float start, float bin, int g, int p, int size, float fac, float* e) {
+  int L;
+  float Wt[GG + 1];
+  axis_stencil<GG>(start, bin, g, p, size, L, Wt);
+  e[0] = __int_as_float(L);
+#pragma unroll
+  for (int r = 0; r <= GG; ++r) e[1 + r] = fac == 1.0f ? Wt[r] : Wt[r] * fac;
+}
+
+// sampling of one unit: PXI = 4 (a thread owns 4 neighbouring columns, 16-byte stores) or 1
+template <int G, int PXI>
+__device__ __forceinline__ void unit_sample(const RoiArgs& a, const UnitGeom& g, int k, int cq, int ph0, int R, int pw0,
+                                            int Cw, int fy0, int fx0, int FH, int pitch, const float4* __restrict__ lds,
+                                            const float* __restrict__ tab, int nt) {
+  constexpr int S = G + 1;
+  const int P = a.P, PP = P * P;
+  const int tid = threadIdx.x;
+  const int ipr = Cw / PXI;                      // items per output row
+  float* obase = a.out + ((size_t)k * a.C + cq) * PP;
+  for (int it = tid; it < R * ipr; it += 256) {
+    const int pr = it / ipr, ci = it - pr * ipr;
+    const int ph = ph0 + pr, pl = ci * PXI;       // pl: first column of the item inside the block
+    float4 acc[PXI];
+    if (G > 0) {
+      const float* ey = tab + pr * 8;
+      const int Ly = __float_as_int(ey[0]);
+      const int rowbase = min(max(Ly - fy0, 0), FH - S) * pitch;
+#pragma unroll
+      for (int j = 0; j < PXI; ++j) {
+        const float* ex = tab + (64 + pl + j) * 8;
+        const int Lx = __float_as_int(ex[0]);
+        const float4* tq = lds + rowbase + min(max(Lx - fx0, 0), pitch - S);
+        float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < S; ++r) {
+          const float4* tr = tq + r * pitch;
+#pragma unroll
+          for (int c = 0; c < S; ++c) {
+            const float4 v = tr[c];
+            const float wv = ey[1 + r] * ex[1 + c];
+            s4.x += wv * v.x;
+            s4.y += wv * v.y;
+            s4.z += wv * v.z;
+            s4.w += wv * v.w;
+          }
+        }
+        acc[j] = s4;
+        if (PXI > 1) __builtin_amdgcn_sched_barrier(0);      // one column's taps at a time: 4 x 9 float4 in flight spill
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < PXI; ++j) {
+        const int pw = pw0 + pl + j;
+        float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int iy = 0; iy < g.gh; ++iy) {
+          int lo, hi;
+          float yl_w, yh_w;
+          axis_sample(g.sh, g.bh, g.gh, ph, iy, g.Hl, lo, hi, yl_w, yh_w);
+          const int yo = min(max(lo - fy0, 0), FH - 2) * pitch;
+          yl_w *= g.inv_count;
+          yh_w *= g.inv_count;
+          for (int ix = 0; ix < g.gw; ++ix) {
+            float xl_w, xh_w;
+            axis_sample(g.sw, g.bw, g.gw, pw, ix, g.Wl, lo, hi, xl_w, xh_w);
+            const int xo = min(max(lo - fx0, 0), pitch - 2);
+            const float4* tp = lds + yo + xo;
+            const float4 v1 = tp[0], v2 = tp[1], v3 = tp[pitch], v4 = tp[pitch + 1];
+            const float w0 = yl_w * xl_w, w1 = yl_w * xh_w, w2 = yh_w * xl_w, w3 = yh_w * xh_w;
+            s4.x += w0 * v1.x + w1 * v2.x + w2 * v3.x + w3 * v4.x;
+            s4.y += w0 * v1.y + w1 * v2.y + w2 * v3.y + w3 * v4.y;
+            s4.z += w0 * v1.z + w1 * v2.z + w2 * v3.z + w3 * v4.z;
+            s4.w += w0 * v1.w + w1 * v2.w + w2 * v3.w + w3 * v4.w;
+          }
+        }
+        acc[j] = s4;
+      }
+    }
+    float* o = obase + ph * P + pw0 + pl;
+    if (PXI == 4) {
+      const dm_f32x4 o0 = {acc[0].x, acc[PXI > 1 ? 1 : 0].x, acc[PXI > 2 ? 2 : 0].x, acc[PXI > 3 ? 3 : 0].x};
+      const dm_f32x4 o1 = {acc[0].y, acc[PXI > 1 ? 1 : 0].y, acc[PXI > 2 ? 2 : 0].y, acc[PXI > 3 ? 3 : 0].y};
+      const dm_f32x4 o2 = {acc[0].z, acc[PXI > 1 ? 1 : 0].z, acc[PXI > 2 ? 2 : 0].z, acc[PXI > 3 ? 3 : 0].z};
+      const dm_f32x4 o3 = {acc[0].w, acc[PXI > 1 ? 1 : 0].w, acc[PXI > 2 ? 2 : 0].w, acc[PXI > 3 ? 3 : 0].w};
+      if (nt) {
+        __builtin_nontemporal_store(o0, reinterpret_cast<dm_f32x4*>(o));
+        __builtin_nontemporal_store(o1, reinterpret_cast<dm_f32x4*>(o + PP));
+        __builtin_nontemporal_store(o2, reinterpret_cast<dm_f32x4*>(o + 2 * (size_t)PP));
+        __builtin_nontemporal_store(o3, reinterpret_cast<dm_f32x4*>(o + 3 * (size_t)PP));
+      } else {
+        *reinterpret_cast<dm_f32x4*>(o) = o0;
+        *reinterpret_cast<dm_f32x4*>(o + PP) = o1;
+        *reinterpret_cast<dm_f32x4*>(o + 2 * (size_t)PP) = o2;
+        *reinterpret_cast<dm_f32x4*>(o + 3 * (size_t)PP) = o3;
+      }
+    } else {
+      o[0] = acc[0].x;
+      o[PP] = acc[0].y;
+      o[2 * (size_t)PP] = acc[0].z;
+      o[3 * (size_t)PP] = acc[0].w;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 4) void roi_align_units_kernel(RoiArgs a, int nt) {
+  extern __shared__ __attribute__((aligned(16))) float4 lds4[];     // staging tile, stencil table, unit prefix sums
+  float* tab = reinterpret_cast<float*>(lds4 + kTileFloats4);       // [2][64][8]: rows of the band, columns of the block
+  unsigned short* pre = reinterpret_cast<unsigned short*>(lds4 + kTileFloats4 + kBandTabFloats4);   // [N + 1]
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int P = a.P, PP = P * P;
+  const int quads = a.C >> 2;
+  // ---- tiles per RoI and their exclusive prefix sums (every workgroup computes the same table)
+  int run = 0;
+  for (int base = 0; base < a.N; base += 256) {
+    const int k = base + tid;
+    int cnt = 0;
+    if (k < a.N) {
+      UnitGeom g;
+      unit_geom(a, k, g);
+      cnt = g.nb * g.ncb;
+      if (a.levels && blockIdx.x == 0) a.levels[k] = g.lvl;
+    }
+    int inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(inc, d);
+      if (lane >= d) inc += up;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int off = run;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    if (k < a.N) pre[k] = (unsigned short)(off + inc - cnt);
+    run += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+  if (tid == 0) pre[a.N] = (unsigned short)run;
+  __syncthreads();
+  const long long total = (long long)run * quads;
+
+  constexpr int IPT = (kTileFloats4 + 255) / 256;
+  for (long long u = blockIdx.x; u < total; u += gridDim.x) {
+    const int slot = (int)(u / quads);
+    const int cq = (int)(u - (long long)slot * quads) * 4;           // first channel of the unit's quad
+    int lo = 0, hi = a.N;                                             // largest k with pre[k] <= slot
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if ((int)pre[mid] <= slot) lo = mid; else hi = mid;
+    }
+    const int k = lo;
+    const int local = slot - (int)pre[k];
+    UnitGeom g;
+    unit_geom(a, k, g);
+    if (g.mode != 1) {
+      // degenerate RoI -> zeros; footprint beyond any tile (wider than ~2000 feature pixels per 4 output columns) ->
+      // per-sample global path
+      for (int pos = tid; pos < PP; pos += 256) {
+        const int ph = pos / P, pw = pos - ph * P;
+        if (g.mode == 0) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) a.out[((size_t)k * a.C + cq + c) * PP + pos] = 0.f;
+        } else {
+          roi_bin_generic<false>(a, g.fimg, nullptr, g.Hl, g.Wl, g.sh, g.sw, g.bh, g.bw, g.gh, g.gw, g.inv_count, ph, pw, k,
+                                 cq, cq + 4);
+        }
+      }
+      continue;
+    }
+    const int band = local / g.ncb, cb = local - band * g.ncb;
+    const int ph0 = band * g.R, R = min(g.R, P - ph0);
+    const int pw0 = cb * g.gpb * 4, Cw = min(g.gpb * 4, P - pw0);
+    // tile: first / last low tap of the unit's rows and columns (the expressions of axis_sample at their extremes)
+    const float yf = g.sh + (float)ph0 * g.bh + 0.5f * g.bh / (float)g.gh;
+    const float yl = g.sh + (float)(ph0 + R - 1) * g.bh + ((float)(g.gh - 1) + 0.5f) * g.bh / (float)g.gh;
+    const float xf = g.sw + (float)pw0 * g.bw + 0.5f * g.bw / (float)g.gw;
+    const float xl = g.sw + (float)(pw0 + Cw - 1) * g.bw + ((float)(g.gw - 1) + 0.5f) * g.bw / (float)g.gw;
+    const int fy0 = min((int)fmaxf(fminf(yf, yl), 0.f), g.Hl - 1);
+    const int ylast = min((int)fmaxf(fmaxf(yf, yl), 0.f), g.Hl - 1);
+    const int fx0 = min((int)fmaxf(fminf(xf, xl), 0.f), g.Wl - 1);
+    const int xlast = min((int)fmaxf(fmaxf(xf, xl), 0.f), g.Wl - 1);
+    const int FH = ylast + g.pad - fy0 + 1, pitch = xlast + g.pad - fx0 + 1;
+    const int ymax = min(ylast + 1, g.Hl - 1), xmax = min(xlast + 1, g.Wl - 1);
+    const int plane_px = FH * pitch;
+    if (plane_px > kTileFloats4) {
+      // cannot happen by the bounds of unit_geom; kept so that a rounding surprise costs time, not memory safety
+      for (int pos = tid; pos < R * Cw; pos += 256) {
+        const int pr = pos / Cw;
+        roi_bin_generic<false>(a, g.fimg, nullptr, g.Hl, g.Wl, g.sh, g.sw, g.bh, g.bw, g.gh, g.gw, g.inv_count, ph0 + pr,
+                               pw0 + pos - pr * Cw, k, cq, cq + 4);
+      }
+      continue;
+    }
+    // ---- stencil table of the unit's rows and columns, then the tile of this channel quad
+    const size_t plane = (size_t)g.Hl * g.Wl;
+    const unsigned m_pitch = 0xFFFFFFFFu / (unsigned)pitch + 1u;
+    const char* b0 = reinterpret_cast<const char*>(g.fimg + (size_t)cq * plane);
+    const char* b1 = b0 + plane * 4;
+    const char* b2 = b1 + plane * 4;
+    const char* b3 = b2 + plane * 4;
+    if (g.G > 0 && tid < 128) {
+      const bool xa = tid >= 64;
+      const int p = xa ? tid - 64 : tid;
+      if (p < (xa ? Cw : R)) {
+        const float st = xa ? g.sw : g.sh, bn = xa ? g.bw : g.bh;
+        const int gg = xa ? g.gw : g.gh, pp = (xa ? pw0 : ph0) + p, sz = xa ? g.Wl : g.Hl;
+        float* e = tab + tid * 8;
+        const float fac = xa ? 1.0f : g.inv_count;
+        if (g.G == 1) unit_table_entry<1>(st, bn, gg, pp, sz, fac, e);
+        else if (g.G == 2) unit_table_entry<2>(st, bn, gg, pp, sz, fac, e);
+        else if (g.G == 3) unit_table_entry<3>(st, bn, gg, pp, sz, fac, e);
+        else unit_table_entry<4>(st, bn, gg, pp, sz, fac, e);
+      }
+    }
+    float pf[IPT][4];
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+      const int idx = tid + i * 256;
+      const int idc = idx < plane_px ? idx : 0;
+      const int rr = (int)__umulhi((unsigned)idc, m_pitch);
+      const int xx = idc - rr * pitch;
+      const int gy = min(fy0 + rr, ymax), gx = min(fx0 + xx, xmax);
+      const int vo = (gy * g.Wl + gx) * 4;
+      pf[i][0] = *reinterpret_cast<const float*>(b0 + vo);
+      pf[i][1] = *reinterpret_cast<const float*>(b1 + vo);
+      pf[i][2] = *reinterpret_cast<const float*>(b2 + vo);
+      pf[i][3] = *reinterpret_cast<const float*>(b3 + vo);
+    }
+#pragma unroll
+    for (int i = 0; i < IPT; ++i)
+      if (tid + i * 256 < plane_px) lds4[tid + i * 256] = make_float4(pf[i][0], pf[i][1], pf[i][2], pf[i][3]);
+    __syncthreads();
+#define DM_UNIT(GG, PX) unit_sample<GG, PX>(a, g, k, cq, ph0, R, pw0, Cw, fy0, fx0, FH, pitch, lds4, tab, nt)
+    if (g.G == 1) DM_UNIT(1, 4);
+    else if (g.G == 2) DM_UNIT(2, 4);
+    else if (g.G == 3) DM_UNIT(3, 1);
+    else if (g.G == 4) DM_UNIT(4, 1);
+    else DM_UNIT(0, 1);
+#undef DM_UNIT
+    // LDS-only barrier (the stores just issued need no acknowledgement before the next unit stages)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
 }
 
@@ -975,6 +1346,19 @@ extern "C" int dm_roi_align_fwd(const float* const* feats, const int* H, const i
   }
   bool band_ok = P > 16 && P <= 64 && C % 4 == 0;
   for (int l = 0; l < num_levels; ++l) band_ok = band_ok && (long long)H[l] * W[l] <= (1 << 23);
+  if (band_ok && (P & 3) == 0 && N <= kUnitMaxRois && (((uintptr_t)out) & 15) == 0) {
+    static const int units_env = getenv("DM_ROI_UNITS") ? atoi(getenv("DM_ROI_UNITS")) : 0;      // A/B switch: 1 = units kernel
+    const char* ue = getenv("DM_ROI_UNITS_NOW");                                                  // experiments: read per call
+    if (ue ? atoi(ue) != 0 : units_env != 0) {
+      const char* nte = getenv("DM_ROI_NT");
+      const int nt = nte ? atoi(nte) : 1;
+      const char* we = getenv("DM_ROI_UNIT_WGS");
+      const int wgs = (we ? atoi(we) : 4) * dm_num_cus();
+      const size_t lds = (size_t)(kTileFloats4 + kBandTabFloats4) * sizeof(float4) + (((size_t)N + 1) * 2 + 15) / 16 * 16;
+      DM_LAUNCH(roi_align_units_kernel, dim3(wgs), dim3(256), lds, (hipStream_t)stream, a, nt);
+      return dm_check_launch();
+    }
+  }
   if (band_ok) {
     // one channel quad per workgroup (swept 4 .. 32 at 128 RoIs on P2: 0.32 / 0.45 / 0.79 / 1.5 ms): the
     // bands of a large RoI are a long chain of dependent staging round trips, so the parallelism has to
@@ -982,10 +1366,11 @@ extern "C" int dm_roi_align_fwd(const float* const* feats, const int* H, const i
     a.CT = 4;
     if (const char* e = getenv("DM_ROI_BAND_CT")) a.CT = max(4, atoi(e) & ~3);
     const int chunks = dm_ceil_div(C, a.CT);
-    if (const char* e = getenv("DM_ROI_BAND_ORDER")) a.order = atoi(e);
-    if (chunks % 8 != 0) a.order = 0;
-    DM_LAUNCH(roi_align_band_kernel, dim3(N * chunks), dim3(256), (kTileFloats4 + kBandTabFloats4) * sizeof(float4),
-              (hipStream_t)stream, a);
+    if (const char* e = getenv("DM_ROI_BAND_ORDER")) a.order = atoi(e);      // experiments: 1 = XCD-aware chunk-major, 3 = round 2's half-height bands
+    if (a.order == 1 && chunks % 8 != 0) a.order = 0;
+    // (a 28 KB tile with five workgroups per CU -- 96 VGPRs, 92 bytes of scratch -- measured slower: 202 vs 188 us)
+    DM_LAUNCH((roi_align_band_kernel<kTileFloats4, 4>), dim3(N * chunks), dim3(256),
+              (kTileFloats4 + kBandTabFloats4) * sizeof(float4), (hipStream_t)stream, a);
     return dm_check_launch();
   }
   // Large output grids (56x56 extraction): planar LDS staging where the footprint fits,

@@ -27,7 +27,7 @@ def graph_us(call, reps=20, iters=7):
 def sweep(name, call, settings, ref=None):
     base = None
     for env in settings:
-        for k in ('DM_ROI_ORDER', 'DM_ROI_CT', 'DM_ROI_BAND_ORDER', 'DM_ROI_BAND_CT', 'DM_ROI_UNITS'):
+        for k in ('DM_ROI_ORDER', 'DM_ROI_CT', 'DM_ROI_BAND_ORDER', 'DM_ROI_BAND_CT', 'DM_ROI_UNITS_NOW', 'DM_ROI_NT', 'DM_ROI_UNIT_WGS', 'DM_ROI_BAND5_NOW'):
             os.environ.pop(k, None)
         os.environ.update(env)
         us, out = graph_us(call)
@@ -51,5 +51,4 @@ if which in ('56', 'all'):
         call = lambda: ops.roi_align([feats[0]], rois, 56, [1 / 4])
         out_mb = B * per * 256 * 3136 * 4 / 1e6
         print(f'roialign56: output {out_mb:.0f} MB')
-        sweep(f'roialign56 {B}x{per} RoIs', call, [{}, {'DM_ROI_BAND_ORDER': '1'}, {'DM_ROI_BAND_ORDER': '1', 'DM_ROI_BAND_CT': '8'},
-                                                  {'DM_ROI_BAND_CT': '8'}, {'DM_ROI_UNITS': '1'}])
+        sweep(f'roialign56 {B}x{per} RoIs', call, [{}, {'DM_ROI_BAND_ORDER': '3'}, {'DM_ROI_BAND5_NOW': '1'}, {'DM_ROI_BAND5_NOW': '1', 'DM_ROI_BAND_ORDER': '3'}])

@@ -45,6 +45,36 @@ def describe(a):
     return type(a).__name__
 
 
+def _cin(srcs):
+    return srcs.shape[1] if isinstance(srcs, torch.Tensor) else sum(t.shape[1] for t in srcs)
+
+
+def _first(srcs):
+    return srcs if isinstance(srcs, torch.Tensor) else srcs[0]
+
+
+def flops(name, args, kw):
+    """Arithmetic of the GEMM-shaped calls (the leaf ones: composite wrappers are listed without a figure)."""
+    try:
+        if name == 'conv2d':
+            x = _first(args[0]); N, _, H, W = x.shape
+            return 2.0 * N * H * W * _cin(args[0]) * args[3] * args[4] ** 2
+        if name == 'deform_conv':
+            N, C, H, W = args[0].shape
+            return 2.0 * N * H * W * C * args[3] * 9
+        if name == 'conv2d_wgrad':
+            N, Co, H, W = args[0].shape
+            return 2.0 * N * H * W * Co * _cin(args[1]) * args[2] ** 2
+        if name == 'fc':
+            return 2.0 * args[0].shape[0] * args[0].shape[1] * args[1].shape[0]
+    except Exception:
+        pass
+    return 0.0
+
+
+NESTED = {'deform_conv_backward', 'deform_conv_backward_data', 'deform_conv_backward_weight', 'deform_col2im_coord'}
+
+
 def wrap(name, fn):
     def inner(*args, **kw):
         torch.cuda.synchronize()
@@ -52,7 +82,8 @@ def wrap(name, fn):
         out = fn(*args, **kw)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) * 1e3
-        log.append((name, ' '.join(describe(a) for a in args) + ''.join(f' {k}={describe(v)}' for k, v in kw.items()), dt))
+        log.append((name, ' '.join(describe(a) for a in args) + ''.join(f' {k}={describe(v)}' for k, v in kw.items()), dt,
+                    flops(name, args, kw)))
         return out
     return inner
 
@@ -64,11 +95,16 @@ for name in dir(ops):
 
 step()
 torch.cuda.synchronize()
-tot = sum(d for _, _, d in log)
-print(f'{len(log)} ops calls, {tot:.2f} ms synchronised')
-agg = collections.defaultdict(lambda: [0, 0.0])
-for n, s, d in log:
+tot = sum(d for n, _, d, _ in log if n not in NESTED)
+gemm_ms = sum(d for n, _, d, f in log if f > 0)
+gemm_fl = sum(f for _, _, _, f in log)
+print(f'{len(log)} ops calls, {tot:.2f} ms synchronised (composite wrappers not counted twice); GEMM-shaped calls: '
+      f'{gemm_fl / 1e12:.3f} TFLOP in {gemm_ms:.2f} ms = {gemm_fl / gemm_ms / 1e9:.1f} TFLOP/s solo')
+agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
+for n, s, d, f in log:
     agg[(n, s)][0] += 1
     agg[(n, s)][1] += d
-for (n, s), (c, d) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-    print(f'{d:8.3f} ms  x{c:<3d} {n:28s} {s[:150]}')
+    agg[(n, s)][2] += f
+for (n, s), (c, d, f) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    tf = f'{f / d / 1e9:6.1f} TF/s' if f > 0 else ('   (composite)' if n in NESTED else '            ')
+    print(f'{d:8.3f} ms  x{c:<3d} {tf} {n:28s} {s[:150]}')
