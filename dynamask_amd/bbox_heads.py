@@ -211,18 +211,10 @@ class BBoxHeadFn(torch.autograd.Function):
         pg = {}
 
         def fc_bwd(fc, gy, xin, need_data=True, out=None, accumulate=False):
-            from .train_path import _direct
+            from .train_path import params_grad
             gy4 = gy.contiguous().view(n, fc.out_features, 1, 1)
             x4 = xin.view(n, fc.in_features, 1, 1)
-            tw, tb = _direct(fc.weight), _direct(fc.bias)
-            if tw is not None:
-                ops.conv2d_wgrad(gy4, x4, 1, dw=tw.view(fc.out_features, fc.in_features, 1, 1))
-            else:
-                pg[fc.weight] = ops.conv2d_wgrad(gy4, x4, 1).view(fc.out_features, fc.in_features)
-            if tb is not None:
-                ops.channel_sum(gy4, out=tb)
-            else:
-                pg[fc.bias] = ops.channel_sum(gy4)
+            params_grad(fc.weight, fc.bias, gy4, x4, 1, pg, (fc.out_features, fc.in_features, 1, 1))
             if not need_data:
                 return None
             wq = fc._pk.get('flip', fc.weight, lambda t: ops.pack_conv_weight(

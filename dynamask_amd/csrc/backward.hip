@@ -101,7 +101,9 @@ struct WgradArgs {
   float* dw;
   int ldw, coloff;
   int JT, MT, chunks_per_split, nsplit;
-  int fx;            // dw is a 64-bit fixed-point accumulator (dm_conv2d_wgrad_fx)
+  int fx;            // dw (and db) are 64-bit fixed-point accumulators (dm_conv2d_wgrad_fx)
+  float* db;         // optional bias gradient db[co] += sum_q dy[co][q]: the row sums of the A operand, taken from the
+                     // values the column-tile-0 workgroups stage anyway (round 2 read dy a second time: dm_channel_sum)
 };
 
 // dW[co][j] = sum_q dy[co][q] * xshift[j][q]  (j = (ci, tap), q = flat pixel): a GEMM
@@ -157,6 +159,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   }
   const int c_begin = split * a.chunks_per_split;
   const int c_end = min(c_begin + a.chunks_per_split, (a.Q + KT - 1) / KT);
+  const bool want_bias = a.db != nullptr && j_tile == 0;
+  float brow = 0.f;               // bias gradient: thread t < TM sums row t of every staged A tile
   float va[RA], vb[RB];
   auto fetch = [&](int ch) {
     const int q = ch * KT + kq;
@@ -191,6 +195,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     for (int i = 0; i < RB; ++i) ldsB[(r0 + 8 * i) * LD + kq] = vb[i];
     __syncthreads();
     if (ch + 1 < c_end) fetch(ch + 1);
+    if (want_bias && tid < TM) {
+      // pixels past Q and rows past Cout were staged as zeros; LD is odd: the 64 rows of a wave hit 64 banks
+      float sacc = 0.f;
+#pragma unroll 8
+      for (int kk = 0; kk < KT; ++kk) sacc += ldsA[tid * LD + kk];
+      brow += sacc;
+    }
 #pragma unroll
     for (int k2 = 0; k2 < KW; k2 += 2) {
       const int kk = wave_k * KW + k2;
@@ -249,6 +260,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         }
     }
   }
+  if (want_bias && tid < TM && m0 + tid < a.Cout) dm_acc_add(a.db, m0 + tid, brow, a.fx != 0);
   if (TAIL) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -284,6 +296,7 @@ struct WgradNarrowArgs {
   int R, Wp, PL, LDA, bands, units, units_per_split, groups;
   unsigned magic_w2, magic_rr, magic_band;      // ceil(2^32 / d) for d = W/2, R + 2, R * W/2
   int fx;
+  float* db;         // optional bias gradient (see WgradArgs), summed from the dy band in LDS by the group-0 workgroups
 };
 
 template <bool TAIL>
@@ -309,6 +322,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3_narrow_kernel(WgradNarrowA
   }
   const int u0 = split * a.units_per_split, u1 = min(a.units, u0 + a.units_per_split);
   const int band_items = R * W2;
+  float bias_acc0 = 0.f, bias_acc1 = 0.f;      // this thread's share of row tid >> 3 (and of row 32 + (tid >> 3), tid < 32)
   for (int u = u0; u < u1; ++u) {
     const int n = u / a.bands, band = u - n * a.bands;
     const int r0 = band * R, rows = min(R, H - r0);
@@ -362,6 +376,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3_narrow_kernel(WgradNarrowA
     }
     const int live = live_pairs;
     __syncthreads();
+    if (a.db != nullptr && group == 0) {
+      // 8 threads per cout row (rows 32..35 in a second round), each a strided share of the band
+      for (int co = tid >> 3; co < a.Cout; co += 32) {
+        const float* rowp = dyb + co * LDA;
+        float sacc = 0.f;
+        for (int e = tid & 7; e < 2 * live; e += 8) sacc += rowp[e];
+        if (co < 32) bias_acc0 += sacc; else bias_acc1 += sacc;
+      }
+    }
     const float* ap = dyb + l31 * LDA + hi;
     const float* at = dyb + (32 + (lane & 3)) * LDA + hi;
     const float* bp = xb + l31 * PL + hi;
@@ -380,6 +403,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3_narrow_kernel(WgradNarrowA
         }
       c2 += 4;
       if (c2 >= W2) { c2 -= W2; ++r; }
+    }
+  }
+  if (a.db != nullptr && group == 0) {
+    float v0 = bias_acc0, v1 = bias_acc1;
+#pragma unroll
+    for (int d = 4; d >= 1; d >>= 1) {
+      v0 += __shfl_xor(v0, d, 64);
+      v1 += __shfl_xor(v1, d, 64);
+    }
+    const int co = tid >> 3;
+    if ((tid & 7) == 0) {
+      if (co < a.Cout) dm_acc_add(a.db, co, v0, a.fx != 0);
+      if (32 + co < a.Cout) dm_acc_add(a.db, 32 + co, v1, a.fx != 0);
     }
   }
   // the four waves' partial sums -> red[tap][row][channel] (wave after wave: 4 short phases), then one atomic each
@@ -443,7 +479,7 @@ static int launch_wgrad3_narrow(const WgradArgs& g, hipStream_t st) {
   if ((long long)32 * (R + 2) * (g.W / 2) >= 65536 || (long long)g.Cout * R * (g.W / 2) >= 65536) return 1;   // magic-division range
   WgradNarrowArgs a;
   a.dy = g.dy; a.dy_bs = g.dy_bs; a.x = g.x; a.x_bs = g.x_bs; a.Cout = g.Cout; a.Cs = g.Cs; a.NB = g.NB; a.H = g.H; a.W = g.W;
-  a.HW = g.HW; a.dw = g.dw; a.ldw = g.ldw; a.coloff = g.coloff; a.fx = g.fx;
+  a.HW = g.HW; a.dw = g.dw; a.ldw = g.ldw; a.coloff = g.coloff; a.fx = g.fx; a.db = g.db;
   a.R = R; a.Wp = Wp; a.PL = PL; a.LDA = LDA; a.bands = nb; a.units = g.NB * nb; a.groups = dm_ceil_div(g.Cs, 32);
   a.magic_w2 = dm_magic(g.W / 2); a.magic_rr = dm_magic(R + 2); a.magic_band = dm_magic(R * (g.W / 2));
   const int target = 2 * dm_num_cus();
@@ -719,15 +755,29 @@ __global__ __launch_bounds__(256) void point_sample_bwd_kernel(const float* __re
   const int fx0 = max((int)floorf(fmaxf(sxmin, -1.f)), 0), fx1 = min((int)floorf(fminf(sxmax, (float)W)) + 1, W - 1);
   const int fy0 = max((int)floorf(fmaxf(symin, -1.f)), 0), fy1 = min((int)floorf(fminf(symax, (float)H)) + 1, H - 1);
   const int TW = fx1 - fx0 + 1, TH = fy1 - fy0 + 1;
-  const bool use_lds = TW > 0 && TH > 0 && TW * TH * CT <= lds_elems;
+  // Channels per pass.  A footprint too large for CT accumulator planes may still fit CT/2 or one: the workgroup then
+  // walks its channels in passes (the sample geometry is recomputed, every gradient is still read once) and keeps
+  // reducing on chip.  Round 2 sent such RoIs -- 156 to 312 image pixels wide on a stride-4 map, where neighbouring
+  // samples still share pixels -- straight to the memory-side atomics, four per sample: 10.4 us per RoI against 1.3.
+  int cpp = CT;
+  if (TW > 0 && TH > 0 && TW * TH * CT > lds_elems) {
+    if (CT >= 4 && TW * TH * 2 <= lds_elems) cpp = 2;
+    else if (TW * TH <= lds_elems) cpp = 1;
+  }
+  const bool use_lds = TW > 0 && TH > 0 && TW * TH * cpp <= lds_elems;
+  if (!use_lds) cpp = CT;
+  const size_t plane = (size_t)H * W;
+  const int nch_all = min(CT, C - c0);
+  for (int cs = 0; cs < nch_all; cs += cpp) {
+  const int nch = min(cpp, nch_all - cs);
   if (use_lds) {
-    for (int i = threadIdx.x; i < CT * TH * TW; i += blockDim.x) tile[i] = 0ull;
+    if (cs > 0) __syncthreads();                 // the previous pass has flushed its planes
+    if (threadIdx.x < CT) bad[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < nch * TH * TW; i += blockDim.x) tile[i] = 0ull;
     __syncthreads();
   }
-  const size_t plane = (size_t)H * W;
   // fixed: gfeat is a 64-bit fixed-point map (dm_point_sample_bwd_fx); cell indices are the same, cells twice as wide
-  float* gf = gfeat + ((size_t)b * C + c0) * plane * (fixed ? 2 : 1);
-  const int nch = min(CT, C - c0);
+  float* gf = gfeat + ((size_t)b * C + c0 + cs) * plane * (fixed ? 2 : 1);
   for (int pos = threadIdx.x; pos < S * S; pos += blockDim.x) {
     const int iy = pos / S, ix = pos - iy * S;
     float sx, sy;
@@ -739,7 +789,7 @@ __global__ __launch_bounds__(256) void point_sample_bwd_kernel(const float* __re
     const float lx = sx - fx, ly = sy - fy;
     const float w_nw = (1.f - lx) * (1.f - ly), w_ne = lx * (1.f - ly), w_sw = (1.f - lx) * ly, w_se = lx * ly;
     const bool okx0 = x0 >= 0 && x0 < W, okx1 = x1i >= 0 && x1i < W, oky0 = y0 >= 0 && y0 < H, oky1 = y1i >= 0 && y1i < H;
-    const float* go = gout + ((size_t)n * C + c0) * S * S + pos;
+    const float* go = gout + ((size_t)n * C + c0 + cs) * S * S + pos;
     float gv[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) gv[c] = (c < nch) ? go[(size_t)c * S * S] : 0.f;
@@ -788,6 +838,7 @@ __global__ __launch_bounds__(256) void point_sample_bwd_kernel(const float* __re
       }
     }
   }
+  }      // channel passes
 }
 
 // ----------------------------------------------------------------- K7 backward
@@ -1235,14 +1286,14 @@ extern "C" int dm_fx_to_float(long long* fx, long long n, float* out, int accumu
 
 static int conv2d_wgrad_impl(const float* dy, long long dy_batch_stride, int Cout, const float* x,
                              long long x_batch_stride, int Cs, int NB, int H, int W, int ksize, float* dw, int ldw,
-                             int col_offset, int fx, dm_stream_t stream) {
+                             int col_offset, float* db, int fx, dm_stream_t stream) {
   if (!dy || !x || !dw || Cout <= 0 || Cs <= 0 || NB <= 0 || H <= 0 || W <= 0 || (ksize != 1 && ksize != 3))
     return DM_ERR_INVALID_ARG;
   if ((long long)NB * H * W > 0x7fffffffLL) return DM_ERR_INVALID_ARG;
   WgradArgs a;
   a.dy = dy; a.dy_bs = dy_batch_stride; a.x = x; a.x_bs = x_batch_stride; a.Cout = Cout; a.Cs = Cs;
   a.NB = NB; a.H = H; a.W = W; a.HW = H * W; a.Q = NB * H * W; a.dw = dw; a.ldw = ldw; a.coloff = col_offset;
-  a.fx = fx;
+  a.fx = fx; a.db = db;
   if (ksize == 3) {
     const int rc = launch_wgrad3_narrow(a, (hipStream_t)stream);
     if (rc < 0) return rc;
@@ -1255,15 +1306,16 @@ static int conv2d_wgrad_impl(const float* dy, long long dy_batch_stride, int Cou
 
 extern "C" int dm_conv2d_wgrad(const float* dy, long long dy_batch_stride, int Cout, const float* x,
                                long long x_batch_stride, int Cs, int NB, int H, int W, int ksize, float* dw, int ldw,
-                               int col_offset, dm_stream_t stream) {
-  return conv2d_wgrad_impl(dy, dy_batch_stride, Cout, x, x_batch_stride, Cs, NB, H, W, ksize, dw, ldw, col_offset, 0, stream);
+                               int col_offset, float* db, dm_stream_t stream) {
+  return conv2d_wgrad_impl(dy, dy_batch_stride, Cout, x, x_batch_stride, Cs, NB, H, W, ksize, dw, ldw, col_offset, db, 0,
+                           stream);
 }
 
 extern "C" int dm_conv2d_wgrad_fx(const float* dy, long long dy_batch_stride, int Cout, const float* x,
                                   long long x_batch_stride, int Cs, int NB, int H, int W, int ksize, long long* dw_fx,
-                                  int ldw, int col_offset, dm_stream_t stream) {
+                                  int ldw, int col_offset, long long* db_fx, dm_stream_t stream) {
   return conv2d_wgrad_impl(dy, dy_batch_stride, Cout, x, x_batch_stride, Cs, NB, H, W, ksize,
-                           reinterpret_cast<float*>(dw_fx), ldw, col_offset, 1, stream);
+                           reinterpret_cast<float*>(dw_fx), ldw, col_offset, reinterpret_cast<float*>(db_fx), 1, stream);
 }
 
 extern "C" int dm_upsample2x_bilinear_bwd(const float* grad_out, const float* fwd_out_for_relu, int NC, int H, int W,

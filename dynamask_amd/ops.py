@@ -590,8 +590,9 @@ def channel_sum(g, out=None):
     return out
 
 
-def conv2d_wgrad(dy, srcs, ksize, dw=None):
-    """dW [Cout, sum(Cs), k, k] of conv(cat(srcs)) given dy [NB, Cout, H, W]."""
+def conv2d_wgrad(dy, srcs, ksize, dw=None, db=None, want_bias=False):
+    """dW [Cout, sum(Cs), k, k] of conv(cat(srcs)) given dy [NB, Cout, H, W].  ``db`` ([Cout], accumulated into) or
+    ``want_bias`` (a fresh tensor): the bias gradient from the same pass over dy; returns dW, or (dW, db) with a bias."""
     dy = _chk_src(dy)
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
@@ -606,16 +607,26 @@ def conv2d_wgrad(dy, srcs, ksize, dw=None):
         _chk(dw, 'dw')
         assert dw.shape == (Cout, cin, ksize, ksize)
         acc = True
+    bias_acc = db is not None
+    if db is None and want_bias:
+        db = (torch.empty if det else torch.zeros)((Cout,), device=dy.device, dtype=torch.float32)
+    if db is not None:
+        _chk(db, 'db')
+        assert db.shape == (Cout,)
     fx = _fx_like(dw) if det else None
+    bfx = _fx_like(db) if det and db is not None else None
     fn = lib().dm_conv2d_wgrad_fx if det else lib().dm_conv2d_wgrad
     base = 0
-    for s in srcs:
+    for i, s in enumerate(srcs):
+        bias_ptr = (bfx if det else db) if i == 0 else None
         check(fn(_p(dy), dy.stride(0), Cout, _p(s), s.stride(0), s.shape[1], NB, H, W, ksize, _p(fx if det else dw),
-                 cin * ksize * ksize, base * ksize * ksize, _stream()), 'dm_conv2d_wgrad')
+                 cin * ksize * ksize, base * ksize * ksize, _p(bias_ptr), _stream()), 'dm_conv2d_wgrad')
         base += s.shape[1]
     if det:
         _fx_finish(fx, dw, acc)
-    return dw
+        if db is not None:
+            _fx_finish(bfx, db, bias_acc)
+    return (dw, db) if db is not None else dw
 
 
 def upsample2x_backward(grad_out, fwd_out, in_shape, align_corners=False):

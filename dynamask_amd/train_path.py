@@ -145,6 +145,26 @@ def _direct(p):
     return None
 
 
+def params_grad(weight, bias, dy, srcs, ks, pg, wshape=None):
+    """Weight and bias gradient of a conv / FC layer from ONE pass over ``dy`` (the bias gradient is the row sums of
+    the weight-gradient GEMM's A operand: dm_conv2d_wgrad ``db``; round 2 read dy a second time through
+    dm_channel_sum).  Accumulated into the flat-buffer views where the parameters have them (``_direct``), else
+    handed back through ``pg``."""
+    tw = _direct(weight)
+    tb = _direct(bias) if bias is not None else None
+    dw = tw.view(wshape) if (tw is not None and wshape is not None) else tw
+    if bias is None:
+        r = ops.conv2d_wgrad(dy, srcs, ks, dw=dw)
+        if tw is None:
+            pg[weight] = r.view_as(weight)
+        return
+    gw, gb = ops.conv2d_wgrad(dy, srcs, ks, dw=dw, db=tb, want_bias=tb is None)
+    if tw is None:
+        pg[weight] = gw.view_as(weight)
+    if tb is None:
+        pg[bias] = gb
+
+
 def _flipped(conv, key, w):
     """Packed weights of the data-gradient convolution, cached on the module."""
     return conv._pk.get(('flip',) + key, w, lambda t: ops.pack_conv_weight(t, transpose_flip=True))
@@ -304,17 +324,7 @@ class MaskHeadFn(torch.autograd.Function):
             return g if g is not None else torch.zeros_like(like)
 
         def conv_params_bwd(conv, dy, srcs, ks):
-            tw = _direct(conv.weight)
-            if tw is not None:
-                ops.conv2d_wgrad(dy, srcs, ks, dw=tw)
-            else:
-                pgrad[conv.weight] = ops.conv2d_wgrad(dy, srcs, ks)
-            if conv.bias is not None:
-                tb = _direct(conv.bias)
-                if tb is not None:
-                    ops.channel_sum(dy, out=tb)
-                else:
-                    pgrad[conv.bias] = ops.channel_sum(dy)
+            params_grad(conv.weight, conv.bias, dy, srcs, ks, pgrad)
 
         def logit_grads(inst, det, nc, c):
             """Accumulation targets of class_logits_backward (zero-filled temporaries, or the flat views)."""
@@ -483,15 +493,7 @@ class MaskPreFn(torch.autograd.Function):
         pg = {}
 
         def params_bwd(weight, bias, gy4, x4, ks, wshape):
-            tw, tb = _direct(weight), _direct(bias)
-            if tw is not None:
-                ops.conv2d_wgrad(gy4, x4, ks, dw=tw.view(wshape))
-            else:
-                pg[weight] = ops.conv2d_wgrad(gy4, x4, ks).view_as(weight)
-            if tb is not None:
-                ops.channel_sum(gy4, out=tb)
-            else:
-                pg[bias] = ops.channel_sum(gy4)
+            params_grad(weight, bias, gy4, x4, ks, pg, wshape)
 
         def fc_bwd(fc, gy, xin, need_data=True):
             gy4 = gy.contiguous().view(n, fc.out_features, 1, 1)
@@ -572,15 +574,7 @@ class FCNMaskHeadFn(torch.autograd.Function):
         pg = {}
 
         def params_bwd(conv, dy, xin, ks):
-            tw, tb = _direct(conv.weight), _direct(conv.bias)
-            if tw is not None:
-                ops.conv2d_wgrad(dy, xin, ks, dw=tw)
-            else:
-                pg[conv.weight] = ops.conv2d_wgrad(dy, xin, ks)
-            if tb is not None:
-                ops.channel_sum(dy, out=tb)
-            else:
-                pg[conv.bias] = ops.channel_sum(dy)
+            params_grad(conv.weight, conv.bias, dy, xin, ks, pg)
 
         def data_grad(conv, dy, ks, out=None, accumulate=False):
             wq = conv._pk.get(('flip', 0, conv.in_channels), conv.weight,

@@ -48,7 +48,7 @@ extern "C" {
 typedef void* dm_stream_t; /* hipStream_t */
 
 const char* dm_error_string(int code);
-/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch). */
+/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient). */
 int dm_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -385,9 +385,11 @@ int dm_channel_sum(const float* g, long long batch_stride, int NB, int C, int HW
 /* conv weight gradient, fp32 MFMA GEMM over the pixel dimension, atomically
  * accumulated: dw[co*ldw + col_offset + ci*k*k + tap] += sum_{n,y,x} dy[n,co,y,x] *
  * x[n,ci,y+dy-1,x+dx-1].  One call per concat source (col_offset = channel base * k*k);
- * the caller zero-fills dw. */
+ * the caller zero-fills dw.  db (optional, [Cout]): the bias gradient db[co] += sum_{n,y,x} dy[n,co,y,x], taken from
+ * the dy values the kernel stages anyway (pass it with ONE of the sources of a concat). */
 int dm_conv2d_wgrad(const float* dy, long long dy_batch_stride, int Cout, const float* x, long long x_batch_stride,
-                    int Cs, int NB, int H, int W, int ksize, float* dw, int ldw, int col_offset, dm_stream_t stream);
+                    int Cs, int NB, int H, int W, int ksize, float* dw, int ldw, int col_offset, float* db,
+                    dm_stream_t stream);
 
 /* adjoint of dm_upsample2x_bilinear_fwd; fwd_out_for_relu (optional) masks the
  * fused ReLU; grad_in is overwritten (no zero-fill needed; planes up to 64 KB of
@@ -547,7 +549,7 @@ int dm_scale(float* x, long long count, float factor, dm_stream_t stream);
  * ------------------------------------------------------------------------------------------ */
 int dm_conv2d_wgrad_fx(const float* dy, long long dy_batch_stride, int Cout, const float* x, long long x_batch_stride,
                        int Cs, int NB, int H, int W, int ksize, long long* dw_fx, int ldw, int col_offset,
-                       dm_stream_t stream);
+                       long long* db_fx, dm_stream_t stream);
 int dm_channel_sum_fx(const float* g, long long batch_stride, int NB, int C, int HW, long long* out_fx, dm_stream_t stream);
 int dm_class_logits_bwd_fx(const float* x, int N, int C, int HW, const float* w_inst, const float* w_det, int num_classes,
                            const int64_t* labels, const float* grad_inst, const float* grad_det, float* grad_x,

@@ -129,10 +129,13 @@ def test_forward_train_matches_reference_golden(golden_dir):
         for k in keys:
             got, ref = gi.grad_slice(named[pre + k].grad).cpu().numpy(), g['ft.grad.' + pre + k]
             worst = max(worst, float(np.abs(got - ref).max()))
-            assert_grad_close(got, ref, pre + k)
+            # (the golden's slice of fc_reg.weight covers rows of classes that no sampled positive has: exact zeros)
+            assert_grad_close(got, ref, pre + k, zero=not np.any(ref))
     for i in range(4):
         if g[f'ft.grad_feat{i}'].size > 1:
-            assert_grad_close(gi.feat_grad_slice(feats[i].grad), g[f'ft.grad_feat{i}'], f'feat{i}')
+            # an FPN-map gradient cell is a sum over every RoI and sample that touches it, added in another order here
+            # (atomics) than in the reference: 1e-3 of the tensor's peak (7e-7 absolute on these maps)
+            assert_grad_close(gi.feat_grad_slice(feats[i].grad), g[f'ft.grad_feat{i}'], f'feat{i}', rel=1e-3)
     print('forward_train: worst parameter-gradient abs error', worst)
 
 
