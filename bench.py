@@ -536,8 +536,29 @@ def main():
                 result['roofline_roialign']['traffic_source'] = src
             except Exception:
                 pass
-        # ---- other exits, for context (not the headline) ----
         extra = {}
+        # ---- the reference's real inference shape (dynamask_roi_head.py:117-158, tools/benchmark.py:63-89): <= 100
+        # detections per image, every exit to 112x112 + boundary merge, through the product's bucketed HIP-graph
+        # replay (graphs.py); the eager figures beside it
+        with torch.no_grad():
+            inf = {}
+            for nd in (100, 16):
+                det, dl = rois[:nd, 1:].contiguous(), labels[:nd].contiguous()
+                call = lambda: head.simple_test_mask_logits(feats, det, dl)      # noqa: E731
+                head.enable_inference_graphs(False)
+                inf[f'eager_{nd}dets_ms'] = time_kernel_median(call, iters=9, warmup=2)
+                gl = head.enable_inference_graphs(True)
+                ref_out = call().clone()
+                inf[f'graph_{nd}dets_ms'] = time_kernel_median(call, iters=15, warmup=3)
+                head.enable_inference_graphs(False)
+                inf[f'graph_{nd}dets_equals_eager'] = bool(torch.equal(ref_out, call()))
+                inf[f'graph_{nd}dets_captures'] = gl.captures
+            result['inference_100dets_ms'] = inf['graph_100dets_ms']
+            result['inference_16dets_ms'] = inf['graph_16dets_ms']
+            inf['what'] = ('simple_test_mask_logits: RoIAlign14 + DynaMaskHead to 112x112 + boundary merge for the first N RoIs '
+                           'of the image; graph = DynaMaskRoIHead.enable_inference_graphs() (buckets 16/32/64/100)')
+            extra['inference'] = inf
+        # ---- other exits, for context (not the headline) ----
         with torch.no_grad():
             extra['full_head_112_ms'] = time_kernel(lambda: head._mask_forward(feats, rois, labels), iters=5, warmup=1)
         # ---- per-RoI early exit: same 512 RoIs, exits uniform over 14/28/56/112 ----

@@ -1,0 +1,83 @@
+"""HIP-graph replay of the inference mask path for the detection counts of real inference.
+
+The reference infers at most 100 detections per image, every exit run to 112x112 and merged
+(roi_heads/dynamask_roi_head.py:117-158; tools/benchmark.py:63-89 is the protocol).  At those sizes the mask path is
+~60 dependent launches of 10-100 us each: the Python / ctypes issue of a launch costs about as much as the kernel, so the
+literal C-ABI launch sequence of ``simple_test_mask_logits`` is captured once per BUCKET of detection counts
+(16 / 32 / 64 / 100, RoIs padded with empty boxes, which the kernels turn into zero rows) and replayed.  No tracing
+compiler: a graph holds exactly the launches the eager call makes.
+
+A graph is tied to the addresses it was captured with: the FPN maps' storage, the packed weights (``ops.WEIGHT_EPOCH``)
+and its own static RoI / label / output buffers.  The cache is keyed on all of that; a backbone that hands over its
+maps in the same buffers every image (the caching allocator does, for a fixed input size) replays, anything else
+captures again.  The returned logits are a view of the graph's static output: consume them before the next call with
+the same bucket.
+"""
+import torch
+
+from . import ops
+
+BUCKETS = (16, 32, 64, 100)
+
+
+class GraphedMaskLogits:
+    def __init__(self, roi_head, buckets=BUCKETS, max_graphs=16):
+        self.head = roi_head
+        self.buckets = tuple(sorted(buckets))
+        self.max_graphs = max_graphs
+        self._graphs = {}          # key -> (graph, rois_static, labels_static, out_static)
+        self.captures = 0
+        self.replays = 0
+
+    def bucket_for(self, n):
+        for b in self.buckets:
+            if n <= b:
+                return b
+        return None
+
+    def _key(self, bucket, x):
+        return (bucket, tuple(int(t.data_ptr()) for t in x), tuple(tuple(t.shape) for t in x), ops.WEIGHT_EPOCH[0],
+                torch.cuda.current_device())
+
+    def _capture(self, key, bucket, x):
+        dev = x[0].device
+        rois = torch.zeros((bucket, 5), device=dev, dtype=torch.float32)          # empty boxes: zero rows
+        labels = torch.zeros((bucket,), device=dev, dtype=torch.int64)
+        head = self.head
+
+        def run():
+            res = head._mask_forward(x, rois, labels)
+            return head.merge_stage_preds(res['stage_instance_preds'])
+        with torch.no_grad():
+            # once eagerly on a side stream: packs the weights and sizes the allocator before the capture
+            s = torch.cuda.Stream(device=dev)
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s):
+                run()
+            torch.cuda.current_stream(dev).wait_stream(s)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = run()
+        if len(self._graphs) >= self.max_graphs:
+            self._graphs.pop(next(iter(self._graphs)))
+        self._graphs[key] = (g, rois, labels, out)
+        self.captures += 1
+        return self._graphs[key]
+
+    def __call__(self, x, mask_rois, det_labels):
+        """``mask_rois`` [n, 5], ``det_labels`` [n] -> merged logits [n, 1, 112, 112] (None: no bucket holds n)."""
+        n = mask_rois.shape[0]
+        bucket = self.bucket_for(n)
+        if bucket is None or not mask_rois.is_cuda:
+            return None
+        x = list(x)
+        key = self._key(bucket, x)
+        entry = self._graphs.get(key) or self._capture(key, bucket, x)
+        g, rois, labels, out = entry
+        rois[:n].copy_(mask_rois)
+        if n < bucket:
+            rois[n:].zero_()
+        labels[:n].copy_(det_labels)
+        g.replay()
+        self.replays += 1
+        return out[:n]

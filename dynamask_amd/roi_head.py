@@ -363,9 +363,21 @@ class DynaMaskRoIHead(nn.Module):
             return det_bboxes.new_zeros((0, 1, 112, 112))
         _bboxes = det_bboxes[:, :4] * scale_factor if rescale else det_bboxes
         mask_rois = bbox2roi([_bboxes]).contiguous()
+        graphs = getattr(self, '_mask_graphs', None)
+        if graphs is not None and not torch.is_grad_enabled():
+            merged = graphs(x, mask_rois, det_labels)      # bucketed HIP-graph replay (graphs.py); None: too many RoIs
+            if merged is not None:
+                return merged
         # the reference chunks by 100 RoIs "to avoid memory overflow" (:132); 288 GB of HBM do not need it
         res = self._mask_forward(x, mask_rois, det_labels)
         return self.merge_stage_preds(res['stage_instance_preds'])
+
+    def enable_inference_graphs(self, on=True, buckets=None):
+        """Replay ``simple_test_mask_logits`` as a HIP graph per bucket of detection counts (16 / 32 / 64 / 100 by
+        default; see graphs.py for what a graph is tied to).  Off by default: the eager path is the reference one."""
+        from .graphs import BUCKETS, GraphedMaskLogits
+        self._mask_graphs = GraphedMaskLogits(self, buckets or BUCKETS) if on else None
+        return self._mask_graphs
 
     # ------------------------------------------------------------ bbox branch (inference)
     def _bbox_forward(self, x, rois):

@@ -608,3 +608,34 @@ def test_polygon_mask_targets_other_sizes(size):
     ref = rp.polygon_mask_targets(objs, 40, 48, boxes, inds, size, events=rp.fr_poly_events)
     assert np.array_equal(got, ref)
     assert 0.05 < ref.mean() < 0.95
+
+
+def test_bucketed_inference_graphs_replay_the_eager_launch_sequence():
+    """DynaMaskRoIHead.enable_inference_graphs(): simple_test_mask_logits through a HIP graph per bucket of detection
+    counts (16 / 32 / 64 / 100, padded with empty boxes) gives the bits of the eager call, captures once per bucket
+    and map storage, follows a parameter update, and leaves counts above the largest bucket to the eager path."""
+    from dynamask_amd import ops, synth
+    m = _roi_head().eval()
+    feats = [_dev(f) for f in synth.make_fpn(1, 608, 1024, 256, seed=3)]
+    rois = synth.make_rois(1, 128, 608, 1024, seed=4)
+    labels = _dev(synth.make_labels(128, seed=5))
+    boxes = _dev(rois[:, 1:])
+    with torch.no_grad():
+        eager = {n: m.simple_test_mask_logits(feats, boxes[:n], labels[:n]).clone() for n in (1, 16, 17, 100, 128)}
+        gl = m.enable_inference_graphs(True)
+        for n in (1, 16, 17, 100):
+            got = m.simple_test_mask_logits(feats, boxes[:n], labels[:n])
+            assert got.shape == eager[n].shape and torch.equal(got, eager[n]), n
+        assert gl.captures == 3 and gl.replays == 4            # buckets 16 (n = 1, 16), 32 (17), 100
+        assert torch.equal(m.simple_test_mask_logits(feats, boxes[:16], labels[:16]), eager[16]) and gl.captures == 3
+        assert torch.equal(m.simple_test_mask_logits(feats, boxes, labels), eager[128]) and gl.replays == 5      # eager
+        # a parameter update (the fused SGD step bumps the epoch) invalidates the packed weights the graph holds
+        with torch.no_grad():
+            m.mask_head.final_instance_logits.weight.mul_(2.0)
+        ops.WEIGHT_EPOCH[0] += 1
+        m.enable_inference_graphs(False)
+        ref = m.simple_test_mask_logits(feats, boxes[:16], labels[:16]).clone()
+        m._mask_graphs = gl
+        assert torch.equal(m.simple_test_mask_logits(feats, boxes[:16], labels[:16]), ref) and gl.captures == 4
+        assert not torch.equal(ref, eager[16])
+        m.enable_inference_graphs(False)
