@@ -32,7 +32,17 @@ struct RoiArgs {
   int lds_floats;      // forward: LDS budget of the footprint tile (0 = direct global path)
   int order;           // forward tile / band kernels: 0 = workgroup b -> (RoI b / chunks, chunk b % chunks);
                        // 1 = XCD-aware (see roi_unit)
+  int abl;             // ablation bits of the tile kernel (tools/micro/roi_tile_ablate.hip only, see DM_ABL)
 };
+
+// Ablations of the 14x14 tile kernel for the ceiling measurement (profiles/r03_roialign_ceiling.txt): the micro
+// benchmark compiles THIS file with DM_ROI_ABLATE defined and switches phases off at run time (bit 1: no global
+// loads, 2: one tap instead of the stencil, 4: no output stores); in the library the condition is the constant false.
+#ifdef DM_ROI_ABLATE
+#define DM_ABL(a, bit) (((a).abl & (bit)) != 0)
+#else
+#define DM_ABL(a, bit) false
+#endif
 
 // Which (RoI, channel chunk) a workgroup of the forward tile / band kernels takes.
 // Workgroups are dealt round-robin to the 8 XCDs (b % 8), each with its own 4 MB L2.  In the plain order the
@@ -506,6 +516,10 @@ __device__ __forceinline__ void roi_tile_fwd(const RoiArgs& a, const float* __re
 #pragma unroll
     for (int i = 0; i < IPT; ++i) {
       const int vo = (tid + i * 256 < live) ? voff[i] : 0;   // surplus items re-read pixel 0 (never committed)
+      if (DM_ABL(a, 1)) {
+        pf[i][0] = pf[i][1] = pf[i][2] = pf[i][3] = __int_as_float(vo);
+        continue;
+      }
       pf[i][0] = *reinterpret_cast<const float*>(b0 + vo);
       pf[i][1] = *reinterpret_cast<const float*>(b1 + vo);
       pf[i][2] = *reinterpret_cast<const float*>(b2 + vo);
@@ -573,19 +587,24 @@ __device__ __forceinline__ void roi_tile_fwd(const RoiArgs& a, const float* __re
           const int cq = cb + 4 * q;
           float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
           const float4* tq = t + q * plane_px + base;
+          if (DM_ABL(a, 2)) {
+            acc = tq[0];
+          } else {
 #pragma unroll
-          for (int r = 0; r < S; ++r) {
-            const float4* tr = tq + r * tg.pitch;
+            for (int r = 0; r < S; ++r) {
+              const float4* tr = tq + r * tg.pitch;
 #pragma unroll
-            for (int c = 0; c < S; ++c) {
-              const float4 v = tr[c];
-              const float wv = W[G > 0 ? r * S + c : 0];
-              acc.x += wv * v.x;
-              acc.y += wv * v.y;
-              acc.z += wv * v.z;
-              acc.w += wv * v.w;
+              for (int c = 0; c < S; ++c) {
+                const float4 v = tr[c];
+                const float wv = W[G > 0 ? r * S + c : 0];
+                acc.x += wv * v.x;
+                acc.y += wv * v.y;
+                acc.z += wv * v.z;
+                acc.w += wv * v.w;
+              }
             }
           }
+          if (DM_ABL(a, 4) && acc.x != 12345.678f) continue;      // (keeps the value live without the store)
           o[(size_t)(4 * q) * PP] = acc.x;
           if (cq + 1 < c1) o[(size_t)(4 * q + 1) * PP] = acc.y;
           if (cq + 2 < c1) o[(size_t)(4 * q + 2) * PP] = acc.z;
@@ -1310,6 +1329,7 @@ int fill_args(RoiArgs& a, const int* H, const int* W, const float* spatial_scale
   a.CT = (P * P >= 1024) ? 4 : 16;
   a.lds_floats = 0;
   a.order = 0;
+  a.abl = 0;
   a.out = nullptr; a.gout = nullptr; a.levels = nullptr;
   return DM_OK;
 }
@@ -1341,6 +1361,9 @@ extern "C" int dm_roi_align_fwd(const float* const* feats, const int* H, const i
     int chunks = dm_ceil_div(C, a.CT);
     if (const char* e = getenv("DM_ROI_ORDER")) a.order = atoi(e);
     if (chunks % 8 != 0) a.order = 0;
+#ifdef DM_ROI_ABLATE
+    if (const char* e = getenv("DM_ROI_ABL")) a.abl = atoi(e);
+#endif
     DM_LAUNCH(roi_align_tile_kernel, dim3(N * chunks), dim3(256), (kTileFloats4 + 64) * sizeof(float4), (hipStream_t)stream, a);
     return dm_check_launch();
   }
