@@ -52,9 +52,11 @@ __global__ __launch_bounds__(256) void polygon_target_kernel(PolyArgs a) {
   for (int i = tid; i < words; i += 256) res[i] = 0u;
   const long long g = a.inds[n];
   const float bx1 = a.boxes[4 * n], by1 = a.boxes[4 * n + 1], bx2 = a.boxes[4 * n + 2], by2 = a.boxes[4 * n + 3];
-  // structures.py:486-491 in float32 (numpy of the reference's era keeps int / float32 scalars in float32)
-  const float bw = fmaxf(bx2 - bx1, 1.f), bh = fmaxf(by2 - by1, 1.f);
-  const double w_scale = (double)((float)S / fmaxf(bw, 0.1f)), h_scale = (double)((float)S / fmaxf(bh, 0.1f));
+  // structures.py:486-491: the box differences are float32; under the NumPy of the reference's era (1.x) a NumPy
+  // scalar combined with a Python scalar takes the Python scalar's default type, so np.maximum(x2 - x1, 1) and
+  // out_w / max(w, 0.1) are float64 (NumPy >= 2 would keep float32: oracle/ref_poly.py restates both)
+  const double bw = fmax((double)(bx2 - bx1), 1.0), bh = fmax((double)(by2 - by1), 1.0);
+  const double w_scale = (double)S / fmax(bw, 0.1), h_scale = (double)S / fmax(bh, 0.1);
   const double ox = (double)bx1, oy = (double)by1;
   int p0 = 0, p1 = 0;
   if (g >= 0 && g < a.G) { p0 = a.inst_start[g]; p1 = a.inst_start[g + 1]; }

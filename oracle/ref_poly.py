@@ -209,19 +209,34 @@ def polygon_to_bitmap(polygons, h, w, events=fr_poly_points_literal):
     return out
 
 
-def crop_and_resize_polygons(masks, bboxes, out_shape, inds):
-    """structures.py:469-503 with its dtypes: ``bboxes`` float32 (``proposals_np``); width / height and the scales
-    stay float32 (numpy of the reference's era: a Python int divided by a float32 scalar is float32), the vertices
-    are float64 and are shifted / scaled in float64 by the exactly widened float32 values."""
+def crop_and_resize_polygons(masks, bboxes, out_shape, inds, scalar_promotion='legacy'):
+    """structures.py:469-503 with its dtypes: ``bboxes`` float32 (``proposals_np``), the vertices float64.
+
+    The box differences ``x2 - x1`` are float32 (two float32 scalars).  What happens next depends on the NumPy the
+    reference runs under:
+    * ``'legacy'`` (NumPy 1.x, the reference's own era -- mmdet 2.x pins numpy<2): a NumPy scalar combined with a
+      Python scalar follows the Python scalar's default type, so ``np.maximum(x2 - x1, 1)`` and
+      ``out_w / max(w, 0.1)`` are float64: scale = float64(out) / float64(float32 difference).  The product
+      (polygon.hip) follows this.
+    * ``'nep50'`` (NumPy >= 2): Python scalars are weak, everything stays float32 and the scale is a float32 quotient
+      (6e-8 relative away from the legacy one).  Golden g12b was produced by running the reference's class in THIS
+      container (numpy 2.2), so it pins this variant; tests/test_oracle_poly.py checks the restatement against it and
+      the two variants against each other."""
     out_h, out_w = out_shape
     bboxes = np.asarray(bboxes, dtype=np.float32)
     res = []
     for i in range(len(bboxes)):
         x1, y1, x2, y2 = bboxes[i]
-        w = np.maximum(x2 - x1, np.float32(1))
-        h = np.maximum(y2 - y1, np.float32(1))
-        h_scale = np.float32(out_h) / np.maximum(h, np.float32(0.1))
-        w_scale = np.float32(out_w) / np.maximum(w, np.float32(0.1))
+        if scalar_promotion == 'legacy':
+            w = max(float(np.float32(x2 - x1)), 1.0)
+            h = max(float(np.float32(y2 - y1)), 1.0)
+            h_scale = np.float64(out_h) / max(h, 0.1)
+            w_scale = np.float64(out_w) / max(w, 0.1)
+        else:
+            w = np.maximum(x2 - x1, np.float32(1))
+            h = np.maximum(y2 - y1, np.float32(1))
+            h_scale = np.float32(out_h) / np.maximum(h, np.float32(0.1))
+            w_scale = np.float32(out_w) / np.maximum(w, np.float32(0.1))
         parts = []
         for p in masks[int(inds[i])]:
             p = np.asarray(p, dtype=np.float64).copy()

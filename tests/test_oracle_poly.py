@@ -61,12 +61,17 @@ def test_closed_form_equals_the_literal_edge_walk():
 
 def test_vertex_transform_matches_the_reference_class():
     """g12b: PolygonMasks.crop_and_resize of the reference itself (pure numpy) on random polygons and float32 boxes --
-    the oracle's shifted / scaled vertices are the same float64 bits (boxes thinner than one pixel included)."""
+    the oracle's shifted / scaled vertices are the same float64 bits (boxes thinner than one pixel included).  The
+    golden was produced under numpy 2.2 (this container), whose scalar promotion (NEP 50) keeps the scale in float32:
+    it pins the restatement's ``'nep50'`` variant; the ``'legacy'`` variant (NumPy 1.x, the reference's own era, what
+    the device kernel follows) differs from it only by that rounding of the scale (<= 1.2e-7 relative)."""
     g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'g12b_polygon_vertices.npz'))
     masks = [[g[f'obj{i}_{j}'] for j in range(int(g[f'obj{i}_parts']))] for i in range(int(g['n_obj']))]
     for size in (14, 112):
-        res = rp.crop_and_resize_polygons(masks, g['boxes'], (size, size), g['inds'])
+        res = rp.crop_and_resize_polygons(masks, g['boxes'], (size, size), g['inds'], scalar_promotion='nep50')
+        leg = rp.crop_and_resize_polygons(masks, g['boxes'], (size, size), g['inds'])
         for i, parts in enumerate(res):
             for j, p in enumerate(parts):
                 ref = g[f's{size}_roi{i}_{j}']
                 assert p.dtype == np.float64 and np.array_equal(p, ref), (size, i, j)
+                np.testing.assert_allclose(leg[i][j], ref, rtol=1.3e-7, atol=0)

@@ -18,10 +18,9 @@ res=$out/${tag}_roialign_ceiling.txt
   echo "## 1. event-timed variants (tools/micro/roi_tile_ablate.hip = the library's roi_align.hip + DM_ROI_ABLATE)"
   $bin $rois
   echo
-  echo "## 1b. the same with the XCD-aware workgroup order (DM_ROI_ORDER=1) and 16 channels per workgroup"
-  DM_ROI_ORDER=1 ROI_ABL_ONLY=0 $bin $rois | tail -1
-  DM_ROI_CT=16 ROI_ABL_ONLY=0 $bin $rois | tail -1
-  DM_ROI_ORDER=1 DM_ROI_CT=16 ROI_ABL_ONLY=0 $bin $rois | tail -1
+  echo "## 1b. round 2's configuration (launch order, 32 channels per workgroup), and launch order with 16 channels"
+  DM_ROI_ORDER=0 DM_ROI_CT=32 ROI_ABL_ONLY=0 $bin $rois | tail -1
+  DM_ROI_ORDER=0 DM_ROI_CT=16 ROI_ABL_ONLY=0 $bin $rois | tail -1
   echo
   echo "## 1c. 7x7 (bbox extraction) full kernel"
   ROI_P=7 ROI_ABL_ONLY=0 $bin $rois | tail -1
@@ -43,12 +42,12 @@ pmc() {   # pmc <label> <env...> -- counters...
     pmc "abl=$v wave-state" ROI_ABL_ONLY=$v -- SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
     pmc "abl=$v instructions" ROI_ABL_ONLY=$v -- SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU
   done
-  pmc "abl=0 FETCH_SIZE (plain order)" ROI_ABL_ONLY=0 -- FETCH_SIZE
-  pmc "abl=0 WRITE_SIZE (plain order)" ROI_ABL_ONLY=0 -- WRITE_SIZE
-  pmc "abl=0 FETCH_SIZE (DM_ROI_ORDER=1)" ROI_ABL_ONLY=0 DM_ROI_ORDER=1 -- FETCH_SIZE
-  pmc "abl=0 FETCH_SIZE (DM_ROI_ORDER=1, DM_ROI_CT=16)" ROI_ABL_ONLY=0 DM_ROI_ORDER=1 DM_ROI_CT=16 -- FETCH_SIZE
-  pmc "abl=0 L2 hit/miss (plain order)" ROI_ABL_ONLY=0 -- TCC_HIT_sum TCC_MISS_sum
-  pmc "abl=0 L2 hit/miss (DM_ROI_ORDER=1)" ROI_ABL_ONLY=0 DM_ROI_ORDER=1 -- TCC_HIT_sum TCC_MISS_sum
+  pmc "abl=0 FETCH_SIZE (default: XCD-aware order, 16 channels)" ROI_ABL_ONLY=0 -- FETCH_SIZE
+  pmc "abl=0 WRITE_SIZE (default)" ROI_ABL_ONLY=0 -- WRITE_SIZE
+  pmc "abl=0 FETCH_SIZE (round 2: launch order, 32 channels)" ROI_ABL_ONLY=0 DM_ROI_ORDER=0 DM_ROI_CT=32 -- FETCH_SIZE
+  pmc "abl=0 FETCH_SIZE (launch order, 16 channels)" ROI_ABL_ONLY=0 DM_ROI_ORDER=0 DM_ROI_CT=16 -- FETCH_SIZE
+  pmc "abl=0 L2 hit and miss (default)" ROI_ABL_ONLY=0 -- TCC_HIT_sum TCC_MISS_sum
+  pmc "abl=0 L2 hit and miss (round 2 order)" ROI_ABL_ONLY=0 DM_ROI_ORDER=0 DM_ROI_CT=32 -- TCC_HIT_sum TCC_MISS_sum
 } >> $res 2>&1
 rm -rf $out/ceil_pmc
 cat $res
