@@ -324,12 +324,19 @@ class DynaMaskRoIHead(nn.Module):
         from . import train_path
         side = train_path.side_stream(pos_rois.device, 'selector') if torch.is_grad_enabled() else None
         if side is not None:
+            # the head is issued FIRST (the host feeds the chain of the step before anything that has slack, see
+            # train_path.MaskHeadFn.forward); the selector waits for the inputs' event, not for the head
             main = torch.cuda.current_stream(pos_rois.device)
-            side.wait_stream(main)
+            ready = main.record_event()
+            train_path._INPUTS_READY[0] = ready
+            try:
+                mask_results = self._mask_forward(x, pos_rois, pos_labels)
+            finally:
+                train_path._INPUTS_READY[0] = None
+            side.wait_event(ready)
             with torch.cuda.stream(side):
                 ins_semantic_feats = self.semantic_roi_extractor([x[0].detach(), ], pos_rois)
                 mask_labels, idx, logits, y = self.get_mask_label(ins_semantic_feats, noise, return_index=True)
-            mask_results = self._mask_forward(x, pos_rois, pos_labels)
             main.wait_stream(side)
             for t in (mask_labels, idx, logits):
                 t.record_stream(main)

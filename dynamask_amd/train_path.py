@@ -69,11 +69,16 @@ class _SideWork:
             self.main = torch.cuda.current_stream(dev)
             self.enabled = self.side != self.main
 
-    def run(self, fn, *tensors):
+    def run(self, fn, *tensors, after=None):
+        """``after``: an event the side stream waits for INSTEAD of everything issued so far on the main stream
+        (work whose inputs were ready long before, issued late so that the host feeds the main stream first)."""
         if not self.enabled:
             return fn()
         self.keep.extend(t for t in tensors if t is not None)
-        self.side.wait_stream(self.main)
+        if after is not None:
+            self.side.wait_event(after)
+        else:
+            self.side.wait_stream(self.main)
         with torch.cuda.stream(self.side):
             return fn()
 
@@ -128,6 +133,12 @@ def _prepack_backward(head, feats):
             _flip_pack(stage.fuse_conv[0], lo, hi)
         _flip_pack(stage.semantic_transform_in, 0, feats[len(feats) - idx - 3].shape[1])
         dcn._pk.get('colgrad', dcn.weight, ops.pack_dcn_colgrad_weight)
+
+
+# event after which the step's inputs (FPN maps, RoIs, labels) are ready on the device: recorded by the caller at the
+# very start of the step (roi_head._mask_forward_train_tensors) so that branches issued late do not wait for the main
+# stream's queue; None = record one where it is needed
+_INPUTS_READY = [None]
 
 
 def _direct(p):
@@ -186,15 +197,22 @@ class MaskHeadFn(torch.autograd.Function):
         sw = _SideWork(rois.device)
         sems, isfs = [], []
 
+        # HOST ISSUE ORDER (round 3).  A step is ~350 launches; the host needs 3.5 ms to issue the forward's.  Round 2
+        # issued them in program order -- selector branch, semantic branches, the ~45 weight packs of forward and
+        # backward, the second stream's half of the head -- and the main stream's first convolution reached the GPU
+        # 3.9 ms into the step (profiles/r03_train_timeline_before.txt: the chain's queue empty for 3.4 of its first
+        # 3.9 ms).  Now what the chain needs first is issued first: the forward's packs, the instance convs of both
+        # halves, then the semantic branches (needed at the first fusion conv), the stages, and only then what has
+        # slack until the loss or the backward (selector branch in roi_head.py, the backward's packs below).  Work
+        # issued late waits for the event of its inputs, not for the main stream's queue.
+        ready = _INPUTS_READY[0] if _INPUTS_READY[0] is not None else (
+            torch.cuda.current_stream(rois.device).record_event() if rois.is_cuda else None)
+
         def semantic_branches():
             for idx, stage in enumerate(head.stages):
                 sem = stage.semantic_transform_in.run(feats[len(feats) - idx - 3], relu=True)
                 sems.append(sem)
                 isfs.append(ops.point_sample(sem, rois, stage.out_size, stage.spatial_scale))
-            # the backward's kernel-layout weights (transposed / rotated packs of every data gradient, the DCN
-            # column-gradient GEMM's) are refreshed here, beside the forward, instead of on the backward's chain
-            _prepack_backward(head, feats)
-        sw.run(semantic_branches)
         # Everything below is per RoI: the buffers are allocated for the whole batch (the backward sees whole
         # tensors) and filled by rows -- two halves on two streams when the batch is large enough, so that the
         # memory-bound kernels of one half (logit gathers, deformable im2col, upsampling) run beside the GEMMs of the
@@ -277,19 +295,28 @@ class MaskHeadFn(torch.autograd.Function):
             for stage, st in zip(head.stages, stbuf):
                 if st['col'] is not None:
                     stage.fuse_conv[1]._pk.get('w_cm', stage.fuse_conv[1].weight, _pack_dcn_colmajor)
-            second.wait_stream(main)
+            packed = main.record_event()            # ins_feats and the forward's packs are ready
+            convs(0, h)
+            second.wait_event(packed)
             with torch.cuda.stream(second):
                 convs(h, n)
-                second.wait_stream(sw.side)         # the semantic branches
-                stages(h, n)
-            convs(0, h)
+            sw.run(semantic_branches, after=ready)
             sw.join(*sems, *isfs)
             stages(0, h)
+            with torch.cuda.stream(second):
+                second.wait_stream(sw.side)         # the semantic branches
+                stages(h, n)
             main.wait_stream(second)
         else:
+            sw.run(semantic_branches, after=ready)
             convs(0, n)
             sw.join(*sems, *isfs)
             stages(0, n)
+        # the backward's kernel-layout weights (transposed / rotated packs of every data gradient, the DCN
+        # column-gradient GEMM's): beside the rest of the forward on the side stream, issued last; the main stream
+        # joins it (the packs are read by the backward's chain and leaves)
+        sw.run(lambda: _prepack_backward(head, feats), after=ready)
+        sw.join()
         saved['conv_in'] = conv_in[:-1]
         saved['stages'] = []
         ips, dps = [], []
@@ -431,9 +458,15 @@ class MaskHeadFn(torch.autograd.Function):
             y = sv['conv_in'][i + 1] if i + 1 < len(sv['conv_in']) else sv['stages'][0]['xin']
             if i == len(head.instance_convs) - 1:
                 ops.relu_backward_(g_x, y)          # (the earlier convs' masks ride in the data gradient below)
-            sw.run(lambda conv=conv, g_x=g_x, x_in=x_in: conv_params_bwd(conv, g_x, x_in, conv.kernel_size), g_x)
+            g_y = g_x
+            if i > 0:
+                sw.run(lambda conv=conv, g_y=g_y, x_in=x_in: conv_params_bwd(conv, g_y, x_in, conv.kernel_size), g_y)
             # x_in of conv i > 0 is the ReLU output of conv i - 1: its adjoint is fused into this data gradient
-            g_x = data_grad(conv, g_x, 0, conv.in_channels, conv.kernel_size, mask=x_in if i > 0 else None)
+            g_x = data_grad(conv, g_y, 0, conv.in_channels, conv.kernel_size, mask=x_in if i > 0 else None)
+            if i == 0:
+                # the chain ends here: its stream takes the last weight gradient itself instead of queueing it behind
+                # the leaf stream's backlog (the step used to end with the chain's queue empty for 1.4 ms)
+                conv_params_bwd(conv, g_y, x_in, conv.kernel_size)
 
         sw.join(*g_feats, *pgrad.values())
         params = list(head.parameters())

@@ -64,3 +64,29 @@ for s_, e_, n_, q_ in step:
 for q_ in sorted(per):
     top = sorted(per[q_].items(), key=lambda kv: -kv[1])[:14]
     print(f'queue {q_}: ' + ', '.join(f'{n_} {v:.2f}' for n_, v in top))
+
+# ---- the chain: queue with the most busy time.  Its kernels in order, the gap in front of each (time the queue sat
+# empty: launch latency or a cross-stream wait), and what ran elsewhere during the longest gaps.
+if len(sys.argv) > 2 and sys.argv[2] == 'chain':
+    chain_q = max(per_q, key=per_q.get)
+    ch = [(s, e, n) for s, e, n, q in step if q == chain_q]
+    gaps = []
+    prev_end = ch[0][0]
+    tot_gap = 0
+    for s, e, n in ch:
+        g = max(0, s - prev_end)
+        tot_gap += g
+        gaps.append((g, s, n))
+        prev_end = max(prev_end, e)
+    print(f'\nchain = queue {chain_q}: {len(ch)} kernels, busy {per_q[chain_q]:.2f} ms, gaps in front of its kernels {tot_gap / 1e6:.2f} ms '
+          f'(first start to last end {(ch[-1][1] - ch[0][0]) / 1e6:.2f} ms)')
+    hist = collections.Counter(min(int(g / 1e3) // 5 * 5, 100) for g, _, _ in gaps)
+    print('gap histogram (us bucket: count):', dict(sorted(hist.items())))
+    print('largest gaps on the chain (us | at ms | kernel that follows | kernels running elsewhere during the gap):')
+    for g, s, n in sorted(gaps, reverse=True)[:25]:
+        others = sorted({short(nn) for ss, ee, nn, qq in step if qq != chain_q and ss < s and ee > s - g})
+        print(f'{g / 1e3:8.1f} | {(s - t0) / 1e6:7.3f} | {short(n)[:50]:50s} | {", ".join(o[:28] for o in others[:4])}')
+    # per-kernel-family: time on the chain, solo-equivalent unknown; print the chain's sequence compactly
+    if len(sys.argv) > 3 and sys.argv[3] == 'seq':
+        for s, e, n in ch:
+            print(f'{(s - t0) / 1e6:8.3f} +{(e - s) / 1e3:7.1f} us  {short(n)}')
