@@ -19,6 +19,7 @@ SIGNATURES = {
     'dm_conv_packed_cout': ([_c_int], _c_int),
     'dm_conv_packed_floats': ([_c_int, _c_int, _c_int, _vp], ctypes.c_longlong),
     'dm_conv_pack_weight': ([_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp], _c_int),
+    'dm_conv_pack_weight_batch': ([_vp, _c_int, _vp], _c_int),
     'dm_conv2d_fwd': ([_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp], _c_int),
     'dm_conv2d_fwd_masked': ([_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _vp], _c_int),
     'dm_point_sample_fwd': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_float, _vp, _vp], _c_int),
@@ -89,6 +90,12 @@ SIGNATURES = {
     'dm_point_sample_bwd_fx': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_float, _vp, _vp], _c_int),
     'dm_fx_to_float': ([_vp, ctypes.c_longlong, _vp, _c_int, _c_int, _vp], _c_int),
 }
+
+class PackJob(ctypes.Structure):
+    """dm_pack_job of include/dynamask_hip.h."""
+    _fields_ = [('w', ctypes.c_void_p), ('w_packed', ctypes.c_void_p), ('Cout', _c_int), ('Cin', _c_int), ('ksize', _c_int),
+                ('transpose_flip', _c_int), ('num_srcs', _c_int), ('src_channels', _c_int * 4), ('ld', _c_int), ('c0', _c_int)]
+
 
 _LIB = None
 

@@ -119,7 +119,8 @@ def _pack_dcn_colmajor(w):
 def _flip_pack(conv, lo, hi):
     """Packed weights of d/d(input channels lo:hi) of ``conv`` (forward kernel, transposed + rotated)."""
     return conv._pk.get(('flip', lo, hi), conv.weight,
-                        lambda t: ops.pack_conv_weight(t[:, lo:hi].contiguous(), transpose_flip=True))
+                        lambda t: ops.pack_conv_weight(t[:, lo:hi].contiguous(), transpose_flip=True),
+                        job=(True, None, lo, hi))
 
 
 def _prepack_backward(head, feats):
@@ -178,7 +179,8 @@ def params_grad(weight, bias, dy, srcs, ks, pg, wshape=None):
 
 def _flipped(conv, key, w):
     """Packed weights of the data-gradient convolution, cached on the module."""
-    return conv._pk.get(('flip',) + key, w, lambda t: ops.pack_conv_weight(t, transpose_flip=True))
+    return conv._pk.get(('flip',) + key, w, lambda t: ops.pack_conv_weight(t, transpose_flip=True),
+                        job=(True, None, None, None))
 
 
 class MaskHeadFn(torch.autograd.Function):
@@ -270,7 +272,8 @@ class MaskHeadFn(torch.autograd.Function):
                     f2 = ops.conv2d([col], dcn._pk.get('w_cm', dcn.weight, _pack_dcn_colmajor), None, dcn.out_channels, 1,
                                     relu=True, out=st['f2'][lo:hi])
                 else:
-                    f2 = ops.deform_conv(f1, off, dcn._pk.get('w', dcn.weight, ops.pack_conv_weight), dcn.out_channels,
+                    f2 = ops.deform_conv(f1, off, dcn._pk.get('w', dcn.weight, ops.pack_conv_weight,
+                                                              job=(False, None, None, None)), dcn.out_channels,
                                          dcn.deform_groups, relu=True, out=st['f2'][lo:hi])
                 stage.fuse_transform_out.run(f2, relu=True, out=tail, out_ch_offset=0)
                 if st['up'] is not None:
@@ -543,7 +546,7 @@ class MaskPreFn(torch.autograd.Function):
             if not need_data:
                 return None
             wq = conv._pk.get(('flip', 0, conv.in_channels), conv.weight,
-                              lambda t: ops.pack_conv_weight(t, transpose_flip=True))
+                              lambda t: ops.pack_conv_weight(t, transpose_flip=True), job=(True, None, None, None))
             return ops.conv2d(gy, wq, None, conv.in_channels, conv.kernel_size)
 
         g_h = fc_bwd(mp.fc2, g, h)
@@ -611,7 +614,7 @@ class FCNMaskHeadFn(torch.autograd.Function):
 
         def data_grad(conv, dy, ks, out=None, accumulate=False):
             wq = conv._pk.get(('flip', 0, conv.in_channels), conv.weight,
-                              lambda t: ops.pack_conv_weight(t, transpose_flip=True))
+                              lambda t: ops.pack_conv_weight(t, transpose_flip=True), job=(True, None, None, None))
             return ops.conv2d(dy, wq, None, conv.in_channels, ks, out=out, accumulate=accumulate)
 
         g = g.contiguous()

@@ -48,7 +48,7 @@ extern "C" {
 typedef void* dm_stream_t; /* hipStream_t */
 
 const char* dm_error_string(int code);
-/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient). */
+/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient, dm_conv_pack_weight_batch). */
 int dm_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -91,6 +91,20 @@ int dm_conv_packed_cout(int Cout);
 long long dm_conv_packed_floats(int Cout, int ksize, int num_srcs, const int* src_channels);
 int dm_conv_pack_weight(const float* w_oihw, int Cout, int Cin, int ksize, int transpose_flip,
                         int num_srcs, const int* src_channels, float* w_packed, dm_stream_t stream);
+
+/* All the packs of a training step in one launch (the weights change with every optimizer step).  A job is
+ * dm_conv_pack_weight's arguments plus a window: the packed [Cout][Cin] tensor may be the input-channel slice
+ * [c0, c0 + Cin) of a [Cout][ld][k][k] tensor (the data gradient towards one concat source); ld = Cin, c0 = 0 for
+ * a whole tensor.  `jobs_device`: num_jobs structs in DEVICE memory (the caller uploads the table once and reuses
+ * it while the tensors stay where they are). */
+typedef struct dm_pack_job {
+  const float* w;
+  float* w_packed;
+  int Cout, Cin, ksize, transpose_flip;
+  int num_srcs, src_channels[DM_MAX_SOURCES];
+  int ld, c0;
+} dm_pack_job;
+int dm_conv_pack_weight_batch(const dm_pack_job* jobs_device, int num_jobs, dm_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * K5/K6  dense convolution forward, stride 1, "same" padding, ksize in {1,3},
