@@ -84,6 +84,7 @@ SIGNATURES = {
     'dm_scale': ([_vp, ctypes.c_longlong, _c_float, _vp], _c_int),
     'dm_mask_loss_scratch_floats': ([_c_int], ctypes.c_longlong),
     'dm_mask_loss_fwd_bwd': ([_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp], _c_int),
+    'dm_mask_loss_stage': ([_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _vp, _vp, _vp, _vp, _vp, _vp], _c_int),
     'dm_conv2d_wgrad_fx': ([_vp, ctypes.c_longlong, _c_int, _vp, ctypes.c_longlong, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _vp], _c_int),
     'dm_channel_sum_fx': ([_vp, ctypes.c_longlong, _c_int, _c_int, _c_int, _vp, _vp], _c_int),
     'dm_class_logits_bwd_fx': ([_vp, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _vp], _c_int),

@@ -34,40 +34,34 @@ class _DynaLossFn(torch.autograd.Function):
         ips = tensors[:n_stage]
         dps = tensors[n_stage:2 * n_stage]
         tgts = tensors[2 * n_stage:3 * n_stage]
-        N = mask_labels.shape[0]
         ml = mask_labels.detach().contiguous()
-        loss_mask = None
-        gi_last = None
-        total_detail = torch.zeros((), device=ml.device, dtype=torch.float32)
+        used = [idx for idx in range(n_stage) if idx <= start_stage]
+        # per stage: the detail target and ONE fused kernel (+ its finishing workgroup) that applies the stage's
+        # normalisers where the values are produced (dm_mask_loss_stage); round 2 finished every stage with ~30 small
+        # tensor operations -- 130 launches between the forward and the backward, with the GPU idle behind them
+        terms = torch.zeros((2,), device=ml.device, dtype=torch.float32)      # [mean BCE of the last stage, detail terms]
         grad_ml = torch.zeros_like(ml)
-        g_dps = []
-        last_idx = -1
-        for idx in range(n_stage):
+        g_dps = [None] * n_stage
+        gi_last, last_idx = None, -1
+        for idx in used:
             ip = ips[idx].detach().contiguous()
             dp = dps[idx].detach().contiguous()
             tg = tgts[idx].detach().contiguous()
-            if idx > start_stage:
-                g_dps.append(None)
-                continue
-            w = ml[:, idx].contiguous()
             dt = ops.detail_target(tg, fuse)
-            sums, per_roi, gi, gd = ops.mask_loss(ip, dp, tg, dt, w, need_grad=True)
-            n_el = float(ip.numel())
-            den = w.sum() + 1e-5                      # device scalar, detached (reference: .item())
-            scale = (N / n_el) / den
-            loss_mask = sums[0] / n_el
-            gi_last, last_idx = gi / n_el, idx
-            total_detail = total_detail + detail_w[idx] * sums[1] * scale
-            g_dps.append(gd * (detail_w[idx] * scale))
-            grad_ml[:, idx] = per_roi * (detail_w[idx] * scale)
+            gi, gd = ops.mask_loss_stage(ip, dp, tg, dt, ml, idx, detail_w[idx], terms, grad_ml,
+                                         want_inst_grad=(idx == used[-1]))
+            g_dps[idx] = gd
+            if gi is not None:
+                gi_last, last_idx = gi, idx
         cb, g_cb = ops.class_balance(ml)
-        grad_ml += cb_w * g_cb
+        grad_ml.add_(g_cb, alpha=cb_w)
+        loss = terms.sum() + cb_w * cb
         ctx.n_stage = n_stage
         ctx.last_idx = last_idx
         ctx.save_for_backward(grad_ml, gi_last, *[g for g in g_dps if g is not None])
         ctx.dp_mask = [g is not None for g in g_dps]
         ctx.shapes = [t.shape for t in ips]
-        return loss_mask + total_detail + cb_w * cb
+        return loss
 
     @staticmethod
     def backward(ctx, g):

@@ -297,6 +297,7 @@ class PackPlan:
         self.table = None
         self.table_ids = None
         self.launches = 0
+        self.uploads = 0
 
     @staticmethod
     def _ver(param):
@@ -323,6 +324,7 @@ class PackPlan:
         e['used'] = True
         if e['ver'] != self._ver(p):
             self.refresh()
+            e['used'] = True          # (refresh clears the flag of what it packed; this one is in use now)
         return e['out']
 
     def refresh(self):
@@ -349,6 +351,7 @@ class PackPlan:
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
             self.table = host.to(todo[0][1].device)
             self.table_ids = ids
+            self.uploads += 1
         check(lib().dm_conv_pack_weight_batch(_p(self.table), len(todo), _stream()), 'dm_conv_pack_weight_batch')
         self.launches += 1
         for e, p in todo:
@@ -561,6 +564,24 @@ def mask_loss(inst_pred, det_pred, inst_tgt, det_tgt, weight, need_grad=True):
     check(lib().dm_mask_loss_fwd_bwd(_p(inst_pred), _p(det_pred), _p(inst_tgt), _p(det_tgt), _p(weight), N, HW,
                                      _p(sums), _p(per_roi), _p(gi), _p(gd), _p(scratch), _stream()), 'dm_mask_loss_fwd_bwd')
     return sums, per_roi, gi, gd
+
+
+def mask_loss_stage(inst_pred, det_pred, inst_tgt, det_tgt, mask_labels, stage, detail_weight, loss_terms, grad_ml,
+                    want_inst_grad):
+    """dm_mask_loss_stage: one stage of DynaCrossEntropyLoss, normalisers applied in the kernel.  ``loss_terms`` [2]
+    and ``grad_ml`` [N, K] are accumulated into / written in place; returns (grad_inst | None, grad_det)."""
+    for t, n in ((inst_pred, 'inst_pred'), (det_pred, 'det_pred'), (inst_tgt, 'inst_tgt'), (det_tgt, 'det_tgt'),
+                 (mask_labels, 'mask_labels'), (loss_terms, 'loss_terms'), (grad_ml, 'grad_ml')):
+        _chk(t, n)
+    N, K = mask_labels.shape
+    HW = inst_pred.numel() // max(N, 1)
+    gi = torch.empty_like(inst_pred) if want_inst_grad else None
+    gd = torch.empty_like(det_pred)
+    scratch = torch.empty((max(16 * N, 1),), device=inst_pred.device, dtype=torch.float32)
+    check(lib().dm_mask_loss_stage(_p(inst_pred), _p(det_pred), _p(inst_tgt), _p(det_tgt), _p(mask_labels), K, int(stage), N,
+                                   HW, float(detail_weight), _p(loss_terms), _p(grad_ml), _p(gi), _p(gd), _p(scratch),
+                                   _stream()), 'dm_mask_loss_stage')
+    return gi, gd
 
 
 def gumbel_select_backward(y_soft, grad_y, temperature=0.5):

@@ -167,13 +167,13 @@ class DynaMaskRoIHead(nn.Module):
             self.mask_roi_extractor.init_weights()
 
     # ------------------------------------------------------------------ forward
-    def _mask_forward(self, x, rois, roi_labels, last_stage=None):
-        """dynamask_roi_head.py:75-81."""
+    def _mask_forward(self, x, rois, roi_labels, last_stage=None, _between=None):
+        """dynamask_roi_head.py:75-81.  (``_between``: see train_path.mask_head_forward_train.)"""
         if torch.is_grad_enabled() and last_stage is None:
             # training: same kernels, forward keeps what the hand-sequenced backward needs
             from . import train_path
             ins_feats = train_path.roi_extract_train(self.mask_roi_extractor, x, rois)
-            ips, dps = train_path.mask_head_forward_train(self.mask_head, ins_feats, x, rois, roi_labels)
+            ips, dps = train_path.mask_head_forward_train(self.mask_head, ins_feats, x, rois, roi_labels, between=_between)
             return dict(stage_instance_preds=ips, stage_detail_preds=dps)
         n = rois.shape[0]
         n_streams = self.num_streams if n >= self.stream_split_min else 1
@@ -330,14 +330,18 @@ class DynaMaskRoIHead(nn.Module):
             ops.PACK_PLAN.refresh()          # every kernel-layout weight of the step in one launch, before the event
             ready = main.record_event()
             train_path._INPUTS_READY[0] = ready
+            sel = {}
+
+            def selector():
+                side.wait_event(ready)
+                with torch.cuda.stream(side):
+                    ins_semantic_feats = self.semantic_roi_extractor([x[0].detach(), ], pos_rois)
+                    sel['out'] = self.get_mask_label(ins_semantic_feats, noise, return_index=True)
             try:
-                mask_results = self._mask_forward(x, pos_rois, pos_labels)
+                mask_results = self._mask_forward(x, pos_rois, pos_labels, _between=selector)
             finally:
                 train_path._INPUTS_READY[0] = None
-            side.wait_event(ready)
-            with torch.cuda.stream(side):
-                ins_semantic_feats = self.semantic_roi_extractor([x[0].detach(), ], pos_rois)
-                mask_labels, idx, logits, y = self.get_mask_label(ins_semantic_feats, noise, return_index=True)
+            mask_labels, idx, logits, y = sel['out']
             main.wait_stream(side)
             for t in (mask_labels, idx, logits):
                 t.record_stream(main)

@@ -140,6 +140,8 @@ def _prepack_backward(head, feats):
 # very start of the step (roi_head._mask_forward_train_tensors) so that branches issued late do not wait for the main
 # stream's queue; None = record one where it is needed
 _INPUTS_READY = [None]
+# launches already issued for the next MaskHeadFn.apply (mask_head_forward_train ``between``)
+_PRECOMPUTED = [None]
 
 
 def _direct(p):
@@ -189,7 +191,19 @@ class MaskHeadFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, head, rois, labels, ins_feats, n_feats, *tensors):
-        feats = [t.contiguous() for t in tensors[:n_feats]]
+        pre = _PRECOMPUTED[0]
+        _PRECOMPUTED[0] = None
+        if pre is None:
+            pre = MaskHeadFn.issue(head, rois, labels, ins_feats, tensors[:n_feats])
+        ips, dps, saved, feats, rois, labels = pre
+        ctx.head, ctx.saved, ctx.feats, ctx.rois, ctx.labels = head, saved, feats, rois, labels
+        ctx.n_feats = n_feats
+        return (*ips, *dps)
+
+    @staticmethod
+    def issue(head, rois, labels, ins_feats, fpn_feats):
+        """The launches of the forward (no autograd state): -> (ips, dps, saved, feats, rois, labels)."""
+        feats = [t.contiguous() for t in fpn_feats]
         labels = labels.long().contiguous()
         rois = rois.contiguous()
         saved = {}
@@ -332,9 +346,7 @@ class MaskHeadFn(torch.autograd.Function):
         saved['lab_last'] = lab_last
         ips.append(fin_ip if fin_up is None else fin_up[0])
         dps.append(fin_dp if fin_up is None else fin_up[1])
-        ctx.head, ctx.saved, ctx.feats, ctx.rois, ctx.labels = head, saved, feats, rois, labels
-        ctx.n_feats = n_feats
-        return (*ips, *dps)
+        return ips, dps, saved, feats, rois, labels
 
     @staticmethod
     def backward(ctx, *grads):
@@ -480,9 +492,21 @@ class MaskHeadFn(torch.autograd.Function):
         return (None, None, None, g_x, None, *g_feats, *out_p)
 
 
-def mask_head_forward_train(head, ins_feats, feats, rois, labels):
-    """Differentiable ``DynaMaskHead.forward`` -> (stage_instance_preds, stage_detail_preds)."""
+def mask_head_forward_train(head, ins_feats, feats, rois, labels, between=None):
+    """Differentiable ``DynaMaskHead.forward`` -> (stage_instance_preds, stage_detail_preds).
+
+    ``between``: a callable run after the head's launches have been issued and BEFORE its autograd node is created.
+    The autograd engine runs ready nodes newest first, and it issues one node's launches at a time: whatever is
+    created inside ``between`` (the selector branch) gets older sequence numbers than the head's node, so in the
+    backward the head -- the chain that decides the length of the step -- is issued first and the branch with slack
+    after it, while in the forward the head's launches were issued first as well."""
     feats = list(feats)
+    if between is not None:
+        with torch.no_grad():
+            _PRECOMPUTED[0] = None
+            pre = MaskHeadFn.issue(head, rois, labels, ins_feats.detach(), [f.detach() for f in feats])
+        between()
+        _PRECOMPUTED[0] = pre
     # (Two half-batches on two streams -- the inference path's arrangement -- were measured here too: 25.8 ms
     # against 23.8 ms per step at 256 RoIs.  The backward already shares the GPU between the chain and its leaves;
     # halving every launch on top of that only adds tails.)

@@ -48,7 +48,7 @@ extern "C" {
 typedef void* dm_stream_t; /* hipStream_t */
 
 const char* dm_error_string(int code);
-/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient, dm_conv_pack_weight_batch). */
+/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient, dm_conv_pack_weight_batch, dm_mask_loss_stage). */
 int dm_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -256,6 +256,18 @@ long long dm_mask_loss_scratch_floats(int N);
 int dm_mask_loss_fwd_bwd(const float* inst_pred, const float* det_pred, const float* inst_tgt,
                          const float* det_tgt, const float* weight, int N, int HW, float* sums,
                          float* per_roi_det, float* grad_inst, float* grad_det, float* scratch, dm_stream_t stream);
+
+/* One stage of DynaCrossEntropyLoss.forward (cross_entropy_loss.py:455-476) with its normalisers applied in the kernel:
+ * w_n = mask_labels[n, stage] ([N, num_stages]), den = sum_n w_n + 1e-5 (detached, :462), n_el = N * HW.
+ *   loss_terms[0]  = mean BCE-with-logits of this stage (overwritten: only the last stage's reaches the loss, Quirk Q2)
+ *   loss_terms[1] += detail_weight * (N / n_el) / den * sum_n w_n * epsBCE_n
+ *   grad_mask_labels[n, stage] = detail_weight / (HW * den) * epsBCE_n           (d loss / d mask_labels, den detached)
+ *   grad_inst (optional) = (sigmoid(x) - t) / n_el;  grad_det (optional) = d(detail term) / d det_pred
+ * scratch: dm_mask_loss_scratch_floats(N).  Replaces dm_mask_loss_fwd_bwd + ~30 host-side tensor operations per stage. */
+int dm_mask_loss_stage(const float* inst_pred, const float* det_pred, const float* inst_tgt, const float* det_tgt,
+                       const float* mask_labels, int num_stages, int stage, int N, int HW, float detail_weight,
+                       float* loss_terms, float* grad_mask_labels, float* grad_inst, float* grad_det, float* scratch,
+                       dm_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * K9  resolution predictor MaskPre (roi_heads/base_roi_head.py:10-27): BatchNorm

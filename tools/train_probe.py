@@ -38,6 +38,9 @@ for i in range(int(os.environ.get('TP_STEPS', 12))):
     print(f'step {i}: wall {1e3*(t4-t0):7.2f} ms  device {e0.elapsed_time(e1):7.2f} ms  host fwd {1e3*(t1-t0):6.2f} bwd {1e3*(t2-t1):6.2f} opt {1e3*(t3-t2):5.2f}  '
           f'mem {torch.cuda.memory_allocated()/2**30:.2f}/{torch.cuda.memory_reserved()/2**30:.2f} GiB', flush=True)
 
+from dynamask_amd import ops as _ops
+print(f'pack plan: {len(_ops.PACK_PLAN.entries)} packs, {_ops.PACK_PLAN.launches} batch launches, {_ops.PACK_PLAN.uploads} table uploads', flush=True)
+
 # windows of 4 steps without a sync in between (what bench.py times): the host runs ahead of the GPU
 if os.environ.get('TP_WINDOWS'):
     import gc
