@@ -155,7 +155,9 @@ class Shared2FCBBoxHead(nn.Module):
                 losses['loss_cls'] = self.loss_cls(cls_score, labels, label_weights, avg_factor=avg_factor,
                                                    reduction_override=reduction_override)
                 losses['acc'] = accuracy(cls_score, labels)
-        if bbox_pred is not None:
+        if bbox_pred is not None and bbox_pred.shape[0] == 0:
+            losses['loss_bbox'] = bbox_pred.sum() * 0            # no sampled RoI at all (bbox_head.py:181-182)
+        elif bbox_pred is not None:
             # the reference gathers bbox_pred[pos, labels[pos]] and calls loss_bbox on the gathered rows
             # (avg_factor = number of samples); rows with a background label contribute nothing, and
             # with no positive row the loss is `bbox_pred.sum() * 0`: both are what the fused kernel gives

@@ -165,7 +165,13 @@ __global__ __launch_bounds__(256) void fc_reduce_kernel(const float* __restrict_
 // launch.  Short K (the 1024 -> 1024 / 320 / 81 layers of the bbox head: 8 .. 64 output tiles) is cut finer:
 // with one workgroup per tile those layers were a chain of 32 dependent staging round trips (0.105 ms);
 // long K (12544) coarser, or the partial slabs would cost more traffic than the operands.
-static inline int fc_seg(int K) { return K <= 4096 ? 256 : 1024; }
+static inline int fc_seg(int K) {
+  if (const char* e = getenv("DM_FC_SEG")) {          // experiments
+    const int v = atoi(e);
+    if (v > 0 && K > 4096) return (v + 31) / 32 * 32;
+  }
+  return K <= 4096 ? 256 : 1024;
+}
 
 extern "C" long long dm_fc_scratch_floats(int N, int K, int M) {
   const int splits = (K + fc_seg(K) - 1) / fc_seg(K);

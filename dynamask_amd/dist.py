@@ -21,7 +21,14 @@ import torch.distributed as dist
 
 class FlatParamGroup:
     """Re-homes ``params`` into one flat buffer (``p.data`` and ``p.grad`` become
-    views), so that the all-reduce and the optimiser touch a single tensor."""
+    views), so that the all-reduce and the optimiser touch a single tensor.
+
+    The parameters are marked ``_dm_direct_grad``: the backward kernels of this package then ADD their gradients
+    straight into ``p.grad`` (the flat view) and hand autograd ``None``, so no AccumulateGrad node runs for them.
+    Consequence: tensor hooks, post-accumulate-grad hooks and DistributedDataParallel's reducer hooks never fire on
+    these parameters -- this class IS the gradient reduction for them (``all_reduce_async``); do not wrap the same
+    parameters in DDP.  ``release()`` (also run when the group is garbage-collected) clears the marks, after which
+    the parameters behave like any others again (their storage stays in the flat buffer)."""
 
     def __init__(self, params, process_group=None):
         self.params = [p for p in params if p.requires_grad]
@@ -40,14 +47,28 @@ class FlatParamGroup:
                 self.flat_param[off:off + k].copy_(p.detach().reshape(-1))
                 p.data = self.flat_param[off:off + k].view_as(p)
                 p.grad = self.flat_grad[off:off + k].view_as(p)
-                p._dm_direct_grad = True       # train_path._direct: backward kernels may accumulate into the view
+                p._dm_direct_grad = id(self)   # train_path._direct: backward kernels may accumulate into the view (owner: this group)
                 off += k
         self.group = process_group
         self.steps = 0
         self._work = None
         self._synced = False
         from . import streams
-        self._stream = streams.side(dev, 2) if dev.type == 'cuda' else None      # shared pool: hardware queues are few
+        # shared pool (hardware queues are few): slot 2 is also the training step's coordinate-gradient stream, which is
+        # idle by the time the collective is issued (after the whole backward)
+        self._stream = streams.side(dev, 2) if dev.type == 'cuda' else None
+
+    def release(self):
+        """Clear the direct-gradient marks of this group's parameters (the mark used to outlive the group)."""
+        for p in getattr(self, 'params', ()):
+            if getattr(p, '_dm_direct_grad', False) == id(self):      # (a later group may own the parameter by now)
+                p._dm_direct_grad = False
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:      # noqa: BLE001  (interpreter shutdown)
+            pass
 
     @property
     def world_size(self):

@@ -208,6 +208,11 @@ class L1Loss(nn.Module):
 
     def forward_pos(self, bbox_pred, labels, bbox_targets, bbox_weights, num_classes, avg_factor=None,
                     reduction_override=None):
+        if avg_factor is None and (reduction_override or self.reduction) == 'mean':
+            # the reference takes the mean over the rows it has GATHERED (positives only, bbox_head.py:166-180): that
+            # count lives on the device; the RoI head always passes avg_factor, so this form is not supported here
+            raise NotImplementedError("L1Loss.forward_pos: 'mean' without avg_factor would need the number of positive "
+                                      "rows on the host; pass avg_factor (bbox_head.py:175 does)")
         scale = self._scale(bbox_pred.shape[0] * 4, avg_factor, reduction_override)
         return _L1PosFn.apply(bbox_pred, labels, bbox_targets, bbox_weights, num_classes, scale)
 

@@ -255,6 +255,13 @@ class DynaMaskRoIHead(nn.Module):
                                                              feats=[lvl_feat[i][None] for lvl_feat in x]))
         # the bbox branch and the mask branch meet only in the sum of the losses: the bbox branch is issued on its own
         # stream (its backward follows it there) and joined before the losses are handed back
+        losses = {}
+        if not self.with_bbox:
+            # dynamask_roi_head.py:40-45 guards both branches (with_bbox / with_mask)
+            if self.with_mask:
+                losses.update(self._mask_forward_train(x, sampling_results, None, gt_bboxes, gt_masks, gt_labels, img_metas,
+                                                       noise=noise)['loss_mask'])
+            return losses
         side = None
         if torch.is_grad_enabled() and x[0].is_cuda:
             from . import train_path
@@ -266,16 +273,18 @@ class DynaMaskRoIHead(nn.Module):
                 bbox_results = self._bbox_forward_train(x, sampling_results, gt_bboxes, gt_labels, img_metas)
         else:
             bbox_results = self._bbox_forward_train(x, sampling_results, gt_bboxes, gt_labels, img_metas)
-        mask_results = self._mask_forward_train(x, sampling_results, bbox_results['bbox_feats'], gt_bboxes, gt_masks,
-                                                gt_labels, img_metas, noise=noise)
+        mask_results = None
+        if self.with_mask:
+            mask_results = self._mask_forward_train(x, sampling_results, bbox_results['bbox_feats'], gt_bboxes, gt_masks,
+                                                    gt_labels, img_metas, noise=noise)
         if side is not None:
             main.wait_stream(side)
             for v in bbox_results['loss_bbox'].values():
                 if isinstance(v, torch.Tensor):
                     v.record_stream(main)
-        losses = {}
         losses.update(bbox_results['loss_bbox'])
-        losses.update(mask_results['loss_mask'])
+        if mask_results is not None:
+            losses.update(mask_results['loss_mask'])
         return losses
 
     def _bbox_forward_train(self, x, sampling_results, gt_bboxes, gt_labels, img_metas):
