@@ -14,6 +14,9 @@ stats() {  # stats <dir> <dest>: copy the kernel_stats.csv of a rocprofv3 --stat
 python3 bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.stderr
 tail -1 $out/${tag}_bench.json | cut -c1-200
 python3 bench.py --end-to-end > $out/${tag}_bench_end_to_end.json 2>> $out/${tag}_bench.stderr
+# the N > 1 launch path rehearsed on the one GPU (both ranks on cuda:0, gloo), and the training step as the headline
+DM_BENCH_REHEARSAL=1 python3 bench.py --gpus 2 --steps 10 --warmup 2 --cpu-sample 0 > $out/${tag}_bench_rehearsal_gpus2.json 2>> $out/${tag}_bench.stderr
+python3 bench.py --leg train --steps 8 --warmup 4 --cpu-sample 0 > $out/${tag}_bench_leg_train.json 2>> $out/${tag}_bench.stderr
 echo "bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_bench -- python3 bench.py --cpu-sample 0 > /dev/null 2>&1
 stats $out/prof_bench $out/${tag}_bench_kernel_stats.csv
@@ -23,6 +26,13 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_head -- python
 stats $out/prof_head $out/${tag}_headline_kernel_stats.csv
 TP_STEPS=6 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_train -- python3 tools/train_probe.py > /dev/null 2>&1
 stats $out/prof_train $out/${tag}_train_step_kernel_stats.csv
+# training-step timeline: busy time per queue, what runs alone, the gaps of the chain's queue
+rm -rf $out/prof_tl
+TP_STEPS=6 rocprofv3 --kernel-trace --output-format csv -d $out/prof_tl -- python3 tools/train_probe.py > /dev/null 2>&1
+python3 tools/timeline.py "$(ls $out/prof_tl/*/*kernel_trace.csv | head -1)" chain > $out/${tag}_train_timeline.txt 2>&1
+rm -rf $out/prof_tl
+python3 tools/step_shapes.py > $out/${tag}_step_shapes_solo.txt 2>&1
+python3 tools/roi_exp.py all > $out/${tag}_roi_exp.txt 2>&1
 echo "traces done"
 python3 tools/kbench.py > $out/${tag}_kbench.txt 2>&1
 python3 tools/tail_probe.py > $out/${tag}_tail_probe.txt 2>&1

@@ -1,6 +1,7 @@
 """RoIAlign experiments: 14x14 over P2..P5 (512 RoIs, bench shape) and 56x56 on P2 (128 RoIs of one image = the kbench
 shape; 2 x 128 = the training step's), each timed as 20 launches replayed as one HIP graph, for a list of knob settings
-(DM_ROI_ORDER / DM_ROI_CT / DM_ROI_BAND_ORDER / DM_ROI_BAND_CT are read by the library at every call).
+(DM_ROI_ORDER / DM_ROI_CT / DM_ROI_BAND_ORDER / DM_ROI_BAND_CT / DM_ROI_UNITS_NOW are read by the library at every call;
+{} = the defaults: 14x14 in the XCD-aware order with 16 channels per workgroup, 56x56 full-height bands with column blocks).
 usage: python tools/roi_exp.py [14|56|all]"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,7 +28,7 @@ def graph_us(call, reps=20, iters=7):
 def sweep(name, call, settings, ref=None):
     base = None
     for env in settings:
-        for k in ('DM_ROI_ORDER', 'DM_ROI_CT', 'DM_ROI_BAND_ORDER', 'DM_ROI_BAND_CT', 'DM_ROI_UNITS_NOW', 'DM_ROI_NT', 'DM_ROI_UNIT_WGS', 'DM_ROI_BAND5_NOW'):
+        for k in ('DM_ROI_ORDER', 'DM_ROI_CT', 'DM_ROI_BAND_ORDER', 'DM_ROI_BAND_CT', 'DM_ROI_UNITS_NOW', 'DM_ROI_NT', 'DM_ROI_UNIT_WGS'):
             os.environ.pop(k, None)
         os.environ.update(env)
         us, out = graph_us(call)
@@ -41,9 +42,8 @@ if which in ('14', 'all'):
     feats = [f.to(dev) for f in synth.make_fpn(1, 800, 1333, 256, seed=0)]
     rois = synth.make_rois(1, 512, 800, 1333, seed=1).to(dev)
     call = lambda: ops.roi_align(feats[:4], rois, 14, [1 / 4, 1 / 8, 1 / 16, 1 / 32])
-    sweep('roialign14 512 RoIs', call, [{}, {'DM_ROI_ORDER': '1'}, {'DM_ROI_ORDER': '1', 'DM_ROI_CT': '16'},
-                                       {'DM_ROI_ORDER': '1', 'DM_ROI_CT': '8'}, {'DM_ROI_CT': '16'}, {'DM_ROI_CT': '8'},
-                                       {'DM_ROI_ORDER': '1', 'DM_ROI_CT': '4'}])
+    sweep('roialign14 512 RoIs', call, [{}, {'DM_ROI_ORDER': '0', 'DM_ROI_CT': '32'}, {'DM_ROI_ORDER': '0', 'DM_ROI_CT': '16'},
+                                       {'DM_ROI_ORDER': '1', 'DM_ROI_CT': '32'}, {'DM_ROI_ORDER': '1', 'DM_ROI_CT': '8'}])
 if which in ('56', 'all'):
     for B, per in ((1, 128), (2, 128)):
         feats = [f.to(dev) for f in synth.make_fpn(B, 800, 1333, 256, seed=10)]
@@ -51,4 +51,4 @@ if which in ('56', 'all'):
         call = lambda: ops.roi_align([feats[0]], rois, 56, [1 / 4])
         out_mb = B * per * 256 * 3136 * 4 / 1e6
         print(f'roialign56: output {out_mb:.0f} MB')
-        sweep(f'roialign56 {B}x{per} RoIs', call, [{}, {'DM_ROI_BAND_ORDER': '3'}, {'DM_ROI_BAND5_NOW': '1'}, {'DM_ROI_BAND5_NOW': '1', 'DM_ROI_BAND_ORDER': '3'}])
+        sweep(f'roialign56 {B}x{per} RoIs', call, [{}, {'DM_ROI_BAND_ORDER': '3'}, {'DM_ROI_BAND_ORDER': '1'}, {'DM_ROI_UNITS_NOW': '1'}])
