@@ -170,3 +170,35 @@ def test_flat_group_survives_grad_set_to_none_world1_and_world2():
         for p in procs:
             p.join(timeout=120)
             assert p.exitcode == 0
+
+
+# ---------------------------------------------------------------- what the N > 1 bench line carries
+TOP_LEVEL_TRAIN_KEYS = ('train_ms_per_step', 'train_img_per_s', 'train_imgs_per_gpu', 'allreduce_alone_ms', 'collective',
+                        'infer_ms_per_roi_batch', 'infer_img_per_s', 'inference_100dets_ms')
+
+
+def test_two_rank_rehearsal_line_carries_the_training_step_at_top_level():
+    """the driver's SCALE record keeps only the top-level keys of the line, so the training-step
+    figures (the unit of the north star's scaling curve) must be there at every N.  profiles/r03_bench_rehearsal_gpus2.json
+    is the line `DM_BENCH_REHEARSAL=1 python bench.py --gpus 2` printed on the one-GPU box this round
+    (tools/collect_profiles.sh); bench.py's source must name the same keys."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, 'profiles', 'r03_bench_rehearsal_gpus2.json')) as f:
+        line = [l for l in f.read().splitlines() if l.startswith('{')]
+    assert len(line) == 1
+    out = json.loads(line[0])
+    assert out['n_gpus'] == 2 and out['scaling'] == 'weak'
+    for k in TOP_LEVEL_TRAIN_KEYS:
+        assert k in out, k
+    assert out['train_ms_per_step'] > 0 and out['train_img_per_s'] > 0
+    assert 'all-reduce over 2 rank(s), executed' in out['collective']
+    assert abs(out['train_img_per_s'] - 2 * out['train_imgs_per_gpu'] / (out['train_ms_per_step'] * 1e-3)) < 1e-6 * out['train_img_per_s']
+    src = open(os.path.join(root, 'bench.py')).read()
+    for k in TOP_LEVEL_TRAIN_KEYS:
+        assert f"'{k}'" in src, k
+
+
+def test_bench_leg_train_is_an_option_of_the_command_line():
+    r = _run_bench(['--help'], {})
+    assert r.returncode == 0 and '--leg' in r.stdout and 'train' in r.stdout
