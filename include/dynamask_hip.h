@@ -12,10 +12,12 @@
  *     compute-unit count and "this kernel's dynamic-LDS limit has been raised"
  *     flags (hipFuncSetAttribute once per device).  A few knobs are read from
  *     the environment on first use.  Tuning knobs that never change results,
- *     only tile / split choices: DM_CONV_TAIL, DM_DCN_TAIL, DM_WGRAD_WGS.
- *     A/B switches that select an older kernel for the same
+ *     only tile / split / order choices: DM_CONV_TAIL, DM_DCN_TAIL, DM_WGRAD_WGS, DM_ROI_CT,
+ *     DM_ROI_ORDER, DM_ROI_BAND_CT, DM_ROI_BAND_ORDER, DM_ROI_UNITS / DM_ROI_UNITS_NOW (the
+ *     persistent-units RoIAlign of round 3: same bits as the band kernel), DM_ROI_NT, DM_ROI_UNIT_WGS.
+ *     A/B switches that select an older kernel or another split for the same
  *     operation (same mathematics; sums may differ in the last bits):
- *     DM_WGRAD_NARROW_OFF, DM_DCN_BAND_OFF, DM_IM2COL_V1.
+ *     DM_WGRAD_NARROW_OFF, DM_DCN_BAND_OFF, DM_IM2COL_V1, DM_FC_SEG.
  *     Calls from several host threads are safe (a race only repeats an
  *     idempotent attribute call);
  *   - LDS scatter-accumulators (dm_deform_col2im_coord, dm_point_sample_bwd) are
