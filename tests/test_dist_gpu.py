@@ -142,3 +142,39 @@ def test_scale_grads_of_a_parameter_subset(rccl_world1):
     for p, b in zip(net.parameters(), before):
         exp = b * 0.05 if any(p is q for q in sub) else b
         assert torch.equal(p.grad, exp)
+
+
+def test_gloo_default_group_with_an_rccl_subgroup_as_bench_uses_at_n_gt_1():
+    """At N > 1 bench.py keeps gloo as the default group (host barriers, max over ranks) and creates the RCCL
+    communicator of the data-path collective as a SUBGROUP inside the training leg, destroyed again afterwards.  That
+    combination of torch.distributed calls cannot be exercised at N > 1 on a one-GPU box; here it runs at world size 1
+    in a process of its own (a process has one default group): gloo default + `new_group(backend='nccl', device_id=...)`,
+    the flat-gradient all-reduce forced through the subgroup, the subgroup destroyed, the default group still usable."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, socket, sys, torch, torch.distributed as dist, torch.nn as nn
+sys.path.insert(0, %r)
+s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1')
+dev = torch.device('cuda', 0); torch.cuda.set_device(dev)
+dist.init_process_group('gloo')
+sub = dist.new_group(backend='nccl', device_id=dev)
+from dynamask_amd.dist import FlatParamGroup
+net = nn.Linear(32, 16).to(dev)
+grp = FlatParamGroup(net.parameters(), process_group=sub)
+grp.zero_grad(); net(torch.randn(4, 32, device=dev)).sum().backward()
+before = grp.flat_grad.clone()
+grp.all_reduce_async(force=True); assert grp._work is not None; grp.wait(); torch.cuda.synchronize()
+assert torch.equal(grp.flat_grad, before) and dist.get_backend(sub) == 'nccl' and dist.get_backend() == 'gloo'
+t = torch.tensor([3.0], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); assert float(t) == 3.0
+torch.cuda.synchronize(); dist.barrier(); dist.destroy_process_group(sub)
+dist.barrier(); dist.destroy_process_group()
+print('subgroup ok')
+''' % root
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'subgroup ok' in r.stdout, r.stderr[-3000:]
