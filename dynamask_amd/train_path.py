@@ -201,8 +201,10 @@ class MaskHeadFn(torch.autograd.Function):
         return (*ips, *dps)
 
     @staticmethod
-    def issue(head, rois, labels, ins_feats, fpn_feats):
-        """The launches of the forward (no autograd state): -> (ips, dps, saved, feats, rois, labels)."""
+    def issue(head, rois, labels, ins_feats, fpn_feats, after_convs=None):
+        """The launches of the forward (no autograd state): -> (ips, dps, saved, feats, rois, labels).
+        ``after_convs``: called once the instance convolutions of both halves have been issued (the GPU then has
+        ~2 ms of work queued): the place for a branch that must finish by the loss but feeds nothing before it."""
         feats = [t.contiguous() for t in fpn_feats]
         labels = labels.long().contiguous()
         rois = rois.contiguous()
@@ -317,6 +319,8 @@ class MaskHeadFn(torch.autograd.Function):
             second.wait_event(packed)
             with torch.cuda.stream(second):
                 convs(h, n)
+            if after_convs is not None:
+                after_convs()
             sw.run(semantic_branches, after=ready)
             sw.join(*sems, *isfs)
             stages(0, h)
@@ -325,6 +329,8 @@ class MaskHeadFn(torch.autograd.Function):
                 stages(h, n)
             main.wait_stream(second)
         else:
+            if after_convs is not None:
+                after_convs()
             sw.run(semantic_branches, after=ready)
             convs(0, n)
             sw.join(*sems, *isfs)
@@ -495,17 +501,21 @@ class MaskHeadFn(torch.autograd.Function):
 def mask_head_forward_train(head, ins_feats, feats, rois, labels, between=None):
     """Differentiable ``DynaMaskHead.forward`` -> (stage_instance_preds, stage_detail_preds).
 
-    ``between``: a callable run after the head's launches have been issued and BEFORE its autograd node is created.
+    ``between``: a callable run while the head's launches are being issued (right after its instance convolutions:
+    the GPU has work queued, and the branch gets the rest of the forward to finish in) and BEFORE the head's autograd
+    node is created.
     The autograd engine runs ready nodes newest first, and it issues one node's launches at a time: whatever is
     created inside ``between`` (the selector branch) gets older sequence numbers than the head's node, so in the
     backward the head -- the chain that decides the length of the step -- is issued first and the branch with slack
     after it, while in the forward the head's launches were issued first as well."""
     feats = list(feats)
     if between is not None:
+        def branch():
+            with torch.enable_grad():
+                between()
         with torch.no_grad():
             _PRECOMPUTED[0] = None
-            pre = MaskHeadFn.issue(head, rois, labels, ins_feats.detach(), [f.detach() for f in feats])
-        between()
+            pre = MaskHeadFn.issue(head, rois, labels, ins_feats.detach(), [f.detach() for f in feats], after_convs=branch)
         _PRECOMPUTED[0] = pre
     # (Two half-batches on two streams -- the inference path's arrangement -- were measured here too: 25.8 ms
     # against 23.8 ms per step at 256 RoIs.  The backward already shares the GPU between the chain and its leaves;
