@@ -729,8 +729,18 @@ static int conv2d_launch(const float* const* srcs, const int* src_channels, cons
     if (Cout > 32) return launch_conv<3, 1, 4, 2, 1, 8>(a, st);
     return launch_conv<3, 1, 4, 1, 1, 8>(a, st);
   }
-  if (Cout > 64) return launch_conv<1, 2, 2, 2, 2, 16>(a, st);
-  if (Cout > 32) return launch_conv<1, 1, 4, 2, 2, 16>(a, st);   // 64 couts x 256 px (128 px: 0.69 -> 0.56 ms on 130->64 @56^2)
+  int v = 0;                                                   // DM_CONV1_VARIANT: the other tilings tools/conv1_exp.py times
+  if (const char* e = getenv("DM_CONV1_VARIANT")) v = atoi(e);
+  if (Cout > 64) return v == 1 ? launch_conv<1, 2, 2, 2, 2, 32>(a, st) : launch_conv<1, 2, 2, 2, 2, 16>(a, st);
+  if (Cout > 32) {
+    // 64 couts x 128 px as 4 waves of 32 x 64: 0.437 -> 0.379 ms on 576 -> 64 @56^2 x 128 RoIs, 0.098 -> 0.089 ms on
+    // 64 -> 64 x 256 (profiles/r03_conv1_exp.txt); same bits as the 64 x 256 tiling (v = 5), one k order per output.
+    if (v == 1) return launch_conv<1, 1, 4, 2, 2, 32>(a, st);
+    if (v == 3) return launch_conv<1, 2, 2, 1, 2, 32>(a, st);
+    if (v == 4) return launch_conv<1, 1, 4, 2, 1, 32>(a, st);
+    if (v == 5) return launch_conv<1, 1, 4, 2, 2, 16>(a, st);
+    return launch_conv<1, 2, 2, 1, 2, 16>(a, st);
+  }
   return launch_conv<1, 1, 4, 1, 1, 32>(a, st);
 }
 
