@@ -302,14 +302,18 @@ __global__ __launch_bounds__(WGM* WGN * 64) void deform_conv_kernel(DcnArgs a) {
 // Variant for small maps (128 <= H*W <= 256, i.e. the 14x14 stage): 128 couts x 128 pixels per
 // workgroup like the plain conv kernel.  What kept the kernel above at 128 x 64 is the register
 // cost of gathering from global memory (the raw row pairs of the next chunk live in VGPRs under
-// the MFMAs).  Here the 8 channel planes of the (at most two) images a pixel tile touches are
-// staged in LDS per chunk -- a 14x14 plane is 784 bytes -- and the bilinear gather reads LDS:
+// the MFMAs).  Here the 8 channels of the (at most two) images a pixel tile touches are
+// staged in LDS per chunk and the bilinear gather reads LDS:
 // short latency, so a tap's B operand is produced just in time, three taps ahead of its MFMAs.
+// The staged layout is [image][channel quad][pixel] float4 (the conv kernel's B layout): a sample's corner is ONE
+// 16-byte read for the four channels of the thread's quad -- four reads per tap.  (Round 2 kept whole planes and read
+// every corner pair of every channel with a ds_read2_b32: 8 reads and ~20 register moves per tap; tools/micro/mfma_mix.hip
+// prices 8 such reads next to 16 MFMAs at a third of the MFMAs' own time.)
 //
 // The K loop is a sequence of steps of 3 taps (3 steps per chunk of 8 channels).  Step s does the
 // MFMAs of its 3 taps from ring slot s & 1 of the A (weights) and B (gathered pixels) images while
 // it fills slot (s + 1) & 1 for the next step: B by the gather, A from registers loaded one step
-// earlier.  The channel planes are double buffered by chunk; the planes of chunk c + 1 are loaded
+// earlier.  The channel quads are double buffered by chunk; those of chunk c + 1 are loaded
 // in step 0 of chunk c, stored in step 1, and first read by the gather of step 2.  One barrier per
 // step, no phase without MFMAs.
 __global__ __launch_bounds__(256, 2) void deform_conv_lds_kernel(DcnArgs a) {
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void deform_conv_lds_kernel(DcnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   dm_f32x4* ldsA = reinterpret_cast<dm_f32x4*>(lds);                 // [2][AS_F4]
   dm_f32x4* ldsB = ldsA + 2 * AS_F4;                                 // [2][BS_F4]
-  float* ldsX = reinterpret_cast<float*>(ldsB + 2 * BS_F4);          // [2 buffers][2 image slots][8 ch][H*W]
+  dm_f32x4* ldsX = ldsB + 2 * BS_F4;                                 // [2 buffers][2 image slots][2 quads][H*W] float4
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_m = wave >> 1, wave_n = wave & 1;
@@ -343,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void deform_conv_lds_kernel(DcnArgs a) {
   const int m0 = m_tile * TM, q0 = a.q_begin + n_tile * TN;
   const int HW = a.HW, W = a.W, H = a.H;
   const int n0 = q0 / HW;                          // first image of the tile; the tile touches n0 and n0 + 1 at most
-  const int xbuf = 2 * 8 * HW;                     // floats per plane buffer
+  const int xbuf = 2 * 2 * HW;                     // float4 per staging buffer
 
   int col_n[2], col_p[2];
   bool col_ok[2];
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void deform_conv_lds_kernel(DcnArgs a) {
   gq = min(gq, a.Q - 1);
   const int gn = gq / HW, gp = gq - gn * HW;
   const int gy = gp / W, gx = gp - gy * W;
-  const int xbase = ((gn - n0) * 8 + gh * 4) * HW;           // this thread's 4 planes inside a plane buffer
+  const int xbase = ((gn - n0) * 2 + gh) * HW;               // this thread's quad inside a staging buffer
 
   int otb[9];                                      // top | bottom << 16: offsets inside a plane (< 256)
   float wt0[9], wt1[9], wb0[9], wb1[9];
@@ -405,59 +409,69 @@ __global__ __launch_bounds__(256, 2) void deform_conv_lds_kernel(DcnArgs a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   dm_f32x4 ra[A_PER_T], rx[X_PER_T];
-  const int x_f4_img = 8 * HW / 4;                 // float4 per image and chunk (8 contiguous planes; HW % 4 checked on the host)
+  // staging slot i of this thread: (image slot, quad, pixel) = its place in a staging buffer; x_off = float offset of
+  // the quad's first channel at that pixel, relative to (image n0, channel c0).  Slots past the staging buffer or past
+  // the last image load an address that exists (slot 0 / the last image) and are not stored / never gathered from.
+  int x_off[X_PER_T];
+#pragma unroll
+  for (int i = 0; i < X_PER_T; ++i) {
+    const int idx = tid + i * NT;
+    const int img = idx / (2 * HW), r = idx - img * 2 * HW;
+    const int quad = r / HW, px = r - quad * HW;
+    const int ii = (idx < 4 * HW) ? img : 0, qq = (idx < 4 * HW) ? quad : 0, pp = (idx < 4 * HW) ? px : 0;
+    x_off[i] = ((min(n0 + ii, a.NB - 1) - n0) * a.C + qq * 4) * HW + pp;
+  }
   // weights of taps 3g .. 3g+2, channels c0 .. c0+7
   auto load_a = [&](int c0, int g) {
 #pragma unroll
     for (int i = 0; i < A_PER_T; ++i) {
       const int idx = tid + i * NT;
       const int m = idx % TM, tq = idx / TM;       // tq = (tap of the step) * 2 + quad
-      dm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m0 + m < a.CoutP)
-        v = *reinterpret_cast<const dm_f32x4*>(a.wp + (((size_t)(3 * g + (tq >> 1)) * a.KQ + (c0 >> 2) + (tq & 1)) * a.CoutP + m0 + m) * 4);
-      ra[i] = v;
+      // (rows past CoutP: the last row again -- their products land in accumulator rows the epilogue never stores;
+      // an unconditional load keeps exec-mask branches out of the loop)
+      const int mm = min(m0 + m, a.CoutP - 1);
+      ra[i] = *reinterpret_cast<const dm_f32x4*>(a.wp + (((size_t)(3 * g + (tq >> 1)) * a.KQ + (c0 >> 2) + (tq & 1)) * a.CoutP + mm) * 4);
     }
   };
   auto store_a = [&](int slot) {
 #pragma unroll
     for (int i = 0; i < A_PER_T; ++i) ldsA[slot * AS_F4 + tid + i * NT] = ra[i];
   };
-  auto load_x = [&](int c0) {
+  auto load_x = [&](int c0) {                     // lanes = consecutive pixels: coalesced dword loads, as the conv kernel's B staging
+    const float* xc = a.x + ((size_t)n0 * a.C + c0) * HW;
+#pragma unroll
+    for (int i = 0; i < X_PER_T; ++i) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) rx[i][e] = xc[x_off[i] + e * HW];
+    }
+  };
+  auto store_x = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < X_PER_T; ++i) {
       const int idx = tid + i * NT;
-      const int img = idx / x_f4_img, r = idx - img * x_f4_img;
-      dm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (img < 2 && n0 + img < a.NB)
-        v = *reinterpret_cast<const dm_f32x4*>(a.x + ((size_t)(n0 + img) * a.C + c0) * HW + (size_t)r * 4);
-      rx[i] = v;
+      if (idx < 4 * HW) ldsX[buf * xbuf + idx] = rx[i];
     }
   };
-  auto store_x = [&](int buf) {                   // 8 planes of an image are one contiguous run, copied as is
-#pragma unroll
-    for (int i = 0; i < X_PER_T; ++i) {
-      const int idx = tid + i * NT;
-      if (idx < 2 * x_f4_img) *reinterpret_cast<dm_f32x4*>(ldsX + buf * xbuf + idx * 4) = rx[i];
-    }
-  };
-  struct __attribute__((packed, aligned(4))) F2 { float a, b; };
-  auto gather3 = [&](int t0, int slot, int buf) {   // taps t0 .. t0+2 of the chunk in plane buffer buf -> B slot
-    const float* xb = ldsX + buf * xbuf + xbase;
+  auto gather3 = [&](int t0, int slot, int buf) {   // taps t0 .. t0+2 of the chunk in staging buffer buf -> B slot
+    const dm_f32x4* xq = ldsX + buf * xbuf + xbase;
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       const int tap = t0 + u;
+      const dm_f32x4* pt = xq + (otb[tap] & 0xffff);
+      const dm_f32x4* pb = xq + (otb[tap] >> 16);
+      const dm_f32x4 tl = pt[0], tr = pt[1], bl = pb[0], br = pb[1];
       dm_f32x4 v;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float* pl = xb + e * HW;
-        const F2 top = *reinterpret_cast<const F2*>(pl + (otb[tap] & 0xffff));
-        const F2 bot = *reinterpret_cast<const F2*>(pl + (otb[tap] >> 16));
-        v[e] = dcn_bilinear(wt0[tap], wt1[tap], wb0[tap], wb1[tap], top.a, top.b, bot.a, bot.b);
-      }
+      for (int e = 0; e < 4; ++e) v[e] = dcn_bilinear(wt0[tap], wt1[tap], wb0[tap], wb1[tap], tl[e], tr[e], bl[e], br[e]);
       ldsB[slot * BS_F4 + (u * 2 + gh) * TN + gj] = v;
     }
   };
-  auto mfma3 = [&](int slot) {
+  // One step: the MFMAs of 3 taps from ring slot ``slot``; if ``fill``, the gather of taps t0 .. t0+2 (staging buffer
+  // ``gbuf``) into the other slot, one tap inside each MFMA cluster: the four corner reads are issued with the
+  // cluster's operand reads, the fma chain and the 16-byte write sit in the middle of the cluster -- their LDS latency
+  // passes under MFMAs of the same wave instead of in front of them (round 2 gathered all three taps, then ran the 48 MFMAs).
+  auto step = [&](int slot, bool fill, int t0, int gbuf) {
+    const dm_f32x4* xq = ldsX + gbuf * xbuf + xbase;
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       dm_f32x4 av[2], bv[2];
@@ -465,12 +479,37 @@ __global__ __launch_bounds__(256, 2) void deform_conv_lds_kernel(DcnArgs a) {
       for (int i = 0; i < 2; ++i) av[i] = ldsA[slot * AS_F4 + (u * 2 + hi) * TM + (wave_m * 2 + i) * 32 + l31];
 #pragma unroll
       for (int j = 0; j < 2; ++j) bv[j] = ldsB[slot * BS_F4 + (u * 2 + hi) * TN + (wave_n * 2 + j) * 32 + l31];
+      const int tap = t0 + u;
+      dm_f32x4 tl, tr, bl, br;
+      if (fill) {
+        const dm_f32x4* pt = xq + (otb[tap] & 0xffff);
+        const dm_f32x4* pb = xq + (otb[tap] >> 16);
+        tl = pt[0]; tr = pt[1]; bl = pb[0]; br = pb[1];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);            // a wave in its MFMA cluster wins the issue arbitration (mfma_mix.hip: +4 %)
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int e = 0; e < 2; ++e)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (fill) {
+        dm_f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = dcn_bilinear(wt0[tap], wt1[tap], wb0[tap], wb1[tap], tl[e], tr[e], bl[e], br[e]);
+        ldsB[(slot ^ 1) * BS_F4 + (u * 2 + gh) * TN + gj] = v;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 2; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -491,20 +530,18 @@ __global__ __launch_bounds__(256, 2) void deform_conv_lds_kernel(DcnArgs a) {
     const bool more = cn < a.C;
     // step 0: MFMAs of taps 0..2; fills taps 3..5
     if (more) load_x(cn);
-    gather3(3, slot ^ 1, buf);
     store_a(slot ^ 1);
     load_a(c0, 2);
-    mfma3(slot);
+    step(slot, true, 3, buf);
     __syncthreads();
     slot ^= 1;
-    // step 1: MFMAs of taps 3..5; fills taps 6..8; planes of the next chunk go to the other buffer
-    gather3(6, slot ^ 1, buf);
+    // step 1: MFMAs of taps 3..5; fills taps 6..8; the quads of the next chunk go to the other buffer
     store_a(slot ^ 1);
     if (more) {
       load_a(cn, 0);
       store_x(buf ^ 1);
     }
-    mfma3(slot);
+    step(slot, true, 6, buf);
     __syncthreads();
     slot ^= 1;
     // step 2: MFMAs of taps 6..8; fills taps 0..2 of the next chunk
@@ -514,11 +551,10 @@ __global__ __launch_bounds__(256, 2) void deform_conv_lds_kernel(DcnArgs a) {
         cur_group = group;
         load_params(group);
       }
-      gather3(0, slot ^ 1, buf ^ 1);
       store_a(slot ^ 1);
       load_a(cn, 1);
     }
-    mfma3(slot);
+    step(slot, more, 0, buf ^ 1);
     __syncthreads();
     slot ^= 1;
   }

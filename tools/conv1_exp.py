@@ -30,6 +30,7 @@ for name, cins, cout, S, N in shapes:
     fl = 2.0 * N * S * S * sum(cins) * cout
     mb = (sum(x.numel() for x in xs) + out.numel()) * 4 / 1e6
     base = None
+    t(lambda: ops.conv2d(xs, wq, None, cout, 1, relu=True, out=out), iters=20)      # clocks up before the first variant is timed
     row = f'{name:40s} ({mb:6.0f} MB)'
     for v in ('0', '5', '1', '3', '4'):
         os.environ['DM_CONV1_VARIANT'] = v
