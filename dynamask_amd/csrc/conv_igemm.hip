@@ -338,6 +338,8 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
         const bool live = (NG == 1) || ((st % NG) < ngroups);
         if (st + 1 < STEPS) load_frag(st + 1, av[cur ^ 1], bv[cur ^ 1]);
         if (live) {
+          // (s_setprio 1 around this cluster: +4 % in tools/micro/mfma_mix.hip, -3.5 % on the headline -- with three workgroups
+          // per CU the prioritised waves starve the ones staging the next chunk)
 #pragma unroll
           for (int e = 0; e < 4; ++e)
 #pragma unroll

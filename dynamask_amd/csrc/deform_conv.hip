@@ -487,7 +487,6 @@ __global__ __launch_bounds__(256, 2) void deform_conv_lds_kernel(DcnArgs a) {
         tl = pt[0]; tr = pt[1]; bl = pb[0]; br = pb[1];
       }
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);            // a wave in its MFMA cluster wins the issue arbitration (mfma_mix.hip: +4 %)
 #pragma unroll
       for (int e = 0; e < 2; ++e)
 #pragma unroll
@@ -508,7 +507,6 @@ __global__ __launch_bounds__(256, 2) void deform_conv_lds_kernel(DcnArgs a) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
