@@ -1100,8 +1100,8 @@ __global__ __launch_bounds__(256) void dcn_coord_grad_kernel(const float* __rest
 // measured on gfx950 (tools/micro/lds_atomics.hip) ds_add_f32 runs at 0.38 lane-atomics
 // per clock per CU, ds_add_u64 at 6.4 (17x) -- and integer sums are order-independent,
 // so this gradient is bitwise reproducible run to run.
-template <int CT>
-__global__ __launch_bounds__(256) void dcn_col2im_lds_kernel(const float* __restrict__ colgrad,
+template <int CT, int NTH = 256>
+__global__ __launch_bounds__(NTH) void dcn_col2im_lds_kernel(const float* __restrict__ colgrad,
                                                              const float* __restrict__ offset, int NB, int C, int H, int W,
                                                              int dg, float* __restrict__ gx) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long lds[];   // [CT][HW] fixed point
@@ -1464,7 +1464,9 @@ extern "C" int dm_deform_col2im(const float* colgrad, const float* offset, int N
     DM_LAUNCH(dcn_col2im_lds_kernel<4>, dim3((unsigned)(NB * (C / 4))), dim3(256), 4 * plane_b, st, colgrad, offset, NB, C, H,
               W, deform_groups, grad_x);
   } else if (cpg % 2 == 0 && 2 * plane_b <= 64 * 1024) {
-    DM_LAUNCH(dcn_col2im_lds_kernel<2>, dim3((unsigned)(NB * (C / 2))), dim3(256), 2 * plane_b, st, colgrad, offset, NB, C, H,
+    // (56 x 56: two 25 KB planes, three workgroups per CU -- with 8 waves each 1.09 -> 1.02 ms at 256 RoIs x 64 channels; four
+    // planes in 100 KB: 1.85 ms with 4 waves, 1.17 with 8; one plane: 1.29 -- tools/col2im_exp.py)
+    DM_LAUNCH((dcn_col2im_lds_kernel<2, 512>), dim3((unsigned)(NB * (C / 2))), dim3(512), 2 * plane_b, st, colgrad, offset, NB, C, H,
               W, deform_groups, grad_x);
   } else if (plane_b <= 64 * 1024) {
     DM_LAUNCH(dcn_col2im_lds_kernel<1>, dim3((unsigned)(NB * C)), dim3(256), plane_b, st, colgrad, offset, NB, C, H, W,
