@@ -116,7 +116,10 @@ __global__ __launch_bounds__(256) void point_sample_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------ K7
-// Thread = pixel of one RoI; the two weight rows W[label] are wave-uniform.
+// A workgroup = 64 pixels of one RoI x four interleaved channel subsets (one per wave); the two weight rows W[label] are
+// workgroup-uniform (scalar loads).  The waves' partial sums meet in LDS and are added in wave order.  (Round 2 gave a
+// thread a pixel and ALL channels: one 256-thread workgroup per 14 x 14 RoI, 8 waves per CU with four loads in flight
+// each -- 1.2 TB/s on a kernel that only streams x.)
 __global__ __launch_bounds__(256) void class_logits_kernel(const float* __restrict__ x, int N, int C, int HW,
                                                            const float* __restrict__ wi, const float* __restrict__ bi,
                                                            const float* __restrict__ wd, const float* __restrict__ bd,
@@ -124,20 +127,33 @@ __global__ __launch_bounds__(256) void class_logits_kernel(const float* __restri
                                                            float* __restrict__ inst, float* __restrict__ det,
                                                            float* __restrict__ sig, int sig_ct, int sig_off,
                                                            int pix_blocks) {
+  __shared__ float red[3][64][2];
   const int n = blockIdx.x / pix_blocks;
-  const int p = (blockIdx.x - n * pix_blocks) * blockDim.x + threadIdx.x;
-  if (p >= HW) return;
+  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int p = (blockIdx.x - n * pix_blocks) * 64 + lane;
+  const bool ok = p < HW;
   int lab = (int)labels[n];
   lab = min(max(lab, 0), num_classes - 1);
   const float* wri = wi + (size_t)lab * C;
   const float* wrd = wd + (size_t)lab * C;
-  const float* xp = x + (size_t)n * C * HW + p;
+  const float* xp = x + (size_t)n * C * HW + min(p, HW - 1);
   float ai = 0.f, ad = 0.f;
-#pragma unroll 4
-  for (int c = 0; c < C; ++c) {
+#pragma unroll 8
+  for (int c = part; c < C; c += 4) {
     const float v = xp[(size_t)c * HW];
     ai += wri[c] * v;
     ad += wrd[c] * v;
+  }
+  if (part > 0) {
+    red[part - 1][lane][0] = ai;
+    red[part - 1][lane][1] = ad;
+  }
+  __syncthreads();
+  if (part > 0 || !ok) return;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    ai += red[k][lane][0];
+    ad += red[k][lane][1];
   }
   ai += bi[lab];
   ad += bd[lab];
@@ -146,6 +162,95 @@ __global__ __launch_bounds__(256) void class_logits_kernel(const float* __restri
   if (sig) {
     sig[((size_t)n * sig_ct + sig_off) * HW + p] = sigmoidf_(ai);
     sig[((size_t)n * sig_ct + sig_off + 1) * HW + p] = sigmoidf_(ad);
+  }
+}
+
+// K7 at twice the resolution of its input: logits of relu(upsample2x(x)) without the upsampled tensor (the last stage
+// before an exit only feeds the exit's two logit maps: at the fixed 28 x 28 exit the upsampled features were 205 MB written
+// by one kernel and read once by the next).  A lane owns two horizontally adjacent INPUT pixels -- a 2 x 4 block of
+// outputs, as upsample2x_half_kernel, same expression, so the interpolated values have the same bits; a workgroup = 64
+// such items of one RoI x four interleaved channel subsets (one per wave), partial sums added in wave order through LDS.
+__global__ __launch_bounds__(256) void class_logits_up2x_kernel(const float* __restrict__ x, int item_blocks, int C, int H, int W,
+                                                                const float* __restrict__ wi, const float* __restrict__ bi,
+                                                                const float* __restrict__ wd, const float* __restrict__ bd,
+                                                                int num_classes, const int64_t* __restrict__ labels,
+                                                                float* __restrict__ inst, float* __restrict__ det) {
+  __shared__ float red[3][16][64];
+  const int n = blockIdx.x / item_blocks;
+  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int Wh = W >> 1, items = H * Wh;
+  const int it = (blockIdx.x - n * item_blocks) * 64 + lane;
+  const bool ok = it < items;
+  const int item = min(it, items - 1);
+  const int y = item / Wh, xp = item - y * Wh;
+  int lab = (int)labels[n];
+  lab = min(max(lab, 0), num_classes - 1);
+  const float* wri = wi + (size_t)lab * C;
+  const float* wrd = wd + (size_t)lab * C;
+  const int ym = max(y - 1, 0), yp = min(y + 1, H - 1);
+  const int x0 = 2 * xp;
+  struct __attribute__((packed, aligned(4))) F2 { float a, b; };
+  const bool first = x0 == 0, last = x0 + 2 > W - 1;       // column pair at the left / right border of the row
+  const int la = first ? 0 : x0 - 1, lb = last ? x0 : x0 + 1;
+  const int rows[3] = {ym * W, y * W, yp * W};
+  float acc[16];      // [branch][dy][e]
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+  const float* px = x + (size_t)n * C * H * W;
+#pragma unroll 2
+  for (int c = part; c < C; c += 4) {
+    const float* p = px + (size_t)c * H * W;
+    // the four columns (x0-1, x0, x0+1, x0+2, clamped to the row) as two 8-byte loads: half the gather instructions
+    float v[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float* pr = p + rows[r];
+      const F2 pa = *reinterpret_cast<const F2*>(pr + la);
+      const F2 pb = *reinterpret_cast<const F2*>(pr + lb);
+      v[r][0] = pa.a;
+      v[r][1] = first ? pa.a : pa.b;
+      v[r][2] = last ? pb.b : pb.a;
+      v[r][3] = pb.b;
+    }
+    const float wci = wri[c], wcd = wrd[c];
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+      const int ra = dy == 0 ? 0 : 1, rb = dy == 0 ? 1 : 2;
+      float ly = dy == 0 ? 0.75f : 0.25f;
+      int ia = ra, ib = rb;
+      if (dy == 0 && y == 0) { ia = 1; ib = 1; ly = 0.f; }
+      const float hy = 1.f - ly;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int ja = (e == 0) ? 0 : (e == 3 ? 2 : 1);
+        int jb = ja + 1;
+        float lx = (e & 1) ? 0.25f : 0.75f;
+        if (e == 0 && x0 == 0) { ja = 1; jb = 1; lx = 0.f; }
+        const float hx = 1.f - lx;
+        const float r = fmaxf(hy * (hx * v[ia][ja] + lx * v[ia][jb]) + ly * (hx * v[ib][ja] + lx * v[ib][jb]), 0.f);
+        acc[dy * 4 + e] += wci * r;
+        acc[8 + dy * 4 + e] += wcd * r;
+      }
+    }
+  }
+  if (part > 0) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) red[part - 1][k][lane] = acc[k];
+  }
+  __syncthreads();
+  if (part > 0 || !ok) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] += red[w][k][lane];
+  const float b_i = bi[lab], b_d = bd[lab];
+  const size_t o = ((size_t)n * 2 * H + 2 * y) * (size_t)(2 * W) + 4 * xp;
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy) {
+    *reinterpret_cast<dm_f32x4*>(inst + o + (size_t)dy * 2 * W) =
+        dm_f32x4{acc[dy * 4] + b_i, acc[dy * 4 + 1] + b_i, acc[dy * 4 + 2] + b_i, acc[dy * 4 + 3] + b_i};
+    *reinterpret_cast<dm_f32x4*>(det + o + (size_t)dy * 2 * W) =
+        dm_f32x4{acc[8 + dy * 4] + b_d, acc[8 + dy * 4 + 1] + b_d, acc[8 + dy * 4 + 2] + b_d, acc[8 + dy * 4 + 3] + b_d};
   }
 }
 
@@ -597,10 +702,25 @@ extern "C" int dm_class_logits_fwd(const float* x, int N, int C, int HW, const f
   if (N < 0 || C <= 0 || HW <= 0 || num_classes <= 0) return DM_ERR_INVALID_ARG;
   if (sig_out && (sig_ch_offset < 0 || sig_ch_offset + 2 > sig_ch_total)) return DM_ERR_INVALID_ARG;
   if (N == 0) return DM_OK;
-  const int pix_blocks = dm_ceil_div(HW, 256);
+  const int pix_blocks = dm_ceil_div(HW, 64);
+  if ((long long)N * pix_blocks > 0x7fffffffLL) return DM_ERR_UNSUPPORTED;
   DM_LAUNCH(class_logits_kernel, dim3((unsigned)(N * pix_blocks)), dim3(256), 0, (hipStream_t)stream, x, N, C,
                      HW, w_inst, b_inst, w_det, b_det, num_classes, labels, inst, det, sig_out, sig_ch_total,
                      sig_ch_offset, pix_blocks);
+  return dm_check_launch();
+}
+
+extern "C" int dm_class_logits_up2x_fwd(const float* x, int N, int C, int H, int W, const float* w_inst, const float* b_inst,
+                                        const float* w_det, const float* b_det, int num_classes, const int64_t* labels,
+                                        float* inst, float* det, dm_stream_t stream) {
+  if (!x || !w_inst || !b_inst || !w_det || !b_det || !labels || !inst || !det) return DM_ERR_INVALID_ARG;
+  if (N < 0 || C <= 0 || H <= 0 || W <= 0 || num_classes <= 0) return DM_ERR_INVALID_ARG;
+  if ((W & 1) || H < 2 || W < 2) return DM_ERR_UNSUPPORTED;      // the half-pixel fast path of dm_upsample2x_bilinear_fwd
+  if (N == 0) return DM_OK;
+  const int item_blocks = dm_ceil_div(H * (W / 2), 64);
+  if ((long long)N * item_blocks > 0x7fffffffLL) return DM_ERR_UNSUPPORTED;
+  DM_LAUNCH(class_logits_up2x_kernel, dim3((unsigned)(N * item_blocks)), dim3(256), 0, (hipStream_t)stream, x, item_blocks, C, H, W,
+            w_inst, b_inst, w_det, b_det, num_classes, labels, inst, det);
   return dm_check_launch();
 }
 

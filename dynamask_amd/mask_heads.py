@@ -261,19 +261,25 @@ class DynaMaskHead(nn.Module):
             instance_feats = conv(instance_feats)
         stage_instance_preds, stage_detail_preds = [], []
         roi_labels = roi_labels.long().contiguous()
+        fused_exit = False
         for idx, stage in enumerate(self.stages):
             if last_stage is not None and idx == last_stage:
                 # exit here: only the logits of this resolution are needed
                 c, nc = stage.instance_in_channel, stage.num_classes
-                ip, dp = ops.class_logits(instance_feats, stage.instance_logits.weight.detach().view(nc, c),
-                                          stage.instance_logits.bias.detach(),
-                                          stage.detail_logits.weight.detach().view(nc, c),
-                                          stage.detail_logits.bias.detach(), roi_labels, out=po(idx))
+                logits = ops.class_logits_up2x if fused_exit else ops.class_logits
+                ip, dp = logits(instance_feats, stage.instance_logits.weight.detach().view(nc, c),
+                                stage.instance_logits.bias.detach(), stage.detail_logits.weight.detach().view(nc, c),
+                                stage.detail_logits.bias.detach(), roi_labels, out=po(idx))
                 stage_instance_preds.append(ip)
                 stage_detail_preds.append(dp)
                 return stage_instance_preds, stage_detail_preds
             upsample_flag = self.pre_upsample_last_stage or idx < len(self.stages) - 1
-            ip, dp, instance_feats = stage(instance_feats, semantic_feats[-idx - 3], rois, roi_labels, upsample_flag,
+            # the stage before the exit: its x2 upsample would only feed the exit's two logit maps -- they are computed from
+            # the stage's own resolution instead (ops.class_logits_up2x), the upsampled tensor never exists
+            fused_exit = (last_stage is not None and idx + 1 == last_stage and idx + 1 < len(self.stages) and upsample_flag
+                          and not torch.is_grad_enabled() and ops.class_logits_up2x_supported(instance_feats))
+            ip, dp, instance_feats = stage(instance_feats, semantic_feats[-idx - 3], rois, roi_labels,
+                                           upsample_flag and not fused_exit,
                                            sem=None if sems is None else sems[idx], pred_out=po(idx))
             stage_instance_preds.append(ip)
             stage_detail_preds.append(dp)

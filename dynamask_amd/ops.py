@@ -499,6 +499,32 @@ def class_logits(x, w_inst, b_inst, w_det, b_det, labels, sig_out=None, sig_ch_o
     return inst, det
 
 
+def class_logits_up2x_supported(x):
+    return x.shape[3] % 2 == 0 and x.shape[2] >= 2 and x.shape[3] >= 2
+
+
+def class_logits_up2x(x, w_inst, b_inst, w_det, b_det, labels, out=None):
+    """``class_logits(upsample2x(x, align_corners=False, relu=True), ...)`` in one kernel, without the upsampled tensor
+    (the stage before an exit).  x [N, C, H, W] -> (inst, det) [N, 1, 2H, 2W]."""
+    _chk(x, 'x')
+    for t, n in ((w_inst, 'w_inst'), (b_inst, 'b_inst'), (w_det, 'w_det'), (b_det, 'b_det')):
+        _chk(t, n)
+    _chk(labels, 'labels', torch.int64)
+    N, C, H, W = x.shape
+    nc = w_inst.shape[0]
+    if out is None:
+        inst = torch.empty((N, 1, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+        det = torch.empty((N, 1, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+    else:
+        inst, det = out
+        for t, nm in ((inst, 'out[0]'), (det, 'out[1]')):
+            _chk(t, nm)
+            assert tuple(t.shape) == (N, 1, 2 * H, 2 * W)
+    check(lib().dm_class_logits_up2x_fwd(_p(x), N, C, H, W, _p(w_inst), _p(b_inst), _p(w_det), _p(b_det), nc, _p(labels),
+                                         _p(inst), _p(det), _stream()), 'dm_class_logits_up2x_fwd')
+    return inst, det
+
+
 def upsample2x(x, align_corners=False, relu=False, out=None):
     _chk(x, 'x')
     N, C, H, W = x.shape

@@ -50,7 +50,7 @@ extern "C" {
 typedef void* dm_stream_t; /* hipStream_t */
 
 const char* dm_error_string(int code);
-/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient, dm_conv_pack_weight_batch, dm_mask_loss_stage). */
+/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient, dm_conv_pack_weight_batch, dm_mask_loss_stage; 15: dm_class_logits_up2x_fwd). */
 int dm_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -164,6 +164,15 @@ int dm_class_logits_fwd(const float* x, int N, int C, int HW, const float* w_ins
                         const float* w_det, const float* b_det, int num_classes, const int64_t* labels,
                         float* inst, float* det, float* sig_out, int sig_ch_total, int sig_ch_offset,
                         dm_stream_t stream);
+
+/* K7 on relu(upsample2x(x)) (bilinear, align_corners=False) without the upsampled tensor: the logits an exit needs when
+ * the stage before it would only have been upsampled for them -- dynamask_head.py:120-122 (F.interpolate + relu) followed
+ * by :110-113 of the next stage / :236-237.  x [N, C, H, W] (W even, H, W >= 2: else DM_ERR_UNSUPPORTED and the caller
+ * runs the two kernels); inst/det [N, 2H, 2W].  The interpolated values are those of dm_upsample2x_bilinear_fwd bit for
+ * bit, and the channel sum runs in the four interleaved subsets of dm_class_logits_fwd. */
+int dm_class_logits_up2x_fwd(const float* x, int N, int C, int H, int W, const float* w_inst, const float* b_inst,
+                             const float* w_det, const float* b_det, int num_classes, const int64_t* labels,
+                             float* inst, float* det, dm_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * K8  deformable convolution v1 forward, 3x3, stride 1, pad 1, dilation 1,

@@ -180,6 +180,38 @@ def test_class_logits(ops):
     _close(sig[:, 5:6], rd.sigmoid())
 
 
+@pytest.mark.parametrize('N,C,H,W', [(7, 128, 14, 14), (3, 30, 7, 6), (130, 5, 2, 2), (1, 64, 28, 28)])
+def test_class_logits_of_the_upsampled_stage_without_the_upsampled_tensor(ops, N, C, H, W):
+    """dm_class_logits_up2x_fwd = F.interpolate(x2, bilinear, align_corners=False) -> relu -> the two class-gathered 1x1
+    logits (dynamask_head.py:120-122 then :110-113 of the next stage), against torch and against the two-kernel path."""
+    nc = 80
+    x = torch.randn(N, C, H, W, generator=_g(56))
+    wi = torch.randn(nc, C, 1, 1, generator=_g(57)) / C ** 0.5
+    wd = torch.randn(nc, C, 1, 1, generator=_g(58)) / C ** 0.5
+    bi, bd = torch.randn(nc, generator=_g(59)), torch.randn(nc, generator=_g(49))
+    labels = torch.randint(0, nc, (N,), generator=_g(48))
+    up = F.relu(F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False))
+    ar = torch.arange(N)
+    ri = F.conv2d(up, wi, bi)[ar, labels][:, None]
+    rd = F.conv2d(up, wd, bd)[ar, labels][:, None]
+    args = (_dev(wi.view(nc, C)), _dev(bi), _dev(wd.view(nc, C)), _dev(bd), _dev(labels))
+    oi, od = ops.class_logits_up2x(_dev(x), *args)
+    assert tuple(oi.shape) == (N, 1, 2 * H, 2 * W)
+    _close(oi, ri)
+    _close(od, rd)
+    ti, td = ops.class_logits(ops.upsample2x(_dev(x), align_corners=False, relu=True), *args)
+    _close(oi, ti.cpu(), atol=1e-5, rtol=1e-5)
+    _close(od, td.cpu(), atol=1e-5, rtol=1e-5)
+
+
+def test_class_logits_up2x_refuses_odd_widths(ops):
+    x = torch.randn(2, 4, 6, 7).cuda()
+    assert not ops.class_logits_up2x_supported(x)
+    w, b = torch.randn(3, 4).cuda(), torch.randn(3).cuda()
+    with pytest.raises(Exception):
+        ops.class_logits_up2x(x, w, b, w, b, torch.zeros(2, dtype=torch.int64).cuda())
+
+
 @pytest.mark.parametrize('N,C,S', [(7, 256, 14), (5, 128, 28), (3, 64, 56), (2, 16, 9)])
 def test_deform_conv(ops, N, C, S):
     x = torch.randn(N, C, S, S, generator=_g(60))
