@@ -1091,6 +1091,174 @@ __global__ __launch_bounds__(256) void dcn_coord_grad_kernel(const float* __rest
   goff[(size_t)(2 * tap + 1) * HW] = acc_w;
 }
 
+// Coordinate gradient, second generation (round 3).  The kernel above takes the four corner values of every
+// (channel, tap, pixel) through two scattered 8-byte global loads -- twice as many texture-path gathers as it has column
+// gradients to read, and it ran at half the rate its 1.85 GB stream allows (0.77 ms at 56 x 56).  Here a workgroup owns
+// a band of output rows of one (image, deformable group) and walks the channels in chunks of 8 whose rows around the
+// band are staged in LDS as [quad][pixel] float4 (the DCN forward's layout): a corner of four channels is ONE 16-byte
+// LDS read.  The staged band carries a zero column either side and zero rows beyond the image, so the corners of a
+// sample are always the four neighbours at (h_low, w_low) and an outside corner reads 0 -- the selectors and masks of
+// the first kernel are in the data, and an item keeps three registers (offset, lh, lw).  The column gradients arrive as
+// coalesced dword loads; sums run over the channels in index order: no atomics.  A sample whose rows leave the staged
+// band (an offset beyond DCN_COORD_HALO rows) takes the global loads of the first kernel.
+constexpr int DCN_COORD_HALO = 5;
+template <int IT, int XS, int NT>
+__global__ __launch_bounds__(NT, 4) void dcn_coord_grad_lds_kernel(const float* __restrict__ colgrad, const float* __restrict__ x,
+                                                                 const float* __restrict__ offset, int NB, int C, int H, int W,
+                                                                 int dg, float* __restrict__ goffset, int bands, int BRows,
+                                                                 int XR) {
+  extern __shared__ __attribute__((aligned(16))) dm_f32x4 xs[];      // [2 buffers][2 quads][(XR + 2) * (W + 2)]
+  const int HW = H * W, cpg = C / dg, Wp = W + 2, XP = (XR + 2) * Wp;
+  const int tid = threadIdx.x;
+  int bid = blockIdx.x;
+  const int band = bid % bands; bid /= bands;
+  const int g = bid % dg;
+  const int n = bid / dg;
+  const int y_first = band * BRows;
+  const int band_px = min(BRows, H - y_first) * W;
+  const int items = 9 * band_px;
+  const int band_y0 = min(max(y_first - (XR - BRows) / 2, 0), H - XR);      // first staged image row (host: XR <= H)
+
+  // ---- geometry of this thread's items
+  int ot[IT], ipt[IT];                   // top-left corner inside the staged band; pixel | tap << 20 (-1: no item)
+  float lhv[IT], lwv[IT];
+  float acc_h[IT], acc_w[IT];
+  unsigned oob = 0;                      // items whose rows leave the staged band
+  const float* offb = offset + ((size_t)n * dg + g) * 18 * HW;
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const int it = tid + k * NT;
+    ot[k] = 0; ipt[k] = -1;
+    lhv[k] = lwv[k] = 0.f;
+    acc_h[k] = acc_w[k] = 0.f;
+    if (it < items) {
+      const int tap = it / band_px, pl = it - tap * band_px;
+      const int p = y_first * W + pl;
+      const int y = p / W, xx = p - y * W;
+      ipt[k] = p | (tap << 20);
+      const DcnSample s = dcn_sample(offb + p, tap, HW, y, xx, H, W);
+      if (s.valid) {                      // h_low in [-1, H-1], w_low in [-1, W-1]
+        lhv[k] = s.h_im - (float)s.h_low;
+        lwv[k] = s.w_im - (float)s.w_low;
+        if (s.h_low >= band_y0 - 1 && s.h_low + 1 <= band_y0 + XR) ot[k] = (s.h_low - (band_y0 - 1)) * Wp + s.w_low + 1;
+        else oob |= 1u << k;
+      } else {
+        ipt[k] |= 1 << 30;               // void sample: the gradient is 0
+      }
+    }
+  }
+
+  // ---- channel chunks: stage the band rows of 8 channels, then every item adds its 8 channels
+  int x_off[XS];                          // float offset of staging slot i relative to (n, first channel of the chunk); -1: a zero
+#pragma unroll
+  for (int i = 0; i < XS; ++i) {
+    const int idx = tid + i * NT;
+    x_off[i] = -1;
+    if (idx < 2 * XP) {
+      const int quad = idx / XP, ppx = idx - quad * XP;
+      const int r = ppx / Wp, c = ppx - r * Wp;
+      const int yy = band_y0 - 1 + r, xc = c - 1;
+      if (yy >= 0 && yy < H && xc >= 0 && xc < W) x_off[i] = quad * 4 * HW + yy * W + xc;
+    }
+  }
+  dm_f32x4 rx[XS];
+  const float* xg = x + ((size_t)n * C + (size_t)g * cpg) * HW;          // this group's planes
+  auto load_x = [&](int c0) {
+    const float* xc = xg + (size_t)c0 * HW;
+#pragma unroll
+    for (int i = 0; i < XS; ++i) {
+      dm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (x_off[i] >= 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = xc[x_off[i] + e * HW];
+      }
+      rx[i] = v;
+    }
+  };
+  auto store_x = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < XS; ++i) {
+      const int idx = tid + i * NT;
+      if (idx < 2 * XP) xs[buf * 2 * XP + idx] = rx[i];
+    }
+  };
+  struct __attribute__((packed, aligned(4))) F2 { float a, b; };
+  load_x(0);
+  store_x(0);
+  __syncthreads();
+  const float* cgb = colgrad + ((size_t)n * 9 * C + (size_t)g * cpg) * HW;
+  for (int c0 = 0, buf = 0; c0 < cpg; c0 += 8, buf ^= 1) {
+    const bool more = c0 + 8 < cpg;
+    if (more) load_x(c0 + 8);
+    const dm_f32x4* xq = xs + buf * 2 * XP;
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+      if (ipt[k] < 0 || (ipt[k] >> 30) || ((oob >> k) & 1u)) continue;
+      const int p = ipt[k] & 0xfffff, tap = ipt[k] >> 20;
+      const float* cgp = cgb + ((size_t)tap * C + c0) * HW + p;
+      float cg[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) cg[c] = cgp[(size_t)c * HW];
+      const float lh = lhv[k], lw = lwv[k], hh = 1.f - lh, hw = 1.f - lw;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const dm_f32x4* pt = xq + q * XP + ot[k];
+        const dm_f32x4 x1 = pt[0], x2 = pt[1], x3 = pt[Wp], x4 = pt[Wp + 1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // d val / d h = -hw x1 - lw x2 + hw x3 + lw x4, d val / d w = -hh x1 + hh x2 - lh x3 + lh x4
+          // (get_coordinate_weight, deform_conv_cuda_kernel.cu:145-188)
+          const float gh = __builtin_fmaf(lw, x4[e], __builtin_fmaf(hw, x3[e], __builtin_fmaf(-lw, x2[e], -hw * x1[e])));
+          const float gw = __builtin_fmaf(lh, x4[e], __builtin_fmaf(-lh, x3[e], __builtin_fmaf(hh, x2[e], -hh * x1[e])));
+          acc_h[k] = __builtin_fmaf(cg[q * 4 + e], gh, acc_h[k]);
+          acc_w[k] = __builtin_fmaf(cg[q * 4 + e], gw, acc_w[k]);
+        }
+      }
+    }
+    if (more) store_x(buf ^ 1);          // the other buffer was last read in the previous iteration, behind its barrier
+    __syncthreads();
+  }
+  if (oob) {
+    // far samples: corners from global memory, outside ones masked (the first kernel's arithmetic), all channels
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+      if (!((oob >> k) & 1u)) continue;
+      const int p = ipt[k] & 0xfffff, tap = ipt[k] >> 20;
+      const int y = p / W, xx = p - y * W;
+      const DcnSample s = dcn_sample(offb + p, tap, HW, y, xx, H, W);
+      const int h_high = s.h_low + 1, w_high = s.w_low + 1;
+      const int rt = min(max(s.h_low, 0), H - 1), rbm = min(max(h_high, 0), H - 1);
+      const int cb = min(max(s.w_low, 0), W - 2);
+      const float sa0 = (s.w_low == cb) ? 1.f : 0.f, sa1 = (s.w_low == cb + 1) ? 1.f : 0.f;
+      const float sb0 = (w_high == cb) ? 1.f : 0.f, sb1 = (w_high == cb + 1) ? 1.f : 0.f;
+      const float mt = (s.h_low >= 0) ? 1.f : 0.f, mb = (h_high <= H - 1) ? 1.f : 0.f;
+      const float lh = lhv[k], lw = lwv[k], hh = 1.f - lh, hw = 1.f - lw;
+      float ah = 0.f, aw = 0.f;
+      for (int c = 0; c < cpg; ++c) {
+        const float cgv = cgb[((size_t)tap * C + c) * HW + p];
+        const F2 top = *reinterpret_cast<const F2*>(xg + (size_t)c * HW + rt * W + cb);
+        const F2 bot = *reinterpret_cast<const F2*>(xg + (size_t)c * HW + rbm * W + cb);
+        const float x1 = mt * (sa0 * top.a + sa1 * top.b), x2 = mt * (sb0 * top.a + sb1 * top.b);
+        const float x3 = mb * (sa0 * bot.a + sa1 * bot.b), x4 = mb * (sb0 * bot.a + sb1 * bot.b);
+        const float gh = __builtin_fmaf(lw, x4, __builtin_fmaf(hw, x3, __builtin_fmaf(-lw, x2, -hw * x1)));
+        const float gw = __builtin_fmaf(lh, x4, __builtin_fmaf(-lh, x3, __builtin_fmaf(hh, x2, -hh * x1)));
+        ah = __builtin_fmaf(cgv, gh, ah);
+        aw = __builtin_fmaf(cgv, gw, aw);
+      }
+      acc_h[k] = ah;
+      acc_w[k] = aw;
+    }
+  }
+  float* goff = goffset + ((size_t)n * dg + g) * 18 * HW;
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    if (ipt[k] < 0) continue;
+    const int p = ipt[k] & 0xfffff, tap = (ipt[k] >> 20) & 15;
+    goff[(size_t)(2 * tap) * HW + p] = acc_h[k];
+    goff[(size_t)(2 * tap + 1) * HW + p] = acc_w[k];
+  }
+}
+
 // Deformable col2im (data gradient).  Every contribution to gx[n, c] comes from the
 // colgrad rows (tap, c) of the same image, so a workgroup owns (n, CT channels),
 // accumulates the 9 x HW x 4 scatter-adds in an LDS copy of the planes and writes each
@@ -1443,6 +1611,28 @@ extern "C" int dm_deform_coord_grad(const float* colgrad, const float* x, const 
                                     int deform_groups, float* grad_offset, dm_stream_t stream) {
   if (!dcn_bwd_args_ok(colgrad, offset, NB, C, H, W, deform_groups) || !x || !grad_offset) return DM_ERR_INVALID_ARG;
   if (NB == 0) return DM_OK;
+  {
+    // LDS-staged build: 8 | channels per group, W >= 2, H * W < 65536; a band of BRows rows (<= 224 pixels: 8 items per
+    // thread) with DCN_COORD_HALO rows staged either side
+    static const bool v1_env = getenv("DM_COORD_V1") != nullptr;      // A/B switch
+    const int cpg = C / deform_groups;
+    const int BRows = max(1, min(H, 224 / W));
+    const int XR = min(H, BRows + 2 * DCN_COORD_HALO);
+    const int bands = dm_ceil_div(H, BRows);
+    const int slots = 2 * (XR + 2) * (W + 2);
+    const size_t lds = (size_t)2 * slots * 16;
+    if (!v1_env && cpg % 8 == 0 && W >= 2 && W <= 224 && H * W < (1 << 20) && 9 * BRows * W <= 2048 && slots <= 2048 &&
+        lds <= 64 * 1024 && (long long)NB * deform_groups * bands <= 0x7fffffffLL) {
+      const dim3 grid((unsigned)(NB * deform_groups * bands));
+      if (slots <= 2 * 512)
+        DM_LAUNCH((dcn_coord_grad_lds_kernel<4, 2, 512>), grid, dim3(512), lds, (hipStream_t)stream, colgrad, x, offset, NB, C, H, W,
+                  deform_groups, grad_offset, bands, BRows, XR);
+      else
+        DM_LAUNCH((dcn_coord_grad_lds_kernel<2, 2, 1024>), grid, dim3(1024), lds, (hipStream_t)stream, colgrad, x, offset, NB, C, H, W,
+                  deform_groups, grad_offset, bands, BRows, XR);
+      return dm_check_launch();
+    }
+  }
   const int pblocks = dm_ceil_div(H * W, 256);
   DM_LAUNCH(dcn_coord_grad_kernel, dim3((unsigned)(NB * deform_groups * 9 * pblocks)), dim3(256), 0, (hipStream_t)stream,
             colgrad, x, offset, NB, C, H, W, deform_groups, grad_offset);
