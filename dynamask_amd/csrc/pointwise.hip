@@ -319,16 +319,21 @@ __global__ __launch_bounds__(256) void upsample2x_half_kernel(const float* __res
     const float* p = in + nc * H * W;
     const int ym = max(y - 1, 0), yp = min(y + 1, H - 1);
     const int x0 = 2 * xp;
-    const int c0 = max(x0 - 1, 0), c3 = min(x0 + 2, W - 1);
+    // the four columns (x0-1, x0, x0+1, x0+2, clamped to the row) as two 8-byte loads
+    struct __attribute__((packed, aligned(4))) F2 { float a, b; };
+    const bool first = x0 == 0, last = x0 + 2 > W - 1;
+    const int la = first ? 0 : x0 - 1, lb = last ? x0 : x0 + 1;
     float v[3][4];
     const int rows[3] = {ym, y, yp};
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const float* pr = p + (long long)rows[r] * W;
-      v[r][0] = pr[c0];
-      v[r][1] = pr[x0];
-      v[r][2] = pr[x0 + 1];
-      v[r][3] = pr[c3];
+      const F2 pa = *reinterpret_cast<const F2*>(pr + la);
+      const F2 pb = *reinterpret_cast<const F2*>(pr + lb);
+      v[r][0] = pa.a;
+      v[r][1] = first ? pa.a : pa.b;
+      v[r][2] = last ? pb.b : pb.a;
+      v[r][3] = pb.b;
     }
     // output column ox = 2*x0 + e: (left tap, right tap, lx); at the borders the generic code clamps
     // the source coordinate to 0 (lx = 0) or repeats the last column (x1 == x0)
