@@ -365,7 +365,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
   // rest is uniform (SALU); the store modes are uniform too and pick one of three straight-line
   // variants.  (Written naively -- the full index expression per store, mode tests inside -- the
   // epilogue was 3700 VALU instructions per wave, as many as the 32 chunks of the main loop together,
-  // and VALU work is not free next to MFMAs: tools/micro/mfma_lds.hip.)
+  // and VALU work is not free next to MFMAs: tools/micro/mfma_mix.hip.)
   if (a.shuffle == 0) {
     float* pj[WN];
 #pragma unroll

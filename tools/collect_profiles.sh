@@ -44,6 +44,9 @@ cat $out/${tag}_traffic_pmc.txt
 # the file bench.py reads roofline.traffic from: regenerated with every collection (copy to profiles/pmc_traffic.json)
 python3 tools/make_pmc_json.py $out/traffic_fetch $out/traffic_write $out/traffic_mfma $out/${tag}_roofline_kernel_stats.csv 6 $out/${tag}_pmc_traffic.json > /dev/null
 echo "pmc json done"
-hipcc --offload-arch=gfx950 -O3 tools/micro/mfma_lds.hip -o $out/mfma_lds && $out/mfma_lds > $out/${tag}_mfma_lds_micro.txt
+hipcc --offload-arch=gfx950 -O3 -w tools/micro/mfma_mix.hip -o /tmp/mfma_mix 2> /dev/null && /tmp/mfma_mix > $out/${tag}_mfma_mix.txt
+python3 tools/conv1_exp.py > $out/${tag}_conv1_exp.txt 2>&1
+python3 tools/coord_exp.py > $out/${tag}_coord_exp.txt 2>&1
+python3 tools/dcn_offsets_exp.py > $out/${tag}_dcn_offsets_exp.txt 2>&1
 python3 tools/small_n.py > $out/${tag}_small_n.txt 2>&1
 echo "all done"
