@@ -155,6 +155,22 @@ def test_deform_conv_backward(ops, N, C, S):
     _close(gw, w.grad, atol=1e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize('N,C,S,sigma', [(2, 16, 56, 6.0), (3, 32, 28, 8.0), (2, 16, 14, 5.0), (1, 16, 56, 0.0)])
+def test_deform_coord_grad_with_samples_far_from_their_pixel(ops, N, C, S, sigma):
+    """The coordinate gradient stages a band of rows around a workgroup's pixels (DCN_COORD_HALO = 5 rows either side);
+    offsets of many rows leave the band and take the global-memory path, samples at the image border read the band's
+    zero rows / columns.  Checked against autograd of the oracle (deform_conv_cuda_kernel.cu:145-188, 338-408)."""
+    x = torch.randn(N, C, S, S, generator=_g(170), requires_grad=True)
+    w = torch.randn(C, C, 3, 3, generator=_g(171)) / (9 * C) ** 0.5
+    off = (torch.randn(N, 36, S, S, generator=_g(172)) * sigma).requires_grad_(True)
+    y = ref_ops.deform_conv2d(x, off, w, 1, 1, 1, 2)
+    go = torch.randn(y.shape, generator=_g(173))
+    y.backward(go)
+    gx, goff = ops.deform_conv_backward_data(_dev(x.detach()), _dev(off.detach()), _dev(w), _dev(go), 2)
+    _close(goff, off.grad, atol=1e-4, rtol=1e-4)
+    _close(gx, x.grad, atol=1e-4, rtol=1e-4)
+
+
 def test_fixed_point_scatter_accumulators_propagate_non_finite_gradients(ops):
     """The LDS accumulators of the DCN col2im and the point-sample adjoint are 64-bit fixed point; a NaN or
     Inf gradient has no fixed-point value and must show up as NaN in the plane it belongs to (a diverged step
