@@ -30,6 +30,15 @@ __device__ __forceinline__ float block_sum(float v, float* smem) {
   return r;
 }
 
+// One bilinear x2 value, spelled as an explicit fma chain: the three kernels that interpolate (generic, half-pixel fast
+// path, logits of the upsampled stage) must round alike -- left to the compiler, the same source expression contracted
+// differently next to different code and the fused exit differed from upsample + logits in the last bit.
+__device__ __forceinline__ float dm_up2x_interp(float hy, float ly, float hx, float lx, float a, float b, float c, float d) {
+  const float top = __builtin_fmaf(lx, b, hx * a);
+  const float bot = __builtin_fmaf(lx, d, hx * c);
+  return __builtin_fmaf(ly, bot, hy * top);
+}
+
 // ------------------------------------------------------------------ K4
 // grid_sample(bilinear, zeros, align_corners=False) at RoI-relative pixel
 // centres.  Thread = one sample point; its 4 taps/weights are computed once and
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(256) void class_logits_up2x_kernel(const float* __r
         float lx = (e & 1) ? 0.25f : 0.75f;
         if (e == 0 && x0 == 0) { ja = 1; jb = 1; lx = 0.f; }
         const float hx = 1.f - lx;
-        const float r = fmaxf(hy * (hx * v[ia][ja] + lx * v[ia][jb]) + ly * (hx * v[ib][ja] + lx * v[ib][jb]), 0.f);
+        const float r = fmaxf(dm_up2x_interp(hy, ly, hx, lx, v[ia][ja], v[ia][jb], v[ib][ja], v[ib][jb]), 0.f);
         acc[dy * 4 + e] += wci * r;
         acc[8 + dy * 4 + e] += wcd * r;
       }
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict
       x0 = min(x0, W - 1);
       const int x1 = x0 + ((x0 < W - 1) ? 1 : 0);
       const float lx = sx - (float)x0, hx = 1.f - lx;
-      float r = hy * (hx * r0[x0] + lx * r0[x1]) + ly * (hx * r1[x0] + lx * r1[x1]);
+      float r = dm_up2x_interp(hy, ly, hx, lx, r0[x0], r0[x1], r1[x0], r1[x1]);
       if (relu) r = fmaxf(r, 0.f);
       v[e] = r;
     }
@@ -354,7 +363,7 @@ __global__ __launch_bounds__(256) void upsample2x_half_kernel(const float* __res
         float lx = (e & 1) ? 0.25f : 0.75f;
         if (e == 0 && x0 == 0) { ja = 1; jb = 1; lx = 0.f; }     // sx clamped to 0
         const float hx = 1.f - lx;
-        float r = hy * (hx * v[ia][ja] + lx * v[ia][jb]) + ly * (hx * v[ib][ja] + lx * v[ib][jb]);
+        float r = dm_up2x_interp(hy, ly, hx, lx, v[ia][ja], v[ia][jb], v[ib][ja], v[ib][jb]);
         if (relu) r = fmaxf(r, 0.f);
         o[dy][e] = r;
       }

@@ -316,6 +316,7 @@ class DynaMaskHead(nn.Module):
             instance_feats = conv(instance_feats)
         roi_labels = roi_labels.long().contiguous()
         preds = []
+        exit_ip = None      # logits of the RoIs that exit at the coming stage, computed from the previous stage's own resolution
         for idx, stage in enumerate(self.stages):
             n_here, n_cont = n_ge[idx], n_ge[idx + 1]
             if n_here == 0:
@@ -323,19 +324,38 @@ class DynaMaskHead(nn.Module):
                 continue
             parts = []
             feats_here = instance_feats
+            carried, exit_ip = exit_ip, None
             if n_cont > 0:
                 upsample_flag = self.pre_upsample_last_stage or idx < len(self.stages) - 1
-                ip, _, instance_feats = stage(feats_here[:n_cont], semantic_feats[-idx - 3], rois[:n_cont],
-                                              roi_labels[:n_cont], upsample_flag,
-                                              sem=None if sems is None else sems[idx])
+                n_keep = n_ge[idx + 2] if idx + 2 < len(n_ge) else 0        # RoIs that go on past the next stage
+                fuse_next = (upsample_flag and idx + 1 < len(self.stages) and n_keep < n_cont
+                             and ops.class_logits_up2x_supported(feats_here))
+                ip, _, tail = stage(feats_here[:n_cont], semantic_feats[-idx - 3], rois[:n_cont], roi_labels[:n_cont],
+                                    upsample_flag and not fuse_next, sem=None if sems is None else sems[idx])
+                if fuse_next:
+                    # the RoIs that exit at the next stage need its two logit maps only: from this stage's resolution, the
+                    # upsampled features exist for the rows that go on (same bits as the fixed path's exit: same kernel)
+                    nxt = self.stages[idx + 1]
+                    c, nc = nxt.instance_in_channel, nxt.num_classes
+                    exit_ip, _ = ops.class_logits_up2x(tail[n_keep:n_cont], nxt.instance_logits.weight.detach().view(nc, c),
+                                                       nxt.instance_logits.bias.detach(), nxt.detail_logits.weight.detach().view(nc, c),
+                                                       nxt.detail_logits.bias.detach(), roi_labels[n_keep:n_cont])
+                    instance_feats = (ops.upsample2x(tail[:n_keep], align_corners=False, relu=True) if n_keep > 0
+                                      else tail.new_zeros((0, tail.shape[1], 2 * tail.shape[2], 2 * tail.shape[3])))
+                else:
+                    instance_feats = tail
                 parts.append(ip)
             if n_cont < n_here:
-                c, nc = stage.instance_in_channel, stage.num_classes
-                ip, _ = ops.class_logits(feats_here[n_cont:n_here], stage.instance_logits.weight.detach().view(nc, c),
-                                         stage.instance_logits.bias.detach(),
-                                         stage.detail_logits.weight.detach().view(nc, c),
-                                         stage.detail_logits.bias.detach(), roi_labels[n_cont:n_here])
-                parts.append(ip)
+                if carried is not None:
+                    assert carried.shape[0] == n_here - n_cont
+                    parts.append(carried)
+                else:
+                    c, nc = stage.instance_in_channel, stage.num_classes
+                    ip, _ = ops.class_logits(feats_here[n_cont:n_here], stage.instance_logits.weight.detach().view(nc, c),
+                                             stage.instance_logits.bias.detach(),
+                                             stage.detail_logits.weight.detach().view(nc, c),
+                                             stage.detail_logits.bias.detach(), roi_labels[n_cont:n_here])
+                    parts.append(ip)
             preds.append(parts[0] if len(parts) == 1 else torch.cat(parts))
         n_last = n_ge[len(self.stages)]
         s_last = self.stage_sup_size[-1]

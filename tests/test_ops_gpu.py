@@ -202,9 +202,9 @@ def test_class_logits_of_the_upsampled_stage_without_the_upsampled_tensor(ops, N
     assert tuple(oi.shape) == (N, 1, 2 * H, 2 * W)
     _close(oi, ri)
     _close(od, rd)
+    # the two-kernel path: same interpolated values (dm_up2x_interp), same channel-sum order -> the same bits
     ti, td = ops.class_logits(ops.upsample2x(_dev(x), align_corners=False, relu=True), *args)
-    _close(oi, ti.cpu(), atol=1e-5, rtol=1e-5)
-    _close(od, td.cpu(), atol=1e-5, rtol=1e-5)
+    assert torch.equal(oi, ti) and torch.equal(od, td)
 
 
 def test_class_logits_up2x_refuses_odd_widths(ops):
