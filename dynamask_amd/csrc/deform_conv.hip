@@ -589,8 +589,8 @@ __global__ __launch_bounds__(256, 2) void deform_conv_lds_kernel(DcnArgs a) {
 // two 8-byte global loads (texture path, L2 hits), a combine, a 16-byte LDS write, and an LDS read back by
 // every cout wave -- with 64 couts a sample feeds 128 flop.  Here a workgroup owns 128 pixels of ONE image
 // and all couts; a wave owns 32 of those pixels and ALL cout tiles, so the B operand of an MFMA
-// (lane = pixel, lane half = channel quad) is exactly what the lane itself can gather: four LDS reads from a
-// band of the chunk's 8 channel planes (BR rows around the tile's rows; a 128-pixel tile spans <= 4 rows of
+// (lane = pixel, lane half = channel quad) is exactly what the lane itself can gather: four 16-byte LDS reads per tap from a
+// band of the chunk's 8 channels, staged as [quad][pixel] float4 (BR rows around the tile's rows; a 128-pixel tile spans <= 4 rows of
 // a 56-wide map, offsets of +-6 rows stay inside), one fma chain, and the value goes straight into WM
 // MFMAs.  No B image in LDS, no texture-path gathers; a sample outside the band (rare: large offsets) is
 // loaded from global memory by the lanes concerned.  Per chunk: A (weights) and the band are loaded into
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(256, 2) void deform_conv_band_kernel(DcnArgs a, int
   constexpr int A_PER_T = (A_F4 + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   dm_f32x4* ldsA = reinterpret_cast<dm_f32x4*>(lds);
-  float* ldsX = lds + 4 * A_F4;                          // [8][BR * W]
+  dm_f32x4* ldsX = reinterpret_cast<dm_f32x4*>(lds) + A_F4;      // [2 quads][BR * W] float4: the 4 channels of a quad at a band pixel
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
   const int wave_m = wave % WGM, wave_n = wave / WGM;
@@ -684,15 +684,16 @@ __global__ __launch_bounds__(256, 2) void deform_conv_band_kernel(DcnArgs a, int
       ra[i] = v;
     }
   };
-  auto load_x = [&](int c0) {          // the band of a plane is one contiguous run of BR * W floats
+  // staging slot i of this thread = (quad, band pixel) = idx / PS, idx % PS (two quads: one compare); the loads of a slot
+  // are the quad's four channels at that pixel.  Slots past the band load slot 0 and are not stored.
+  auto load_x = [&](int c0) {          // lanes = consecutive band pixels: coalesced dword loads, four channels per slot
     const float* xb = a.x + ((size_t)n * a.C + c0) * HW + (size_t)band_y0 * W;
 #pragma unroll
     for (int i = 0; i < XR; ++i) {
       const int idx = tid + i * NT;
-      const int ch = idx / PS4, f = idx - ch * PS4;
-      dm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ch < 8) v = *reinterpret_cast<const dm_f32x4*>(xb + (size_t)ch * HW + f * 4);
-      rx[i] = v;
+      const int off = (idx < PS) ? idx : (idx < 2 * PS ? 4 * HW + idx - PS : 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) rx[i][e] = xb[off + e * HW];
     }
   };
   auto store_ax = [&]() {
@@ -704,10 +705,10 @@ __global__ __launch_bounds__(256, 2) void deform_conv_band_kernel(DcnArgs a, int
 #pragma unroll
     for (int i = 0; i < XR; ++i) {
       const int idx = tid + i * NT;
-      if (idx < 8 * PS4) *reinterpret_cast<dm_f32x4*>(ldsX + idx * 4) = rx[i];      // [ch][PS] is one run too
+      if (idx < 2 * PS) ldsX[idx] = rx[i];
     }
   };
-  struct __attribute__((packed, aligned(4))) F2 { float a, b; };
+  struct __attribute__((packed, aligned(4))) F2 { float a, b; };      // (the slow pass's global row pairs)
 
   int cur_group = 0;
   load_params(0);
@@ -723,33 +724,45 @@ __global__ __launch_bounds__(256, 2) void deform_conv_band_kernel(DcnArgs a, int
       load_x(cn);
     }
     const unsigned any_oob_s = __builtin_amdgcn_readfirstlane(any_oob);
-    const float* pl = ldsX + 4 * hi * PS;                                   // this lane half's quad of planes
-    const float* gl = a.x + ((size_t)n * a.C + c0 + 4 * hi) * HW;          // the same planes in global memory
-    // 36 steps (tap, element), software-pipelined by one: the four LDS reads of step s + 1 (and, at a tap boundary,
-    // the next tap's weight fragments) are issued before the combine + MFMAs of step s, so their latency runs under
-    // 2 * WM MFMAs instead of in front of them (left to the compiler, every step waited for its own reads)
-    dm_f32x4 av[2][WM];
-    F2 top[2], bot[2];
-    auto issue = [&](int s, int slot) {
-      const int tap = s >> 2, e = s & 3;
-      const float* pc = pl + e * PS;
-      top[slot] = *reinterpret_cast<const F2*>(pc + (otb[tap] & 0xffff));
-      bot[slot] = *reinterpret_cast<const F2*>(pc + (otb[tap] >> 16));
-      if (e == 0) {
-#pragma unroll
-        for (int i = 0; i < WM; ++i) av[tap & 1][i] = ldsA[(tap * 2 + hi) * TM + (wave_m * WM + i) * 32 + l31];
-      }
+    const dm_f32x4* pq = ldsX + hi * PS;                                    // this lane half's channel quad
+    const float* gl = a.x + ((size_t)n * a.C + c0 + 4 * hi) * HW;          // the same channels in global memory
+    // Nine taps: the four corners of a tap are four 16-byte reads for the quad's four channels (round 2 kept channel
+    // planes: two ds_read2_b32 per sample, 72 reads per chunk and wave against 36).  Software-pipelined by one tap: the
+    // four values of a tap are formed first, then the next tap's corners and weight fragments are issued and run under
+    // this tap's 4 * WM MFMAs.
+    // (the weight fragments are double-buffered where the registers allow: with four cout tiles per wave a second set
+    // spills, and they are read behind the tap's MFMAs instead -- their latency passes under the next tap's fma chains)
+    constexpr int AB = (WM < 4) ? 2 : 1;
+    dm_f32x4 av[AB][WM];
+    dm_f32x4 tl, tr, bl, br;
+    auto issue_x = [&](int tap) {
+      const dm_f32x4* pt = pq + (otb[tap] & 0xffff);
+      const dm_f32x4* pb = pq + (otb[tap] >> 16);
+      tl = pt[0]; tr = pt[1]; bl = pb[0]; br = pb[1];
     };
-    issue(0, 0);
+    auto issue_a = [&](int tap) {
 #pragma unroll
-    for (int s = 0; s < 36; ++s) {
-      const int tap = s >> 2, e = s & 3, slot = s & 1;
-      if (s + 1 < 36) issue(s + 1, slot ^ 1);
-      __builtin_amdgcn_sched_barrier(0);
-      const float v = dcn_bilinear(wt0[tap], wt1[tap], wb0[tap], wb1[tap], top[slot].a, top[slot].b, bot[slot].a, bot[slot].b);
+      for (int i = 0; i < WM; ++i) av[tap % AB][i] = ldsA[(tap * 2 + hi) * TM + (wave_m * WM + i) * 32 + l31];
+    };
+    issue_x(0);
+    issue_a(0);
 #pragma unroll
-      for (int i = 0; i < WM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tap & 1][i][e], v, acc[i], 0, 0, 0);
+    for (int tap = 0; tap < 9; ++tap) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = dcn_bilinear(wt0[tap], wt1[tap], wb0[tap], wb1[tap], tl[e], tr[e], bl[e], br[e]);
       __builtin_amdgcn_sched_barrier(0);
+      if (tap + 1 < 9) {
+        issue_x(tap + 1);
+        if (AB == 2) issue_a(tap + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < WM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tap % AB][i][e], v[e], acc[i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (AB == 1 && tap + 1 < 9) issue_a(tap + 1);
     }
     if (any_oob_s) {
       // Slow pass: taps that leave the band for some lane of this wave.  The lanes concerned recompute the tap
