@@ -4,7 +4,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DYNAMASK_HIP_LIB') or os.path.join(_HERE, 'libdynamask_hip.so')      # override: kernel experiments
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -41,6 +41,8 @@ SIGNATURES = {
     'dm_relu_bwd': ([_vp, _vp, ctypes.c_longlong, _vp], _c_int),
     'dm_sigmoid_bwd': ([_vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _c_int, _c_int, _vp, _c_int, _vp], _c_int),
     'dm_channel_sum': ([_vp, ctypes.c_longlong, _c_int, _c_int, _c_int, _vp, _c_int, _vp], _c_int),
+    'dm_conv2d_wgrad_scratch_floats': ([], ctypes.c_longlong),
+    'dm_conv2d_wgrad_slab': ([_vp, ctypes.c_longlong, _c_int, _vp, ctypes.c_longlong, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _vp, ctypes.c_longlong, _vp], _c_int),
     'dm_conv2d_wgrad': ([_vp, ctypes.c_longlong, _c_int, _vp, ctypes.c_longlong, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _vp], _c_int),
     'dm_upsample2x_bilinear_bwd': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp], _c_int),
     'dm_point_sample_bwd': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_float, _vp, _vp], _c_int),

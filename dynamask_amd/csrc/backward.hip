@@ -104,6 +104,16 @@ struct WgradArgs {
   int fx;            // dw (and db) are 64-bit fixed-point accumulators (dm_conv2d_wgrad_fx)
   float* db;         // optional bias gradient db[co] += sum_q dy[co][q]: the row sums of the A operand, taken from the
                      // values the column-tile-0 workgroups stage anyway (round 2 read dy a second time: dm_channel_sum)
+  // slab mode (dm_conv2d_wgrad_slab): every (split, K-wave) writes its partial tile to its own slab instead of adding into
+  // dw with atomics, wgrad_slab_reduce_kernel adds the slabs in index order -- the reference's weight gradient is a
+  // deterministic addmm_ (deform_conv_cuda.cpp:460-465), and 2 M float atomics onto the 4 K addresses of a 64 x 64 tile cost
+  // 40 us.  slab == nullptr: atomics.
+  float* scratch = nullptr;    // host side: the caller's scratch (dm_conv2d_wgrad_slab) the launcher carves the slabs from
+  long long scratch_floats = 0;
+  float* slab = nullptr;       // [slabs][slab_rows][slab_ld]
+  float* slab_db = nullptr;    // [splits][slab_rows]
+  long long slab_stride = 0;   // floats per slab
+  int slab_ld = 0, slab_rows = 0;
 };
 
 // dW[co][j] = sum_q dy[co][q] * xshift[j][q]  (j = (ci, tap), q = flat pixel): a GEMM
@@ -231,7 +241,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     }
     const int co_lane = m0 + wave_m * 64 + 4 * hi;
     const size_t off_lane = (size_t)co_lane * a.ldw;
-    if (!a.fx) {
+    if (a.slab) {
+      // the slab is padded to whole tiles: no bounds checks, 32 consecutive floats per store instruction
+      float* sp = a.slab + (size_t)(split * WGK + wave_k) * a.slab_stride;
+#pragma unroll
+      for (int i = 0; i < (TAIL ? 1 : 2); ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k = i * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) sp[(size_t)(co_lane + k) * a.slab_ld + j0 + (wave_n * 2 + j) * 32 + l31] = acc[i][j][r];
+        }
+    } else if (!a.fx) {
 #pragma unroll
       for (int i = 0; i < (TAIL ? 1 : 2); ++i)
 #pragma unroll
@@ -260,7 +281,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         }
     }
   }
-  if (want_bias && tid < TM && m0 + tid < a.Cout) dm_acc_add(a.db, m0 + tid, brow, a.fx != 0);
+  if (want_bias && tid < TM) {
+    if (a.slab) a.slab_db[(size_t)split * a.slab_rows + m0 + tid] = brow;
+    else if (m0 + tid < a.Cout) dm_acc_add(a.db, m0 + tid, brow, a.fx != 0);
+  }
   if (TAIL) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -269,8 +293,53 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       for (int i = 0; i < 4; ++i) {
         const float v = acct[j][i] + __shfl_xor(acct[j][i], 32, 64);      // the two k parities
         const int co = m0 + 32 + i;
-        if (hi == 0 && co < a.Cout && jg < Jtot) dm_acc_add(a.dw, (size_t)co * a.ldw + a.coloff + jg, v, a.fx != 0);
+        if (hi != 0) continue;
+        if (a.slab) a.slab[(size_t)(split * WGK + wave_k) * a.slab_stride + (size_t)co * a.slab_ld + jg] = v;
+        else if (co < a.Cout && jg < Jtot) dm_acc_add(a.dw, (size_t)co * a.ldw + a.coloff + jg, v, a.fx != 0);
       }
+    }
+  }
+}
+
+// dw[co][coloff + j] += sum over the slabs (and db[co] += sum over the splits' bias rows), in a fixed order: a workgroup
+// owns 256 / P consecutive outputs, partition p of P adds the slabs p, p + P, p + 2P ... in that order (independent loads,
+// unrolled), and the partitions' sums are added in order p = 0 .. P-1.  (One thread per output walking up to 2048 slabs
+// one after the other took 0.4 ms for a 64 x 64 tile.)
+template <int P>
+__global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __restrict__ slab, int slabs, long long stride, int ld,
+                                                                int Cout, int Jtot, float* __restrict__ dw, int ldw, int coloff,
+                                                                const float* __restrict__ slab_db, int splits, int rows,
+                                                                float* __restrict__ db) {
+  constexpr int OUT = 256 / P;
+  __shared__ float part[P][OUT];
+  const int o = threadIdx.x % OUT, pidx = threadIdx.x / OUT;
+  const long long total = (long long)Cout * Jtot;
+  const long long nblk = (total + OUT - 1) / OUT;
+  if ((long long)blockIdx.x < nblk) {
+    const long long idx = (long long)blockIdx.x * OUT + o;
+    float sacc = 0.f;
+    int co = 0, j = 0;
+    if (idx < total) {
+      co = (int)(idx / Jtot); j = (int)(idx - (long long)co * Jtot);
+      const float* p = slab + (size_t)co * ld + j;
+#pragma unroll 8
+      for (int k = pidx; k < slabs; k += P) sacc += p[(size_t)k * stride];
+    }
+    if (P > 1) {
+      part[pidx][o] = sacc;
+      __syncthreads();
+      if (pidx == 0) {
+#pragma unroll
+        for (int q = 1; q < P; ++q) sacc += part[q][o];
+      }
+    }
+    if (pidx == 0 && idx < total) dw[(size_t)co * ldw + coloff + j] += sacc;
+  } else if (db) {
+    // the last workgroup: bias rows
+    for (int c = threadIdx.x; c < Cout; c += blockDim.x) {
+      float sacc = slab_db[c];
+      for (int k = 1; k < splits; ++k) sacc += slab_db[(size_t)k * rows + c];
+      db[c] += sacc;
     }
   }
 }
@@ -297,6 +366,10 @@ struct WgradNarrowArgs {
   unsigned magic_w2, magic_rr, magic_band;      // ceil(2^32 / d) for d = W/2, R + 2, R * W/2
   int fx;
   float* db;         // optional bias gradient (see WgradArgs), summed from the dy band in LDS by the group-0 workgroups
+  float* slab = nullptr;       // slab mode (see WgradArgs): [splits][Cout][slab_ld], slab_db [splits][slab_rows]
+  float* slab_db = nullptr;
+  long long slab_stride = 0;
+  int slab_ld = 0, slab_rows = 0;
 };
 
 template <bool TAIL>
@@ -414,8 +487,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3_narrow_kernel(WgradNarrowA
     }
     const int co = tid >> 3;
     if ((tid & 7) == 0) {
-      if (co < a.Cout) dm_acc_add(a.db, co, v0, a.fx != 0);
-      if (32 + co < a.Cout) dm_acc_add(a.db, 32 + co, v1, a.fx != 0);
+      if (a.slab) {
+        if (co < a.Cout) a.slab_db[(size_t)split * a.slab_rows + co] = v0;
+        if (32 + co < a.Cout) a.slab_db[(size_t)split * a.slab_rows + 32 + co] = v1;
+      } else {
+        if (co < a.Cout) dm_acc_add(a.db, co, v0, a.fx != 0);
+        if (32 + co < a.Cout) dm_acc_add(a.db, 32 + co, v1, a.fx != 0);
+      }
     }
   }
   // the four waves' partial sums -> red[tap][row][channel] (wave after wave: 4 short phases), then one atomic each
@@ -448,13 +526,38 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3_narrow_kernel(WgradNarrowA
     const int co = i / (CG * 9), jj = i - co * (CG * 9);
     if (jj >= ncols) continue;
     const int cil = jj / 9, t = jj - cil * 9;
-    dm_acc_add(a.dw, (size_t)co * a.ldw + a.coloff + (size_t)ci0 * 9 + jj, red[(t * MR + co) * 32 + cil], a.fx != 0);
+    const float v = red[(t * MR + co) * 32 + cil];
+    if (a.slab) a.slab[(size_t)split * a.slab_stride + (size_t)co * a.slab_ld + (size_t)ci0 * 9 + jj] = v;
+    else dm_acc_add(a.dw, (size_t)co * a.ldw + a.coloff + (size_t)ci0 * 9 + jj, v, a.fx != 0);
   }
 }
 
 static unsigned dm_magic(unsigned d) { return (unsigned)((0x100000000ULL + d - 1) / d); }
 
 // returns DM_OK after launching, or 1 when the shape is not this kernel's
+static int wgrad_target_wgs() {
+  // split-K until the launch is one round of workgroups (two per CU): every further split adds an epilogue
+  // (2048 workgroups: 256->256 1x1 at 14x14 0.140 ms, 512: 0.091 ms; the 2304-row DCN GEMMs 0.63 -> 0.60 ms)
+  static const int wgs_env = getenv("DM_WGRAD_WGS") ? atoi(getenv("DM_WGRAD_WGS")) : 0;      // tuning knob (read once)
+  return wgs_env > 0 ? wgs_env : 2 * dm_num_cus();
+}
+
+static void launch_slab_reduce(const WgradArgs& a, int slabs, int splits, int Jtot, hipStream_t st) {
+  const long long total = (long long)a.Cout * Jtot;
+  const int P = slabs <= 8 ? 1 : (slabs <= 64 ? 4 : 16);
+  const long long nblk = (total + 256 / P - 1) / (256 / P) + (a.db ? 1 : 0);       // + one workgroup for the bias rows
+  const float* sdb = a.db ? a.slab_db : nullptr;
+  if (P == 1)
+    DM_LAUNCH((wgrad_slab_reduce_kernel<1>), dim3((unsigned)nblk), dim3(256), 0, st, a.slab, slabs, a.slab_stride, a.slab_ld, a.Cout, Jtot,
+              a.dw, a.ldw, a.coloff, sdb, splits, a.slab_rows, a.db);
+  else if (P == 4)
+    DM_LAUNCH((wgrad_slab_reduce_kernel<4>), dim3((unsigned)nblk), dim3(256), 0, st, a.slab, slabs, a.slab_stride, a.slab_ld, a.Cout, Jtot,
+              a.dw, a.ldw, a.coloff, sdb, splits, a.slab_rows, a.db);
+  else
+    DM_LAUNCH((wgrad_slab_reduce_kernel<16>), dim3((unsigned)nblk), dim3(256), 0, st, a.slab, slabs, a.slab_stride, a.slab_ld, a.Cout, Jtot,
+              a.dw, a.ldw, a.coloff, sdb, splits, a.slab_rows, a.db);
+}
+
 static int launch_wgrad3_narrow(const WgradArgs& g, hipStream_t st) {
   static const bool off = getenv("DM_WGRAD_NARROW_OFF") != nullptr;          // A/B switch
   if (off || g.Cout > 36 || (g.W & 1) || g.W < 8 || g.H < 1) return 1;
@@ -482,10 +585,20 @@ static int launch_wgrad3_narrow(const WgradArgs& g, hipStream_t st) {
   a.HW = g.HW; a.dw = g.dw; a.ldw = g.ldw; a.coloff = g.coloff; a.fx = g.fx; a.db = g.db;
   a.R = R; a.Wp = Wp; a.PL = PL; a.LDA = LDA; a.bands = nb; a.units = g.NB * nb; a.groups = dm_ceil_div(g.Cs, 32);
   a.magic_w2 = dm_magic(g.W / 2); a.magic_rr = dm_magic(R + 2); a.magic_band = dm_magic(R * (g.W / 2));
-  const int target = 2 * dm_num_cus();
+  const int target = wgrad_target_wgs();
   const int nsplit = max(1, min(a.units, target / a.groups));
   a.units_per_split = dm_ceil_div(a.units, nsplit);
   const int splits = dm_ceil_div(a.units, a.units_per_split);
+  WgradArgs red = g;
+  if (g.scratch && !g.fx) {
+    const int ld = a.groups * 32 * 9;
+    const long long stride = (long long)g.Cout * ld, need = (long long)splits * stride + (long long)splits * MR;
+    if (need <= g.scratch_floats) {
+      a.slab = g.scratch; a.slab_db = g.scratch + (long long)splits * stride;
+      a.slab_stride = stride; a.slab_ld = ld; a.slab_rows = MR;
+      red.slab = a.slab; red.slab_db = a.slab_db; red.slab_stride = stride; red.slab_ld = ld; red.slab_rows = MR;
+    }
+  }
   static bool attr_t[DM_MAX_DEVICES] = {false}, attr_n[DM_MAX_DEVICES] = {false};
   if (tail) {
     if (dm_ensure_lds_limit(reinterpret_cast<const void*>(&conv_wgrad3_narrow_kernel<true>), 80 * 1024, attr_t) != DM_OK) return DM_ERR_LAUNCH;
@@ -494,6 +607,7 @@ static int launch_wgrad3_narrow(const WgradArgs& g, hipStream_t st) {
     if (dm_ensure_lds_limit(reinterpret_cast<const void*>(&conv_wgrad3_narrow_kernel<false>), 80 * 1024, attr_n) != DM_OK) return DM_ERR_LAUNCH;
     DM_LAUNCH((conv_wgrad3_narrow_kernel<false>), dim3((unsigned)(a.groups * splits)), dim3(256), bytes, st, a);
   }
+  if (a.slab) launch_slab_reduce(red, splits, splits, g.Cs * 9, st);
   return DM_OK;
 }
 
@@ -514,15 +628,20 @@ void launch_wgrad(WgradArgs a, hipStream_t st) {
   a.MT = dm_ceil_div(a.Cout, TM);
   a.JT = dm_ceil_div(J, TN);
   const int chunks = dm_ceil_div(a.Q, 32);
-  // split-K until the launch is one round of workgroups (two per CU): every further split adds an
-  // epilogue of 64 float atomics per lane onto the same addresses (2048 workgroups: 256->256 1x1 at
-  // 14x14 0.140 ms, 512: 0.091 ms; the 2304-row DCN GEMMs 0.63 -> 0.60 ms)
-  static const int wgs_env = getenv("DM_WGRAD_WGS") ? atoi(getenv("DM_WGRAD_WGS")) : 0;      // tuning knob (read once)
-  const int target_wgs = wgs_env > 0 ? wgs_env : 2 * dm_num_cus();
+  const int target_wgs = wgrad_target_wgs();
   int nsplit = max(1, min(chunks, target_wgs / max(1, a.MT * a.JT)));
   a.chunks_per_split = dm_ceil_div(chunks, nsplit);
   a.nsplit = dm_ceil_div(chunks, a.chunks_per_split);
   const dim3 grid((unsigned)(a.MT * a.JT * a.nsplit));
+  const int WGK = (TM == 128 && TN == 128) ? 1 : (TM == 128) ? 2 : (TN == 256) ? 1 : (TN == 128) ? 2 : 4;
+  if (a.scratch && !a.fx) {
+    const int rows = a.MT * TM, ld = a.JT * TN;
+    const long long stride = (long long)rows * ld, need = (long long)a.nsplit * WGK * stride + (long long)a.nsplit * rows;
+    if (need <= a.scratch_floats) {
+      a.slab = a.scratch; a.slab_db = a.scratch + (long long)a.nsplit * WGK * stride;
+      a.slab_stride = stride; a.slab_ld = ld; a.slab_rows = rows;
+    }
+  }
   if (TM == 128 && TN == 128) DM_LAUNCH((conv_wgrad_kernel<KS, 2, 2, 1>), grid, dim3(256), 0, st, a);
   else if (TM == 128) DM_LAUNCH((conv_wgrad_kernel<KS, 2, 1, 2>), grid, dim3(256), 0, st, a);
   else if (TN == 256 && a.Cout > 32 && a.Cout <= 36) DM_LAUNCH((conv_wgrad_kernel<KS, 1, 4, 1, true>), grid, dim3(256), 0, st, a);
@@ -530,6 +649,7 @@ void launch_wgrad(WgradArgs a, hipStream_t st) {
   else if (TN == 256) DM_LAUNCH((conv_wgrad_kernel<KS, 1, 4, 1>), grid, dim3(256), 0, st, a);
   else if (TN == 128) DM_LAUNCH((conv_wgrad_kernel<KS, 1, 2, 2>), grid, dim3(256), 0, st, a);
   else DM_LAUNCH((conv_wgrad_kernel<KS, 1, 1, 4>), grid, dim3(256), 0, st, a);
+  if (a.slab) launch_slab_reduce(a, a.nsplit * WGK, a.nsplit, J, st);
 }
 
 // ----------------------------------------------------------------- K11 backward
@@ -1454,14 +1574,15 @@ extern "C" int dm_fx_to_float(long long* fx, long long n, float* out, int accumu
 
 static int conv2d_wgrad_impl(const float* dy, long long dy_batch_stride, int Cout, const float* x,
                              long long x_batch_stride, int Cs, int NB, int H, int W, int ksize, float* dw, int ldw,
-                             int col_offset, float* db, int fx, dm_stream_t stream) {
+                             int col_offset, float* db, int fx, dm_stream_t stream, float* scratch = nullptr,
+                             long long scratch_floats = 0) {
   if (!dy || !x || !dw || Cout <= 0 || Cs <= 0 || NB <= 0 || H <= 0 || W <= 0 || (ksize != 1 && ksize != 3))
     return DM_ERR_INVALID_ARG;
   if ((long long)NB * H * W > 0x7fffffffLL) return DM_ERR_INVALID_ARG;
   WgradArgs a;
   a.dy = dy; a.dy_bs = dy_batch_stride; a.x = x; a.x_bs = x_batch_stride; a.Cout = Cout; a.Cs = Cs;
   a.NB = NB; a.H = H; a.W = W; a.HW = H * W; a.Q = NB * H * W; a.dw = dw; a.ldw = ldw; a.coloff = col_offset;
-  a.fx = fx; a.db = db;
+  a.fx = fx; a.db = db; a.scratch = scratch; a.scratch_floats = scratch_floats;
   if (ksize == 3) {
     const int rc = launch_wgrad3_narrow(a, (hipStream_t)stream);
     if (rc < 0) return rc;
@@ -1477,6 +1598,19 @@ extern "C" int dm_conv2d_wgrad(const float* dy, long long dy_batch_stride, int C
                                int col_offset, float* db, dm_stream_t stream) {
   return conv2d_wgrad_impl(dy, dy_batch_stride, Cout, x, x_batch_stride, Cs, NB, H, W, ksize, dw, ldw, col_offset, db, 0,
                            stream);
+}
+
+extern "C" long long dm_conv2d_wgrad_scratch_floats(void) {
+  // an upper bound for every shape: slabs x tile <= target workgroups x (K-waves x tile) = target x 16384, + the bias rows
+  return (long long)wgrad_target_wgs() * (16384 + 256);
+}
+
+extern "C" int dm_conv2d_wgrad_slab(const float* dy, long long dy_batch_stride, int Cout, const float* x, long long x_batch_stride,
+                                    int Cs, int NB, int H, int W, int ksize, float* dw, int ldw, int col_offset, float* db,
+                                    float* scratch, long long scratch_floats, dm_stream_t stream) {
+  if (!scratch || scratch_floats <= 0) return DM_ERR_INVALID_ARG;
+  return conv2d_wgrad_impl(dy, dy_batch_stride, Cout, x, x_batch_stride, Cs, NB, H, W, ksize, dw, ldw, col_offset, db, 0, stream,
+                           scratch, scratch_floats);
 }
 
 extern "C" int dm_conv2d_wgrad_fx(const float* dy, long long dy_batch_stride, int Cout, const float* x,

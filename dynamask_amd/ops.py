@@ -715,6 +715,16 @@ def channel_sum(g, out=None):
     return out
 
 
+WGRAD_SLAB = [os.environ.get('DM_WGRAD_SLAB', '1') not in ('', '0')]      # weight gradients by slab reduce (no atomics); 0: float atomics
+_WGRAD_SCRATCH = [0]
+
+
+def _wgrad_scratch_floats():
+    if not _WGRAD_SCRATCH[0]:
+        _WGRAD_SCRATCH[0] = int(lib().dm_conv2d_wgrad_scratch_floats())
+    return _WGRAD_SCRATCH[0]
+
+
 def conv2d_wgrad(dy, srcs, ksize, dw=None, db=None, want_bias=False):
     """dW [Cout, sum(Cs), k, k] of conv(cat(srcs)) given dy [NB, Cout, H, W].  ``db`` ([Cout], accumulated into) or
     ``want_bias`` (a fresh tensor): the bias gradient from the same pass over dy; returns dW, or (dW, db) with a bias."""
@@ -738,6 +748,22 @@ def conv2d_wgrad(dy, srcs, ksize, dw=None, db=None, want_bias=False):
     if db is not None:
         _chk(db, 'db')
         assert db.shape == (Cout,)
+    if WGRAD_SLAB[0]:
+        # split-K partial tiles into slabs, added in a fixed order: no atomics, the same bits every run (in either mode)
+        if det:
+            if not acc:
+                dw.zero_()
+            if db is not None and not bias_acc:
+                db.zero_()
+        nfl = _wgrad_scratch_floats()
+        scratch = torch.empty((nfl,), device=dy.device, dtype=torch.float32)      # from the calling stream's pool
+        base = 0
+        for i, s in enumerate(srcs):
+            check(lib().dm_conv2d_wgrad_slab(_p(dy), dy.stride(0), Cout, _p(s), s.stride(0), s.shape[1], NB, H, W, ksize, _p(dw),
+                                             cin * ksize * ksize, base * ksize * ksize, _p(db if i == 0 else None), _p(scratch),
+                                             nfl, _stream()), 'dm_conv2d_wgrad_slab')
+            base += s.shape[1]
+        return (dw, db) if db is not None else dw
     fx = _fx_like(dw) if det else None
     bfx = _fx_like(db) if det and db is not None else None
     fn = lib().dm_conv2d_wgrad_fx if det else lib().dm_conv2d_wgrad

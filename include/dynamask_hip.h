@@ -50,7 +50,7 @@ extern "C" {
 typedef void* dm_stream_t; /* hipStream_t */
 
 const char* dm_error_string(int code);
-/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient, dm_conv_pack_weight_batch, dm_mask_loss_stage; 15: dm_class_logits_up2x_fwd). */
+/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient, dm_conv_pack_weight_batch, dm_mask_loss_stage; 15: dm_class_logits_up2x_fwd; 16: dm_conv2d_wgrad_slab / dm_conv2d_wgrad_scratch_floats). */
 int dm_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -427,6 +427,16 @@ int dm_channel_sum(const float* g, long long batch_stride, int NB, int C, int HW
 int dm_conv2d_wgrad(const float* dy, long long dy_batch_stride, int Cout, const float* x, long long x_batch_stride,
                     int Cs, int NB, int H, int W, int ksize, float* dw, int ldw, int col_offset, float* db,
                     dm_stream_t stream);
+
+/* The same sums without atomics: every split of the pixel axis writes its partial tile to a slab of `scratch`, a second
+ * kernel adds the slabs in index order into dw (and the splits' bias rows into db) -- bit-identical from run to run, as the
+ * reference's weight gradient is (a deterministic addmm_, mmdet/ops/dcn/src/deform_conv_cuda.cpp:460-465).  scratch: at
+ * least dm_conv2d_wgrad_scratch_floats() floats for ANY shape (a launch that would need more falls back to the atomics of
+ * dm_conv2d_wgrad); contents undefined afterwards; not shared between streams.  dw / db are accumulated into, as above. */
+long long dm_conv2d_wgrad_scratch_floats(void);
+int dm_conv2d_wgrad_slab(const float* dy, long long dy_batch_stride, int Cout, const float* x, long long x_batch_stride,
+                         int Cs, int NB, int H, int W, int ksize, float* dw, int ldw, int col_offset, float* db,
+                         float* scratch, long long scratch_floats, dm_stream_t stream);
 
 /* adjoint of dm_upsample2x_bilinear_fwd; fwd_out_for_relu (optional) masks the
  * fused ReLU; grad_in is overwritten (no zero-fill needed; planes up to 64 KB of

@@ -155,6 +155,39 @@ def test_deform_conv_backward(ops, N, C, S):
     _close(gw, w.grad, atol=1e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize('N,cins,cout,H,W,ks', [(9, [64], 64, 14, 14, 1), (5, [64, 64, 2], 64, 28, 28, 1), (3, [48], 200, 10, 6, 3),
+                                                (4, [64], 36, 28, 28, 3), (3, [40], 16, 14, 14, 3), (6, [128], 1152, 7, 8, 1),
+                                                (2, [30], 64, 56, 56, 1)])
+def test_weight_gradient_by_slab_reduce_is_reproducible_and_equals_the_atomic_sum(ops, N, cins, cout, H, W, ks):
+    """dm_conv2d_wgrad_slab: split-K partial tiles written to slabs and added in index order.  Two runs give the same
+    bits (the reference's weight gradient is a deterministic addmm_, deform_conv_cuda.cpp:460-465); the values are the
+    atomic path's (dm_conv2d_wgrad) and torch's up to summation order; accumulation into an existing dw / db is kept."""
+    dy = torch.randn(N, cout, H, W, generator=_g(300)).cuda()
+    xs = [torch.randn(N, c, H, W, generator=_g(301 + i)).cuda() for i, c in enumerate(cins)]
+    assert ops.WGRAD_SLAB[0]
+    dw1, db1 = ops.conv2d_wgrad(dy, xs, ks, want_bias=True)
+    dw2, db2 = ops.conv2d_wgrad(dy, xs, ks, want_bias=True)
+    assert torch.equal(dw1, dw2) and torch.equal(db1, db2)
+    xc = torch.cat(xs, 1).double().cpu().requires_grad_(True)
+    w = torch.zeros(cout, sum(cins), ks, ks, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(xc, w, b, padding=ks // 2).backward(dy.double().cpu())
+    from tolerances import assert_grad_close
+    assert_grad_close(dw1, w.grad.float(), 'dw', rel=1e-4)
+    assert_grad_close(db1, b.grad.float(), 'db', rel=1e-4)
+    ops.WGRAD_SLAB[0] = False
+    try:
+        dwa, dba = ops.conv2d_wgrad(dy, xs, ks, want_bias=True)
+    finally:
+        ops.WGRAD_SLAB[0] = True
+    sw, sb = float(dwa.abs().max()), float(dba.abs().max())           # same sums in another order: a few ulp of the largest value
+    assert float((dw1 - dwa).abs().max()) <= 2e-6 * sw and float((db1 - dba).abs().max()) <= 2e-6 * sb
+    # accumulate into existing tensors
+    dw3, db3 = dw1.clone(), db1.clone()
+    ops.conv2d_wgrad(dy, xs, ks, dw=dw3, db=db3)
+    assert float((dw3 - 2 * dw1).abs().max()) <= 1e-6 * sw and float((db3 - 2 * db1).abs().max()) <= 1e-6 * sb
+
+
 @pytest.mark.parametrize('N,C,S,sigma', [(2, 16, 56, 6.0), (3, 32, 28, 8.0), (2, 16, 14, 5.0), (1, 16, 56, 0.0)])
 def test_deform_coord_grad_with_samples_far_from_their_pixel(ops, N, C, S, sigma):
     """The coordinate gradient stages a band of rows around a workgroup's pixels (DCN_COORD_HALO = 5 rows either side);
