@@ -32,6 +32,18 @@ __global__ __launch_bounds__(256) void k_write_rows(float* __restrict__ a, size_
     a[(rb + r2) * hw + px + lane] = v;
   }
 }
+// the store shape of a TRANSPOSED accumulator tile (pixels along the registers): a lane stores 4 consecutive pixels of ITS
+// row as one 16-byte piece, lanes 0-31 = 32 rows, lanes 32-63 the next 4 pixels; four such instructions complete a 128-byte line
+__global__ __launch_bounds__(256) void k_write_cols(float* __restrict__ a, size_t rows, int hw, float v) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hi = lane >> 5;
+  const size_t tiles = (size_t)hw / 32;
+  const f32x4 x = {v, v, v, v};
+  for (size_t t = blockIdx.x; t < tiles * (rows / 128); t += gridDim.x) {
+    const size_t rb = (t / tiles) * 128 + wave * 32, px = (t % tiles) * 32;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(a + (rb + l31) * hw + px + 8 * g + 4 * hi) = x;
+  }
+}
 template <class F> float timeit(F f) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   f(); hipDeviceSynchronize();
@@ -52,5 +64,8 @@ int main() {
   const int hw = 3136; const size_t rows = bytes / 4 / hw / 8 * 8;
   ms = timeit([&] { k_write_rows<<<8192, 256>>>((float*)a, rows, hw, 1.f); });
   printf("write, 128-byte row pieces 12.5 KB apart (the tile kernels' store shape)  %.3f ms  %.2f TB/s\n", ms, (double)rows * (hw / 32 * 32) * 4 / ms / 1e9);
+  const size_t rows2 = rows / 128 * 128;
+  ms = timeit([&] { k_write_cols<<<8192, 256>>>((float*)a, rows2, hw, 1.f); });
+  printf("write, 16-byte pieces per lane across 32 rows (a transposed tile's store shape)  %.3f ms  %.2f TB/s\n", ms, (double)rows2 * (hw / 32 * 32) * 4 / ms / 1e9);
   return 0;
 }
