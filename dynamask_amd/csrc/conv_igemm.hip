@@ -49,6 +49,7 @@ struct ConvArgs {
   int q_begin = 0;  // first flat pixel of this launch (Q is its end): a launch may cover a pixel range
   int shuffle;    // deconv 2x2/s2 epilogue: packed cout = phase*shuffle + co, stored at (2y+dy, 2x+dx)
   const float* mask = nullptr;   // same layout as out: outputs whose mask value is not > 0 are stored as 0 (a ReLU adjoint)
+  int off32 = 0;     // every source spans < 4 GB: a pixel's offset inside a source fits 32 bits (the 1x1 builds' branch-free staging)
 };
 
 // CK input channels per chunk (multiple of 8); MAXPOS = plane positions per thread (3x3)
@@ -196,15 +197,17 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
 
   // ---- chunk iterator over (source, channel offset) ------------------------
   int cs = 0, cc0 = 0, ckq = 0;   // current source, channel offset in it, global quad index of the chunk
+  int curC = a.src_c[0];          // channels of the current source (kept in a register: a.src_c[cs] is a scalar load from the
+                                  // argument block, and its s_waitcnt lgkmcnt(0) in the K loop also waits for the LDS)
   auto chunk_valid = [&]() { return cs < a.num_srcs; };
   auto chunk_advance = [&]() {
-    const int Cs = a.src_c[cs];
-    const int ckv = min(CK, Cs - cc0);
+    const int ckv = min(CK, curC - cc0);
     ckq += ((ckv + 7) / 8) * 2;
     cc0 += CK;
-    if (cc0 >= Cs) {
+    if (cc0 >= curC) {
       cs++;
       cc0 = 0;
+      curC = cs < a.num_srcs ? a.src_c[cs] : 0;
     }
   };
 
@@ -215,20 +218,46 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
   for (int i = 0; i < A_PER_T; ++i) {
     const int idx = tid + i * NT;
     const int m = idx % TMA, tq = idx / TMA;
-    a_off[i] = (unsigned)((((size_t)(tq / NQ) * a.KQ + tq % NQ) * a.CoutP + m0 + m) * 4);
+    a_off[i] = (unsigned)((((size_t)(tq / NQ) * a.KQ + tq % NQ) * a.CoutP + min(m0 + m, a.CoutP - 1)) * 4);      // (rows past CoutP: the last row)
   }
   constexpr int NPOS = (KS == 3) ? MAXPOS : 1;
   size_t b_off[NPOS];               // float offset of this thread's pixel(s) inside the current source
   int b_src = -1;
+  unsigned b_off32 = 0;             // 1x1 fast path: the same offset in 32 bits
+  const float* b_srcp = nullptr;    // 1x1 fast path: base of the current source
 
   // issue the global loads of the chunk at (cs, cc0, ckq) into registers
   auto prefetch = [&]() {
-    const int Cs = a.src_c[cs];
-    const int ckv = min(CK, Cs - cc0);
+    const int ckv = min(CK, curC - cc0);
     const int nq = ((ckv + 7) / 8) * 2;    // quads of this chunk present in the packed weights
     // the chunk's part of an address is uniform (ckq, cc0); the thread's part is fixed for the K loop
     // (per source for B) and kept in a register: no 64-bit multiplies per load next to the MFMAs
     const float* abase = a.wq + (size_t)ckq * a.CoutP * 4;
+    if (KS == 1 && A_F4 % NT == 0 && NQ * TN % NT == 0 && a.off32 && ckv == CK) {
+      // Full chunk of a 1x1 build: nothing is predicated.  (The general path below guards every dword -- pixel inside the
+      // matrix, channel inside the source, quad inside the chunk -- with an exec-mask branch and a 64-bit vector address:
+      // ~150 instructions per 16 MFMAs in the 64-cout build, 4.8 VALU + 5.6 SALU per MFMA on the 576 -> 64 GEMM
+      // (profiles/r03_sq_pmc.txt) against 1.65 + 0.97 in the 3x3 build.)  A pixel past the matrix stages the pixel the
+      // thread was clamped to -- its output column is never stored; rows past CoutP repeat the last row.  Addresses are a
+      // uniform row base (SALU) plus the thread's 32-bit pixel offset.
+#pragma unroll
+      for (int i = 0; i < A_PER_T; ++i) ra[i] = *reinterpret_cast<const dm_f32x4*>(abase + a_off[i]);
+      if (b_src != cs) {
+        b_off32 = (unsigned)((size_t)max(st_n[0], 0) * (size_t)a.src_bs[cs] + st_pix[0]);
+        b_srcp = a.src[cs];
+        b_src = cs;
+        b_off[0] = b_off32;
+      }
+      const float* rp = b_srcp + (size_t)cc0 * HW;
+      const int qw = __builtin_amdgcn_readfirstlane(tid / TN);
+#pragma unroll
+      for (int i = 0; i < B1_PER_T; ++i) {
+        const float* rq = rp + (size_t)((qw + i * (NT / TN)) * 4) * HW;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rb[i][e] = rq[(size_t)e * HW + b_off32];
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < A_PER_T; ++i) {
       const int idx = tid + i * NT;
@@ -306,7 +335,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
 
   if (chunk_valid()) prefetch();
   while (chunk_valid()) {
-    const int ckv_cur = min(CK, a.src_c[cs] - cc0);
+    const int ckv_cur = min(CK, curC - cc0);
     const int ngroups = (ckv_cur + 7) / 8;   // quad pairs holding live channels
     commit();
     __syncthreads();
@@ -683,6 +712,9 @@ static int conv2d_launch(const float* const* srcs, const int* src_channels, cons
   a.shuffle = 0;
   a.q_begin = 0;
   a.mask = mask;
+  a.off32 = 1;
+  for (int s = 0; s < num_srcs; ++s)
+    if ((long long)NB * a.src_bs[s] * 4 >= (1LL << 32)) a.off32 = 0;
   // outputs that cannot stay in the 256 MB Infinity Cache next to their consumer's other traffic are
   // written with nontemporal stores (measured: -10 % on the 1.85 GB column-gradient GEMM, neutral
   // below); accumulating launches read the destination and keep the default policy
