@@ -172,8 +172,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   const bool want_bias = a.db != nullptr && j_tile == 0;
   float brow = 0.f;               // bias gradient: thread t < TM sums row t of every staged A tile
   float va[RA], vb[RB];
+  // 1x1, chunk inside the matrix: nothing is predicated -- rows past the matrix repeat its last row (their products land in
+  // rows / columns of the tile that are never stored), addresses are a per-thread base plus per-row offsets kept in
+  // registers.  (The guarded fetch below spends an exec-mask branch or a select per dword: ~250 branches in the K loop of the
+  // 128 x 128 build, the same disease conv_igemm's 1x1 staging had.)
+  int a_roff[RA], b_roff[(KS == 1) ? RB : 1];
+#pragma unroll
+  for (int i = 0; i < RA; ++i) a_roff[i] = min(m0 + r0 + 8 * i, a.Cout - 1) * HW;
+  if (KS == 1) {
+#pragma unroll
+    for (int i = 0; i < RB; ++i) b_roff[i] = min(j0 + r0 + 8 * i, Jtot - 1) * HW;
+  }
   auto fetch = [&](int ch) {
     const int q = ch * KT + kq;
+    if (KS == 1 && !TAIL && ch * KT + KT <= a.Q) {
+      const int n = q / HW;
+      const int p = q - n * HW;
+      const float* dyp = a.dy + (size_t)n * a.dy_bs + p;
+      const float* xp = a.x + (size_t)n * a.x_bs + p;
+#pragma unroll
+      for (int i = 0; i < RA; ++i) va[i] = dyp[a_roff[i]];
+#pragma unroll
+      for (int i = 0; i < RB; ++i) vb[i] = xp[b_roff[i]];
+      return;
+    }
     const bool qok = q < a.Q;
     const int qq = min(q, a.Q - 1);
     const int n = qq / HW;
