@@ -671,18 +671,19 @@ __global__ __launch_bounds__(256, 2) void deform_conv_band_kernel(DcnArgs a, int
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   dm_f32x4 ra[A_PER_T], rx[XR];        // XR * 256 float4 cover the 8 band planes (host)
-  auto load_a = [&](int c0) {
+  // weights: slot offsets fixed per thread (rows past CoutP and slots past the chunk repeat a row that exists: their products
+  // land in accumulator rows that are never stored / their LDS slots are never written) -- no exec-mask branch per load
+  unsigned a_off[A_PER_T];
 #pragma unroll
-    for (int i = 0; i < A_PER_T; ++i) {
-      const int idx = tid + i * NT;
-      dm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (idx < A_F4) {
-        const int m = idx % TM, tq = idx / TM;           // tq = tap * 2 + quad
-        if (m < a.CoutP)
-          v = *reinterpret_cast<const dm_f32x4*>(a.wp + (((size_t)(tq >> 1) * a.KQ + (c0 >> 2) + (tq & 1)) * a.CoutP + m) * 4);
-      }
-      ra[i] = v;
-    }
+  for (int i = 0; i < A_PER_T; ++i) {
+    const int idx = min(tid + i * NT, A_F4 - 1);
+    const int m = idx % TM, tq = idx / TM;               // tq = tap * 2 + quad
+    a_off[i] = (unsigned)((((size_t)(tq >> 1) * a.KQ + (tq & 1)) * a.CoutP + min(m, a.CoutP - 1)) * 4);
+  }
+  auto load_a = [&](int c0) {
+    const float* wb = a.wp + (size_t)(c0 >> 2) * a.CoutP * 4;
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) ra[i] = *reinterpret_cast<const dm_f32x4*>(wb + a_off[i]);
   };
   // staging slot i of this thread = (quad, band pixel) = idx / PS, idx % PS (two quads: one compare); the loads of a slot
   // are the quad's four channels at that pixel.  Slots past the band load slot 0 and are not stored.
