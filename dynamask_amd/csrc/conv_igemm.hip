@@ -276,7 +276,22 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
       b_src = cs;
     }
     const float* sp = a.src[cs] + (size_t)cc0 * HW;
-    if (KS == 3) {
+    if (KS == 3 && ckv == CK) {
+      // full chunk: ONE guard per plane position (its pixel exists or it is padding) instead of one per dword
+#pragma unroll
+      for (int k = 0; k < MAXPOS; ++k) {
+        const float* gp = sp + b_off[k];
+        if (st_n[k] >= 0) {
+#pragma unroll
+          for (int qd = 0; qd < NQ; ++qd)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rb[k * NQ + qd][e] = gp[(size_t)(qd * 4 + e) * HW];
+        } else {
+#pragma unroll
+          for (int qd = 0; qd < NQ; ++qd) rb[k * NQ + qd] = dm_f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    } else if (KS == 3) {
 #pragma unroll
       for (int k = 0; k < MAXPOS; ++k) {
         const bool ok = st_n[k] >= 0;
