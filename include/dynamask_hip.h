@@ -14,10 +14,12 @@
  *     the environment on first use.  Tuning knobs that never change results,
  *     only tile / split / order choices: DM_CONV_TAIL, DM_DCN_TAIL, DM_WGRAD_WGS, DM_ROI_CT,
  *     DM_ROI_ORDER, DM_ROI_BAND_CT, DM_ROI_BAND_ORDER, DM_ROI_UNITS / DM_ROI_UNITS_NOW (the
- *     persistent-units RoIAlign of round 3: same bits as the band kernel), DM_ROI_NT, DM_ROI_UNIT_WGS.
+ *     persistent-units RoIAlign of round 3: same bits as the band kernel), DM_ROI_NT, DM_ROI_UNIT_WGS,
+ *     DM_CONV1_VARIANT (other tilings of the 1x1 GEMM: same products in the same order), DM_PS_CT.
  *     A/B switches that select an older kernel or another split for the same
  *     operation (same mathematics; sums may differ in the last bits):
- *     DM_WGRAD_NARROW_OFF, DM_DCN_BAND_OFF, DM_IM2COL_V1, DM_FC_SEG.
+ *     DM_WGRAD_NARROW_OFF, DM_DCN_BAND_OFF, DM_IM2COL_V1, DM_FC_SEG, DM_COORD_V1 (the first-generation
+ *     coordinate-gradient kernel).
  *     Calls from several host threads are safe (a race only repeats an
  *     idempotent attribute call);
  *   - LDS scatter-accumulators (dm_deform_col2im_coord, dm_point_sample_bwd) are
