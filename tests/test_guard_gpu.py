@@ -177,6 +177,11 @@ def test_inference_surface_keeps_its_guard_bands(monkeypatch, H, W):
                 assert _finite(r['stage_instance_preds'] + r['stage_detail_preds']), (H, W, N)
                 d = m.dynamic_mask_logits(feats, rois[:, 1:].contiguous(), labels)
                 assert _finite(d['preds']), (H, W, N)
+                # the fixed 28x28 exit and exits spread over the four resolutions: the logits-of-the-upsampled-stage kernel
+                r1 = m._mask_forward(feats, rois, labels, last_stage=1)
+                assert _finite(r1['stage_instance_preds']), (H, W, N)
+                d2 = m.dynamic_mask_logits(feats, rois[:, 1:].contiguous(), labels, exits=(torch.arange(N) * 7 + 3) % 4)
+                assert _finite(d2['preds']), (H, W, N)
                 metas = [dict(img_shape=(H, W, 3), ori_shape=(H, W, 3), scale_factor=1.0)]
                 bb, sg = m.simple_test(feats, [rois[:, 1:].contiguous()], metas, rescale=False, encode=True)
                 assert sum(len(b) for b in bb) == sum(len(s) for s in sg)
