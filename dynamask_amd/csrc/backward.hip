@@ -987,6 +987,62 @@ __global__ __launch_bounds__(256) void point_sample_bwd_kernel(const float* __re
 // gx[n,c,p] (+)= wi[lab][c]*gi[n,p] + wd[lab][c]*gd[n,p];
 // gWi[lab][c] += sum_p gi*x ; gbi[lab] += sum_p gi  (same for the detail branch).
 // grid = (C, N): one workgroup per (RoI, channel).
+// Small maps (H*W <= 1024, a multiple of 4): a WAVE owns a channel plane (16-byte accesses, its sums by wave shuffles: no LDS, no
+// barrier) and walks CPW channels; a workgroup = 4 waves.  The kernel below gives every (channel, RoI) plane a 256-thread
+// workgroup of its own -- 65536 workgroups of 196 elements at 14 x 14, each ending in a barrier and two global atomics.
+template <int CPW>
+__global__ __launch_bounds__(256) void class_logits_bwd_wave_kernel(const float* __restrict__ x, int N, int C, int HW,
+                                                                    const float* __restrict__ wi, const float* __restrict__ wd,
+                                                                    int num_classes, const int64_t* __restrict__ labels,
+                                                                    const float* __restrict__ gi, const float* __restrict__ gd,
+                                                                    float* __restrict__ gx, int accumulate,
+                                                                    float* __restrict__ gwi, float* __restrict__ gbi,
+                                                                    float* __restrict__ gwd, float* __restrict__ gbd, int fx) {
+  const int n = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int lab = (int)labels[n];
+  lab = min(max(lab, 0), num_classes - 1);
+  const int HWq = HW >> 2;
+  const dm_f32x4* gip = reinterpret_cast<const dm_f32x4*>(gi + (size_t)n * HW);
+  const dm_f32x4* gdp = reinterpret_cast<const dm_f32x4*>(gd + (size_t)n * HW);
+  const int cbase = (blockIdx.x * 4 + wave) * CPW;
+  for (int k = 0; k < CPW; ++k) {
+    const int c = cbase + k;
+    if (c >= C) break;
+    const float a = wi[(size_t)lab * C + c], b = wd[(size_t)lab * C + c];
+    const dm_f32x4* xp = reinterpret_cast<const dm_f32x4*>(x + ((size_t)n * C + c) * HW);
+    dm_f32x4* gxp = reinterpret_cast<dm_f32x4*>(gx + ((size_t)n * C + c) * HW);
+    float si = 0.f, sd = 0.f, ti = 0.f, td = 0.f;
+    for (int p = lane; p < HWq; p += 64) {
+      const dm_f32x4 g1 = gip[p], g2 = gdp[p], xv = xp[p];
+      dm_f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = a * g1[e] + b * g2[e];
+        si += g1[e] * xv[e];
+        sd += g2[e] * xv[e];
+        ti += g1[e];
+        td += g2[e];
+      }
+      if (accumulate) v += gxp[p];
+      gxp[p] = v;
+    }
+    si = wsum(si);
+    sd = wsum(sd);
+    if (lane == 0) {
+      dm_acc_add(gwi, (size_t)lab * C + c, si, fx != 0);
+      dm_acc_add(gwd, (size_t)lab * C + c, sd, fx != 0);
+    }
+    if (c == 0) {   // bias gradient once per RoI
+      ti = wsum(ti);
+      td = wsum(td);
+      if (lane == 0) {
+        dm_acc_add(gbi, lab, ti, fx != 0);
+        dm_acc_add(gbd, lab, td, fx != 0);
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void class_logits_bwd_kernel(const float* __restrict__ x, int N, int C, int HW,
                                                                const float* __restrict__ wi, const float* __restrict__ wd,
                                                                int num_classes, const int64_t* __restrict__ labels,
@@ -1704,6 +1760,14 @@ static int class_logits_bwd_impl(const float* x, int N, int C, int HW, const flo
     return DM_ERR_INVALID_ARG;
   if (N < 0 || C <= 0 || HW <= 0 || num_classes <= 0) return DM_ERR_INVALID_ARG;
   if (N == 0) return DM_OK;
+  static const bool v1_env = getenv("DM_CLB_V1") != nullptr;      // A/B switch
+  if (!v1_env && (HW & 3) == 0 && HW <= 1024 && ((((uintptr_t)x | (uintptr_t)grad_x | (uintptr_t)grad_inst | (uintptr_t)grad_det) & 15) == 0)) {
+    constexpr int CPW = 4;
+    DM_LAUNCH((class_logits_bwd_wave_kernel<CPW>), dim3((unsigned)dm_ceil_div(C, 4 * CPW), N), dim3(256), 0, (hipStream_t)stream, x, N, C, HW,
+              w_inst, w_det, num_classes, labels, grad_inst, grad_det, grad_x, accumulate_x, grad_w_inst, grad_b_inst, grad_w_det,
+              grad_b_det, fx);
+    return dm_check_launch();
+  }
   DM_LAUNCH(class_logits_bwd_kernel, dim3(C, N), dim3(256), 0, (hipStream_t)stream, x, N, C, HW, w_inst, w_det, num_classes,
             labels, grad_inst, grad_det, grad_x, accumulate_x, grad_w_inst, grad_b_inst, grad_w_det, grad_b_det, fx);
   return dm_check_launch();
