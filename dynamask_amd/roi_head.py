@@ -142,7 +142,7 @@ class DynaMaskRoIHead(nn.Module):
         self.mask_predictor = MaskPre()
         # inference: RoI chunks on separate HIP streams (see _mask_forward)
         self.num_streams = 2
-        self.stream_split_min = 128
+        self.stream_split_min = 64           # (100 detections to 112x112: 2.34 ms on one stream, 2.27 split over two; 32: no further gain)
 
     def init_assigner_sampler(self):
         """standard_roi_head.py:13-20."""
