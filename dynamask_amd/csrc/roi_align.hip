@@ -724,12 +724,19 @@ constexpr int kBandTabFloats4 = 2 * 64 * 8 / 4;      // stencil table for P <= 6
 template <int G, int TB>
 __device__ __forceinline__ void roi_band_fwd(const RoiArgs& a, const float* __restrict__ fimg, int Hl, int Wl, float sh,
                                              float sw, float bh, float bw, int gh, int gw, float inv_count, int k,
-                                             int c0, int c1, int fx0, int pitch, int xmax, int rows_per_band,
+                                             int c0, int fx0, int pitch, int xmax, int rows_per_band,
                                              int pw0, int Cw, float4* __restrict__ lds) {
   // pw0, Cw: the block of output columns this call produces (the whole width unless the RoI is too wide for a tile)
+  // One channel quad (c0 .. c0+3) per workgroup.  A tile slot's (row, column) does not depend on the band, so the
+  // division is done once per RoI (packed: row << 20 | map column) and a band's gather offset is five full-rate
+  // VALU instructions per slot; loads and stores are a scalar base + a 32-bit lane offset.  (SQ counters,
+  // profiles/r03_sq_pmc_roi.txt: the kernel issued 2700 VALU instructions per wave where its stencils need 500 --
+  // per band and slot two magic divisions and five 32-bit multiplies at a quarter of the rate, and a 64-bit
+  // address add in front of every load and store -- and was VALU-bound: 0.35 M of its 0.52 M cycles.)
+  static_assert(TB % 256 == 0, "tile slots are dealt 256 at a time");
   constexpr int S = G + 1;
   constexpr int GG = G > 0 ? G : 1;
-  constexpr int IPT = (TB + 255) / 256;
+  constexpr int IPT = TB / 256;
   const int tid = threadIdx.x;
   const int P = a.P, PP = P * P;
   const size_t plane = (size_t)Hl * Wl;
@@ -750,127 +757,131 @@ __device__ __forceinline__ void roi_band_fwd(const RoiArgs& a, const float* __re
   }
   const int pad = G > 0 ? G : 1;
   const unsigned m_pitch = 0xFFFFFFFFu / (unsigned)pitch + 1u;
-  for (int ph0 = 0; ph0 < P; ph0 += rows_per_band) {
-    const int R = min(rows_per_band, P - ph0);
-    // band tile rows: first / last sample of the band (the expressions of axis_sample)
+  const unsigned m_cw = Cw > 1 ? 0xFFFFFFFFu / (unsigned)Cw + 1u : 0u;
+  unsigned slot[IPT];                                   // row in the tile << 20 | column in the map (H * W <= 2^23)
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) {
+    const int idx = tid + i * 256;
+    const int r = (int)__umulhi((unsigned)idx, m_pitch);
+    const int x = idx - __mul24(r, pitch);
+    slot[i] = ((unsigned)r << 20) | (unsigned)min(fx0 + x, xmax);
+  }
+  const char* const b0 = reinterpret_cast<const char*>(fimg + (size_t)c0 * plane);
+  const char* const b1 = b0 + plane * 4;
+  const char* const b2 = b1 + plane * 4;
+  const char* const b3 = b2 + plane * 4;
+  char* const o0 = reinterpret_cast<char*>(a.out + ((size_t)k * a.C + c0) * PP);
+  char* const o1 = o0 + PP * 4;
+  char* const o2 = o1 + PP * 4;
+  char* const o3 = o2 + PP * 4;
+  // A band's tile: rows fy0 .. fy0 + FH - 1 of the map (first / last sample of the band: the expressions of
+  // axis_sample), nsl groups of 256 slots.
+  struct Band { int R, fy0, FH, ymax, nsl; };
+  auto band_of = [&](int ph0) {
+    Band g;
+    g.R = min(rows_per_band, P - ph0);
     const float yf = sh + (float)ph0 * bh + 0.5f * bh / (float)gh;
-    const float yl = sh + (float)(ph0 + R - 1) * bh + ((float)(gh - 1) + 0.5f) * bh / (float)gh;
-    const int fy0 = min((int)fmaxf(fminf(yf, yl), 0.f), Hl - 1);
+    const float yl = sh + (float)(ph0 + g.R - 1) * bh + ((float)(gh - 1) + 0.5f) * bh / (float)gh;
+    g.fy0 = min((int)fmaxf(fminf(yf, yl), 0.f), Hl - 1);
     const int ylast = min((int)fmaxf(fmaxf(yf, yl), 0.f), Hl - 1);
-    const int FH = ylast + pad - fy0 + 1;
-    const int ymax = min(ylast + 1, Hl - 1);
-    const int plane_px = FH * pitch;                       // <= TB by the choice of rows_per_band
-    const int NQ = min(TB / plane_px, (c1 - c0) >> 2);
-    const int NCB = NQ * 4;
-    const unsigned m_plane = 0xFFFFFFFFu / (unsigned)plane_px + 1u;
-    int voff[IPT];
+    g.FH = ylast + pad - g.fy0 + 1;
+    g.ymax = min(ylast + 1, Hl - 1);
+    g.nsl = (min(g.FH * pitch, TB) + 255) >> 8;            // FH * pitch <= TB by the choice of rows_per_band
+    return g;
+  };
+  // every slot's offset lies inside the map (rows past the tile or the map repeat row ymax, columns are clamped)
+  // and all TB slots exist in LDS: whole groups are skipped, nothing is predicated
+  float pf[IPT][4];
+  auto fetch = [&](const Band& g) {
 #pragma unroll
-    for (int i = 0; i < IPT; ++i) {
-      const int idx = tid + i * 256;
-      const int idc = idx < NQ * plane_px ? idx : 0;
-      const int q = (int)__umulhi((unsigned)idc, m_plane);
-      const int rem = idc - q * plane_px;
-      const int r = (int)__umulhi((unsigned)rem, m_pitch);
-      const int x = rem - r * pitch;
-      const int gy = min(fy0 + r, ymax);
-      const int gx = min(fx0 + x, xmax);
-      voff[i] = (q * 4 * (int)plane + gy * Wl + gx) * 4;
-    }
-    for (int cb = c0; cb < c1; cb += NCB) {
-      const int nq = min(NQ, (c1 - cb) >> 2);
-      const int live = nq * plane_px;
-      {
-        const char* b0 = reinterpret_cast<const char*>(fimg + (size_t)cb * plane);
-        const char* b1 = b0 + plane * 4;
-        const char* b2 = b1 + plane * 4;
-        const char* b3 = b2 + plane * 4;
-        float pf[IPT][4];
-#pragma unroll
-        for (int i = 0; i < IPT; ++i) {
-          const int vo = (tid + i * 256 < live) ? voff[i] : 0;
-          pf[i][0] = *reinterpret_cast<const float*>(b0 + vo);
-          pf[i][1] = *reinterpret_cast<const float*>(b1 + vo);
-          pf[i][2] = *reinterpret_cast<const float*>(b2 + vo);
-          pf[i][3] = *reinterpret_cast<const float*>(b3 + vo);
-        }
-#pragma unroll
-        for (int i = 0; i < IPT; ++i)
-          if (tid + i * 256 < live) lds[tid + i * 256] = make_float4(pf[i][0], pf[i][1], pf[i][2], pf[i][3]);
+    for (int i = 0; i < IPT; ++i)
+      if (i < g.nsl) {
+        const int gy = min(g.fy0 + (int)(slot[i] >> 20), g.ymax);
+        const unsigned vo = ((unsigned)__mul24(gy, Wl) + (slot[i] & 0xFFFFFu)) << 2;
+        pf[i][0] = *reinterpret_cast<const float*>(b0 + vo);
+        pf[i][1] = *reinterpret_cast<const float*>(b1 + vo);
+        pf[i][2] = *reinterpret_cast<const float*>(b2 + vo);
+        pf[i][3] = *reinterpret_cast<const float*>(b3 + vo);
       }
-      __syncthreads();
-      for (int i = tid; i < R * Cw; i += 256) {
-        const int pr = i / Cw;
-        const int ph = ph0 + pr, pw = pw0 + i - pr * Cw;
-        float* o = a.out + ((size_t)k * a.C + cb) * PP + ph * P + pw;
-        if (G > 0) {
-          const float* ey = tab + ph * 8;
-          const float* ex = tab + (P + pw) * 8;
-          const int Ly = __float_as_int(ey[0]), Lx = __float_as_int(ex[0]);
-          const int base = min(max(Ly - fy0, 0), FH - S) * pitch + min(max(Lx - fx0, 0), pitch - S);
-          float W[G > 0 ? S * S : 1];
+  };
+  // The bands of a RoI used to be a chain of dependent round trips (fetch, stage, compute, fetch ...): the next
+  // band's fetch is now in flight while this band's bins are computed and stored.
+  Band g = band_of(0);
+  fetch(g);
+  for (int ph0 = 0; ph0 < P; ph0 += rows_per_band) {
+    const int R = g.R, fy0 = g.fy0, FH = g.FH;
 #pragma unroll
-          for (int r = 0; r < S; ++r)
+    for (int i = 0; i < IPT; ++i)
+      if (i < g.nsl) lds[tid + i * 256] = make_float4(pf[i][0], pf[i][1], pf[i][2], pf[i][3]);
+    __syncthreads();
+    if (ph0 + rows_per_band < P) {
+      g = band_of(ph0 + rows_per_band);
+      fetch(g);
+    }
+    // Full-width bands are one contiguous run of every channel plane: lanes are dealt by absolute position, so that a
+    // wave's 64 dwords are a 256-byte-aligned piece (4 full 64-byte write requests instead of 5 with two partial
+    // ones: the L2 counted 26 % more write requests than the output has 64-byte pieces)
+    const int skew = Cw == P ? (int)(((reinterpret_cast<uintptr_t>(o0) >> 2) + (unsigned)__mul24(ph0, P)) & 63u) : 0;
+    for (int j = tid; j < R * Cw + skew; j += 256) {
+      const int i = j - skew;
+      if (i < 0) continue;
+      const int pr = Cw > 1 ? (int)__umulhi((unsigned)i, m_cw) : i;
+      const int ph = ph0 + pr, pw = pw0 + i - __mul24(pr, Cw);
+      const unsigned oo = (unsigned)(__mul24(ph, P) + pw) << 2;        // byte offset inside a channel plane
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (G > 0) {
+        const float* ey = tab + ph * 8;
+        const float* ex = tab + (P + pw) * 8;
+        const int Ly = __float_as_int(ey[0]), Lx = __float_as_int(ex[0]);
+        const float4* tq = lds + __mul24(min(max(Ly - fy0, 0), FH - S), pitch) + min(max(Lx - fx0, 0), pitch - S);
+        float Wx[S];
 #pragma unroll
-            for (int c = 0; c < S; ++c) W[G > 0 ? r * S + c : 0] = ey[1 + r] * ex[1 + c];
-          for (int q = 0; q < nq; ++q) {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4* tq = lds + q * plane_px + base;
+        for (int c = 0; c < S; ++c) Wx[c] = ex[1 + c];
 #pragma unroll
-            for (int r = 0; r < S; ++r) {
-              const float4* tr = tq + r * pitch;
+        for (int r = 0; r < S; ++r) {
+          const float4* tr = tq + r * pitch;
+          const float wy = ey[1 + r];
 #pragma unroll
-              for (int c = 0; c < S; ++c) {
-                const float4 v = tr[c];
-                const float wv = W[G > 0 ? r * S + c : 0];
-                acc.x += wv * v.x;
-                acc.y += wv * v.y;
-                acc.z += wv * v.z;
-                acc.w += wv * v.w;
-              }
-            }
-            o[(size_t)(4 * q) * PP] = acc.x;
-            o[(size_t)(4 * q + 1) * PP] = acc.y;
-            o[(size_t)(4 * q + 2) * PP] = acc.z;
-            o[(size_t)(4 * q + 3) * PP] = acc.w;
+          for (int c = 0; c < S; ++c) {
+            const float4 v = tr[c];
+            const float wv = wy * Wx[c];
+            acc.x += wv * v.x;
+            acc.y += wv * v.y;
+            acc.z += wv * v.z;
+            acc.w += wv * v.w;
           }
-        } else {
-          for (int q = 0; q < nq; ++q) {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int iy = 0; iy < gh; ++iy) {
-              int lo, hi;
-              float yl_w, yh_w;
-              axis_sample(sh, bh, gh, ph, iy, Hl, lo, hi, yl_w, yh_w);
-              const int yo = min(max(lo - fy0, 0), FH - 2) * pitch;
-              yl_w *= inv_count;
-              yh_w *= inv_count;
-              for (int ix = 0; ix < gw; ++ix) {
-                float xl_w, xh_w;
-                axis_sample(sw, bw, gw, pw, ix, Wl, lo, hi, xl_w, xh_w);
-                const int xo = min(max(lo - fx0, 0), pitch - 2);
-                const float4* tp = lds + q * plane_px + yo + xo;
-                const float4 v1 = tp[0], v2 = tp[1], v3 = tp[pitch], v4 = tp[pitch + 1];
-                const float w0 = yl_w * xl_w, w1 = yl_w * xh_w, w2 = yh_w * xl_w, w3 = yh_w * xh_w;
-                acc.x += w0 * v1.x + w1 * v2.x + w2 * v3.x + w3 * v4.x;
-                acc.y += w0 * v1.y + w1 * v2.y + w2 * v3.y + w3 * v4.y;
-                acc.z += w0 * v1.z + w1 * v2.z + w2 * v3.z + w3 * v4.z;
-                acc.w += w0 * v1.w + w1 * v2.w + w2 * v3.w + w3 * v4.w;
-              }
-            }
-            o[(size_t)(4 * q) * PP] = acc.x;
-            o[(size_t)(4 * q + 1) * PP] = acc.y;
-            o[(size_t)(4 * q + 2) * PP] = acc.z;
-            o[(size_t)(4 * q + 3) * PP] = acc.w;
+        }
+      } else {
+        for (int iy = 0; iy < gh; ++iy) {
+          int lo, hi;
+          float yl_w, yh_w;
+          axis_sample(sh, bh, gh, ph, iy, Hl, lo, hi, yl_w, yh_w);
+          const int yo = min(max(lo - fy0, 0), FH - 2) * pitch;
+          yl_w *= inv_count;
+          yh_w *= inv_count;
+          for (int ix = 0; ix < gw; ++ix) {
+            float xl_w, xh_w;
+            axis_sample(sw, bw, gw, pw, ix, Wl, lo, hi, xl_w, xh_w);
+            const int xo = min(max(lo - fx0, 0), pitch - 2);
+            const float4* tp = lds + yo + xo;
+            const float4 v1 = tp[0], v2 = tp[1], v3 = tp[pitch], v4 = tp[pitch + 1];
+            const float w0 = yl_w * xl_w, w1 = yl_w * xh_w, w2 = yh_w * xl_w, w3 = yh_w * xh_w;
+            acc.x += w0 * v1.x + w1 * v2.x + w2 * v3.x + w3 * v4.x;
+            acc.y += w0 * v1.y + w1 * v2.y + w2 * v3.y + w3 * v4.y;
+            acc.z += w0 * v1.z + w1 * v2.z + w2 * v3.z + w3 * v4.z;
+            acc.w += w0 * v1.w + w1 * v2.w + w2 * v3.w + w3 * v4.w;
           }
         }
       }
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      *reinterpret_cast<float*>(o0 + oo) = acc.x;
+      *reinterpret_cast<float*>(o1 + oo) = acc.y;
+      *reinterpret_cast<float*>(o2 + oo) = acc.z;
+      *reinterpret_cast<float*>(o3 + oo) = acc.w;
     }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
 }
 
-// Column blocks and band height of a RoI.  (Also tried on top of it: taking the RoIs longest-first, every workgroup
-// ranking the RoIs by their number of staging rounds -- once the wide RoIs below stopped falling to the per-sample
-// path the tail was gone, and the ranking cost more than it saved: 237 vs 207 us at 128 RoIs.)
 template <int TB>
 __device__ __forceinline__ void band_plan(const RoiArgs& a, int P, float bh, float bw, int gh, int gw, int& ncb, int& Cwb,
                                           int& R) {
@@ -935,9 +946,8 @@ __global__ __launch_bounds__(256, WPC) void roi_align_band_kernel(RoiArgs a) {
     int ncb, Cwb, R;
     band_plan<TB>(a, P, bh, bw, gh, gw, ncb, Cwb, R);
     if (ncb == 1) {
-      // the whole width in one tile: as many rows per band as the tile holds.  (Round 2 halved the bands where that
-      // still left >= 4 rows, so that a batch could hold two channel quads; with one quad per workgroup that only
-      // doubled the dependent staging rounds: 207 -> 188 us at 128 RoIs without it.  DM_ROI_BAND_ORDER=3 brings it back.)
+      // the whole width in one tile: as many rows per band as the tile holds, or a fraction of that (a.order >= 2,
+      // experiments: bands of 1/2 .. 1/4 of the height measure the same as full ones, within the noise)
       const float xf = sw + 0.5f * bw / (float)gw;
       const float xl = sw + (float)(P - 1) * bw + ((float)(gw - 1) + 0.5f) * bw / (float)gw;
       const int fx0 = min((int)fmaxf(fminf(xf, xl), 0.f), Wl - 1);
@@ -946,8 +956,9 @@ __global__ __launch_bounds__(256, WPC) void roi_align_band_kernel(RoiArgs a) {
       const int fh_max = TB / pitch;
       const float abh = fmaxf(fabsf(bh), 1e-6f);
       R = (int)fminf((float)P, floorf((float)(fh_max - pad - 2) / abh));
-      const int R2 = (int)fminf((float)P, floorf((float)(fh_max / 2 - pad - 2) / abh));
-      if (R2 >= 4 && a.order == 3) R = R2;
+      const int dv = a.order >= 2 ? a.order - 1 : 1;
+      const int R2 = (int)fminf((float)P, floorf((float)(fh_max / dv - pad - 2) / abh));
+      if (R2 >= 4 && dv > 1) R = R2;
     }
     if (R >= 1) {
       for (int cb = 0; cb < ncb; ++cb) {
@@ -959,7 +970,7 @@ __global__ __launch_bounds__(256, WPC) void roi_align_band_kernel(RoiArgs a) {
         const int pitch = xlast + pad - fx0 + 1;
         const int xmax = min(xlast + 1, Wl - 1);
         if ((R * fmaxf(fabsf(bh), 1e-6f) + (float)(pad + 2)) * (float)pitch > (float)TB) { R = 0; break; }   // (bounds of band_plan: never)
-#define DM_ROI_BAND(GG) roi_band_fwd<GG, TB>(a, fimg, Hl, Wl, sh, sw, bh, bw, gh, gw, inv_count, k, c0, c1, fx0, pitch, xmax, R, pw0, Cw, lds4)
+#define DM_ROI_BAND(GG) roi_band_fwd<GG, TB>(a, fimg, Hl, Wl, sh, sw, bh, bw, gh, gw, inv_count, k, c0, fx0, pitch, xmax, R, pw0, Cw, lds4)
         if (!merged) DM_ROI_BAND(0);
         else if (G == 1) DM_ROI_BAND(1);
         else if (G == 2) DM_ROI_BAND(2);
@@ -1389,10 +1400,9 @@ extern "C" int dm_roi_align_fwd(const float* const* feats, const int* H, const i
     // one channel quad per workgroup (swept 4 .. 32 at 128 RoIs on P2: 0.32 / 0.45 / 0.79 / 1.5 ms): the
     // bands of a large RoI are a long chain of dependent staging round trips, so the parallelism has to
     // come from the number of workgroups
-    a.CT = 4;
-    if (const char* e = getenv("DM_ROI_BAND_CT")) a.CT = max(4, atoi(e) & ~3);
+    a.CT = 4;            // (roi_band_fwd is written for exactly one quad)
     const int chunks = dm_ceil_div(C, a.CT);
-    if (const char* e = getenv("DM_ROI_BAND_ORDER")) a.order = atoi(e);      // experiments: 1 = XCD-aware chunk-major, 3 = round 2's half-height bands
+    if (const char* e = getenv("DM_ROI_BAND_ORDER")) a.order = atoi(e);      // experiments: 0 = full-height bands, 1 = XCD-aware chunk-major, 2 + d = bands of 1 / (d + 1) of the height
     if (a.order == 1 && chunks % 8 != 0) a.order = 0;
     // (a 28 KB tile with five workgroups per CU -- 96 VGPRs, 92 bytes of scratch -- measured slower: 202 vs 188 us)
     DM_LAUNCH((roi_align_band_kernel<kTileFloats4, 4>), dim3(N * chunks), dim3(256),

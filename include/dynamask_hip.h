@@ -13,7 +13,7 @@
  *     flags (hipFuncSetAttribute once per device).  A few knobs are read from
  *     the environment on first use.  Tuning knobs that never change results,
  *     only tile / split / order choices: DM_CONV_TAIL, DM_DCN_TAIL, DM_WGRAD_WGS, DM_ROI_CT,
- *     DM_ROI_ORDER, DM_ROI_BAND_CT, DM_ROI_BAND_ORDER, DM_ROI_UNITS / DM_ROI_UNITS_NOW (the
+ *     DM_ROI_ORDER, DM_ROI_BAND_ORDER, DM_ROI_UNITS / DM_ROI_UNITS_NOW (the
  *     persistent-units RoIAlign of round 3: same bits as the band kernel), DM_ROI_NT, DM_ROI_UNIT_WGS,
  *     DM_CONV1_VARIANT (other tilings of the 1x1 GEMM: same products in the same order), DM_PS_CT.
  *     A/B switches that select an older kernel or another split for the same
