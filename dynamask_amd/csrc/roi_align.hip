@@ -441,13 +441,76 @@ __device__ __forceinline__ void roi_tile_fwd(const RoiArgs& a, const float* __re
   const int tid = threadIdx.x;
   const int P = a.P, PP = P * P;
   const bool active = tid < PP;
-  const int ph = active ? tid / P : 0;
+  const int ph = active ? (int)__umulhi((unsigned)tid, 0xFFFFFFFFu / (unsigned)P + 1u) : 0;      // tid / P (P >= 2)
   const int pw = active ? tid - ph * P : 0;
   const int plane_px = tg.FH * tg.pitch;              // <= kBufPx (checked by the caller)
   // as many channel quads per batch as the buffer holds: the staging is bound by bytes in
   // flight, so every fetch should fill the 2 x 4 x 16-byte loads each thread can issue
   const int NQ = min(kBufPx / plane_px, (c1 - c0) >> 2);      // the caller guarantees C % 4 == 0
   const int NCB = NQ * 4;
+
+  // ---- staging.  Item = one tile pixel of one channel quad: 4 dword loads (the 4 channel
+  // planes; consecutive lanes read consecutive pixels -> coalesced) and ONE 16-byte LDS
+  // store, already channel-interleaved -- no register transposition.  The tile layout
+  // [quad][row][col] makes the LDS slot of item `idx` simply `idx`; which pixel it is does
+  // not depend on the batch, so its global byte offset is computed once.  Columns past the
+  // map's last one are clamped duplicates (weight 0), like rows.
+  constexpr int IPT = (kBufPx + 255) / 256;      // items per thread and batch: 8
+  const size_t plane = (size_t)Hl * Wl;
+  unsigned voff[IPT];
+  // idx -> (quad, row, col) with multiply-high by ceil(2^32 / d): exact for idx * d < 2^32
+  // (idx < 2048, d <= 2048; d >= 4 so the constants fit 32 bits); the two real divisions are uniform
+  const unsigned m_plane = 0xFFFFFFFFu / (unsigned)plane_px + 1u;
+  const unsigned m_pitch = 0xFFFFFFFFu / (unsigned)tg.pitch + 1u;
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) {
+    const int idx = tid + i * 256;
+    const int idc = idx < NQ * plane_px ? idx : 0;
+    const int q = (int)__umulhi((unsigned)idc, m_plane);
+    const int rem = idc - __mul24(q, plane_px);                     // (24-bit multiplies: full rate; 32-bit ones a quarter)
+    const int r = (int)__umulhi((unsigned)rem, m_pitch);
+    const int x = rem - __mul24(r, tg.pitch);
+    // cells that only pad the stencil repeat the last weighted row / column: same cache lines, no extra traffic
+    const int gy = min(tg.fy0 + r, tg.ymax);
+    const int gx = min(tg.fx0 + x, tg.xmax);
+    voff[i] = (unsigned)(__mul24(q * 4, (int)plane) + __mul24(gy, Wl) + gx) * 4u;       // bytes; H * W <= 2^23 (launcher)
+  }
+  float pf[IPT][4];
+  // (scalar base + unsigned 32-bit lane offset: no address arithmetic per load; groups of 256 items past the batch's
+  // live ones are skipped as a whole, the surplus items of the last live group re-read pixel 0 and commit it to a
+  // slot of the buffer nothing samples)
+  auto fetch = [&](int cb) {
+    const int live = min(NQ, (c1 - cb) >> 2) * plane_px;     // items of this batch (short last batch)
+    const int ngr = (live + 255) >> 8;
+    const char* b0 = reinterpret_cast<const char*>(fimg + (size_t)cb * plane);   // uniform bases: the 4 channel
+    const char* b1 = b0 + plane * 4;                                              // planes of a quad
+    const char* b2 = b1 + plane * 4;
+    const char* b3 = b2 + plane * 4;
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+      if (i >= ngr) continue;
+      const unsigned vo = (tid + i * 256 < live) ? voff[i] : 0u;
+      if (DM_ABL(a, 1)) {
+        pf[i][0] = pf[i][1] = pf[i][2] = pf[i][3] = __uint_as_float(vo);
+        continue;
+      }
+      pf[i][0] = *reinterpret_cast<const float*>(b0 + vo);
+      pf[i][1] = *reinterpret_cast<const float*>(b1 + vo);
+      pf[i][2] = *reinterpret_cast<const float*>(b2 + vo);
+      pf[i][3] = *reinterpret_cast<const float*>(b3 + vo);
+    }
+  };
+  auto commit = [&](int cb, int buf) {
+    const int live = min(NQ, (c1 - cb) >> 2) * plane_px;
+    const int ngr = (live + 255) >> 8;
+    float4* dst = lds + buf * kBufPx + tid;
+#pragma unroll
+    for (int i = 0; i < IPT; ++i)
+      if (i < ngr) dst[i * 256] = make_float4(pf[i][0], pf[i][1], pf[i][2], pf[i][3]);
+  };
+
+  // The first batch is on its way while the stencil table is built (one wave's work, everybody else's wait).
+  fetch(c0);
 
   // ---- stencils (channel independent).  Only 2*P of them are distinct (one per output
   // row and per output column): 2*P threads build them into a table in the -- still
@@ -468,7 +531,7 @@ __device__ __forceinline__ void roi_tile_fwd(const RoiArgs& a, const float* __re
 #pragma unroll
       for (int r = 0; r <= GG; ++r) e[1 + r] = xa ? Wt[r] : Wt[r] * inv_count;
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (LDS only: the fetch stays in flight)
     const float* ey = tab + ph * 8;
     const float* ex = tab + (P + pw) * 8;
     const int Ly = __float_as_int(ey[0]), Lx = __float_as_int(ex[0]);
@@ -480,65 +543,14 @@ __device__ __forceinline__ void roi_tile_fwd(const RoiArgs& a, const float* __re
     // (the second buffer is first written after the barrier that follows the first commit)
   }
 
-  // ---- staging.  Item = one tile pixel of one channel quad: 4 dword loads (the 4 channel
-  // planes; consecutive lanes read consecutive pixels -> coalesced) and ONE 16-byte LDS
-  // store, already channel-interleaved -- no register transposition.  The tile layout
-  // [quad][row][col] makes the LDS slot of item `idx` simply `idx`; which pixel it is does
-  // not depend on the batch, so its global byte offset is computed once.  Columns past the
-  // map's last one are clamped duplicates (weight 0), like rows.
-  constexpr int IPT = (kBufPx + 255) / 256;      // items per thread and batch: 8
-  const size_t plane = (size_t)Hl * Wl;
-  int voff[IPT];
-  // idx -> (quad, row, col) with multiply-high by ceil(2^32 / d): exact for idx * d < 2^32
-  // (idx < 2048, d <= 2048; d >= 4 so the constants fit 32 bits); the two real divisions are uniform
-  const unsigned m_plane = 0xFFFFFFFFu / (unsigned)plane_px + 1u;
-  const unsigned m_pitch = 0xFFFFFFFFu / (unsigned)tg.pitch + 1u;
-#pragma unroll
-  for (int i = 0; i < IPT; ++i) {
-    const int idx = tid + i * 256;
-    const int idc = idx < NQ * plane_px ? idx : 0;
-    const int q = (int)__umulhi((unsigned)idc, m_plane);
-    const int rem = idc - q * plane_px;
-    const int r = (int)__umulhi((unsigned)rem, m_pitch);
-    const int x = rem - r * tg.pitch;
-    // cells that only pad the stencil repeat the last weighted row / column: same cache lines, no extra traffic
-    const int gy = min(tg.fy0 + r, tg.ymax);
-    const int gx = min(tg.fx0 + x, tg.xmax);
-    voff[i] = (q * 4 * (int)plane + gy * Wl + gx) * 4;       // bytes; the launcher checked they fit 31 bits
-  }
-  float pf[IPT][4];
-  auto fetch = [&](int cb) {
-    const int live = min(NQ, (c1 - cb) >> 2) * plane_px;     // items of this batch (short last batch)
-    const char* b0 = reinterpret_cast<const char*>(fimg + (size_t)cb * plane);   // uniform bases: the 4 channel
-    const char* b1 = b0 + plane * 4;                                              // planes of a quad
-    const char* b2 = b1 + plane * 4;
-    const char* b3 = b2 + plane * 4;
-#pragma unroll
-    for (int i = 0; i < IPT; ++i) {
-      const int vo = (tid + i * 256 < live) ? voff[i] : 0;   // surplus items re-read pixel 0 (never committed)
-      if (DM_ABL(a, 1)) {
-        pf[i][0] = pf[i][1] = pf[i][2] = pf[i][3] = __int_as_float(vo);
-        continue;
-      }
-      pf[i][0] = *reinterpret_cast<const float*>(b0 + vo);
-      pf[i][1] = *reinterpret_cast<const float*>(b1 + vo);
-      pf[i][2] = *reinterpret_cast<const float*>(b2 + vo);
-      pf[i][3] = *reinterpret_cast<const float*>(b3 + vo);
-    }
-  };
-  auto commit = [&](int cb, int buf) {
-    const int live = min(NQ, (c1 - cb) >> 2) * plane_px;
-    float4* dst = lds + buf * kBufPx + tid;
-#pragma unroll
-    for (int i = 0; i < IPT; ++i)
-      if (tid + i * 256 < live) dst[i * 256] = make_float4(pf[i][0], pf[i][1], pf[i][2], pf[i][3]);
-  };
-
   auto sample = [&](int cb, int buf) {
     if (active) {
       const int nq = min(NQ, (c1 - cb) >> 2);
       const float4* t = lds + buf * kBufPx;
-      float* o = a.out + ((size_t)k * a.C + cb) * PP + tid;
+      // (uniform base + 32-bit lane offset; C % 4 == 0 and CT % 4 == 0: a quad is never cut by c1)
+      char* const ob = reinterpret_cast<char*>(a.out + ((size_t)k * a.C + cb) * PP);
+      const unsigned ot = (unsigned)tid << 2;
+      const size_t PB = (size_t)PP * 4;
       if (G == 0) {
         // run-time grid (slivers): samples outermost, groups of 4 channel quads accumulate per sample
         for (int q0 = 0; q0 < nq; q0 += 4) {
@@ -571,12 +583,12 @@ __device__ __forceinline__ void roi_tile_fwd(const RoiArgs& a, const float* __re
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int q = q0 + u;
-            const int cq = cb + 4 * q;
             if (q < nq) {
-              if (cq < c1) o[(size_t)(4 * q) * PP] = acc[u].x;
-              if (cq + 1 < c1) o[(size_t)(4 * q + 1) * PP] = acc[u].y;
-              if (cq + 2 < c1) o[(size_t)(4 * q + 2) * PP] = acc[u].z;
-              if (cq + 3 < c1) o[(size_t)(4 * q + 3) * PP] = acc[u].w;
+              char* const oq = ob + (size_t)(4 * q) * PB;
+              *reinterpret_cast<float*>(oq + ot) = acc[u].x;
+              *reinterpret_cast<float*>(oq + PB + ot) = acc[u].y;
+              *reinterpret_cast<float*>(oq + 2 * PB + ot) = acc[u].z;
+              *reinterpret_cast<float*>(oq + 3 * PB + ot) = acc[u].w;
             }
           }
         }
@@ -584,7 +596,6 @@ __device__ __forceinline__ void roi_tile_fwd(const RoiArgs& a, const float* __re
         constexpr int kUnrollQ = (S >= 4) ? 1 : 2;
 #pragma unroll kUnrollQ
         for (int q = 0; q < nq; ++q) {
-          const int cq = cb + 4 * q;
           float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
           const float4* tq = t + q * plane_px + base;
           if (DM_ABL(a, 2)) {
@@ -605,10 +616,11 @@ __device__ __forceinline__ void roi_tile_fwd(const RoiArgs& a, const float* __re
             }
           }
           if (DM_ABL(a, 4) && acc.x != 12345.678f) continue;      // (keeps the value live without the store)
-          o[(size_t)(4 * q) * PP] = acc.x;
-          if (cq + 1 < c1) o[(size_t)(4 * q + 1) * PP] = acc.y;
-          if (cq + 2 < c1) o[(size_t)(4 * q + 2) * PP] = acc.z;
-          if (cq + 3 < c1) o[(size_t)(4 * q + 3) * PP] = acc.w;
+          char* const oq = ob + (size_t)(4 * q) * PB;
+          *reinterpret_cast<float*>(oq + ot) = acc.x;
+          *reinterpret_cast<float*>(oq + PB + ot) = acc.y;
+          *reinterpret_cast<float*>(oq + 2 * PB + ot) = acc.z;
+          *reinterpret_cast<float*>(oq + 3 * PB + ot) = acc.w;
         }
       }
     }
@@ -621,7 +633,7 @@ __device__ __forceinline__ void roi_tile_fwd(const RoiArgs& a, const float* __re
   // 69.6 vs 71.0 us at 512 RoIs, 23.5 vs 29.4 us at 128 -- a whole-buffer batch holds more
   // channel quads, so there are fewer dependent round trips per workgroup.
   for (int cb = c0; cb < c1; cb += NCB) {
-    fetch(cb);
+    if (cb != c0) fetch(cb);
     commit(cb, 0);
     __syncthreads();
     sample(cb, 0);
@@ -740,21 +752,6 @@ __device__ __forceinline__ void roi_band_fwd(const RoiArgs& a, const float* __re
   const int tid = threadIdx.x;
   const int P = a.P, PP = P * P;
   const size_t plane = (size_t)Hl * Wl;
-  float* tab = reinterpret_cast<float*>(lds + TB);     // [2][P][8]: {L, W0 .. WG}
-  if (G > 0 && pw0 == 0) {                                        // (same table for every column block of the RoI)
-    if (tid < 2 * P) {
-      const bool xa = tid >= P;
-      const int p = xa ? tid - P : tid;
-      int L;
-      float Wt[GG + 1];
-      axis_stencil<GG>(xa ? sw : sh, xa ? bw : bh, xa ? gw : gh, p, xa ? Wl : Hl, L, Wt);
-      float* e = tab + tid * 8;
-      e[0] = __int_as_float(L);
-#pragma unroll
-      for (int r = 0; r <= GG; ++r) e[1 + r] = xa ? Wt[r] : Wt[r] * inv_count;
-    }
-    __syncthreads();
-  }
   const int pad = G > 0 ? G : 1;
   const unsigned m_pitch = 0xFFFFFFFFu / (unsigned)pitch + 1u;
   const unsigned m_cw = Cw > 1 ? 0xFFFFFFFFu / (unsigned)Cw + 1u : 0u;
@@ -808,6 +805,22 @@ __device__ __forceinline__ void roi_band_fwd(const RoiArgs& a, const float* __re
   // band's fetch is now in flight while this band's bins are computed and stored.
   Band g = band_of(0);
   fetch(g);
+  // (the first band is on its way while one wave builds the stencil table)
+  float* tab = reinterpret_cast<float*>(lds + TB);     // [2][P][8]: {L, W0 .. WG}
+  if (G > 0 && pw0 == 0) {                                        // (same table for every column block of the RoI)
+    if (tid < 2 * P) {
+      const bool xa = tid >= P;
+      const int p = xa ? tid - P : tid;
+      int L;
+      float Wt[GG + 1];
+      axis_stencil<GG>(xa ? sw : sh, xa ? bw : bh, xa ? gw : gh, p, xa ? Wl : Hl, L, Wt);
+      float* e = tab + tid * 8;
+      e[0] = __int_as_float(L);
+#pragma unroll
+      for (int r = 0; r <= GG; ++r) e[1 + r] = xa ? Wt[r] : Wt[r] * inv_count;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (LDS only: the fetch stays in flight)
+  }
   for (int ph0 = 0; ph0 < P; ph0 += rows_per_band) {
     const int R = g.R, fy0 = g.fy0, FH = g.FH;
 #pragma unroll
