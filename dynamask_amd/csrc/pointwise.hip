@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void class_logits_kernel(const float* __restri
                                                            int pix_blocks) {
   __shared__ float red[3][64][2];
   const int n = blockIdx.x / pix_blocks;
-  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (scalar: the weights of the channel loop are scalar loads)
   const int p = (blockIdx.x - n * pix_blocks) * 64 + lane;
   const bool ok = p < HW;
   int lab = (int)labels[n];
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void class_logits_up2x_kernel(const float* __r
                                                                 float* __restrict__ inst, float* __restrict__ det) {
   __shared__ float red[3][16][64];
   const int n = blockIdx.x / item_blocks;
-  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (scalar: the channel loop's addresses and weights are uniform)
   const int Wh = W >> 1, items = H * Wh;
   const int it = (blockIdx.x - n * item_blocks) * 64 + lane;
   const bool ok = it < items;
@@ -201,46 +201,70 @@ __global__ __launch_bounds__(256) void class_logits_up2x_kernel(const float* __r
   struct __attribute__((packed, aligned(4))) F2 { float a, b; };
   const bool first = x0 == 0, last = x0 + 2 > W - 1;       // column pair at the left / right border of the row
   const int la = first ? 0 : x0 - 1, lb = last ? x0 : x0 + 1;
-  const int rows[3] = {ym * W, y * W, yp * W};
+  // byte offsets of the two 8-byte loads of each row inside a channel plane (scalar plane base + 32-bit lane offset)
+  const unsigned oa[3] = {(unsigned)(ym * W + la) * 4u, (unsigned)(y * W + la) * 4u, (unsigned)(yp * W + la) * 4u};
+  const unsigned ob[3] = {(unsigned)(ym * W + lb) * 4u, (unsigned)(y * W + lb) * 4u, (unsigned)(yp * W + lb) * 4u};
   float acc[16];      // [branch][dy][e]
 #pragma unroll
   for (int k = 0; k < 16; ++k) acc[k] = 0.f;
   const float* px = x + (size_t)n * C * H * W;
-#pragma unroll 2
-  for (int c = part; c < C; c += 4) {
-    const float* p = px + (size_t)c * H * W;
-    // the four columns (x0-1, x0, x0+1, x0+2, clamped to the row) as two 8-byte loads: half the gather instructions
+  // a channel's six 8-byte loads (three rows x the column pairs (x0-1, x0) and (x0+1, x0+2), clamped to the row) are
+  // issued one channel ahead of the arithmetic that uses them
+  auto fetch = [&](int c, F2 (&A)[3], F2 (&B)[3]) {
+    const char* p = reinterpret_cast<const char*>(px + (size_t)c * H * W);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      A[r] = *reinterpret_cast<const F2*>(p + oa[r]);
+      B[r] = *reinterpret_cast<const F2*>(p + ob[r]);
+    }
+  };
+  auto accumulate = [&](int c, const F2 (&A)[3], const F2 (&B)[3], float on) {
     float v[3][4];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      const float* pr = p + rows[r];
-      const F2 pa = *reinterpret_cast<const F2*>(pr + la);
-      const F2 pb = *reinterpret_cast<const F2*>(pr + lb);
-      v[r][0] = pa.a;
-      v[r][1] = first ? pa.a : pa.b;
-      v[r][2] = last ? pb.b : pb.a;
-      v[r][3] = pb.b;
+      v[r][0] = A[r].a;
+      v[r][1] = first ? A[r].a : A[r].b;
+      v[r][2] = last ? B[r].b : B[r].a;
+      v[r][3] = B[r].b;
     }
-    const float wci = wri[c], wcd = wrd[c];
+    const float wci = wri[c] * on, wcd = wrd[c] * on;      // on = 1, or 0 for the padding half of an odd channel count
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
-      const int ra = dy == 0 ? 0 : 1, rb = dy == 0 ? 1 : 2;
+      // (compile-time indices into v[][]: at the top row rows 0 and 1 are the same row of the map, at the left border
+      // columns 0 and 1 the same column -- the weight goes to zero instead of the index moving, same operands either way;
+      // run-time indices put v[][] in scratch memory, a store and a reload per channel in this loop)
+      const int ia = dy == 0 ? 0 : 1, ib = dy == 0 ? 1 : 2;
       float ly = dy == 0 ? 0.75f : 0.25f;
-      int ia = ra, ib = rb;
-      if (dy == 0 && y == 0) { ia = 1; ib = 1; ly = 0.f; }
+      if (dy == 0 && y == 0) ly = 0.f;
       const float hy = 1.f - ly;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        int ja = (e == 0) ? 0 : (e == 3 ? 2 : 1);
-        int jb = ja + 1;
+        const int ja = (e == 0) ? 0 : (e == 3 ? 2 : 1);
+        const int jb = ja + 1;
         float lx = (e & 1) ? 0.25f : 0.75f;
-        if (e == 0 && x0 == 0) { ja = 1; jb = 1; lx = 0.f; }
+        if (e == 0 && x0 == 0) lx = 0.f;
         const float hx = 1.f - lx;
         const float r = fmaxf(dm_up2x_interp(hy, ly, hx, lx, v[ia][ja], v[ia][jb], v[ib][ja], v[ib][jb]), 0.f);
         acc[dy * 4 + e] += wci * r;
         acc[8 + dy * 4 + e] += wcd * r;
       }
     }
+  };
+  // (the prefetch is unconditional -- past the last channel it re-reads the current one: a branch around it, or around
+  // the second half, makes the compiler wait for the loads it has just issued, at the join)
+  F2 A0[3], B0[3], A1[3], B1[3];
+  fetch(min(part, C - 1), A0, B0);
+  for (int c = part; c < C; c += 8) {
+    const bool two = c + 4 < C;
+    const int c1 = two ? c + 4 : c;
+    fetch(c1, A1, B1);
+    __builtin_amdgcn_sched_barrier(0);             // (or the scheduler sinks the loads to their first use again)
+    accumulate(c, A0, B0, 1.f);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(c + 8 < C ? c + 8 : c, A0, B0);
+    __builtin_amdgcn_sched_barrier(0);
+    accumulate(c1, A1, B1, two ? 1.f : 0.f);       // (no branch: the loop body is one basic block, its waits count loads)
+    __builtin_amdgcn_sched_barrier(0);
   }
   if (part > 0) {
 #pragma unroll
