@@ -271,11 +271,14 @@ def test_narrow_wgrad_kernel_odd_shapes(ops, N, Cs, Cout, H, W):
     _close_sum(dw, ref2, mag2, 'narrow wgrad, two sources')
 
 
-@pytest.mark.parametrize('N,C,H,W', [(3, 5, 10, 6), (2, 7, 7, 9), (4, 16, 28, 28), (1, 3, 12, 20), (2, 2, 56, 56)])
+@pytest.mark.parametrize('N,C,H,W', [(3, 5, 10, 6), (2, 7, 7, 9), (4, 16, 28, 28), (1, 3, 12, 20), (2, 2, 56, 56),
+                                     (16, 4, 12, 20), (19, 3, 28, 28), (16, 3, 7, 9),
+                                     (16, 64, 12, 20), (17, 64, 7, 12), (16, 64, 2, 6), (18, 64, 6, 2), (33, 64, 28, 28)])
 def test_bn_relu_maxpool_forward_and_backward_odd_shapes(ops, N, C, H, W):
     """MaskPre's BatchNorm(train) -> ReLU -> MaxPool(3, 2, 1) block by itself, away from the 56 / 28 maps of the
     golden: non-square maps, odd sizes (the plane-in-LDS backward needs H * W % 4 == 0; 7 x 9 takes the other
-    one), few channels.  Against autograd of the same block (forward 1e-5, gradients at the 1e-4 gate)."""
+    one), few channels; 16 images or more of 64 channels or more take the backward whose pooling adjoint also
+    keeps BatchNorm's sums (2 x 2 blocks on even maps, the element form otherwise).  Against autograd of the same block (forward 1e-5, gradients at the 1e-4 gate)."""
     x = torch.randn(N, C, H, W, generator=_g(110)) * 1.5 + 0.3
     gamma = torch.rand(C, generator=_g(111)) + 0.5
     beta = torch.randn(C, generator=_g(112)) * 0.2
