@@ -4,7 +4,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DYNAMASK_HIP_LIB') or os.path.join(_HERE, 'libdynamask_hip.so')      # override: kernel experiments
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -47,6 +47,8 @@ SIGNATURES = {
     'dm_upsample2x_bilinear_bwd': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp], _c_int),
     'dm_point_sample_bwd': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_float, _vp, _vp], _c_int),
     'dm_class_logits_bwd': ([_vp, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _vp], _c_int),
+    'dm_class_logits_bwd_slab': ([_vp, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _vp], _c_int),
+    'dm_class_logits_bwd_scratch_floats': ([_c_int, _c_int], ctypes.c_longlong),
     'dm_deform_im2col': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp], _c_int),
     'dm_deform_col2im_coord': ([_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp], _c_int),
     'dm_deform_coord_grad': ([_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp], _c_int),

@@ -990,20 +990,39 @@ __global__ __launch_bounds__(256) void point_sample_bwd_kernel(const float* __re
 // Small maps (H*W <= 1024, a multiple of 4): a WAVE owns a channel plane (16-byte accesses, its sums by wave shuffles: no LDS, no
 // barrier) and walks CPW channels; a workgroup = 4 waves.  The kernel below gives every (channel, RoI) plane a 256-thread
 // workgroup of its own -- 65536 workgroups of 196 elements at 14 x 14, each ending in a barrier and two global atomics.
-template <int CPW>
+template <int CPW, int IT>
 __global__ __launch_bounds__(256) void class_logits_bwd_wave_kernel(const float* __restrict__ x, int N, int C, int HW,
                                                                     const float* __restrict__ wi, const float* __restrict__ wd,
                                                                     int num_classes, const int64_t* __restrict__ labels,
                                                                     const float* __restrict__ gi, const float* __restrict__ gd,
                                                                     float* __restrict__ gx, int accumulate,
                                                                     float* __restrict__ gwi, float* __restrict__ gbi,
-                                                                    float* __restrict__ gwd, float* __restrict__ gbd, int fx) {
+                                                                    float* __restrict__ gwd, float* __restrict__ gbd, int fx,
+                                                                    float* __restrict__ part) {
+  // IT = quads per lane and plane (HW / 4 <= 64 * IT).  The RoI's two logit-gradient planes are read once per wave, and a
+  // plane's x (and gx, when accumulating) quads are all requested before the first is used: written as a loop over the
+  // quads, a 28 x 28 plane was four dependent round trips per channel (1.7 TB/s where the 14 x 14 case ran at 4.4).
   const int n = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int lab = (int)labels[n];
   lab = min(max(lab, 0), num_classes - 1);
   const int HWq = HW >> 2;
   const dm_f32x4* gip = reinterpret_cast<const dm_f32x4*>(gi + (size_t)n * HW);
   const dm_f32x4* gdp = reinterpret_cast<const dm_f32x4*>(gd + (size_t)n * HW);
+  dm_f32x4 g1[IT], g2[IT];
+  float ti = 0.f, td = 0.f;
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int p = lane + it * 64;
+    const bool ok = p < HWq;
+    g1[it] = gip[ok ? p : 0];
+    g2[it] = gdp[ok ? p : 0];
+    if (!ok) g1[it] = g2[it] = dm_f32x4{0.f, 0.f, 0.f, 0.f};      // (zero gradients: surplus lanes add nothing to any sum)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ti += g1[it][e];
+      td += g2[it][e];
+    }
+  }
   const int cbase = (blockIdx.x * 4 + wave) * CPW;
   for (int k = 0; k < CPW; ++k) {
     const int c = cbase + k;
@@ -1011,33 +1030,48 @@ __global__ __launch_bounds__(256) void class_logits_bwd_wave_kernel(const float*
     const float a = wi[(size_t)lab * C + c], b = wd[(size_t)lab * C + c];
     const dm_f32x4* xp = reinterpret_cast<const dm_f32x4*>(x + ((size_t)n * C + c) * HW);
     dm_f32x4* gxp = reinterpret_cast<dm_f32x4*>(gx + ((size_t)n * C + c) * HW);
-    float si = 0.f, sd = 0.f, ti = 0.f, td = 0.f;
-    for (int p = lane; p < HWq; p += 64) {
-      const dm_f32x4 g1 = gip[p], g2 = gdp[p], xv = xp[p];
+    dm_f32x4 xv[IT], gv[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int p = min(lane + it * 64, HWq - 1);
+      xv[it] = xp[p];
+      if (accumulate) gv[it] = gxp[p];
+    }
+    float si = 0.f, sd = 0.f;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int p = lane + it * 64;
       dm_f32x4 v;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v[e] = a * g1[e] + b * g2[e];
-        si += g1[e] * xv[e];
-        sd += g2[e] * xv[e];
-        ti += g1[e];
-        td += g2[e];
+        v[e] = a * g1[it][e] + b * g2[it][e];
+        si += g1[it][e] * xv[it][e];
+        sd += g2[it][e] * xv[it][e];
       }
-      if (accumulate) v += gxp[p];
-      gxp[p] = v;
+      if (accumulate) v += gv[it];
+      if (p < HWq) gxp[p] = v;
     }
     si = wsum(si);
     sd = wsum(sd);
     if (lane == 0) {
-      dm_acc_add(gwi, (size_t)lab * C + c, si, fx != 0);
-      dm_acc_add(gwd, (size_t)lab * C + c, sd, fx != 0);
+      if (part) {            // slab mode: the RoI's partial sums, added per class in RoI order by class_logits_bwd_reduce_kernel
+        part[((size_t)n * C + c) * 2] = si;
+        part[((size_t)n * C + c) * 2 + 1] = sd;
+      } else {
+        dm_acc_add(gwi, (size_t)lab * C + c, si, fx != 0);
+        dm_acc_add(gwd, (size_t)lab * C + c, sd, fx != 0);
+      }
     }
     if (c == 0) {   // bias gradient once per RoI
-      ti = wsum(ti);
-      td = wsum(td);
+      const float tis = wsum(ti), tds = wsum(td);
       if (lane == 0) {
-        dm_acc_add(gbi, lab, ti, fx != 0);
-        dm_acc_add(gbd, lab, td, fx != 0);
+        if (part) {
+          part[(size_t)N * C * 2 + (size_t)n * 2] = tis;
+          part[(size_t)N * C * 2 + (size_t)n * 2 + 1] = tds;
+        } else {
+          dm_acc_add(gbi, lab, tis, fx != 0);
+          dm_acc_add(gbd, lab, tds, fx != 0);
+        }
       }
     }
   }
@@ -1049,7 +1083,8 @@ __global__ __launch_bounds__(256) void class_logits_bwd_kernel(const float* __re
                                                                const float* __restrict__ gi, const float* __restrict__ gd,
                                                                float* __restrict__ gx, int accumulate,
                                                                float* __restrict__ gwi, float* __restrict__ gbi,
-                                                               float* __restrict__ gwd, float* __restrict__ gbd, int fx) {
+                                                               float* __restrict__ gwd, float* __restrict__ gbd, int fx,
+                                                               float* __restrict__ part) {
   __shared__ float red[8];
   const int c = blockIdx.x, n = blockIdx.y;
   int lab = (int)labels[n];
@@ -1078,8 +1113,13 @@ __global__ __launch_bounds__(256) void class_logits_bwd_kernel(const float* __re
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    dm_acc_add(gwi, (size_t)lab * C + c, red[0] + red[1] + red[2] + red[3], fx != 0);
-    dm_acc_add(gwd, (size_t)lab * C + c, red[4] + red[5] + red[6] + red[7], fx != 0);
+    if (part) {
+      part[((size_t)n * C + c) * 2] = red[0] + red[1] + red[2] + red[3];
+      part[((size_t)n * C + c) * 2 + 1] = red[4] + red[5] + red[6] + red[7];
+    } else {
+      dm_acc_add(gwi, (size_t)lab * C + c, red[0] + red[1] + red[2] + red[3], fx != 0);
+      dm_acc_add(gwd, (size_t)lab * C + c, red[4] + red[5] + red[6] + red[7], fx != 0);
+    }
   }
   if (c == 0) {   // bias gradient once per RoI
     __syncthreads();
@@ -1091,9 +1131,85 @@ __global__ __launch_bounds__(256) void class_logits_bwd_kernel(const float* __re
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-      dm_acc_add(gbi, lab, red[0] + red[1] + red[2] + red[3], fx != 0);
-      dm_acc_add(gbd, lab, red[4] + red[5] + red[6] + red[7], fx != 0);
+      if (part) {
+        part[(size_t)N * C * 2 + (size_t)n * 2] = red[0] + red[1] + red[2] + red[3];
+        part[(size_t)N * C * 2 + (size_t)n * 2 + 1] = red[4] + red[5] + red[6] + red[7];
+      } else {
+        dm_acc_add(gbi, lab, red[0] + red[1] + red[2] + red[3], fx != 0);
+        dm_acc_add(gbd, lab, red[4] + red[5] + red[6] + red[7], fx != 0);
+      }
     }
+  }
+}
+
+// Slab mode of the class-gathered logits' parameter gradients.  The kernels above add every RoI's (channel) sums into the
+// row of its class with atomics: the RoIs of an image share a handful of classes, and 256 RoIs of ONE class serialise 256
+// float atomics on each of the row's addresses (measured, 256 x 256 x 14 x 14: 27 us with 80 random classes, 130 us with
+// one).  Here they write their sums to part[n][c][2] (+ part_b[n][2]) and this kernel adds, for class blockIdx.y, the RoIs
+// of that class in RoI order: no contention, and a fixed order of additions (the reference's is autograd's index_put_
+// accumulate: unordered).  One uncontended atomic per touched address lands the sum, so that calls on two streams may share
+// the gradient buffers.
+__global__ __launch_bounds__(256) void class_logits_bwd_reduce_kernel(const float* __restrict__ part, const int64_t* __restrict__ labels,
+                                                                      int N, int C, int num_classes, float* __restrict__ gwi,
+                                                                      float* __restrict__ gbi, float* __restrict__ gwd,
+                                                                      float* __restrict__ gbd) {
+  // workgroup = (16 channels, class l): 16 partitions of the RoIs (n = partition, partition + 16, ...), each added in RoI order
+  // with unconditional loads (a RoI of another class adds 0: a branch per RoI made this loop a chain of dependent round
+  // trips, 80 us for 256 RoIs of one class), the partitions then in partition order
+  __shared__ float red[16][16][4];
+  __shared__ unsigned char hit[1024];
+  const int l = blockIdx.y;
+  const int co = threadIdx.x & 15, pidx = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + co;
+  const int cc = min(c, C - 1);
+  const float* pb = part + (size_t)N * C * 2;
+  float si = 0.f, sd = 0.f, ti = 0.f, td = 0.f;
+  int any = 0;
+  for (int n0 = 0; n0 < N; n0 += 1024) {
+    const int tile = min(1024, N - n0);
+    int mine = 0;
+    for (int i = threadIdx.x; i < tile; i += 256) {
+      int lab = (int)labels[n0 + i];
+      lab = min(max(lab, 0), num_classes - 1);
+      hit[i] = lab == l;
+      mine |= lab == l;
+    }
+    const int here = __syncthreads_or(mine);
+    any |= here;
+    if (here) {
+#pragma unroll 4
+      for (int i = pidx; i < tile; i += 16) {
+        const size_t n = (size_t)(n0 + i);
+        const float a = part[(n * C + cc) * 2], b = part[(n * C + cc) * 2 + 1];
+        const float ba = pb[n * 2], bb = pb[n * 2 + 1];
+        const bool h = hit[i] != 0;
+        si += h ? a : 0.f;
+        sd += h ? b : 0.f;
+        ti += h ? ba : 0.f;
+        td += h ? bb : 0.f;
+      }
+    }
+    __syncthreads();
+  }
+  if (!any) return;
+  red[pidx][co][0] = si;
+  red[pidx][co][1] = sd;
+  red[pidx][co][2] = ti;
+  red[pidx][co][3] = td;
+  __syncthreads();
+  if (pidx != 0) return;
+  float r[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 16; ++q)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] += red[q][co][k];
+  if (c < C) {
+    atomicAdd(gwi + (size_t)l * C + c, r[0]);
+    atomicAdd(gwd + (size_t)l * C + c, r[1]);
+  }
+  if (c == 0) {
+    atomicAdd(gbi + l, r[2]);
+    atomicAdd(gbd + l, r[3]);
   }
 }
 
@@ -1754,7 +1870,7 @@ extern "C" int dm_point_sample_bwd_fx(const float* grad_out, int B, int C, int H
 static int class_logits_bwd_impl(const float* x, int N, int C, int HW, const float* w_inst, const float* w_det,
                                  int num_classes, const int64_t* labels, const float* grad_inst, const float* grad_det,
                                  float* grad_x, int accumulate_x, float* grad_w_inst, float* grad_b_inst,
-                                 float* grad_w_det, float* grad_b_det, int fx, dm_stream_t stream) {
+                                 float* grad_w_det, float* grad_b_det, int fx, dm_stream_t stream, float* part = nullptr) {
   if (!x || !w_inst || !w_det || !labels || !grad_inst || !grad_det || !grad_x || !grad_w_inst || !grad_b_inst ||
       !grad_w_det || !grad_b_det)
     return DM_ERR_INVALID_ARG;
@@ -1763,13 +1879,22 @@ static int class_logits_bwd_impl(const float* x, int N, int C, int HW, const flo
   static const bool v1_env = getenv("DM_CLB_V1") != nullptr;      // A/B switch
   if (!v1_env && (HW & 3) == 0 && HW <= 1024 && ((((uintptr_t)x | (uintptr_t)grad_x | (uintptr_t)grad_inst | (uintptr_t)grad_det) & 15) == 0)) {
     constexpr int CPW = 4;
-    DM_LAUNCH((class_logits_bwd_wave_kernel<CPW>), dim3((unsigned)dm_ceil_div(C, 4 * CPW), N), dim3(256), 0, (hipStream_t)stream, x, N, C, HW,
-              w_inst, w_det, num_classes, labels, grad_inst, grad_det, grad_x, accumulate_x, grad_w_inst, grad_b_inst, grad_w_det,
-              grad_b_det, fx);
-    return dm_check_launch();
+    if (HW <= 256)
+      DM_LAUNCH((class_logits_bwd_wave_kernel<CPW, 1>), dim3((unsigned)dm_ceil_div(C, 4 * CPW), N), dim3(256), 0, (hipStream_t)stream, x, N, C, HW,
+                w_inst, w_det, num_classes, labels, grad_inst, grad_det, grad_x, accumulate_x, grad_w_inst, grad_b_inst, grad_w_det,
+                grad_b_det, fx, part);
+    else
+      DM_LAUNCH((class_logits_bwd_wave_kernel<CPW, 4>), dim3((unsigned)dm_ceil_div(C, 4 * CPW), N), dim3(256), 0, (hipStream_t)stream, x, N, C, HW,
+                w_inst, w_det, num_classes, labels, grad_inst, grad_det, grad_x, accumulate_x, grad_w_inst, grad_b_inst, grad_w_det,
+                grad_b_det, fx, part);
+  } else {
+    DM_LAUNCH(class_logits_bwd_kernel, dim3(C, N), dim3(256), 0, (hipStream_t)stream, x, N, C, HW, w_inst, w_det, num_classes,
+              labels, grad_inst, grad_det, grad_x, accumulate_x, grad_w_inst, grad_b_inst, grad_w_det, grad_b_det, fx, part);
   }
-  DM_LAUNCH(class_logits_bwd_kernel, dim3(C, N), dim3(256), 0, (hipStream_t)stream, x, N, C, HW, w_inst, w_det, num_classes,
-            labels, grad_inst, grad_det, grad_x, accumulate_x, grad_w_inst, grad_b_inst, grad_w_det, grad_b_det, fx);
+  int rc = dm_check_launch();
+  if (rc != DM_OK || !part) return rc;
+  DM_LAUNCH(class_logits_bwd_reduce_kernel, dim3((unsigned)dm_ceil_div(C, 16), (unsigned)num_classes), dim3(256), 0, (hipStream_t)stream,
+            part, labels, N, C, num_classes, grad_w_inst, grad_b_inst, grad_w_det, grad_b_det);
   return dm_check_launch();
 }
 
@@ -1779,6 +1904,20 @@ extern "C" int dm_class_logits_bwd(const float* x, int N, int C, int HW, const f
                                    float* grad_w_det, float* grad_b_det, dm_stream_t stream) {
   return class_logits_bwd_impl(x, N, C, HW, w_inst, w_det, num_classes, labels, grad_inst, grad_det, grad_x, accumulate_x,
                                grad_w_inst, grad_b_inst, grad_w_det, grad_b_det, 0, stream);
+}
+
+extern "C" long long dm_class_logits_bwd_scratch_floats(int N, int C) {
+  return (N < 0 || C <= 0) ? -1 : (long long)N * C * 2 + (long long)N * 2;
+}
+
+extern "C" int dm_class_logits_bwd_slab(const float* x, int N, int C, int HW, const float* w_inst, const float* w_det,
+                                        int num_classes, const int64_t* labels, const float* grad_inst, const float* grad_det,
+                                        float* grad_x, int accumulate_x, float* grad_w_inst, float* grad_b_inst,
+                                        float* grad_w_det, float* grad_b_det, float* scratch, long long scratch_floats,
+                                        dm_stream_t stream) {
+  if (!scratch || scratch_floats < dm_class_logits_bwd_scratch_floats(N, C) || num_classes > 65535) return DM_ERR_INVALID_ARG;
+  return class_logits_bwd_impl(x, N, C, HW, w_inst, w_det, num_classes, labels, grad_inst, grad_det, grad_x, accumulate_x,
+                               grad_w_inst, grad_b_inst, grad_w_det, grad_b_det, 0, stream, scratch);
 }
 
 extern "C" int dm_class_logits_bwd_fx(const float* x, int N, int C, int HW, const float* w_inst, const float* w_det,

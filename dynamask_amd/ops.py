@@ -715,6 +715,7 @@ def channel_sum(g, out=None):
     return out
 
 
+CLB_SLAB = [os.environ.get('DM_CLB_SLAB', '1') != '0']      # class-logit parameter gradients without contended atomics (A/B: DM_CLB_SLAB=0)
 WGRAD_SLAB = [os.environ.get('DM_WGRAD_SLAB', '1') not in ('', '0')]      # weight gradients by slab reduce (no atomics); 0: float atomics
 _WGRAD_SCRATCH = [0]
 
@@ -818,6 +819,14 @@ def class_logits_backward(x, w_inst, w_det, labels, g_inst, g_det, grad_x, accum
     _chk(labels, 'labels', torch.int64)
     N, C, H, W = x.shape
     nc = w_inst.shape[0]
+    if CLB_SLAB[0] and N > 0:
+        # per-RoI sums to a scratch, added per class in RoI order by a second launch: no contended atomics (the RoIs of an
+        # image share a few classes) and a fixed order of additions -- also what the deterministic mode uses
+        scratch = torch.empty((int(lib().dm_class_logits_bwd_scratch_floats(N, C)),), device=x.device, dtype=torch.float32)
+        check(lib().dm_class_logits_bwd_slab(_p(x), N, C, H * W, _p(w_inst), _p(w_det), nc, _p(labels), _p(g_inst), _p(g_det),
+                                             _p(grad_x), 1 if accumulate_x else 0, _p(gw_inst), _p(gb_inst), _p(gw_det), _p(gb_det),
+                                             _p(scratch), scratch.numel(), _stream()), 'dm_class_logits_bwd_slab')
+        return grad_x
     if DETERMINISTIC[0]:
         outs = (gw_inst, gb_inst, gw_det, gb_det)
         fxs = [_fx_like(t) for t in outs]

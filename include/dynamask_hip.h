@@ -19,7 +19,7 @@
  *     A/B switches that select an older kernel or another split for the same
  *     operation (same mathematics; sums may differ in the last bits):
  *     DM_WGRAD_NARROW_OFF, DM_DCN_BAND_OFF, DM_IM2COL_V1, DM_FC_SEG, DM_COORD_V1 (the first-generation
- *     coordinate-gradient kernel).
+ *     coordinate-gradient kernel), DM_BN_BWD_V1 / DM_BN_POOL_V1 (MaskPre's BatchNorm + pool block as first written).
  *     Calls from several host threads are safe (a race only repeats an
  *     idempotent attribute call);
  *   - LDS scatter-accumulators (dm_deform_col2im_coord, dm_point_sample_bwd) are
@@ -52,7 +52,7 @@ extern "C" {
 typedef void* dm_stream_t; /* hipStream_t */
 
 const char* dm_error_string(int code);
-/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient, dm_conv_pack_weight_batch, dm_mask_loss_stage; 15: dm_class_logits_up2x_fwd; 16: dm_conv2d_wgrad_slab / dm_conv2d_wgrad_scratch_floats). */
+/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient, dm_conv_pack_weight_batch, dm_mask_loss_stage; 15: dm_class_logits_up2x_fwd; 16: dm_conv2d_wgrad_slab / dm_conv2d_wgrad_scratch_floats; 17: dm_class_logits_bwd_slab / dm_class_logits_bwd_scratch_floats). */
 int dm_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -456,6 +456,16 @@ int dm_class_logits_bwd(const float* x, int N, int C, int HW, const float* w_ins
                         int num_classes, const int64_t* labels, const float* grad_inst, const float* grad_det,
                         float* grad_x, int accumulate_x, float* grad_w_inst, float* grad_b_inst, float* grad_w_det,
                         float* grad_b_det, dm_stream_t stream);
+/* The same gradients without contended atomics: every RoI's sums go to `scratch` (dm_class_logits_bwd_scratch_floats(N, C)
+ * floats, contents undefined afterwards) and a second launch adds, per class, the RoIs of that class in RoI order.  The RoIs
+ * of an image share a few classes: 256 RoIs of one class are 256 serialised atomics per address in dm_class_logits_bwd
+ * (27 -> 130 us at 256 x 256 x 14 x 14).  Deterministic (fixed order of additions; the reference's autograd accumulates the
+ * gathered rows unordered: mmdet/models/roi_heads/mask_heads/dynamask_head.py:112-113 `[torch.arange(n), labels]`). */
+long long dm_class_logits_bwd_scratch_floats(int N, int C);
+int dm_class_logits_bwd_slab(const float* x, int N, int C, int HW, const float* w_inst, const float* w_det,
+                             int num_classes, const int64_t* labels, const float* grad_inst, const float* grad_det,
+                             float* grad_x, int accumulate_x, float* grad_w_inst, float* grad_b_inst, float* grad_w_det,
+                             float* grad_b_det, float* scratch, long long scratch_floats, dm_stream_t stream);
 
 /* DCNv1 backward pieces.  col / colgrad: [NB, 9*C, H, W] with rows tap-major
  * (row = tap*C + ci).  dm_dcn_weight_permute converts W[co][ci][tap] <->
