@@ -806,17 +806,23 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_lds_kernel(const float* __
 // input pixel gathers the output rows / columns whose forward footprint (y0, y1) contains it, with the
 // forward's own weights: the source coordinate is rh * oy with rh = (H-1)/(2H-1) just under 1/2, so the
 // candidates of input row y are the integers of the open interval ((y-1)/rh, (y+1)/rh), at most 7 of them.
-__global__ __launch_bounds__(256) void upsample2x_bwd_ac_lds_kernel(const float* __restrict__ gout,
-                                                                    const float* __restrict__ yout, int NC, int H, int W,
-                                                                    float* __restrict__ gin) {
-  extern __shared__ __attribute__((aligned(16))) float plane[];     // [2H][2W] masked gradients
+template <int NT>
+__global__ __launch_bounds__(NT) void upsample2x_bwd_ac_lds_kernel(const float* __restrict__ gout,
+                                                                   const float* __restrict__ yout, int NC, int H, int W,
+                                                                   float* __restrict__ gin) {
+  // Two passes over the staged plane, as the sums are written: rows[oy][x] = sum over the candidate columns ox of
+  // wx(ox, x) * plane[oy][ox], then gin[y][x] = sum over the candidate rows oy of wy(oy, y) * rows[oy][x].  (One pass
+  // recomputed every row sum for each of the ~7 output rows that use it: 49 weighted candidates per input pixel, 41 us for
+  // the 256 planes of the 112 -> 56 case on one workgroup of 256 threads per CU.)  Same terms in the same order: same bits.
+  extern __shared__ __attribute__((aligned(16))) float plane[];     // [2H][2W] masked gradients, then rows [2H][W]
   const int OH = 2 * H, OW = 2 * W, OHW = OH * OW, HW = H * W;
+  float* rows = plane + OHW;
   const float rh = (float)(H - 1) / (float)(OH - 1), rw = (float)(W - 1) / (float)(OW - 1);
   const float ih = (float)(OH - 1) / (float)(H - 1), iw = (float)(OW - 1) / (float)(W - 1);
   for (int nc = blockIdx.x; nc < NC; nc += gridDim.x) {
     const dm_f32x4* g4 = reinterpret_cast<const dm_f32x4*>(gout + (size_t)nc * OHW);
     const dm_f32x4* m4 = yout ? reinterpret_cast<const dm_f32x4*>(yout + (size_t)nc * OHW) : nullptr;
-    for (int i = threadIdx.x; i < OHW / 4; i += 256) {
+    for (int i = threadIdx.x; i < OHW / 4; i += NT) {
       dm_f32x4 v = g4[i];
       if (m4) {
         const dm_f32x4 m = m4[i];
@@ -827,11 +833,25 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_ac_lds_kernel(const float*
       reinterpret_cast<dm_f32x4*>(plane)[i] = v;
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < HW; idx += 256) {
-      const int y = idx / W, x = idx - y * W;
-      // one candidate more on either side than the interval needs: rounding of the bounds cannot lose a row
-      const int oy_lo = max((int)((float)(y - 1) * ih) - 1, 0), oy_hi = min((int)((float)(y + 1) * ih) + 2, OH - 1);
+    for (int idx = threadIdx.x; idx < OH * W; idx += NT) {
+      const int oy = idx / W, x = idx - oy * W;
+      // one candidate more on either side than the interval needs: rounding of the bounds cannot lose a column
       const int ox_lo = max((int)((float)(x - 1) * iw) - 1, 0), ox_hi = min((int)((float)(x + 1) * iw) + 2, OW - 1);
+      float row = 0.f;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        const float sx = rw * (float)ox;
+        const int x0 = (int)sx;
+        const int x1 = x0 + ((x0 < W - 1) ? 1 : 0);
+        const float lx = sx - (float)x0;
+        const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
+        row += wx * plane[oy * OW + ox];
+      }
+      rows[idx] = row;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < HW; idx += NT) {
+      const int y = idx / W, x = idx - y * W;
+      const int oy_lo = max((int)((float)(y - 1) * ih) - 1, 0), oy_hi = min((int)((float)(y + 1) * ih) + 2, OH - 1);
       float acc = 0.f;
       for (int oy = oy_lo; oy <= oy_hi; ++oy) {
         const float sy = rh * (float)oy;
@@ -840,16 +860,7 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_ac_lds_kernel(const float*
         const float ly = sy - (float)y0;
         const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
         if (wy == 0.f) continue;
-        float row = 0.f;
-        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-          const float sx = rw * (float)ox;
-          const int x0 = (int)sx;
-          const int x1 = x0 + ((x0 < W - 1) ? 1 : 0);
-          const float lx = sx - (float)x0;
-          const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
-          row += wx * plane[oy * OW + ox];
-        }
-        acc += wy * row;
+        acc += wy * rows[oy * W + x];
       }
       gin[(size_t)nc * HW + idx] = acc;
     }
@@ -1831,10 +1842,20 @@ extern "C" int dm_upsample2x_bilinear_bwd(const float* grad_out, const float* fw
               fwd_out_for_relu, NC, H, W, grad_in);
     return dm_check_launch();
   }
-  if (align_corners && H >= 2 && W >= 2 && (size_t)16 * H * W <= 64 * 1024) {
+  if (align_corners && H >= 2 && W >= 2 && (size_t)24 * H * W <= 96 * 1024) {
+    // planes [2H][2W] + row sums [2H][W] (56 x 56 inputs: 75 KB).  Few planes (the 256 x 1 x 112 x 112 logit gradients): 1024
+    // threads per workgroup, so that a CU with one plane still has 16 waves
+    static bool attr_a[DM_MAX_DEVICES] = {false}, attr_b[DM_MAX_DEVICES] = {false};
+    if (dm_ensure_lds_limit(reinterpret_cast<const void*>(&upsample2x_bwd_ac_lds_kernel<1024>), 96 * 1024, attr_a) != DM_OK ||
+        dm_ensure_lds_limit(reinterpret_cast<const void*>(&upsample2x_bwd_ac_lds_kernel<256>), 96 * 1024, attr_b) != DM_OK)
+      return DM_ERR_LAUNCH;
     const int blocks = min(NC, 8 * dm_num_cus());
-    DM_LAUNCH(upsample2x_bwd_ac_lds_kernel, dim3(blocks), dim3(256), (size_t)16 * H * W, (hipStream_t)stream, grad_out,
-              fwd_out_for_relu, NC, H, W, grad_in);
+    if (NC <= 2 * dm_num_cus())
+      DM_LAUNCH((upsample2x_bwd_ac_lds_kernel<1024>), dim3(blocks), dim3(1024), (size_t)24 * H * W, (hipStream_t)stream, grad_out,
+                fwd_out_for_relu, NC, H, W, grad_in);
+    else
+      DM_LAUNCH((upsample2x_bwd_ac_lds_kernel<256>), dim3(blocks), dim3(256), (size_t)24 * H * W, (hipStream_t)stream, grad_out,
+                fwd_out_for_relu, NC, H, W, grad_in);
     return dm_check_launch();
   }
   // scatter form (1-pixel inputs, planes beyond 64 KB with align_corners): accumulates, so clear the output first

@@ -343,12 +343,23 @@ __global__ __launch_bounds__(256) void upsample2x_half_kernel(const float* __res
   const int Wh = W >> 1;
   const long long total = NC * H * Wh;
   const int OW = 2 * W;
+  const bool small = total < (1LL << 31);       // 32-bit index arithmetic (two 64-bit divisions per item cost more than its eight outputs)
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
-    const int xp = (int)(idx % Wh);
-    const long long t = idx / Wh;
-    const int y = (int)(t % H);
-    const long long nc = t / H;
+    int xp, y;
+    long long nc;
+    if (small) {
+      const unsigned u = (unsigned)idx, t = u / (unsigned)Wh;
+      xp = (int)(u - t * (unsigned)Wh);
+      const unsigned n32 = t / (unsigned)H;
+      y = (int)(t - n32 * (unsigned)H);
+      nc = n32;
+    } else {
+      xp = (int)(idx % Wh);
+      const long long t = idx / Wh;
+      y = (int)(t % H);
+      nc = t / H;
+    }
     const float* p = in + nc * H * W;
     const int ym = max(y - 1, 0), yp = min(y + 1, H - 1);
     const int x0 = 2 * xp;
@@ -374,18 +385,19 @@ __global__ __launch_bounds__(256) void upsample2x_half_kernel(const float* __res
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
       // oy = 2y + dy: rows (y-1, y) with ly = 0.75, or (y, y+1) with ly = 0.25; oy = 0 -> ly = 0
-      const int ra = dy == 0 ? 0 : 1, rb = dy == 0 ? 1 : 2;
+      // (compile-time indices: at y = 0 rows 0 and 1 of v are the same row of the map, at x0 = 0 columns 0 and 1 the same
+      // column, so the clamped cases only zero the weight -- same operands, no run-time indexing of v[][])
+      const int ia = dy == 0 ? 0 : 1, ib = dy == 0 ? 1 : 2;
       float ly = dy == 0 ? 0.75f : 0.25f;
-      int ia = ra, ib = rb;
-      if (dy == 0 && y == 0) { ia = 1; ib = 1; ly = 0.f; }       // sy clamped to 0: y0 = 0
+      if (dy == 0 && y == 0) ly = 0.f;                           // sy clamped to 0: y0 = 0
       const float hy = 1.f - ly;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         // e: 0 -> (x0-1, x0, .75)  1 -> (x0, x0+1, .25)  2 -> (x0, x0+1, .75)  3 -> (x0+1, x0+2, .25)
-        int ja = (e == 0) ? 0 : (e == 3 ? 2 : 1);
-        int jb = ja + 1;
+        const int ja = (e == 0) ? 0 : (e == 3 ? 2 : 1);
+        const int jb = ja + 1;
         float lx = (e & 1) ? 0.25f : 0.75f;
-        if (e == 0 && x0 == 0) { ja = 1; jb = 1; lx = 0.f; }     // sx clamped to 0
+        if (e == 0 && x0 == 0) lx = 0.f;                         // sx clamped to 0
         const float hx = 1.f - lx;
         float r = dm_up2x_interp(hy, ly, hx, lx, v[ia][ja], v[ia][jb], v[ib][ja], v[ib][jb]);
         if (relu) r = fmaxf(r, 0.f);
