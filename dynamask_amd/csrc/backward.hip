@@ -1767,6 +1767,145 @@ __global__ __launch_bounds__(256) void fx_to_float_kernel(long long* __restrict_
   out[i] = accumulate ? out[i] + v : v;
   if (clear) fx[i] = 0;
 }
+// Gather form of the point-sample adjoint.  The scatter kernel above is bound by its LDS atomics: four per sample and channel,
+// and the samples of a 56 x 56 lattice over a 30 x 30-pixel footprint hit the same cells (0.46 ms at 256 x 64 x 56 x 56 for
+// 0.24 GB of traffic; cheaper arithmetic and float LDS atomics were both tried -- DESIGN.md).  Here a thread owns a CELL of
+// the footprint: the samples whose bilinear hat covers column gx are those with floor(sx) = gx - 1 (weight lx) or gx (weight
+// 1 - lx), and since the sample coordinate is monotonic in the lattice index each of the two sets is a run of consecutive
+// indices -- found once per workgroup (first / last index and count per map column and row, in LDS; a count that disagrees with
+// the run length means rounding broke the monotonicity of a degenerate RoI: that RoI takes the per-sample path).  The CT
+// gradient planes are staged in LDS and only read; a cell's sum is formed in a fixed order (rows, then columns) and lands
+// with ONE atomic per cell and channel.
+template <int CT>
+__global__ __launch_bounds__(256) void point_sample_bwd_gather_kernel(const float* __restrict__ gout, int B, int C, int H, int W,
+                                                                      const float* __restrict__ rois, int N, int S, float scale,
+                                                                      float* __restrict__ gfeat, int fixed) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  __shared__ int broken;
+  const int SS = S * S;
+  float* gpl = sm;                                    // [CT][S * S] gradients
+  float* lxs = gpl + CT * SS;                         // [S] fractional parts
+  float* lys = lxs + S;
+  int* x0s = reinterpret_cast<int*>(lys + S);         // [S] floor(sx), clipped to [-2, W + 1]
+  int* y0s = x0s + S;
+  int* cfirst = y0s + S;                              // [W + 4] per value v + 2: first index, last index + 1, count
+  int* clast = cfirst + (W + 4);
+  int* ccnt = clast + (W + 4);
+  int* rfirst = ccnt + (W + 4);                       // [H + 4]
+  int* rlast = rfirst + (H + 4);
+  int* rcnt = rlast + (H + 4);
+  const int n = blockIdx.y;
+  const int c0 = blockIdx.x * CT;
+  const float* r = rois + (size_t)n * 5;
+  const int b = (int)r[0];
+  if (b < 0 || b >= B) return;
+  const float x1 = r[1], y1 = r[2], x2 = r[3], y2 = r[4];
+  float sxa, sxb, sya, syb;
+  ps_coord(x1, x2, 0, S, W, scale, sxa);
+  ps_coord(x1, x2, S - 1, S, W, scale, sxb);
+  ps_coord(y1, y2, 0, S, H, scale, sya);
+  ps_coord(y1, y2, S - 1, S, H, scale, syb);
+  const float sxmin = fminf(sxa, sxb), sxmax = fmaxf(sxa, sxb), symin = fminf(sya, syb), symax = fmaxf(sya, syb);
+  if (sxmax < -1.f || sxmin > (float)W || symax < -1.f || symin > (float)H) return;   // every tap void
+  const int fx0 = max((int)floorf(fmaxf(sxmin, -1.f)), 0), fx1 = min((int)floorf(fminf(sxmax, (float)W)) + 1, W - 1);
+  const int fy0 = max((int)floorf(fmaxf(symin, -1.f)), 0), fy1 = min((int)floorf(fminf(symax, (float)H)) + 1, H - 1);
+  const int TW = fx1 - fx0 + 1, TH = fy1 - fy0 + 1;
+  if (TW <= 0 || TH <= 0) return;
+  const int nch = min(CT, C - c0);
+  const int tid = threadIdx.x;
+  if (tid == 0) broken = 0;
+  for (int i = tid; i < W + 4; i += 256) { cfirst[i] = 0x7fffffff; clast[i] = 0; ccnt[i] = 0; }
+  for (int i = tid; i < H + 4; i += 256) { rfirst[i] = 0x7fffffff; rlast[i] = 0; rcnt[i] = 0; }
+  __syncthreads();
+  if (tid < 2 * S) {
+    const bool ax = tid < S;
+    const int i = ax ? tid : tid - S;
+    float sc;
+    if (ax) ps_coord(x1, x2, i, S, W, scale, sc);
+    else ps_coord(y1, y2, i, S, H, scale, sc);
+    const int size = ax ? W : H;
+    const float f = floorf(sc);
+    const int v = (f < -1.f) ? -2 : (f > (float)size ? size + 1 : (int)f);      // out-of-range samples: sentinel values
+    (ax ? lxs : lys)[i] = sc - f;
+    (ax ? x0s : y0s)[i] = v;
+    atomicMin((ax ? cfirst : rfirst) + v + 2, i);
+    atomicMax((ax ? clast : rlast) + v + 2, i + 1);
+    atomicAdd((ax ? ccnt : rcnt) + v + 2, 1);
+  }
+  // the gradient planes
+  {
+    const float* go = gout + ((size_t)n * C + c0) * SS;
+    for (int i = tid; i < nch * SS; i += 256) gpl[i] = go[i];
+  }
+  __syncthreads();
+  // a value whose indices are not one run: not monotonic
+  for (int i = tid; i < W + 4; i += 256)
+    if (ccnt[i] > 0 && clast[i] - cfirst[i] != ccnt[i]) broken = 1;
+  for (int i = tid; i < H + 4; i += 256)
+    if (rcnt[i] > 0 && rlast[i] - rfirst[i] != rcnt[i]) broken = 1;
+  __syncthreads();
+  const size_t plane = (size_t)H * W;
+  float* gf = gfeat + ((size_t)b * C + c0) * plane * (fixed ? 2 : 1);
+  if (broken) {
+    // per-sample path (as the scatter kernel's direct form)
+    for (int pos = tid; pos < SS; pos += 256) {
+      const int iy = pos / S, ix = pos - iy * S;
+      const int x0 = x0s[ix], y0 = y0s[iy];
+      if (x0 < -1 || x0 > W || y0 < -1 || y0 > H) continue;
+      const int x1i = x0 + 1, y1i = y0 + 1;
+      const float lx = lxs[ix], ly = lys[iy];
+      const float w_nw = (1.f - lx) * (1.f - ly), w_ne = lx * (1.f - ly), w_sw = (1.f - lx) * ly, w_se = lx * ly;
+      const bool okx0 = x0 >= 0 && x0 < W, okx1 = x1i >= 0 && x1i < W, oky0 = y0 >= 0 && y0 < H, oky1 = y1i >= 0 && y1i < H;
+      for (int c = 0; c < nch; ++c) {
+        const float g = gpl[c * SS + pos];
+        const size_t cb = (size_t)c * plane;
+        if (okx0 && oky0) dm_acc_add(gf, cb + y0 * W + x0, g * w_nw, fixed != 0);
+        if (okx1 && oky0) dm_acc_add(gf, cb + y0 * W + x1i, g * w_ne, fixed != 0);
+        if (okx0 && oky1) dm_acc_add(gf, cb + y1i * W + x0, g * w_sw, fixed != 0);
+        if (okx1 && oky1) dm_acc_add(gf, cb + y1i * W + x1i, g * w_se, fixed != 0);
+      }
+    }
+    return;
+  }
+  const unsigned m_tw = TW > 1 ? 0xFFFFFFFFu / (unsigned)TW + 1u : 0u;
+  for (int cell = tid; cell < TH * TW; cell += 256) {
+    const int ty = TW > 1 ? (int)__umulhi((unsigned)cell, m_tw) : cell;      // cell * TW < 2^32 (H * W of the map < 2^31)
+    const int tx = cell - ty * TW;
+    const int gx = fx0 + tx, gy = fy0 + ty;
+    // the two runs per axis: value gx - 1 (the sample's right / lower tap lands here) and value gx (its own cell)
+    const int ca0 = cfirst[gx + 1], ca1 = clast[gx + 1], cb0 = cfirst[gx + 2], cb1 = clast[gx + 2];
+    const int ra0 = rfirst[gy + 1], ra1 = rlast[gy + 1], rb0 = rfirst[gy + 2], rb1 = rlast[gy + 2];
+    if ((ca1 <= ca0 && cb1 <= cb0) || (ra1 <= ra0 && rb1 <= rb0)) continue;
+    float acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int rs = 0; rs < 2; ++rs) {
+      const int i0 = rs == 0 ? ra0 : rb0, i1 = rs == 0 ? ra1 : rb1;
+      for (int iy = i0; iy < i1; ++iy) {
+        const float ly = lys[iy];
+        const float wy = rs == 0 ? ly : 1.f - ly;
+        const float* grow = gpl + iy * S;
+#pragma unroll
+        for (int cs = 0; cs < 2; ++cs) {
+          const int j0 = cs == 0 ? ca0 : cb0, j1 = cs == 0 ? ca1 : cb1;
+          for (int ix = j0; ix < j1; ++ix) {
+            const float lx = lxs[ix];
+            const float w = (cs == 0 ? lx : 1.f - lx) * wy;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[c] += grow[c * SS + ix] * w;      // (planes past nch hold stale values: not flushed)
+          }
+        }
+      }
+    }
+    const size_t o = (size_t)gy * W + gx;
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+      if (c < nch && acc[c] != 0.f) dm_acc_add(gf, (size_t)c * plane + o, acc[c], fixed != 0);
+  }
+}
+
+
 }  // namespace
 
 extern "C" int dm_fx_to_float(long long* fx, long long n, float* out, int accumulate, int clear, dm_stream_t stream) {
@@ -1870,6 +2009,13 @@ static int point_sample_bwd_impl(const float* grad_out, int B, int C, int H, int
   if (!grad_out || !rois || !grad_feat || B <= 0 || C <= 0 || H <= 0 || W <= 0 || N < 0 || S <= 0) return DM_ERR_INVALID_ARG;
   if (N == 0) return DM_OK;
   constexpr int CT = 4;
+  static const int v1_env = getenv("DM_PSB_V1") ? atoi(getenv("DM_PSB_V1")) : 0;      // A/B switch: 1 = the scatter kernel
+  const size_t glds = sizeof(float) * ((size_t)CT * S * S + 4 * (size_t)S + 3 * ((size_t)W + 4) + 3 * ((size_t)H + 4));
+  if (!v1_env && glds <= 64 * 1024 && S <= 128 && (long long)H * W * W < (1LL << 32)) {      // (2 S threads build the tables; cell * TW < 2^32)
+    DM_LAUNCH(point_sample_bwd_gather_kernel<CT>, dim3((unsigned)dm_ceil_div(C, CT), (unsigned)N), dim3(256), glds,
+              (hipStream_t)stream, grad_out, B, C, H, W, rois, N, S, spatial_scale, grad_feat, fx);
+    return dm_check_launch();
+  }
   const int lds_elems = 6144;                    // 48 KB of 64-bit accumulators
   DM_LAUNCH(point_sample_bwd_kernel<CT>, dim3((unsigned)dm_ceil_div(C, CT), (unsigned)N), dim3(256),
             (size_t)lds_elems * sizeof(unsigned long long), (hipStream_t)stream, grad_out, B, C, H, W, rois, N, S,

@@ -19,7 +19,8 @@
  *     A/B switches that select an older kernel or another split for the same
  *     operation (same mathematics; sums may differ in the last bits):
  *     DM_WGRAD_NARROW_OFF, DM_DCN_BAND_OFF, DM_IM2COL_V1, DM_FC_SEG, DM_COORD_V1 (the first-generation
- *     coordinate-gradient kernel), DM_BN_BWD_V1 / DM_BN_POOL_V1 (MaskPre's BatchNorm + pool block as first written).
+ *     coordinate-gradient kernel), DM_BN_BWD_V1 / DM_BN_POOL_V1 (MaskPre's BatchNorm + pool block as first written), DM_PSB_V1 (the
+ *     scatter form of dm_point_sample_bwd).
  *     Calls from several host threads are safe (a race only repeats an
  *     idempotent attribute call);
  *   - LDS scatter-accumulators (dm_deform_col2im_coord, dm_point_sample_bwd) are
