@@ -1297,7 +1297,12 @@ __global__ __launch_bounds__(256) void deform_im2col_kernel(const float* __restr
 template <int CT>
 __global__ __launch_bounds__(256) void deform_im2col_lds_kernel(const float* __restrict__ x, const float* __restrict__ offset,
                                                                 int C, int H, int W, int dg, float* __restrict__ col) {
-  extern __shared__ __attribute__((aligned(16))) float planes[];      // [CT][HW]
+  // Third generation (end of round 3): the CT planes are staged as float4 per pixel and channel quad ([CT / 4][HW] quads, the
+  // layout of the DCN forward kernels), so that a sample's corner is ONE 16-byte LDS read for four channels -- 16 reads per
+  // four pixels and quad where the planar layout took 64.
+  extern __shared__ __attribute__((aligned(16))) float planes[];      // [CT / 4][HW] float4
+  static_assert(CT % 4 == 0, "channel quads");
+  constexpr int NQ = CT / 4;
   const int HW = H * W, HWq = HW >> 2;
   const int cpg = C / dg;
   const int chunks = cpg / CT;
@@ -1307,10 +1312,20 @@ __global__ __launch_bounds__(256) void deform_im2col_lds_kernel(const float* __r
   const int n = bid / dg;
   const int c0 = g * cpg + chunk * CT;
   const int tid = threadIdx.x;
+  dm_f32x4* pq = reinterpret_cast<dm_f32x4*>(planes);
   {
-    const dm_f32x4* src = reinterpret_cast<const dm_f32x4*>(x + ((size_t)n * C + c0) * HW);     // CT planes are contiguous
-    dm_f32x4* dst = reinterpret_cast<dm_f32x4*>(planes);
-    for (int i = tid; i < CT * HWq; i += 256) dst[i] = src[i];
+    // a thread loads 4 consecutive pixels of the 4 planes of a quad (16-byte loads) and writes 4 interleaved float4
+    const float* src = x + ((size_t)n * C + c0) * HW;
+    for (int i = tid; i < NQ * HWq; i += 256) {
+      const int q = i / HWq, p4 = i - q * HWq;
+      const dm_f32x4 a = reinterpret_cast<const dm_f32x4*>(src + (size_t)(4 * q) * HW)[p4];
+      const dm_f32x4 b = reinterpret_cast<const dm_f32x4*>(src + (size_t)(4 * q + 1) * HW)[p4];
+      const dm_f32x4 c = reinterpret_cast<const dm_f32x4*>(src + (size_t)(4 * q + 2) * HW)[p4];
+      const dm_f32x4 d = reinterpret_cast<const dm_f32x4*>(src + (size_t)(4 * q + 3) * HW)[p4];
+      dm_f32x4* dst = pq + (size_t)q * HW + 4 * p4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst[e] = dm_f32x4{a[e], b[e], c[e], d[e]};
+    }
   }
   __syncthreads();
   const float* offb = offset + ((size_t)n * dg + g) * 18 * HW;
@@ -1346,16 +1361,18 @@ __global__ __launch_bounds__(256) void deform_im2col_lds_kernel(const float* __r
       }
     }
     float* dst = col + ((size_t)n * 9 * C + (size_t)tap * C + c0) * HW + p0;
-#pragma unroll 4
-    for (int c = 0; c < CT; ++c) {
-      const float* pl = planes + c * HW;
-      dm_f32x4 v;
+#pragma unroll 2
+    for (int q = 0; q < NQ; ++q) {
+      const dm_f32x4* pl = pq + (size_t)q * HW;
+      dm_f32x4 v[4];      // [channel of the quad][pixel]
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float ta = pl[ot[e]], tb = pl[ot[e] + 1], ba = pl[ob[e]], bb = pl[ob[e] + 1];
-        v[e] = wt0[e] * ta + wt1[e] * tb + wb0[e] * ba + wb1[e] * bb;
+        const dm_f32x4 ta = pl[ot[e]], tb = pl[ot[e] + 1], ba = pl[ob[e]], bb = pl[ob[e] + 1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k][e] = wt0[e] * ta[k] + wt1[e] * tb[k] + wb0[e] * ba[k] + wb1[e] * bb[k];
       }
-      *reinterpret_cast<dm_f32x4*>(dst + (size_t)c * HW) = v;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) *reinterpret_cast<dm_f32x4*>(dst + (size_t)(4 * q + k) * HW) = v[k];
     }
   }
 }
