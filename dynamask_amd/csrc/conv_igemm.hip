@@ -438,18 +438,23 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
         for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(bias_r[i][r]));
     }
     const ptrdiff_t mask_off = a.mask ? a.mask - a.out : 0;
-    auto store_all = [&](auto acc_mode, auto nt_mode, auto mask_mode) {
+    // full: the workgroup's tile lies inside the output (every cout row and every pixel column exists) -- uniform, and then
+    // no store is predicated: the row and column tests cost an exec-mask sequence each, 600 scalar instructions per wave in
+    // front of the 64 stores of a K = 64 GEMM (SQ counters: 4.8 SALU per MFMA on 64 -> 576 @56^2)
+    // (1x1 builds only: in the 3x3 kernel the second copy of the epilogue cost 0.5 % of the headline, its K = 2304 loop hides the tests)
+    const bool full = KS == 1 && m0 + TM <= a.Cout && q0 + TN <= a.Q;
+    auto store_all = [&](auto acc_mode, auto nt_mode, auto mask_mode, auto full_mode) {
 #pragma unroll
       for (int i = 0; i < WM; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int k = i * 32 + (r & 3) + 8 * (r >> 2);       // compile-time part of the channel
-          if (co_lane + k < a.Cout) {
+          if (decltype(full_mode)::value || co_lane + k < a.Cout) {
             const float b = bias_r[i][r];
             const size_t o = off_lane + (size_t)k * HW;
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
-              if (col_ok[j]) {
+              if (decltype(full_mode)::value || col_ok[j]) {
                 float* op = pj[j] + o;
                 float v = acc[i][j][r] + b;
                 if (decltype(acc_mode)::value) v += *op;          // accumulate into the destination (gradient sums)
@@ -465,12 +470,19 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
     };
     using T = std::true_type;
     using F = std::false_type;
-    if (a.mask) {
-      if (a.relu & 2) store_all(T{}, F{}, T{});
-      else store_all(F{}, F{}, T{});
-    } else if (a.relu & 2) store_all(T{}, F{}, F{});
-    else if (a.relu & 4) store_all(F{}, T{}, F{});
-    else store_all(F{}, F{}, F{});
+    if (KS == 1 && full) {
+      if (a.mask) {
+        if (a.relu & 2) store_all(T{}, F{}, T{}, T{});
+        else store_all(F{}, F{}, T{}, T{});
+      } else if (a.relu & 2) store_all(T{}, F{}, F{}, T{});
+      else if (a.relu & 4) store_all(F{}, T{}, F{}, T{});
+      else store_all(F{}, F{}, F{}, T{});
+    } else if (a.mask) {
+      if (a.relu & 2) store_all(T{}, F{}, T{}, F{});
+      else store_all(F{}, F{}, T{}, F{});
+    } else if (a.relu & 2) store_all(T{}, F{}, F{}, F{});
+    else if (a.relu & 4) store_all(F{}, T{}, F{}, F{});
+    else store_all(F{}, F{}, F{}, F{});
   } else {
     // deconv 2x2/s2: packed cout = phase * shuffle + oc, stored at (2y+dy, 2x+dx)
     int sy[WN], sx[WN];
