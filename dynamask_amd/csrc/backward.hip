@@ -1638,14 +1638,17 @@ __global__ __launch_bounds__(NTH) void dcn_col2im_lds_kernel(const float* __rest
     const bool v3 = h_high <= H - 1 && w_low >= 0, v4 = h_high <= H - 1 && w_high <= W - 1;
     const int o1 = h_low * W + w_low, o2 = h_low * W + w_high, o3 = h_high * W + w_low, o4 = h_high * W + w_high;
     const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+    const float a1 = w1 * 16.f, a2 = w2 * 16.f, a3 = w3 * 16.f, a4 = w4 * 16.f;          // (dm_fix36_mul's two scalings of a weight)
+    const float b1 = w1 * 68719476736.f, b2 = w2 * 68719476736.f, b3 = w3 * 68719476736.f, b4 = w4 * 68719476736.f;
+    // (corners outside the map are branched around: adding zero to a clamped cell instead -- no exec-mask sequences -- measured
+    // slower, 0.93 -> 0.98 ms: the atomics it adds cost more than the branches it removes)
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
       unsigned long long* pl = lds + c * HW;
-      const double cgd = (double)cgv[c] * DM_FIX_SCALE;
-      if (v1) atomicAdd(pl + o1, (unsigned long long)__double2ll_rn(cgd * (double)w1));
-      if (v2) atomicAdd(pl + o2, (unsigned long long)__double2ll_rn(cgd * (double)w2));
-      if (v3) atomicAdd(pl + o3, (unsigned long long)__double2ll_rn(cgd * (double)w3));
-      if (v4) atomicAdd(pl + o4, (unsigned long long)__double2ll_rn(cgd * (double)w4));
+      if (v1) atomicAdd(pl + o1, dm_fix36_mul(cgv[c], a1, b1));
+      if (v2) atomicAdd(pl + o2, dm_fix36_mul(cgv[c], a2, b2));
+      if (v3) atomicAdd(pl + o3, dm_fix36_mul(cgv[c], a3, b3));
+      if (v4) atomicAdd(pl + o4, dm_fix36_mul(cgv[c], a4, b4));
     }
   };
   if ((HW & 3) == 0) {

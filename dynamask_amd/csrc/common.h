@@ -65,6 +65,20 @@ static inline int dm_ensure_lds_limit(const void* kernel, int bytes, bool* flags
 // instead of float cells: integer addition is associative, so the sum does not depend on the order in which
 // workgroups arrive.  A non-finite addend becomes 2^62 (dm_fx_to_float turns any |cell| >= 2^61 into NaN).
 #define DM_FX_ONE 68719476736.0 /* 2^36 */
+// g * w -> the same 2^-36 fixed point in eight fp32 / integer instructions (the fp64 route -- a double multiply and
+// __double2ll_rn, for which there is no hardware convert -- is ~11 and the DCN col2im is bound by exactly these: 5.3e8
+// vector instructions per launch, its VALU pipe 100 % busy).  The caller passes w16 = w * 2^4 and w36 = w * 2^36 (exact
+// scalings, shared by the channels of a sample): t = g * w16 and p = g * w36 are the same rounded product at two scales;
+// hi = rne(t) is bits 63..32 (+ a borrow), p - hi * 2^32 is exact in fp32 (|.| <= 2^31, a multiple of p's ulp) and its
+// integer part is the signed low word.  Finite g * w with |g * w| < 2^27; the fraction below 2^-36 is truncated.
+__device__ __forceinline__ unsigned long long dm_fix36_mul(float g, float w16, float w36) {
+  const float hi_f = __builtin_rintf(g * w16);
+  const float rem = __builtin_fmaf(hi_f, -4294967296.0f, g * w36);
+  const int lo = (int)rem;
+  const int hi = (int)hi_f + (lo >> 31);
+  return ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo;
+}
+
 __device__ __forceinline__ unsigned long long dm_to_fx(float v) {
   const long long q = __builtin_isfinite(v) ? __double2ll_rn((double)v * DM_FX_ONE) : (1LL << 62);
   return (unsigned long long)q;

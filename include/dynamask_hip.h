@@ -23,10 +23,12 @@
  *     scatter form of dm_point_sample_bwd).
  *     Calls from several host threads are safe (a race only repeats an
  *     idempotent attribute call);
- *   - LDS scatter-accumulators (dm_deform_col2im_coord, dm_point_sample_bwd) are
- *     64-bit fixed point with 2^-36 resolution: exact and order-independent for
- *     gradient magnitudes in [1.5e-11, 1.3e8]; a non-finite contribution poisons
- *     its output plane with NaN (it is not silently dropped);
+ *   - LDS scatter-accumulators (dm_deform_col2im_coord, the scatter form of
+ *     dm_point_sample_bwd) are 64-bit fixed point with 2^-36 resolution: every
+ *     addend is the fp32 product gradient * bilinear weight cut to that grid and
+ *     integer sums are associative, so a plane's result does not depend on the
+ *     order of arrival, for gradient magnitudes in [1.5e-11, 1.3e8]; a non-finite
+ *     contribution poisons its output plane with NaN (it is not silently dropped);
  *   - return value: 0 = enqueued, negative = error (DM_ERR_*); the host binding
  *     raises on any non-zero code (dm_error_string()).
  *
