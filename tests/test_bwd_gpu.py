@@ -98,6 +98,35 @@ def test_point_sample_backward(ops):
     _close(gf, feat.grad)
 
 
+@pytest.mark.parametrize('S', [14, 28, 56])
+def test_point_sample_backward_corner_case_rois(ops, S):
+    """The gather form's index runs (a cell's samples are two runs of consecutive lattice indices per axis) against
+    autograd through the oracle: RoIs hanging over every border, larger than the map, one pixel wide, of zero width
+    (every sample at one coordinate), inverted (coordinates decreasing in the index), off the map, a bad batch index;
+    22 channels (a short last channel group)."""
+    B, C, H, W = 2, 22, 25, 42
+    feat = torch.randn(B, C, H, W, generator=_g(41)).requires_grad_(True)
+    rois = torch.tensor([
+        [0, 10.0, 8.0, 90.0, 70.0],
+        [1, -30.0, -20.0, 40.0, 35.0],            # over the top-left corner
+        [0, 140.0, 80.0, 200.0, 130.0],           # over the bottom-right corner
+        [1, -50.0, -50.0, 300.0, 250.0],          # larger than the map
+        [0, 60.0, 40.0, 61.0, 41.0],              # one image pixel
+        [1, 77.3, 20.0, 77.3, 60.0],              # zero width: all samples of a row at one x
+        [0, 30.0, 55.5, 90.0, 55.5],              # zero height
+        [1, 120.0, 70.0, 40.0, 10.0],             # inverted
+        [0, 400.0, 300.0, 500.0, 380.0],          # off the map
+        [0, 3.999, 3.999, 4.001, 4.001],          # around a cell boundary: rounding decides the floor
+        [1, 0.0, 0.0, 167.0, 99.0],               # the whole map
+    ], dtype=torch.float32)
+    rois = rois[torch.argsort(rois[:, 0], stable=True)]      # (the reference's SimpleRoIAlign returns rows grouped by image: bbox2roi order)
+    out = ref_ops.simple_roi_align(feat, rois, S, 0.25)
+    go = torch.randn(out.shape, generator=_g(42))
+    out.backward(go)
+    gf = ops.point_sample_backward(_dev(go), tuple(feat.shape), _dev(rois), 0.25)
+    _close(gf, feat.grad, atol=2e-4, rtol=1e-4)
+
+
 def test_class_logits_backward(ops):
     N, C, S, nc = 7, 64, 28, 80
     x = torch.randn(N, C, S, S, generator=_g(50), requires_grad=True)
