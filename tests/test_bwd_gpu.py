@@ -154,6 +154,40 @@ def test_class_logits_backward(ops):
     _close(gbd, bd.grad, atol=1e-4, rtol=1e-4)
 
 
+def test_class_logits_backward_slab_matches_atomics_with_shared_classes(ops):
+    """The slab form of the parameter gradients (per-RoI sums, added per class in RoI order) against the atomic form: 1100
+    RoIs -- more than one 1024-RoI tile of the reduce kernel -- over three classes, one of them empty in the second tile;
+    both give the same sums (fp32 order differs: relative gate), and the slab form twice gives the same bits."""
+    N, C, S, nc = 1100, 40, 14, 80
+    g = _g(57)
+    x = torch.randn(N, C, S, S, generator=g).cuda()
+    wi, wd = torch.randn(nc, C, generator=g).cuda(), torch.randn(nc, C, generator=g).cuda()
+    labels = torch.tensor([5, 17, 79])[torch.randint(0, 3, (N,), generator=g)]
+    labels[1024:] = 17
+    labels = labels.cuda()
+    g1, g2 = torch.randn(N, 1, S, S, generator=g).cuda(), torch.randn(N, 1, S, S, generator=g).cuda()
+
+    def run(slab):
+        old = ops.CLB_SLAB[0]
+        ops.CLB_SLAB[0] = slab
+        try:
+            gx = torch.empty(N, C, S, S, device='cuda')
+            outs = [torch.zeros(nc, C, device='cuda'), torch.zeros(nc, device='cuda'), torch.zeros(nc, C, device='cuda'), torch.zeros(nc, device='cuda')]
+            ops.class_logits_backward(x, wi, wd, labels, g1, g2, gx, False, *outs)
+            torch.cuda.synchronize()
+            return [gx] + outs
+        finally:
+            ops.CLB_SLAB[0] = old
+
+    a, b, c = run(True), run(False), run(True)
+    assert torch.equal(a[0], b[0])
+    for t_slab, t_atom, t_again in zip(a[1:], b[1:], c[1:]):
+        assert torch.equal(t_slab, t_again)
+        scale = float(t_atom.abs().max())
+        assert scale > 0 and float((t_slab - t_atom).abs().max()) <= 2e-5 * scale
+        assert float(t_slab[[0, 1, 2, 78]].abs().max()) == 0.0        # classes without RoIs stay untouched
+
+
 def test_sigmoid_backward(ops):
     logit = torch.randn(4, 1, 9, 9, generator=_g(60), requires_grad=True)
     s = logit.sigmoid()
