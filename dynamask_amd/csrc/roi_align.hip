@@ -1395,7 +1395,7 @@ extern "C" int dm_roi_align_fwd(const float* const* feats, const int* H, const i
     return dm_check_launch();
   }
   bool band_ok = P > 16 && P <= 64 && C % 4 == 0;
-  for (int l = 0; l < num_levels; ++l) band_ok = band_ok && (long long)H[l] * W[l] <= (1 << 23);
+  for (int l = 0; l < num_levels; ++l) band_ok = band_ok && (long long)H[l] * W[l] <= (1 << 23) && W[l] < (1 << 20);      // (the band kernel packs a map column into 20 bits)
   if (band_ok && (P & 3) == 0 && N <= kUnitMaxRois && (((uintptr_t)out) & 15) == 0) {
     static const int units_env = getenv("DM_ROI_UNITS") ? atoi(getenv("DM_ROI_UNITS")) : 0;      // A/B switch: 1 = units kernel
     const char* ue = getenv("DM_ROI_UNITS_NOW");                                                  // experiments: read per call
