@@ -61,13 +61,23 @@ class _SideWork:
     main stream's next allocation while the side stream still reads it).  ``DM_TRAIN_SIDE_STREAM=0`` runs
     everything on the caller's stream."""
 
-    def __init__(self, dev):
+    def __init__(self, dev, alt=None):
+        """``alt``: name of a second side stream; every other ``run`` goes there.  The backward passes 'coord': the leaf
+        queue is what the step ends on (its backlog of weight gradients kept the optimizer waiting ~1 ms after the chain
+        was done) and the coordinate-gradient stream idles between its three kernels: 20.88 -> 20.72 ms per step
+        (three runs each; the selector / bbox stream as the second one: 21.2).  ``DM_LEAF_ALT=0`` turns it off."""
         self.side = side_stream(dev)
         self.enabled = self.side is not None
         self.keep = []
+        self.alt = None
+        self.k = 0
         if self.enabled:
             self.main = torch.cuda.current_stream(dev)
             self.enabled = self.side != self.main
+            if self.enabled and alt is not None and os.environ.get('DM_LEAF_ALT', '1') != '0':
+                self.alt = side_stream(dev, alt)
+                if self.alt is None or self.alt == self.main or self.alt == self.side:
+                    self.alt = None
 
     def run(self, fn, *tensors, after=None):
         """``after``: an event the side stream waits for INSTEAD of everything issued so far on the main stream
@@ -75,17 +85,24 @@ class _SideWork:
         if not self.enabled:
             return fn()
         self.keep.extend(t for t in tensors if t is not None)
+        side = self.side
+        if self.alt is not None:
+            self.k += 1
+            if self.k % 2 == 0:               # (every third or fourth call instead: the same within 0.1 ms)
+                side = self.alt
         if after is not None:
-            self.side.wait_event(after)
+            side.wait_event(after)
         else:
-            self.side.wait_stream(self.main)
-        with torch.cuda.stream(self.side):
+            side.wait_stream(self.main)
+        with torch.cuda.stream(side):
             return fn()
 
     def join(self, *outs):
         """The main stream waits for the side stream; ``outs`` = tensors the side stream produced that live on."""
         if self.enabled:
             self.main.wait_stream(self.side)
+            if self.alt is not None:
+                self.main.wait_stream(self.alt)
             for t in outs:
                 if t is not None:
                     t.record_stream(self.main)
@@ -363,7 +380,7 @@ class MaskHeadFn(torch.autograd.Function):
         g_dps = [g.contiguous() if g is not None else None for g in grads[n_st:]]
         pgrad = {}                      # parameter -> gradient tensor
         g_feats = [None] * len(feats)
-        sw = _SideWork(dev)
+        sw = _SideWork(dev, alt='coord')
 
         def zeros(shape):
             return torch.zeros(shape, device=dev, dtype=torch.float32)
