@@ -62,15 +62,16 @@ class _SideWork:
     everything on the caller's stream."""
 
     def __init__(self, dev, alt=None):
-        """``alt``: name of a second side stream; every other ``run`` goes there.  The backward passes 'coord': the leaf
-        queue is what the step ends on (its backlog of weight gradients kept the optimizer waiting ~1 ms after the chain
-        was done) and the coordinate-gradient stream idles between its three kernels: 20.88 -> 20.72 ms per step
-        (three runs each; the selector / bbox stream as the second one: 21.2).  ``DM_LEAF_ALT=0`` turns it off."""
+        """``alt``: name of a second side stream for the calls that ask for it (``run(..., alt=True)``).  The backward
+        passes 'coord': the leaf queue is what the step ends on (its backlog of weight gradients kept the optimizer
+        waiting ~1 ms after the chain was done) and the coordinate-gradient stream idles between its three kernels.  What
+        goes there is what is issued AFTER a stage's coordinate gradient (the offset convolution's weight gradient, which
+        reads that kernel's output anyway, and the semantic branch): a long launch queued in front of the coordinate
+        gradient would hold up the chain, which waits for it.  ``DM_LEAF_ALT=0`` turns it off."""
         self.side = side_stream(dev)
         self.enabled = self.side is not None
         self.keep = []
         self.alt = None
-        self.k = 0
         if self.enabled:
             self.main = torch.cuda.current_stream(dev)
             self.enabled = self.side != self.main
@@ -79,17 +80,13 @@ class _SideWork:
                 if self.alt is None or self.alt == self.main or self.alt == self.side:
                     self.alt = None
 
-    def run(self, fn, *tensors, after=None):
+    def run(self, fn, *tensors, after=None, alt=False):
         """``after``: an event the side stream waits for INSTEAD of everything issued so far on the main stream
         (work whose inputs were ready long before, issued late so that the host feeds the main stream first)."""
         if not self.enabled:
             return fn()
         self.keep.extend(t for t in tensors if t is not None)
-        side = self.side
-        if self.alt is not None:
-            self.k += 1
-            if self.k % 2 == 0:               # (every third or fourth call instead: the same within 0.1 ms)
-                side = self.alt
+        side = self.alt if (alt and self.alt is not None) else self.side
         if after is not None:
             side.wait_event(after)
         else:
@@ -456,7 +453,7 @@ class MaskHeadFn(torch.autograd.Function):
             g_f1, g_off = ops.deform_conv_backward_data(f1, off, dcn.weight.detach(), g_f2, dcn.deform_groups,
                                                         side=side_stream(dev, 'coord'),
                                                         w_colgrad=dcn._pk.get('colgrad', dcn.weight, ops.pack_dcn_colgrad_weight))
-            sw.run(lambda: conv_params_bwd(dcn.conv_offset, g_off, f1, 3), g_off)
+            sw.run(lambda: conv_params_bwd(dcn.conv_offset, g_off, f1, 3), g_off, alt=True)
             data_grad(dcn.conv_offset, g_off, 0, c, 3, out=g_f1, accumulate=True, mask=f1)
             f0 = stage.fuse_conv[0]
             sw.run(lambda: conv_params_bwd(f0, g_f1, [xin, isf, tail[:, co - 2:]], 1), g_f1)
@@ -486,7 +483,7 @@ class MaskHeadFn(torch.autograd.Function):
                     g_feats[fidx] = data_grad(stage.semantic_transform_in, g_sem, 0, feat.shape[1], 1)
                 else:
                     data_grad(stage.semantic_transform_in, g_sem, 0, feat.shape[1], 1, out=g_feats[fidx], accumulate=True)
-            sw.run(semantic_branch, g_isf)
+            sw.run(semantic_branch, g_isf, alt=True)
             g_x = g_xin
 
         # ---------------- instance convs
