@@ -67,11 +67,15 @@ class _SideWork:
         waiting ~1 ms after the chain was done) and the coordinate-gradient stream idles between its three kernels.  What
         goes there is what is issued AFTER a stage's coordinate gradient (the offset convolution's weight gradient, which
         reads that kernel's output anyway, and the semantic branch): a long launch queued in front of the coordinate
-        gradient would hold up the chain, which waits for it.  ``DM_LEAF_ALT=0`` turns it off."""
+        gradient would hold up the chain, which waits for it.  ``run(..., alt='selector')`` names another stream of the
+        pool: the DCN weight gradient and the 1x1 output convolution's, issued before the coordinate gradient, go to the
+        selector / bbox stream, which is idle in the middle of the backward (20.8 -> 20.45 -> 20.15 ms per step; the fuse
+        convolution's weight gradients there as well: 20.6).  ``DM_LEAF_ALT=0`` puts everything back on the leaf stream."""
         self.side = side_stream(dev)
         self.enabled = self.side is not None
         self.keep = []
         self.alt = None
+        self.extra = set()
         if self.enabled:
             self.main = torch.cuda.current_stream(dev)
             self.enabled = self.side != self.main
@@ -86,7 +90,13 @@ class _SideWork:
         if not self.enabled:
             return fn()
         self.keep.extend(t for t in tensors if t is not None)
-        side = self.alt if (alt and self.alt is not None) else self.side
+        side = self.side
+        if alt and self.alt is not None:                     # (self.alt is None: one leaf stream for everything)
+            side = self.alt if alt is True else (side_stream(self.side.device, alt) or self.side)
+            if side == self.main:
+                side = self.side
+            if side is not self.side and side is not self.alt:
+                self.extra.add(side)
         if after is not None:
             side.wait_event(after)
         else:
@@ -100,6 +110,8 @@ class _SideWork:
             self.main.wait_stream(self.side)
             if self.alt is not None:
                 self.main.wait_stream(self.alt)
+            for e in self.extra:
+                self.main.wait_stream(e)
             for t in outs:
                 if t is not None:
                     t.record_stream(self.main)
@@ -439,7 +451,7 @@ class MaskHeadFn(torch.autograd.Function):
             # masking the whole tensor by tail > 0 only touches the conv channels
             ops.relu_backward_(g_tail, tail)
             dy = g_tail[:, :co - 2]
-            sw.run(lambda: conv_params_bwd(stage.fuse_transform_out, dy, f2, 1), g_tail)
+            sw.run(lambda: conv_params_bwd(stage.fuse_transform_out, dy, f2, 1), g_tail, alt='selector')
             g_f2 = data_grad(stage.fuse_transform_out, dy, 0, c, 1, mask=f2)
             dcn = stage.fuse_conv[1]
 
@@ -449,7 +461,7 @@ class MaskHeadFn(torch.autograd.Function):
                 gw_dcn = ops.deform_conv_backward_weight(f1, off, g_f2, dcn.deform_groups, gw_accum=_direct(dcn.weight), col=col)
                 if gw_dcn is not None:
                     pgrad[dcn.weight] = gw_dcn
-            sw.run(dcn_weight_grad, g_f2, col)
+            sw.run(dcn_weight_grad, g_f2, col, alt='selector')
             g_f1, g_off = ops.deform_conv_backward_data(f1, off, dcn.weight.detach(), g_f2, dcn.deform_groups,
                                                         side=side_stream(dev, 'coord'),
                                                         w_colgrad=dcn._pk.get('colgrad', dcn.weight, ops.pack_dcn_colgrad_weight))
