@@ -69,8 +69,9 @@ class _SideWork:
         reads that kernel's output anyway, and the semantic branch): a long launch queued in front of the coordinate
         gradient would hold up the chain, which waits for it.  ``run(..., alt='selector')`` names another stream of the
         pool: the DCN weight gradient and the 1x1 output convolution's, issued before the coordinate gradient, go to the
-        selector / bbox stream, which is idle in the middle of the backward (20.8 -> 20.45 -> 20.15 ms per step; the fuse
-        convolution's weight gradients there as well: 20.6).  ``DM_LEAF_ALT=0`` puts everything back on the leaf stream."""
+        selector / bbox stream, which is idle in the middle of the backward, and so does the offset convolution's
+        (20.8 -> 20.45 -> 20.15 -> 20.05 ms per step; the fuse convolution's weight gradients there as well: 20.6, on the
+        coordinate-gradient stream: no change; the semantic branch on the selector stream: 20.6).  ``DM_LEAF_ALT=0`` puts everything back on the leaf stream."""
         self.side = side_stream(dev)
         self.enabled = self.side is not None
         self.keep = []
@@ -465,7 +466,7 @@ class MaskHeadFn(torch.autograd.Function):
             g_f1, g_off = ops.deform_conv_backward_data(f1, off, dcn.weight.detach(), g_f2, dcn.deform_groups,
                                                         side=side_stream(dev, 'coord'),
                                                         w_colgrad=dcn._pk.get('colgrad', dcn.weight, ops.pack_dcn_colgrad_weight))
-            sw.run(lambda: conv_params_bwd(dcn.conv_offset, g_off, f1, 3), g_off, alt=True)
+            sw.run(lambda: conv_params_bwd(dcn.conv_offset, g_off, f1, 3), g_off, alt='selector')
             data_grad(dcn.conv_offset, g_off, 0, c, 3, out=g_f1, accumulate=True, mask=f1)
             f0 = stage.fuse_conv[0]
             sw.run(lambda: conv_params_bwd(f0, g_f1, [xin, isf, tail[:, co - 2:]], 1), g_f1)
