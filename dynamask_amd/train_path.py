@@ -18,8 +18,9 @@ import torch
 
 from . import ops
 
-# maps of at least this many pixels keep the DCN column matrix from the forward for the weight gradient (56 x 56)
-_KEEP_COL_MIN_PIXELS = int(os.environ.get('DM_TRAIN_KEEP_COL_MIN_PIXELS', '1024'))
+# maps of at least this many pixels keep the DCN column matrix from the forward for the weight gradient (56 x 56 and, since the
+# leaf work was dealt over three side streams, 28 x 28: 20.09 -> 20.00 ms per step over three runs each; all three: 20.2)
+_KEEP_COL_MIN_PIXELS = int(os.environ.get('DM_TRAIN_KEEP_COL_MIN_PIXELS', '784'))
 # the training forward splits the RoIs in two halves on two streams from this many RoIs on
 _FWD_SPLIT_MIN_ROIS = int(os.environ.get('DM_TRAIN_FWD_SPLIT_MIN_ROIS', '128'))
 _SIDE_STREAMS = {'leaf': 0, 'selector': 1, 'bbox': 1, 'coord': 2}      # slots of the shared pool (streams.py)
@@ -310,7 +311,8 @@ class MaskHeadFn(torch.autograd.Function):
                     # 56 x 56: training keeps the deformable column matrix -- the weight gradient needs it anyway, and
                     # im2col + a 1x1 GEMM over it (0.61 + 0.68 ms, 256 RoIs) cost the chain less than the fused kernel
                     # (0.76 ms) plus an im2col in the backward (0.61 ms, beside the chain on the leaf stream): 23.45 vs
-                    # 23.5 ms per step, and 23.75 with the 28 x 28 stage kept too.  1.85 GB live until the backward.
+                    # 23.5 ms per step, and 23.75 with the 28 x 28 stage kept too (then; kept now, see _KEEP_COL_MIN_PIXELS).
+                    # 1.85 + 0.92 GB live until the backward.
                     col = ops.deform_im2col(f1, off, dcn.deform_groups, out=st['col'][lo:hi])
                     f2 = ops.conv2d([col], dcn._pk.get('w_cm', dcn.weight, _pack_dcn_colmajor), None, dcn.out_channels, 1,
                                     relu=True, out=st['f2'][lo:hi])
