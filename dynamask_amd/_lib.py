@@ -4,7 +4,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DYNAMASK_HIP_LIB') or os.path.join(_HERE, 'libdynamask_hip.so')      # override: kernel experiments
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -14,7 +14,10 @@ _vp = ctypes.c_void_p
 SIGNATURES = {
     'dm_error_string': ([_c_int], ctypes.c_char_p),
     'dm_abi_version': ([], _c_int),
+    'dm_reload_env_knobs': ([], _c_int),
     'dm_roi_align_fwd': ([_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _c_float, _vp, _vp, _vp], _c_int),
+    'dm_roi_align_workspace_bytes': ([_c_int, _c_int], ctypes.c_longlong),
+    'dm_roi_align_fwd_ws': ([_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _c_float, _vp, _vp, _vp, ctypes.c_longlong, _vp], _c_int),
     'dm_roi_align_bwd': ([_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _c_float, _vp], _c_int),
     'dm_conv_packed_cout': ([_c_int], _c_int),
     'dm_conv_packed_floats': ([_c_int, _c_int, _c_int, _vp], ctypes.c_longlong),

@@ -77,6 +77,11 @@ def _float_array(vals):
 
 
 # ------------------------------------------------------------------ RoIAlign
+# DM_ROI_PERSIST=1: route 14x14 / 7x7 extractions through dm_roi_align_fwd_ws (the library's own knob of the same name
+# selects the kernels there)
+ROI_PERSIST = os.environ.get('DM_ROI_PERSIST', '0') == '1'
+
+
 def roi_align(feats, rois, output_size, spatial_scales, sampling_ratio=0, finest_scale=56.0, return_levels=False):
     feats = [_chk(f, 'feat') for f in feats]
     _chk(rois, 'rois')
@@ -84,6 +89,17 @@ def roi_align(feats, rois, output_size, spatial_scales, sampling_ratio=0, finest
     N = rois.shape[0]
     out = torch.empty((N, C, output_size, output_size), device=rois.device, dtype=torch.float32)
     levels = torch.zeros((N,), device=rois.device, dtype=torch.int32) if return_levels else None
+    if ROI_PERSIST:
+        # round 4's plan + persistent kernels (measured slower than the tile kernel; kept as an A/B path, same bits):
+        # the workspace holds per-RoI geometry and stencil tables
+        wsb = int(lib().dm_roi_align_workspace_bytes(N, output_size))
+        ws = torch.empty(((wsb + 15) // 16 * 4,), device=rois.device, dtype=torch.int32) if wsb > 0 else None
+        rc = lib().dm_roi_align_fwd_ws(_ptr_array(feats), _int_array([f.shape[2] for f in feats]),
+                                       _int_array([f.shape[3] for f in feats]), _float_array(spatial_scales), len(feats),
+                                       B, C, _p(rois), N, output_size, sampling_ratio, finest_scale, _p(out), _p(levels),
+                                       _p(ws), wsb, _stream())
+        check(rc, 'dm_roi_align_fwd_ws')
+        return (out, levels) if return_levels else out
     rc = lib().dm_roi_align_fwd(_ptr_array(feats), _int_array([f.shape[2] for f in feats]),
                                 _int_array([f.shape[3] for f in feats]), _float_array(spatial_scales), len(feats),
                                 B, C, _p(rois), N, output_size, sampling_ratio, finest_scale, _p(out), _p(levels),

@@ -12,9 +12,11 @@
  *     compute-unit count and "this kernel's dynamic-LDS limit has been raised"
  *     flags (hipFuncSetAttribute once per device).  A few knobs are read from
  *     the environment on first use.  Tuning knobs that never change results,
- *     only tile / split / order choices: DM_CONV_TAIL, DM_DCN_TAIL, DM_WGRAD_WGS, DM_ROI_CT,
- *     DM_ROI_ORDER, DM_ROI_BAND_ORDER, DM_ROI_UNITS / DM_ROI_UNITS_NOW (the
- *     persistent-units RoIAlign of round 3: same bits as the band kernel), DM_ROI_NT, DM_ROI_UNIT_WGS,
+ *     only tile / split / order choices: DM_CONV_TAIL, DM_DCN_TAIL, DM_WGRAD_WGS, DM_ROI_PIPE (0 = round 3's
+ *     RoIAlign tile kernel instead of the pipelined one: same bits), DM_ROI_PERSIST, DM_ROI_WPC, DM_ROI_CT,
+ *     DM_ROI_ORDER, DM_ROI_BAND_ORDER, DM_ROI_UNITS (the
+ *     persistent-units RoIAlign of round 3: same bits as the band kernel), DM_ROI_NT, DM_ROI_UNIT_WGS
+ *     (the DM_ROI_* set is read once and clamped; dm_reload_env_knobs() re-reads it),
  *     DM_CONV1_VARIANT (other tilings of the 1x1 GEMM: same products in the same order), DM_PS_CT.
  *     A/B switches that select an older kernel or another split for the same
  *     operation (same mathematics; sums may differ in the last bits):
@@ -55,8 +57,11 @@ extern "C" {
 typedef void* dm_stream_t; /* hipStream_t */
 
 const char* dm_error_string(int code);
-/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient, dm_conv_pack_weight_batch, dm_mask_loss_stage; 15: dm_class_logits_up2x_fwd; 16: dm_conv2d_wgrad_slab / dm_conv2d_wgrad_scratch_floats; 17: dm_class_logits_bwd_slab / dm_class_logits_bwd_scratch_floats). */
+/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient, dm_conv_pack_weight_batch, dm_mask_loss_stage; 15: dm_class_logits_up2x_fwd; 16: dm_conv2d_wgrad_slab / dm_conv2d_wgrad_scratch_floats; 17: dm_class_logits_bwd_slab / dm_class_logits_bwd_scratch_floats; 18: dm_reload_env_knobs, dm_roi_align_fwd_ws / dm_roi_align_workspace_bytes). */
 int dm_abi_version(void);
+/* Re-read the DM_ROI_* experiment knobs from the environment (they are otherwise read once, at the first launch, and
+ * clamped to validated ranges).  For measurement tools that sweep settings inside one process; no knob changes a result. */
+int dm_reload_env_knobs(void);
 
 /* ---------------------------------------------------------------------------
  * K1/K2  multi-level RoIAlign forward (avg pooling, aligned=True, adaptive grid)
@@ -75,6 +80,17 @@ int dm_abi_version(void);
 int dm_roi_align_fwd(const float* const* feats, const int* H, const int* W, const float* spatial_scales,
                      int num_levels, int B, int C, const float* rois, int N, int P, int sampling_ratio,
                      float finest_scale, float* out, int32_t* levels_out, dm_stream_t stream);
+
+/* The same extraction with a caller-provided workspace of dm_roi_align_workspace_bytes(N, P) bytes (device memory,
+ * 16-byte aligned, contents irrelevant before and after the call; 0 bytes = no faster path exists for this P).  For
+ * P * P <= 256 (the 14x14 mask and 7x7 bbox extractions) the per-RoI arithmetic -- level, tile geometry, stencil
+ * tables -- then runs once per RoI in a pre-pass and persistent workgroups pipeline the staging across RoIs; same
+ * bits as dm_roi_align_fwd.  A null / too small workspace falls back to dm_roi_align_fwd's kernels. */
+long long dm_roi_align_workspace_bytes(int N, int P);
+int dm_roi_align_fwd_ws(const float* const* feats, const int* H, const int* W, const float* spatial_scales,
+                        int num_levels, int B, int C, const float* rois, int N, int P, int sampling_ratio,
+                        float finest_scale, float* out, int32_t* levels_out, void* workspace,
+                        long long workspace_bytes, dm_stream_t stream);
 
 /* K3  RoIAlign backward: scatter-add (float atomics) of grad_out into the
  * per-level feature gradients, which the caller has zero-filled. */
