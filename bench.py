@@ -106,6 +106,27 @@ def time_kernel_graphed(fn, reps=20, iters=5, warmup=2):
         return time_kernel(fn)
 
 
+def time_kernel_single_in_graph(fn, iters=15):
+    """Duration (ms) of ONE `fn` launch: replay time of a HIP graph holding two launches minus that of a graph holding
+    one (median of `iters` individually timed replays each) -- the second launch's time with exactly one predecessor
+    instead of nineteen.  (Event-record nodes between the launches would time it directly; on this ROCm torch refuses
+    timing events inside a capture and hipEventElapsedTime rejects events recorded by a graph.)"""
+    try:
+        fn()
+        torch.cuda.synchronize()
+        t = []
+        for reps in (1, 2):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(reps):
+                    fn()
+            t.append(time_kernel_median(g.replay, iters=iters, warmup=4))
+        return max(t[1] - t[0], 0.0)
+    except Exception as e:      # noqa: BLE001
+        print(f'[bench] single-launch timing unavailable: {e}', file=sys.stderr)
+        return None
+
+
 def roialign_algorithmic_bytes(rois, levels, feat_shapes, C=256, P=14):
     """output write + rois + per-RoI footprint read (capped per level), overall read capped
     by the size of the levels touched.  ``levels`` = the FPN level of each RoI as the HIP kernel itself
@@ -209,11 +230,14 @@ def train_step_bench(head, dev, rank, world, steps=4, warmup=4, rehearsal=False)
     grp = FlatParamGroup(mask_path_parameters(head), process_group=sub)
     saved = grp.flat_param.clone()          # the SGD steps below must not leak into later legs
 
+    reduce_on = [True]
+
     def step():
         grp.zero_grad()
         res = head._mask_forward_train(feats, rois, labels, targets, noise=noise)
         res['loss_mask']['loss_masks'].backward()
-        grp.all_reduce_async(force=True)        # world 1: nothing to reduce unless a one-rank communicator exists (below)
+        if reduce_on[0]:
+            grp.all_reduce_async(force=True)        # world 1: nothing to reduce unless a one-rank communicator exists (below)
         grp.sgd_step(lr=0.02, momentum=0.9, weight_decay=1e-4)
         return res
 
@@ -251,6 +275,15 @@ def train_step_bench(head, dev, rank, world, steps=4, warmup=4, rehearsal=False)
     comm_ms = 0.0
     forced_ms = None
     own_group = False
+    # what the collective costs the STEP (the curve with the communication isolated): one more window of
+    # the same steps without the all-reduce (the ranks then drift apart -- timing only, parameters are restored below);
+    # exposed = step with - step without.  At world 1 the pair is (forced one-rank all-reduce, plain step), below.
+    noreduce_ms = None
+    if world > 1:
+        reduce_on[0] = False
+        step()
+        noreduce_ms = window()[0] / steps * 1e3
+        reduce_on[0] = True
     if world == 1 and not dist.is_initialized() and os.environ.get('DM_BENCH_NO_RCCL', '0') != '1':
         # World size 1: the step above ran without a collective (a single-GPU job has nothing to reduce: this
         # is the N = 1 point of the scaling curve).  So that the RCCL call, its side stream and the 1/world
@@ -288,7 +321,12 @@ def train_step_bench(head, dev, rank, world, steps=4, warmup=4, rehearsal=False)
         torch.cuda.synchronize()
         dist.barrier()
         dist.destroy_process_group(sub)
-    return dt / steps * 1e3, float(res['loss_mask']['loss_masks'].detach()), grp.numel, B, comm_ms, collective, forced_ms
+    step_ms = dt / steps * 1e3
+    if world > 1:
+        exposed_ms = step_ms - noreduce_ms
+    else:
+        exposed_ms = (forced_ms - step_ms) if forced_ms is not None else None
+    return step_ms, float(res['loss_mask']['loss_masks'].detach()), grp.numel, B, comm_ms, collective, forced_ms, exposed_ms
 
 
 def _free_port():
@@ -347,7 +385,9 @@ def main():
                          "configs[2]/[3] training step, timed over exactly --steps steps (the other leg's figures stay "
                          "top-level keys of the same line)")
     ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of a HIP graph replay')
-    ap.add_argument('--end-to-end', action='store_true', help='also time a stock MIOpen ResNet-50-FPN + the mask path (context)')
+    ap.add_argument('--end-to-end', action='store_true', help='(default since round 4; kept for old command lines)')
+    ap.add_argument('--no-end-to-end', action='store_true',
+                    help='skip the whole-detector context leg (stock MIOpen ResNet-50-FPN + the mask path, rank 0 only)')
     ap.add_argument('--cpu-sample', type=int, default=512, help='RoIs of the batch timed on the host cores (0 = skip)')
     args = ap.parse_args()
 
@@ -410,7 +450,7 @@ def main():
     # (measured: 23.6 ms per step before the capture, 24.3 ms after it).  The headline leg is not affected by the
     # order (the training leg leaves nothing behind but cached allocator memory).
     t_steps, t_warm = (args.steps, args.warmup) if args.leg == 'train' else (4, 4)
-    train_ms, train_loss, n_flat, train_b, comm_ms, collective, forced_ms = train_step_bench(
+    train_ms, train_loss, n_flat, train_b, comm_ms, collective, forced_ms, exposed_ms = train_step_bench(
         head, dev, rank, world, steps=t_steps, warmup=t_warm, rehearsal=rehearsal)
 
     def step():
@@ -473,6 +513,7 @@ def main():
         'config': {'workload': 'BASELINE configs[1]: DynaMask R-50-FPN mask head inference, 1333x800 FPN shapes, '
                                '512 RoIs/img, fixed 28x28 exit (RoIAlign14 + 2 conv3x3 + SFM stage 0 + stage-1 logits)',
                    'rois_per_img': ROIS_PER_IMG, 'imgs_per_gpu': 1, 'parallelism': f'images sharded x{world}, no collective',
+                   'cpu_baseline': 'rank 0 at N = 1 only (omitted from the N > 1 lines)',
                    'launch': 'hip graph replay' if graph is not None else 'eager',
                    'timing': f'median of 3 windows of {args.steps} steps; windows ms/step = '
                              + ', '.join(f'{w / args.steps * 1e3:.3f}' for w in windows)},
@@ -482,7 +523,7 @@ def main():
     result.update({
         'train_ms_per_step': train_ms, 'train_img_per_s': world * train_b / (train_ms * 1e-3),
         'train_imgs_per_gpu': train_b, 'train_steps_timed': t_steps,
-        'allreduce_alone_ms': comm_ms, 'collective': collective,
+        'allreduce_alone_ms': comm_ms, 'allreduce_exposed_ms': exposed_ms, 'collective': collective,
         'infer_ms_per_roi_batch': ms_per_step, 'infer_img_per_s': value,
     })
     if args.leg == 'train':
@@ -517,12 +558,19 @@ def main():
         # ---- RoIAlign 14x14 multi-level (the north star's HBM-roofline kernel) ----
         ext = head.mask_roi_extractor
         ms_r = time_kernel_graphed(lambda: ext(feats[:4], rois))
+        ms_r1 = time_kernel_single_in_graph(lambda: ext(feats[:4], rois))
         _, lv = ops.roi_align(feats[:4], rois, 14, [1 / 4, 1 / 8, 1 / 16, 1 / 32], return_levels=True)
         nbytes = roialign_algorithmic_bytes(rois_c, lv.cpu().long(), [tuple(f.shape[2:]) for f in feats_c[:4]])
         ach_r = nbytes / (ms_r * 1e-3) / 1e9
-        result['roofline_roialign'] = {'kernel': 'roi_align_tile_kernel (one launch; LDS-staged channel-quad tiles, merged stencils; P2..P5 -> [512,256,14,14])', 'bound': 'hbm',
+        result['roofline_roialign'] = {'kernel': 'roi_align_tile_kernel (one launch; LDS-staged channel-quad tiles, merged stencils; P2..P5 -> [512,256,14,14]); '
+                                                 'ms_per_launch = 20 launches replayed back to back as one HIP graph / 20 (maps + output stay in the '
+                                                 'Infinity Cache), median of 7 replays; ms_per_launch_single = replay of a graph of two launches minus '
+                                                 'a graph of one (medians of 15): one launch with one predecessor; rocprofv3 per-kernel averages: '
+                                                 'profiles/r04_roofline_kernel_stats.csv', 'bound': 'hbm',
                                        'achieved': ach_r, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                        'frac': ach_r / PEAK_HBM_GBS, 'traffic': None, 'ms_per_launch': ms_r,
+                                       'ms_per_launch_single': ms_r1,
+                                       'frac_single': (nbytes / (ms_r1 * 1e-3) / 1e9 / PEAK_HBM_GBS) if ms_r1 else None,
                                        'bytes_per_launch': nbytes}
         pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(pmc):
@@ -625,7 +673,7 @@ def main():
                                                 f'{dt_cpu:.2f} s per pass x 7 passes; '
                                                 f'scaled to 512 RoIs/img', 'max_abs_err_vs_gpu': err}
 
-        if args.end_to_end:
+        if not args.no_end_to_end:
             # Context only: the (out-of-scope) stock MIOpen backbone next to the mask path at
             # the reference's inference shape: <=100 detections, all exits to 112x112, boundary
             # merge, paste.  RPN / bbox branch / NMS are not part of this repo and not timed.
@@ -697,6 +745,14 @@ def main():
                 'ms': t_fh, 'detections': n_det, 'bbox_forward_1000_props_ms': t_bbox,
                 'what': 'DynaMaskRoIHead.simple_test on resident FPN maps: 1000 proposals -> RoIAlign7 + Shared2FC (dm_fc_fwd) '
                         '+ softmax/decode + NMS -> masks of the kept detections -> RLE (random-init heads)'}
+            # the north star's whole-detector figure (tools/benchmark.py protocol: synchronise around each forward, data
+            # loading excluded) as top-level keys: context -- the backbone is stock PyTorch-ROCm / MIOpen, out of scope
+            result['end_to_end_img_per_s'] = 1e3 / t_e2e
+            result['end_to_end_img_per_s_rle'] = 1e3 / t_e2e_rle
+            result['backbone_fpn_ms'] = t_bb
+            result['end_to_end_what'] = ('context, not the headline: stock MIOpen ResNet-50+FPN fp32 (out of scope, random weights) + this '
+                                         'repo\'s mask path at 100 detections incl. merge, paste and D2H of the masks (bitmaps / device RLE); '
+                                         'RPN, bbox head and NMS not included')
             result['extra']['end_to_end'] = {
                 'backbone_fpn_ms': t_bb, 'mask_path_100dets_ms': t_mask, 'backbone_plus_mask_path_ms': t_e2e,
                 'backbone_plus_mask_path_rle_ms': t_e2e_rle, 'img_per_s_rle': 1e3 / t_e2e_rle,
@@ -710,6 +766,9 @@ def main():
                                'imgs_per_gpu': train_b, 'pos_rois_per_img': 128, 'loss': train_loss,
                                'allreduce_floats': n_flat, 'allreduce_alone_ms': comm_ms,
                                'collective': collective, 'ms_per_step_with_forced_one_rank_allreduce': forced_ms,
+                               'allreduce_exposed_ms': exposed_ms,
+                               'allreduce_exposed_how': 'N > 1: step with the all-reduce - the same window without it; N = 1: step with the '
+                                                        'forced one-rank all-reduce - plain step',
                                'what': 'fwd + loss + bwd (head, MaskPre, RoIAlign) + RCCL all-reduce of the flat '
                                        'mask-path gradient + fused SGD; BASELINE configs[2] (N=1) / configs[3] (N=8)'}
         os.write(json_fd, (json.dumps(result) + '\n').encode())

@@ -7,8 +7,8 @@ literal C-ABI launch sequence of ``simple_test_mask_logits`` is captured once pe
 (16 / 32 / 64 / 100, RoIs padded with empty boxes, which the kernels turn into zero rows) and replayed.  No tracing
 compiler: a graph holds exactly the launches the eager call makes.
 
-A graph is tied to the addresses it was captured with: the FPN maps' storage, the packed weights (``ops.WEIGHT_EPOCH``)
-and its own static RoI / label / output buffers.  The cache is keyed on all of that; a backbone that hands over its
+A graph is tied to the addresses it was captured with: the FPN maps' storage, the packed weights (``ops.WEIGHT_EPOCH``
+and the (address, version) of every head parameter) and its own static RoI / label / output buffers.  The cache is keyed on all of that; a backbone that hands over its
 maps in the same buffers every image (the caching allocator does, for a fixed input size) replays, anything else
 captures again.  The returned logits are a view of the graph's static output: consume them before the next call with
 the same bucket.
@@ -35,9 +35,15 @@ class GraphedMaskLogits:
                 return b
         return None
 
+    def _weights_key(self):
+        """(address, version) of every parameter the captured launches read, directly or through a kernel-layout pack:
+        an in-place update (optimizer step, load_state_dict, copy_) bumps ``_version`` without touching
+        ops.WEIGHT_EPOCH, and a replay would combine stale packed weights with the new class-logit weights."""
+        return tuple((p.data_ptr(), p._version) for p in self.head.mask_head.parameters())
+
     def _key(self, bucket, x):
         return (bucket, tuple(int(t.data_ptr()) for t in x), tuple(tuple(t.shape) for t in x), ops.WEIGHT_EPOCH[0],
-                torch.cuda.current_device())
+                self._weights_key(), torch.cuda.current_device())
 
     def _capture(self, key, bucket, x):
         dev = x[0].device

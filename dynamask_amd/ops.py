@@ -298,26 +298,54 @@ def pack_conv_weight(w, transpose_flip=False, src_channels=None):
     return wp
 
 
+class _DevicePlan:
+    """The packs of ONE device: entries, the device-resident job table, and the event of the last refresh."""
+
+    def __init__(self, device):
+        self.device = device
+        self.entries = []          # dicts: param (weakref), out, job fields, ver, used
+        self.table = None
+        self.table_ids = None
+        self.old_tables = []       # previous job tables stay alive for two more refreshes: a batch launch on another
+                                   # stream may still be reading one when the next is uploaded
+        self.event = None          # recorded behind the last refresh; streams that read packs wait for it (get)
+        self.generation = 0
+        self.waited = {}           # stream id -> generation it has waited for
+
+
 class PackPlan:
-    """Kernel-layout weights of a training step, refreshed by ONE launch (dm_conv_pack_weight_batch).
+    """Kernel-layout weights of a training step, refreshed by ONE launch (dm_conv_pack_weight_batch) per device.
 
     Every optimizer step changes ~45 weight tensors, each of which the kernels read in a packed layout; packing them
     one launch at a time cost the host 1.3 ms of the 3.7 ms it needs to issue a forward pass, and the forward is the
     part of the step where the GPU waits for the host.  A pack registered here (``get``) owns a persistent output
-    buffer; the first request that finds its pack stale refreshes, in one launch, every registered pack that was used
-    since the previous refresh (a pack nobody asked for in a whole step is left alone and refreshed on demand).  The
-    job table lives on the device and is rebuilt only when the set of jobs changes."""
+    buffer; the first request that finds its pack stale refreshes, in one launch, every registered pack of that device
+    that was used since the previous refresh (a pack nobody asked for in a whole step is left alone and refreshed on
+    demand).  The job table lives on the device and is rebuilt only when the set of jobs changes.
+
+    Streams: a refresh runs on the stream that asked for it and records an event; ``get`` makes any OTHER stream wait
+    for that event before it hands out a buffer (once per stream and refresh), so a pack refreshed on the main stream
+    and read by a side stream -- or the other way round -- is ordered whoever triggers the refresh."""
 
     def __init__(self):
-        self.entries = []          # dicts: param (weakref), out, job fields, ver, used
-        self.table = None
-        self.table_ids = None
+        self.plans = {}            # device index -> _DevicePlan
         self.launches = 0
         self.uploads = 0
+
+    @property
+    def entries(self):
+        return [e for p in self.plans.values() for e in p.entries]
 
     @staticmethod
     def _ver(param):
         return (param.data_ptr(), param._version, WEIGHT_EPOCH[0])
+
+    def _plan(self, device):
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        p = self.plans.get(idx)
+        if p is None:
+            p = self.plans[idx] = _DevicePlan(torch.device('cuda', idx))
+        return p
 
     def register(self, param, transpose_flip, src_channels, lo, hi):
         import weakref
@@ -330,46 +358,71 @@ class PackPlan:
         src_channels = [rows] if src_channels is None else list(src_channels)
         assert sum(src_channels) == rows and kh == kw and kh in (1, 3) and len(src_channels) <= 4
         out = torch.empty((packed_floats(cols, kh, src_channels),), device=param.device, dtype=torch.float32)
+        plan = self._plan(param.device)
         e = dict(param=weakref.ref(param), out=out, cout=cout, cin=cin, ks=kh, flip=1 if transpose_flip else 0,
-                 srcs=src_channels, ld=cin_total, c0=lo, ver=None, used=True)
-        self.entries.append(e)
+                 srcs=src_channels, ld=cin_total, c0=lo, ver=None, used=True, plan=plan)
+        plan.entries.append(e)
         return e
 
     def get(self, e):
         p = e['param']()
+        if p is None:
+            raise RuntimeError('PackPlan.get: the parameter of this pack no longer exists')
+        plan = e['plan']
         e['used'] = True
         if e['ver'] != self._ver(p):
-            self.refresh()
+            self._refresh(plan)
             e['used'] = True          # (refresh clears the flag of what it packed; this one is in use now)
+        if plan.event is not None:
+            st = torch.cuda.current_stream(plan.device)
+            if plan.waited.get(st.cuda_stream) != plan.generation:
+                st.wait_event(plan.event)          # (a no-op for the stream that recorded it)
+                plan.waited[st.cuda_stream] = plan.generation
         return e['out']
 
-    def refresh(self):
+    def refresh(self, device=None):
+        """Refresh the stale packs of ``device`` (default: the current device) on its current stream."""
+        idx = torch.cuda.current_device() if device is None else torch.device(device).index
+        plan = self.plans.get(idx)
+        if plan is not None:
+            self._refresh(plan)
+
+    def _refresh(self, plan):
         from ._lib import PackJob
         live = []
-        for e in self.entries:
+        for e in plan.entries:
             p = e['param']()
             if p is not None:
                 live.append((e, p))
-        self.entries = [e for e, _ in live]
+        plan.entries = [e for e, _ in live]
         todo = [(e, p) for e, p in live if e['used'] and e['ver'] != self._ver(p)]
         if not todo:
             return
-        ids = tuple((id(e), p.data_ptr()) for e, p in todo)
-        if ids != self.table_ids:
-            arr = (PackJob * len(todo))()
-            for j, (e, p) in zip(arr, todo):
-                j.w, j.w_packed = p.data_ptr(), e['out'].data_ptr()
-                j.Cout, j.Cin, j.ksize, j.transpose_flip = e['cout'], e['cin'], e['ks'], e['flip']
-                j.num_srcs = len(e['srcs'])
-                for k, c in enumerate(e['srcs']):
-                    j.src_channels[k] = c
-                j.ld, j.c0 = e['ld'], e['c0']
-            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-            self.table = host.to(todo[0][1].device)
-            self.table_ids = ids
-            self.uploads += 1
-        check(lib().dm_conv_pack_weight_batch(_p(self.table), len(todo), _stream()), 'dm_conv_pack_weight_batch')
-        self.launches += 1
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('PackPlan: a kernel-layout weight is stale inside a HIP-graph capture (the refresh uploads '
+                               'a job table: run the path once eagerly before capturing it)')
+        with torch.cuda.device(plan.device):
+            ids = tuple((id(e), p.data_ptr()) for e, p in todo)
+            if ids != plan.table_ids:
+                arr = (PackJob * len(todo))()
+                for j, (e, p) in zip(arr, todo):
+                    j.w, j.w_packed = p.data_ptr(), e['out'].data_ptr()
+                    j.Cout, j.Cin, j.ksize, j.transpose_flip = e['cout'], e['cin'], e['ks'], e['flip']
+                    j.num_srcs = len(e['srcs'])
+                    for k, c in enumerate(e['srcs']):
+                        j.src_channels[k] = c
+                    j.ld, j.c0 = e['ld'], e['c0']
+                host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+                if plan.table is not None:
+                    plan.old_tables = (plan.old_tables + [plan.table])[-2:]
+                plan.table = host.to(plan.device)
+                plan.table_ids = ids
+                self.uploads += 1
+            check(lib().dm_conv_pack_weight_batch(_p(plan.table), len(todo), _stream()), 'dm_conv_pack_weight_batch')
+            self.launches += 1
+            plan.event = torch.cuda.current_stream(plan.device).record_event()
+            plan.generation += 1
+            plan.waited = {torch.cuda.current_stream(plan.device).cuda_stream: plan.generation}
         for e, p in todo:
             e['ver'] = self._ver(p)
             e['used'] = False

@@ -336,7 +336,7 @@ class DynaMaskRoIHead(nn.Module):
             # the head is issued FIRST (the host feeds the chain of the step before anything that has slack, see
             # train_path.MaskHeadFn.forward); the selector waits for the inputs' event, not for the head
             main = torch.cuda.current_stream(pos_rois.device)
-            ops.PACK_PLAN.refresh()          # every kernel-layout weight of the step in one launch, before the event
+            ops.PACK_PLAN.refresh(pos_rois.device)          # every kernel-layout weight of the step in one launch, before the event
             ready = main.record_event()
             train_path._INPUTS_READY[0] = ready
             sel = {}

@@ -251,8 +251,14 @@ class MaskHeadFn(torch.autograd.Function):
         # halves, then the semantic branches (needed at the first fusion conv), the stages, and only then what has
         # slack until the loss or the backward (selector branch in roi_head.py, the backward's packs below).  Work
         # issued late waits for the event of its inputs, not for the main stream's queue.
-        ready = _INPUTS_READY[0] if _INPUTS_READY[0] is not None else (
-            torch.cuda.current_stream(rois.device).record_event() if rois.is_cuda else None)
+        if _INPUTS_READY[0] is not None:
+            ready = _INPUTS_READY[0]
+        else:
+            # called without the RoI head's up-front refresh (a direct _mask_forward / mask_head_forward_train under
+            # grad, after a weight update): the packs are refreshed here, on the main stream, BEFORE the event the side
+            # work waits for (ops.PackPlan.get additionally orders any stream behind the refresh it reads from)
+            ops.PACK_PLAN.refresh(rois.device)
+            ready = torch.cuda.current_stream(rois.device).record_event() if rois.is_cuda else None
 
         def semantic_branches():
             for idx, stage in enumerate(head.stages):
@@ -546,10 +552,15 @@ def mask_head_forward_train(head, ins_feats, feats, rois, labels, between=None):
             _PRECOMPUTED[0] = None
             pre = MaskHeadFn.issue(head, rois, labels, ins_feats.detach(), [f.detach() for f in feats], after_convs=branch)
         _PRECOMPUTED[0] = pre
+    else:
+        _PRECOMPUTED[0] = None          # (never hand a stale hand-off to this call)
     # (Two half-batches on two streams -- the inference path's arrangement -- were measured here too: 25.8 ms
     # against 23.8 ms per step at 256 RoIs.  The backward already shares the GPU between the chain and its leaves;
     # halving every launch on top of that only adds tails.)
-    outs = MaskHeadFn.apply(head, rois, labels, ins_feats, len(feats), *feats, *list(head.parameters()))
+    try:
+        outs = MaskHeadFn.apply(head, rois, labels, ins_feats, len(feats), *feats, *list(head.parameters()))
+    finally:
+        _PRECOMPUTED[0] = None          # consumed by forward(); cleared here too if the apply never reached it
     n = len(head.stages) + 1
     return list(outs[:n]), list(outs[n:])
 

@@ -178,7 +178,7 @@ def detail_target(gtmasks, fuse_kernel=None):
     b2 = F.interpolate(b2, b.shape[2:], mode='nearest')
     b2 = (b2 > 0.1).float()
     pyr = torch.stack((b, b2), dim=1).squeeze(2)
-    out = F.conv2d(pyr, fuse_kernel)
+    out = F.conv2d(pyr, fuse_kernel.to(pyr.dtype))      # (a float64 fuse kernel: the fp64 triangle of the gradient tests)
     return (out > 0.1).float()
 
 

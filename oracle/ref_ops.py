@@ -57,7 +57,8 @@ def roi_align(feat, rois, output_size, spatial_scale=1.0, sampling_ratio=0, alig
         ph_n = pw_n = output_size
     else:
         ph_n, pw_n = output_size
-    feat = feat.float()
+    if feat.dtype != torch.float64:          # (float64 maps: the fp64 triangle of the gradient tests -- geometry stays fp32)
+        feat = feat.float()
     rois = rois.float()
     B, C, H, W = feat.shape
     K = rois.shape[0]
@@ -87,10 +88,10 @@ def roi_align(feat, rois, output_size, spatial_scale=1.0, sampling_ratio=0, alig
             continue  # empty sample grid -> zeros (loops do not run in mmcv)
         yl, yh, wyl, wyh, vy = _axis_samples(sh, bin_h, gh, ph_n, H)
         xl, xh, wxl, wxh, vx = _axis_samples(sw, bin_w, gw, pw_n, W)
-        wyl = wyl * vy
-        wyh = wyh * vy
-        wxl = wxl * vx
-        wxh = wxh * vx
+        wyl = (wyl * vy).to(feat.dtype)
+        wyh = (wyh * vy).to(feat.dtype)
+        wxl = (wxl * vx).to(feat.dtype)
+        wxh = (wxh * vx).to(feat.dtype)
         f = feat[b]  # [C,H,W]
         top = f[:, yl, :]
         bot = f[:, yh, :]
@@ -205,7 +206,7 @@ def simple_roi_align(feat, rois, output_size, spatial_scale, aligned=True):
     for b in range(B):
         inds = rois[:, 0].long() == b
         if inds.any():
-            r = rois[inds][:, 1:]
+            r = rois[inds][:, 1:].float()
             pts = rel[inds].clone()
             pts[:, :, 0] = pts[:, :, 0] * (r[:, None, 2] - r[:, None, 0])
             pts[:, :, 1] = pts[:, :, 1] * (r[:, None, 3] - r[:, None, 1])
@@ -214,7 +215,7 @@ def simple_roi_align(feat, rois, output_size, spatial_scale, aligned=True):
             scale = torch.tensor([W, H], dtype=torch.float32).view(1, 1, 2)
             pts = pts / scale * spatial_scale
             pts = pts.unsqueeze(0)                  # [1, k, S*S, 2]
-            o = F.grid_sample(feat[b:b + 1], pts * 2.0 - 1.0, mode='bilinear',
+            o = F.grid_sample(feat[b:b + 1], (pts * 2.0 - 1.0).to(feat.dtype), mode='bilinear',
                               padding_mode='zeros', align_corners=not aligned)
             outs.append(o.squeeze(0).transpose(0, 1))   # [k, C, S*S]
     if not outs:

@@ -314,7 +314,9 @@ def test_mask_loss_matches_reference_golden(ops, golden_dir):
     _close(sums0[1] / n_el, g['epsbce_stage1'], atol=1e-5, rtol=1e-4)
     sums, per_roi, gi_, gd_ = ops.mask_loss(_dev(ip), _dev(dp), _dev(t), _dev(dt), _dev(w))
     _close(sums[1] / n_el, ref_model.mask_cross_entropy(dp.squeeze(1), dt, w.view(-1, 1, 1)), atol=1e-5, rtol=1e-4)
-    _close((per_roi * _dev(w)).sum(), sums[1], atol=1e-3, rtol=1e-5)
+    # the stage's sum against the per-RoI sums added in float64 (round 3: atol 1e-3 on a sum of ~1e4)
+    s64 = float((per_roi.double() * _dev(w).double()).sum())
+    assert abs(float(sums[1]) - s64) <= 2e-6 * abs(s64), (float(sums[1]), s64)
     ipr = ip.clone().requires_grad_(True)
     dpr = dp.clone().requires_grad_(True)
     (ref_model.binary_cross_entropy(ipr.squeeze(1), t) * n_el).backward()

@@ -82,11 +82,34 @@ def test_simple_test_mask_logits_vs_oracle():
         rois = torch.cat([torch.zeros(len(boxes), 1), boxes], 1)
         ips, _ = ref_model.mask_forward(sd, hi['feats'], rois, labels)
         ref = ref_model.boundary_merge(ips)
-    # the merge thresholds sigmoid >= 0.5 on logits that differ by ~1e-6 between CPU and GPU:
-    # allow a handful of pixels to flip side, everything else must agree to 1e-4
-    diff = (out.cpu() - ref).abs()
-    bad = (diff > 1e-4 + 1e-4 * ref.abs()).float().mean().item()
-    assert bad < 1e-3, bad
+    # The merge thresholds sigmoid >= 0.5 on logits that differ by ~1e-6 between CPU and GPU: a logit within that of 0
+    # may fall on either side and move its 3x3 boundary block.  Instead of tolerating a fraction of the pixels (round 3:
+    # 1e-3 of them), the ties are PROVEN: the oracle's merge is run with the threshold at -1e-4, 0 and +1e-4 on the
+    # logit; where the three agree no tie is involved and the product must agree to 1e-4; everywhere else it must agree
+    # with one of the three.
+    import torch.nn.functional as F
+
+    def merge_thr(stage_preds, thr):
+        preds = [p.clone() for p in stage_preds[1:]]
+        for idx in range(len(preds) - 1):
+            inst = preds[idx].squeeze(1) >= thr
+            nb = (ref_model.generate_block_target(inst, boundary_width=1) != 1).unsqueeze(1)
+            nb = F.interpolate(nb.float(), preds[idx + 1].shape[-2:], mode='bilinear', align_corners=True) >= 0.5
+            pre_pred = F.interpolate(preds[idx], preds[idx + 1].shape[-2:], mode='bilinear', align_corners=True)
+            preds[idx + 1][nb] = pre_pred[nb]
+        return preds[-1]
+    lo, hi_ = merge_thr(ips, -1e-4), merge_thr(ips, 1e-4)
+    got = out.cpu()
+
+    def near(a, b):
+        return (a - b).abs() <= 1e-4 + 1e-4 * b.abs()
+    certain = near(lo, ref) & near(hi_, ref)
+    assert bool(near(got, ref)[certain].all()), 'a pixel no threshold tie can reach differs from the oracle'
+    tied = ~certain
+    assert bool((near(got, ref) | near(got, lo) | near(got, hi_))[tied].all()), 'a tie-affected pixel matches no side of its tie'
+    print(f'merge: {int(tied.sum())} of {tied.numel()} pixels within reach of a |logit| < 1e-4 tie, '
+          f'{int((~near(got, ref)).sum())} of them on the other side than the oracle')
+    assert float(tied.float().mean()) < 1e-2
 
 
 def test_fcn_mask_head_matches_reference_golden(golden_dir):
@@ -638,4 +661,13 @@ def test_bucketed_inference_graphs_replay_the_eager_launch_sequence():
         m._mask_graphs = gl
         assert torch.equal(m.simple_test_mask_logits(feats, boxes[:16], labels[:16]), ref) and gl.captures == 4
         assert not torch.equal(ref, eager[16])
+        # an in-place update that does NOT bump the epoch (torch.optim step, load_state_dict, copy_): a conv weight the
+        # graph reads through its packed copy -- the key carries every parameter's (address, version)
+        with torch.no_grad():
+            m.mask_head.instance_convs[0].conv.weight.mul_(1.25)
+        m.enable_inference_graphs(False)
+        ref2 = m.simple_test_mask_logits(feats, boxes[:16], labels[:16]).clone()
+        m._mask_graphs = gl
+        assert torch.equal(m.simple_test_mask_logits(feats, boxes[:16], labels[:16]), ref2) and gl.captures == 5
+        assert not torch.equal(ref2, ref)
         m.enable_inference_graphs(False)

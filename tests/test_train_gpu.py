@@ -131,11 +131,26 @@ def test_forward_train_matches_reference_golden(golden_dir):
             worst = max(worst, float(np.abs(got - ref).max()))
             # (the golden's slice of fc_reg.weight covers rows of classes that no sampled positive has: exact zeros)
             assert_grad_close(got, ref, pre + k, zero=not np.any(ref))
+    # FPN-map gradients: a cell is a sum over every RoI and sample that touches it, added in another order here (atomics)
+    # than in the reference.  The fp64 triangle: the oracle's forward_train once more in float64 (same fp32 geometry,
+    # same sampled boxes and selector indices -- asserted), and the product may be as far from it as the reference's own
+    # fp32 run is, or 1e-4 of the map's peak, whichever is larger (round 3 allowed a flat 1e-3 of the peak).
+    from tolerances import assert_close_via_f64
+    sd64 = {k: (v.clone().double().requires_grad_(True) if v.is_floating_point() else v)
+            for k, v in {**gi.head_state(), **gi.mask_pre_state(), **gi.bbox_train_head_state()}.items()}
+    f64 = [f.clone().double().requires_grad_(True) for f in ti['feats']]
+    torch.manual_seed(gi.TRAIN_SEED)
+    l64, s64, _, _ = ref_model.forward_train(sd64, f64, ti['proposals'], ti['gt_bboxes'], ti['gt_labels'], ti['gt_masks'],
+                                             gi.RCNN_TRAIN_CFG)
+    for i in range(2):
+        np.testing.assert_array_equal(s64[i]['pos_inds'].numpy(), g[f'pos_inds{i}'])
+    assert abs(float(l64['loss_masks']) - float(g['ft.loss_masks'].reshape(-1)[0])) < 1e-5
+    (l64['loss_cls'] + l64['loss_bbox'] + l64['loss_masks']).backward()
     for i in range(4):
         if g[f'ft.grad_feat{i}'].size > 1:
-            # an FPN-map gradient cell is a sum over every RoI and sample that touches it, added in another order here
-            # (atomics) than in the reference: 1e-3 of the tensor's peak (7e-7 absolute on these maps)
-            assert_grad_close(gi.feat_grad_slice(feats[i].grad), g[f'ft.grad_feat{i}'], f'feat{i}', rel=1e-3)
+            e, re_, sc = assert_close_via_f64(gi.feat_grad_slice(feats[i].grad), g[f'ft.grad_feat{i}'],
+                                              gi.feat_grad_slice(f64[i].grad), f'feat{i}')
+            print(f'forward_train: d/dP{i + 2}: product - f64 {e:.3g}, reference(fp32) - f64 {re_:.3g}, scale {sc:.3g}')
     print('forward_train: worst parameter-gradient abs error', worst)
 
 
@@ -300,6 +315,46 @@ def test_training_step_on_side_streams_matches_the_single_stream_step(monkeypatc
     assert float((a0[1] - b0[1]).abs().max()) <= 2e-5 * scale, 'first-step gradients differ'
     assert abs(a1[0] - b1[0]) <= 1e-5 * abs(b1[0])
     torch.testing.assert_close(pa, pb, atol=2e-6, rtol=1e-4)
+
+
+def test_direct_mask_forward_after_a_weight_update_reads_refreshed_packs(monkeypatch):
+    """``_mask_forward`` under grad WITHOUT the RoI head's up-front PACK_PLAN.refresh() (no selector branch:
+    ``_INPUTS_READY`` is None), right after an in-place weight update.  The packs are then refreshed inside
+    MaskHeadFn.issue; side streams that read them must be ordered behind that refresh.  Loss and gradients must equal
+    the single-stream run of the same two calls."""
+    from dynamask_amd import synth, registry, roi_head, mask_heads, roi_extractors, losses  # noqa: F401
+    dev = torch.device('cuda')
+    B, per, H, W = 2, 96, 800, 1333
+    feats = [f.to(dev) for f in synth.make_fpn(B, H, W, 256, seed=20)]
+    rois = synth.make_rois(B, per, H, W, seed=21).to(dev)
+    labels = synth.make_labels(B * per, seed=22).to(dev)
+
+    def run(side):
+        monkeypatch.setenv('DM_TRAIN_SIDE_STREAM', '1' if side else '0')
+        m = registry.build_head(dict(type='DynaMaskRoIHead',
+                                     mask_roi_extractor=dict(type='SingleRoIExtractor', **gi.MASK_ROI_EXTRACTOR_CFG),
+                                     mask_head=dict(type='DynaMaskHead', **gi.MASK_HEAD_CFG)))
+        m.load_state_dict({**synth.init_dynamask_head_state(seed=5), **synth.init_mask_pre_state(seed=6)}, strict=True)
+        m = m.to(dev).train()
+        outs = []
+        for it in range(3):
+            for p_ in m.mask_head.parameters():
+                p_.grad = None
+            res = m._mask_forward(feats, rois, labels)
+            loss = sum(t.square().mean() for t in res['stage_instance_preds']) + sum(t.square().mean() for t in res['stage_detail_preds'])
+            loss.backward()
+            g = torch.cat([p_.grad.flatten() for p_ in m.mask_head.parameters() if p_.grad is not None])
+            outs.append((float(loss.detach()), g.clone()))
+            with torch.no_grad():          # an in-place update that bumps _version only
+                for p_ in m.mask_head.parameters():
+                    p_.mul_(1.0 + 0.05 * (it + 1))
+        torch.cuda.synchronize()
+        return outs
+    a, b = run(True), run(False)
+    assert abs(a[1][0] - a[0][0]) > 1e-3 * abs(a[0][0]), 'the update must change the loss'
+    for (la, ga), (lb, gb) in zip(a, b):
+        assert abs(la - lb) <= 1e-5 * abs(lb)
+        assert float((ga - gb).abs().max()) <= 5e-5 * float(gb.abs().max())
 
 
 def test_deterministic_mode_gives_bit_identical_training_runs(monkeypatch):
