@@ -63,9 +63,39 @@ struct ConvArgs {
 // chunks spill 35-55 dwords at 168 and lose a third of their rate; with 16-channel chunks (half the
 // prefetch registers) they fit without scratch, and three per CU beats the longer chunk: the DCN
 // column-gradient GEMMs 1.56 -> 1.20, 0.94 -> 0.78, 0.75 -> 0.67 ms, fusion 130->64 @56^2 0.56 -> 0.45 ms.
-template <int KS, int WGM, int WGN, int WM, int WN, int CK, int MAXPOS, int TAIL = 0>
-__global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && WM == 2 && WN == 2 && MAXPOS == 1) || (KS == 1 && CK == 16) ? 3 : 1) void conv_igemm_kernel(ConvArgs a) {
+// SPLIT (round 4, opt-in: DM_MFMA_SPLIT=3 / flag bit 4 of dm_conv2d_fwd): the same tile, staging and epilogue on the
+// bf16 matrix cores.  An fp32 value is the sum of two bf16 numbers up to 2^-17 relative (hi = bf16(x), lo = bf16(x - hi));
+// a product x * w is hi*hi + hi*lo + lo*hi up to ~2^-16 relative (lo*lo dropped), three v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation: 16 channels per instruction at 32 cycles against 2 at 64 for v_mfma_f32_32x32x2_f32 -- 16 x 32 / (3 x 64)
+// = 5.3 x the matrix rate.  K is walked in chunks of 16 channels; a "word" (16 bytes) holds 8 consecutive channels of one
+// (cout | pixel) as bf16, and the four words of a chunk are (channels 0-7 | 8-15) x (hi | lo): the LDS images keep the
+// fp32 builds' indexing with word = quad.  Weights are split once at pack time (dm_conv_pack_weight_split, sources padded
+// to 16 channels), activations when a thread commits its prefetched floats to LDS.  NOT the parity build: sums are
+// accurate to ~2^-16 of their terms, not to the last fp32 bit, and inf * 0 / NaN propagation differs (inf splits into
+// inf + NaN).
+typedef __bf16 dm_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 dm_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float dm_f32x2 __attribute__((ext_vector_type(2)));
+
+// 8 floats -> the hi word and the lo word (8 bf16 each)
+__device__ __forceinline__ void dm_split8(const dm_f32x4& q0, const dm_f32x4& q1, dm_f32x4& hi, dm_f32x4& lo) {
+  dm_bf16x8 h, l;
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    const float a = e < 4 ? q0[e] : q1[e - 4], b = e < 4 ? q0[e + 1] : q1[e - 3];
+    const dm_bf16x2 hb = __builtin_convertvector(dm_f32x2{a, b}, dm_bf16x2);
+    const dm_bf16x2 lb = __builtin_convertvector(dm_f32x2{a - (float)hb[0], b - (float)hb[1]}, dm_bf16x2);
+    h[e] = hb[0]; h[e + 1] = hb[1];
+    l[e] = lb[0]; l[e + 1] = lb[1];
+  }
+  hi = __builtin_bit_cast(dm_f32x4, h);
+  lo = __builtin_bit_cast(dm_f32x4, l);
+}
+
+template <int KS, int WGM, int WGN, int WM, int WN, int CK, int MAXPOS, int TAIL = 0, int SPLIT = 0>
+__global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && WM == 2 && WN == 2 && MAXPOS == 1) || (KS == 1 && CK == 16) || SPLIT ? 3 : 1) void conv_igemm_kernel(ConvArgs a) {
   static_assert(TAIL == 0 || (TAIL == 4 && WGM == 1), "tail rows need a single cout tile");
+  static_assert(!SPLIT || (CK == 16 && TAIL == 0), "the bf16-split build walks K in 16-channel chunks");
   constexpr int TM = WGM * WM * 32;
   constexpr int TMA = TM + TAIL;              // rows of the LDS A image
   constexpr int TN = WGN * WN * 32;
@@ -139,9 +169,9 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
       const int x = p - y * W;
       const int seg = n - n0;
       const int r = (seg == 0) ? (y - y00 + 1) : (rows0 + 2) + (seg - 1) * (H + 2) + (y + 1);
-      lane_base[wn] = (r - 1) * Wp + x + hi * plane;
+      lane_base[wn] = (r - 1) * Wp + x + (SPLIT ? 2 * hi : hi) * plane;      // (SPLIT: lane half = channels 8 hi .. 8 hi + 7 = words 2 hi, 2 hi + 1)
     } else {
-      lane_base[wn] = j + hi * plane;
+      lane_base[wn] = j + (SPLIT ? 2 * hi : hi) * plane;
     }
   }
 
@@ -202,7 +232,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
   auto chunk_valid = [&]() { return cs < a.num_srcs; };
   auto chunk_advance = [&]() {
     const int ckv = min(CK, curC - cc0);
-    ckq += ((ckv + 7) / 8) * 2;
+    ckq += SPLIT ? 4 : ((ckv + 7) / 8) * 2;      // (SPLIT: every source is padded to whole 16-channel chunks)
     cc0 += CK;
     if (cc0 >= curC) {
       cs++;
@@ -229,7 +259,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
   // issue the global loads of the chunk at (cs, cc0, ckq) into registers
   auto prefetch = [&]() {
     const int ckv = min(CK, curC - cc0);
-    const int nq = ((ckv + 7) / 8) * 2;    // quads of this chunk present in the packed weights
+    const int nq = SPLIT ? NQ : ((ckv + 7) / 8) * 2;    // quads of this chunk present in the packed weights
     // the chunk's part of an address is uniform (ckq, cc0); the thread's part is fixed for the K loop
     // (per source for B) and kept in a register: no 64-bit multiplies per load next to the MFMAs
     const float* abase = a.wq + (size_t)ckq * a.CoutP * 4;
@@ -252,7 +282,8 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
       const int qw = __builtin_amdgcn_readfirstlane(tid / TN);
 #pragma unroll
       for (int i = 0; i < B1_PER_T; ++i) {
-        const float* rq = rp + (size_t)((qw + i * (NT / TN)) * 4) * HW;
+        // (SPLIT: a thread stages the two quads of one 8-channel half -- it converts them to one hi and one lo word)
+        const float* rq = rp + (size_t)((SPLIT ? qw * 2 + i : qw + i * (NT / TN)) * 4) * HW;
 #pragma unroll
         for (int e = 0; e < 4; ++e) rb[i][e] = rq[(size_t)e * HW + b_off32];
       }
@@ -312,7 +343,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
       const float* gp = sp + b_off[0];
 #pragma unroll
       for (int i = 0; i < B1_PER_T; ++i) {
-        const int qd = tid / TN + i * (NT / TN);
+        const int qd = SPLIT ? (tid / TN) * 2 + i : tid / TN + i * (NT / TN);
         dm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -330,7 +361,31 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
       const int idx = tid + i * NT;
       if (idx < A_F4) ldsA[idx] = ra[i];
     }
-    if (KS == 3) {
+    if (SPLIT) {
+      // fp32 -> (hi, lo) bf16 words: [channels 0-7 hi][0-7 lo][8-15 hi][8-15 lo] of the thread's pixel(s)
+      if (KS == 3) {
+#pragma unroll
+        for (int k = 0; k < MAXPOS; ++k) {
+          const int pos = tid + k * NT;
+          if (pos < plane) {
+#pragma unroll
+            for (int h8 = 0; h8 < 2; ++h8) {
+              dm_f32x4 whi, wlo;
+              dm_split8(rb[k * NQ + 2 * h8], rb[k * NQ + 2 * h8 + 1], whi, wlo);
+              ldsB[(2 * h8) * plane + pos] = whi;
+              ldsB[(2 * h8 + 1) * plane + pos] = wlo;
+            }
+          }
+        }
+      } else {
+        static_assert(!SPLIT || KS == 3 || (B1_PER_T == 2 && NT / TN == 2), "1x1 split build: two quads (one half) per thread");
+        const int h8 = tid / TN;
+        dm_f32x4 whi, wlo;
+        dm_split8(rb[0], rb[B1_PER_T > 1 ? 1 : 0], whi, wlo);
+        ldsB[(2 * h8) * plane + (tid % TN)] = whi;
+        ldsB[(2 * h8 + 1) * plane + (tid % TN)] = wlo;
+      }
+    } else if (KS == 3) {
 #pragma unroll
       for (int k = 0; k < MAXPOS; ++k) {
         const int pos = tid + k * NT;
@@ -361,7 +416,38 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
     // Operand fragments are double-buffered in registers: the ds_reads of step s+1 are
     // issued before the 4 x WM x WN MFMAs of step s, so LDS latency never stalls the
     // matrix pipe (the compiler alone re-uses one register set and issues them late).
-    {
+    if (SPLIT) {
+      // one step per tap: the chunk's 16 channels are ONE k of v_mfma_f32_32x32x16_bf16 (lane half hi = channels 8 hi ..)
+      auto load_frag = [&](int tap, dm_f32x4 (*av)[2], dm_f32x4 (*bv)[2]) {
+        const int tapoff = (KS == 3) ? ((tap / 3) * Wp + (tap % 3)) : 0;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int hl = 0; hl < 2; ++hl) av[i][hl] = ldsA[(tap * NQ + 2 * hi + hl) * TMA + (wave_m * WM + i) * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+          for (int hl = 0; hl < 2; ++hl) bv[j][hl] = ldsB[hl * plane + lane_base[j] + tapoff];
+      };
+      dm_f32x4 av[2][WM][2], bv[2][WN][2];
+      load_frag(0, av[0], bv[0]);
+#pragma unroll
+      for (int st = 0; st < TAPS; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < TAPS) load_frag(st + 1, av[cur ^ 1], bv[cur ^ 1]);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j) {
+            const dm_bf16x8 ah = __builtin_bit_cast(dm_bf16x8, av[cur][i][0]), al = __builtin_bit_cast(dm_bf16x8, av[cur][i][1]);
+            const dm_bf16x8 bh = __builtin_bit_cast(dm_bf16x8, bv[cur][j][0]), bl = __builtin_bit_cast(dm_bf16x8, bv[cur][j][1]);
+            // smallest terms first
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);
+          }
+      }
+    } else {
       constexpr int NG = NQ / 2;
       constexpr int STEPS = TAPS * NG;
       auto load_frag = [&](int st, dm_f32x4* av, dm_f32x4* bv) {
@@ -583,14 +669,56 @@ __device__ __forceinline__ void pack_weight_body(const PackArgs& p, int ld, int 
   }
 }
 
+// bf16-split layout (SPLIT builds): [tap][KQ][colsP][16 bytes], sources padded to 16 channels, KQ = sum of
+// roundup(Cs, 16) / 4 words; word 4 b + 2 h + l of a source's 16-channel block b holds channels 16 b + 8 h .. + 7 of
+// one produced channel as bf16, l = 0: hi = bf16(w), l = 1: lo = bf16(w - hi).  One thread per (tap, half block, col).
+__device__ __forceinline__ void pack_weight_split_body(const PackArgs& p, int ld, int c0) {
+  const int HB = p.KQ / 2;                      // 8-channel halves
+  const long long total = (long long)p.kk * HB * p.colsP;
+  dm_f32x4* out = reinterpret_cast<dm_f32x4*>(p.wq);
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int col = (int)(idx % p.colsP);
+    const int hb = (int)(idx / p.colsP % HB);
+    const int tap = (int)(idx / ((long long)p.colsP * HB));
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int pc = hb * 8 + e, row = -1, base = 0;
+      for (int s = 0; s < p.nsrc; ++s) {
+        const int padded = (p.src_c[s] + 15) / 16 * 16;
+        if (pc < padded) {
+          if (pc < p.src_c[s]) row = base + pc;
+          break;
+        }
+        pc -= padded;
+        base += p.src_c[s];
+      }
+      float x = 0.f;
+      if (row >= 0 && col < p.cols) {
+        if (!p.flip) x = p.w[((size_t)col * ld + c0 + row) * p.kk + tap];
+        else x = p.w[((size_t)row * ld + c0 + col) * p.kk + (p.kk - 1 - tap)];
+      }
+      v[e] = x;
+    }
+    dm_f32x4 hi, lo;
+    dm_split8(dm_f32x4{v[0], v[1], v[2], v[3]}, dm_f32x4{v[4], v[5], v[6], v[7]}, hi, lo);
+    const size_t w0 = ((size_t)tap * p.KQ + 2 * hb) * p.colsP + col;
+    out[w0] = hi;
+    out[w0 + p.colsP] = lo;
+  }
+}
+
 __global__ void pack_weight_kernel(PackArgs p) { pack_weight_body(p, p.Cin, 0); }
+__global__ void pack_weight_split_kernel(PackArgs p) { pack_weight_split_body(p, p.Cin, 0); }
 
 // Every pack of a training step in ONE launch (blockIdx.y = job): ~45 weight tensors change with every optimizer
 // step, and a launch per tensor cost the host 1.3 ms of the 3.7 ms it needs to issue a forward pass.
 __global__ void pack_weight_batch_kernel(const dm_pack_job* __restrict__ jobs) {
   const dm_pack_job j = jobs[blockIdx.y];
   PackArgs p;
-  p.w = j.w; p.wq = j.w_packed; p.Cout = j.Cout; p.Cin = j.Cin; p.kk = j.ksize * j.ksize; p.flip = j.transpose_flip ? 1 : 0;
+  const bool split = (j.transpose_flip & 2) != 0;          // bit 1 of transpose_flip: the bf16-split layout
+  p.w = j.w; p.wq = j.w_packed; p.Cout = j.Cout; p.Cin = j.Cin; p.kk = j.ksize * j.ksize; p.flip = (j.transpose_flip & 1) ? 1 : 0;
   p.rows = p.flip ? j.Cout : j.Cin;
   p.cols = p.flip ? j.Cin : j.Cout;
   p.colsP = (p.cols + 31) / 32 * 32;
@@ -598,10 +726,11 @@ __global__ void pack_weight_batch_kernel(const dm_pack_job* __restrict__ jobs) {
   p.KQ = 0;
   for (int s = 0; s < DM_MAX_SOURCES; ++s) {
     p.src_c[s] = s < j.num_srcs ? j.src_channels[s] : 0;
-    if (s < j.num_srcs) p.KQ += (j.src_channels[s] + 7) / 8 * 2;
+    if (s < j.num_srcs) p.KQ += split ? (j.src_channels[s] + 15) / 16 * 4 : (j.src_channels[s] + 7) / 8 * 2;
   }
   p.deconv = 0;
-  pack_weight_body(p, j.ld, j.c0);
+  if (split) pack_weight_split_body(p, j.ld, j.c0);
+  else pack_weight_body(p, j.ld, j.c0);
 }
 
 int packed_quads(int nsrc, const int* src_c) {
@@ -610,19 +739,32 @@ int packed_quads(int nsrc, const int* src_c) {
   return kq;
 }
 
-template <int KS, int WGM, int WGN, int WM, int WN, int CK, int MAXPOS, int TAIL = 0>
+int packed_words_split(int nsrc, const int* src_c) {
+  int kq = 0;
+  for (int s = 0; s < nsrc; ++s) kq += (src_c[s] + 15) / 16 * 4;
+  return kq;
+}
+
+template <int KS, int WGM, int WGN, int WM, int WN, int CK, int MAXPOS, int TAIL = 0, int SPLIT = 0>
 int launch_conv_mp(ConvArgs& a, hipStream_t st) {
   constexpr int TM = WGM * WM * 32;
   constexpr int TN = WGN * WN * 32;
   constexpr int NT = WGM * WGN * 64;
   const int NTiles = dm_ceil_div(a.Q - a.q_begin, TN);
   const size_t lds_bytes = 16 * ((size_t)KS * KS * (CK / 4) * (TM + TAIL) + (size_t)(CK / 4) * a.plane);
-  if (lds_bytes > 64 * 1024) return DM_ERR_UNSUPPORTED;
-  DM_LAUNCH((conv_igemm_kernel<KS, WGM, WGN, WM, WN, CK, MAXPOS, TAIL>), dim3(a.MT * NTiles), dim3(NT), lds_bytes, st, a);
+  if (lds_bytes > 64 * 1024) {
+    // (the bf16-split build of wide maps: 9 taps x 4 words x 64 couts + a two-position plane = 66.5 KB at 56 x 56)
+    if (!SPLIT || lds_bytes > 96 * 1024) return DM_ERR_UNSUPPORTED;
+    static bool raised[DM_MAX_DEVICES] = {false};
+    const int rc = dm_ensure_lds_limit(reinterpret_cast<const void*>(&conv_igemm_kernel<KS, WGM, WGN, WM, WN, CK, MAXPOS, TAIL, SPLIT>),
+                                       96 * 1024, raised);
+    if (rc != DM_OK) return rc;
+  }
+  DM_LAUNCH((conv_igemm_kernel<KS, WGM, WGN, WM, WN, CK, MAXPOS, TAIL, SPLIT>), dim3(a.MT * NTiles), dim3(NT), lds_bytes, st, a);
   return dm_check_launch();
 }
 
-template <int KS, int WGM, int WGN, int WM, int WN, int CK, int TAIL = 0>
+template <int KS, int WGM, int WGN, int WM, int WN, int CK, int TAIL = 0, int SPLIT = 0>
 int launch_conv(ConvArgs& a, hipStream_t st) {
   constexpr int TM = WGM * WM * 32;
   constexpr int TN = WGN * WN * 32;
@@ -633,14 +775,15 @@ int launch_conv(ConvArgs& a, hipStream_t st) {
     const int nsegmax = dm_ceil_div(TN - 1, a.HW) + 1;
     const int rmax = dm_ceil_div(TN - 1, a.W) + 1 + 2 * nsegmax;
     a.plane = rmax * a.Wp;
-    if (a.plane <= NT) return launch_conv_mp<KS, WGM, WGN, WM, WN, CK, 1, TAIL>(a, st);
-    if (a.plane <= 2 * NT) return launch_conv_mp<KS, WGM, WGN, WM, WN, CK, 2, TAIL>(a, st);
-    if (a.plane <= 4 * NT) return launch_conv_mp<KS, WGM, WGN, WM, WN, CK, 4, TAIL>(a, st);
+    if (a.plane <= NT) return launch_conv_mp<KS, WGM, WGN, WM, WN, CK, 1, TAIL, SPLIT>(a, st);
+    if (a.plane <= 2 * NT) return launch_conv_mp<KS, WGM, WGN, WM, WN, CK, 2, TAIL, SPLIT>(a, st);
+    if (SPLIT) return DM_ERR_UNSUPPORTED;
+    if (a.plane <= 4 * NT) return launch_conv_mp<KS, WGM, WGN, WM, WN, CK, 4, TAIL, SPLIT>(a, st);
     return DM_ERR_UNSUPPORTED;
   }
   a.Wp = 0;
   a.plane = TN;
-  return launch_conv_mp<KS, WGM, WGN, WM, WN, CK, 1, TAIL>(a, st);
+  return launch_conv_mp<KS, WGM, WGN, WM, WN, CK, 1, TAIL, SPLIT>(a, st);
 }
 
 int run_pack(PackArgs& p, hipStream_t st) {
@@ -679,6 +822,36 @@ extern "C" int dm_conv_pack_weight(const float* w_oihw, int Cout, int Cin, int k
   p.KQ = packed_quads(num_srcs, src_channels);
   p.deconv = 0;
   return run_pack(p, (hipStream_t)stream);
+}
+
+extern "C" long long dm_conv_packed_floats_split(int Cout, int ksize, int num_srcs, const int* src_channels) {
+  if (Cout <= 0 || ksize <= 0 || num_srcs < 1 || num_srcs > DM_MAX_SOURCES || !src_channels) return -1;
+  return (long long)ksize * ksize * packed_words_split(num_srcs, src_channels) * dm_conv_packed_cout(Cout) * 4;
+}
+
+extern "C" int dm_conv_pack_weight_split(const float* w_oihw, int Cout, int Cin, int ksize, int transpose_flip,
+                                         int num_srcs, const int* src_channels, float* w_packed, dm_stream_t stream) {
+  if (!w_oihw || !w_packed || Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3)) return DM_ERR_INVALID_ARG;
+  if (num_srcs < 1 || num_srcs > DM_MAX_SOURCES || !src_channels) return DM_ERR_INVALID_ARG;
+  PackArgs p;
+  p.w = w_oihw; p.wq = w_packed; p.Cout = Cout; p.Cin = Cin; p.kk = ksize * ksize; p.flip = transpose_flip ? 1 : 0;
+  p.rows = transpose_flip ? Cout : Cin;
+  p.cols = transpose_flip ? Cin : Cout;
+  p.colsP = dm_conv_packed_cout(p.cols);
+  p.nsrc = num_srcs;
+  int sum = 0;
+  for (int s = 0; s < DM_MAX_SOURCES; ++s) {
+    p.src_c[s] = s < num_srcs ? src_channels[s] : 0;
+    if (s < num_srcs && src_channels[s] <= 0) return DM_ERR_INVALID_ARG;
+    sum += p.src_c[s];
+  }
+  if (sum != p.rows) return DM_ERR_INVALID_ARG;
+  p.KQ = packed_words_split(num_srcs, src_channels);
+  p.deconv = 0;
+  const long long total = (long long)p.kk * (p.KQ / 2) * p.colsP;
+  const int blocks = (int)min((long long)dm_ceil_div(total, 256), 4096LL);
+  DM_LAUNCH(pack_weight_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  return dm_check_launch();
 }
 
 extern "C" int dm_conv_pack_weight_batch(const dm_pack_job* jobs_device, int num_jobs, dm_stream_t stream) {
@@ -732,7 +905,8 @@ static int conv2d_launch(const float* const* srcs, const int* src_channels, cons
     }
   }
   a.num_srcs = num_srcs;
-  a.KQ = packed_quads(num_srcs, src_channels);
+  const bool split = (relu & 16) != 0;          // flag bit 4: w_packed is the bf16-split layout (dm_conv_pack_weight_split)
+  a.KQ = split ? packed_words_split(num_srcs, src_channels) : packed_quads(num_srcs, src_channels);
   a.NB = NB; a.H = H; a.W = W; a.HW = H * W; a.Q = NB * H * W;
   a.wq = w_packed; a.bias = bias; a.Cout = Cout; a.CoutP = dm_conv_packed_cout(Cout);
   a.relu = relu & 3; a.out = out; a.out_ch_total = out_ch_total; a.out_ch_offset = out_ch_offset;
@@ -747,6 +921,11 @@ static int conv2d_launch(const float* const* srcs, const int* src_channels, cons
   // below); accumulating launches read the destination and keep the default policy
   if (!(relu & 2) && (long long)NB * Cout * H * W * 4 > (192LL << 20)) a.relu |= 4;
   hipStream_t st = (hipStream_t)stream;
+  if (split) {
+    // 64 couts x 128 pixels, four waves of 32 x 64, three workgroups per CU (53 KB of LDS at 3x3): see the kernel's header
+    if (ksize == 3) return launch_conv<3, 2, 2, 1, 2, 16, 0, 1>(a, st);
+    return launch_conv<1, 2, 2, 1, 2, 16, 0, 1>(a, st);
+  }
   if (ksize == 3) {
     if (Cout > 64) {
       // 128 x 128 tiles run two or three to a CU: a launch is a sequence of rounds of 512 / 768 workgroups,

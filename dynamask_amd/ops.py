@@ -274,16 +274,29 @@ def packed_cout(cout):
     return lib().dm_conv_packed_cout(int(cout))
 
 
-def packed_floats(cout, ksize, src_channels):
-    n = lib().dm_conv_packed_floats(int(cout), int(ksize), len(src_channels), _int_array(src_channels))
+# Opt-in bf16-split matrix mode of the implicit-GEMM convolutions (DM_MFMA_SPLIT=3: three bf16 products per fp32 product,
+# ~2^-16 relative per product; NOT the parity build -- see csrc/conv_igemm.hip).  While it is set, pack_conv_weight and
+# the pack plan produce the split layout and mark the tensor; conv2d follows the mark.  Deformable convolutions, weight
+# gradients and fully connected layers stay on exact fp32.
+MFMA_SPLIT = 3 if os.environ.get('DM_MFMA_SPLIT', '0') == '3' else 0
+
+
+def is_split(w_packed):
+    return bool(getattr(w_packed, '_dm_split', False))
+
+
+def packed_floats(cout, ksize, src_channels, split=False):
+    fn = lib().dm_conv_packed_floats_split if split else lib().dm_conv_packed_floats
+    n = fn(int(cout), int(ksize), len(src_channels), _int_array(src_channels))
     if n < 0:
         raise ValueError('bad conv packing request')
     return int(n)
 
 
-def pack_conv_weight(w, transpose_flip=False, src_channels=None):
+def pack_conv_weight(w, transpose_flip=False, src_channels=None, split=None):
     """OIHW -> [k*k][KQ][CoutP][4] (see include/dynamask_hip.h).  ``src_channels``:
-    how the input channels split over the concat sources (default: one source)."""
+    how the input channels split over the concat sources (default: one source).
+    ``split``: the bf16-split layout (default: ops.MFMA_SPLIT)."""
     _chk(w, 'weight')
     cout, cin, kh, kw = w.shape
     assert kh == kw and kh in (1, 3)
@@ -292,9 +305,12 @@ def pack_conv_weight(w, transpose_flip=False, src_channels=None):
     if src_channels is None:
         src_channels = [rows]
     assert sum(src_channels) == rows
-    wp = torch.empty((packed_floats(cols, kh, src_channels),), device=w.device, dtype=torch.float32)
-    check(lib().dm_conv_pack_weight(_p(w), cout, cin, kh, 1 if transpose_flip else 0, len(src_channels),
-                                    _int_array(src_channels), _p(wp), _stream()), 'dm_conv_pack_weight')
+    split = bool(MFMA_SPLIT) if split is None else bool(split)
+    wp = torch.empty((packed_floats(cols, kh, src_channels, split),), device=w.device, dtype=torch.float32)
+    fn = lib().dm_conv_pack_weight_split if split else lib().dm_conv_pack_weight
+    check(fn(_p(w), cout, cin, kh, 1 if transpose_flip else 0, len(src_channels),
+             _int_array(src_channels), _p(wp), _stream()), 'dm_conv_pack_weight')
+    wp._dm_split = split
     return wp
 
 
@@ -347,8 +363,9 @@ class PackPlan:
             p = self.plans[idx] = _DevicePlan(torch.device('cuda', idx))
         return p
 
-    def register(self, param, transpose_flip, src_channels, lo, hi):
+    def register(self, param, transpose_flip, src_channels, lo, hi, split=None):
         import weakref
+        split = bool(MFMA_SPLIT) if split is None else bool(split)
         cout, cin_total, kh, kw = param.shape
         lo = 0 if lo is None else lo
         hi = cin_total if hi is None else hi
@@ -357,9 +374,10 @@ class PackPlan:
         cols = cin if transpose_flip else cout
         src_channels = [rows] if src_channels is None else list(src_channels)
         assert sum(src_channels) == rows and kh == kw and kh in (1, 3) and len(src_channels) <= 4
-        out = torch.empty((packed_floats(cols, kh, src_channels),), device=param.device, dtype=torch.float32)
+        out = torch.empty((packed_floats(cols, kh, src_channels, split),), device=param.device, dtype=torch.float32)
+        out._dm_split = split
         plan = self._plan(param.device)
-        e = dict(param=weakref.ref(param), out=out, cout=cout, cin=cin, ks=kh, flip=1 if transpose_flip else 0,
+        e = dict(param=weakref.ref(param), out=out, cout=cout, cin=cin, ks=kh, flip=(1 if transpose_flip else 0) | (2 if split else 0),
                  srcs=src_channels, ld=cin_total, c0=lo, ver=None, used=True, plan=plan)
         plan.entries.append(e)
         return e
@@ -461,14 +479,15 @@ def conv2d(srcs, w_packed, bias, cout, ksize, relu=False, out=None, out_ch_offse
     for s in srcs:
         assert s.shape[0] == NB and s.shape[2] == H and s.shape[3] == W
     cin = sum(s.shape[1] for s in srcs)
-    assert w_packed.numel() == packed_floats(cout, ksize, [s.shape[1] for s in srcs]), 'weights packed for other sources'
+    split = is_split(w_packed)
+    assert w_packed.numel() == packed_floats(cout, ksize, [s.shape[1] for s in srcs], split), 'weights packed for other sources'
     if out is None:
         out = torch.empty((NB, cout, H, W), device=srcs[0].device, dtype=torch.float32)
     else:
         _chk(out, 'out')
         assert out.shape[0] == NB and out.shape[2] == H and out.shape[3] == W
     strides = (ctypes.c_longlong * len(srcs))(*[int(s.stride(0)) for s in srcs])
-    flags = (1 if relu else 0) | (2 if accumulate else 0) | (8 if _overlapped else 0)
+    flags = (1 if relu else 0) | (2 if accumulate else 0) | (8 if _overlapped else 0) | (16 if split else 0)
     if mask is not None:
         _chk(mask, 'mask')
         assert mask.shape == out.shape
