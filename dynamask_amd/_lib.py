@@ -22,8 +22,8 @@ SIGNATURES = {
     'dm_conv_packed_cout': ([_c_int], _c_int),
     'dm_conv_packed_floats': ([_c_int, _c_int, _c_int, _vp], ctypes.c_longlong),
     'dm_conv_pack_weight': ([_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp], _c_int),
-    'dm_conv_packed_floats_split': ([_c_int, _c_int, _c_int, _vp], ctypes.c_longlong),
-    'dm_conv_pack_weight_split': ([_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp], _c_int),
+    'dm_conv_packed_floats_split': ([_c_int, _c_int, _c_int, _vp, _c_int], ctypes.c_longlong),
+    'dm_conv_pack_weight_split': ([_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp, _vp], _c_int),
     'dm_conv_pack_weight_batch': ([_vp, _c_int, _vp], _c_int),
     'dm_conv2d_fwd': ([_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp], _c_int),
     'dm_conv2d_fwd_masked': ([_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _vp], _c_int),

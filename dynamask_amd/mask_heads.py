@@ -34,7 +34,7 @@ class _Packed:
         registered with ops.PACK_PLAN and refreshed together in one launch.  Anything else goes through ``fn``.
         ``split``: False for consumers that only take the fp32 layout (the deformable convolution); default: the
         layout ops.MFMA_SPLIT selects (a pack is cached per layout)."""
-        split = bool(ops.MFMA_SPLIT) if split is None else bool(split)
+        split = ops.MFMA_SPLIT if split is None else ops._products(split)
         key = (key, split)
         if job is not None and param.is_cuda and param.dim() == 4 and param.is_contiguous():
             e = self._c.get(key)
@@ -46,7 +46,7 @@ class _Packed:
         ver = (param.data_ptr(), param._version, param.device, ops.WEIGHT_EPOCH[0])
         e = self._c.get(key)
         if e is None or e[0] != ver:
-            with torch.no_grad():
+            with torch.no_grad(), ops.split_packing(split):
                 e = (ver, fn(param.detach().contiguous()))
             self._c[key] = e
         return e[1]

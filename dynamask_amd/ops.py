@@ -274,20 +274,53 @@ def packed_cout(cout):
     return lib().dm_conv_packed_cout(int(cout))
 
 
-# Opt-in bf16-split matrix mode of the implicit-GEMM convolutions (DM_MFMA_SPLIT=3: three bf16 products per fp32 product,
-# ~2^-16 relative per product; NOT the parity build -- see csrc/conv_igemm.hip).  While it is set, pack_conv_weight and
-# the pack plan produce the split layout and mark the tensor; conv2d follows the mark.  Deformable convolutions, weight
+# Opt-in bf16-split matrix modes of the implicit-GEMM convolutions (DM_MFMA_SPLIT=3: three bf16 products per fp32 product,
+# ~2^-16 relative per product; 6: six, fp32-level accuracy; NOT the parity build -- see csrc/conv_igemm.hip).  While it is set, the conv modules'
+# packs (mask_heads._Packed, the pack plan) are produced in the split layout and marked; conv2d follows the mark.  Deformable convolutions, weight
 # gradients and fully connected layers stay on exact fp32.
-MFMA_SPLIT = 3 if os.environ.get('DM_MFMA_SPLIT', '0') == '3' else 0
+MFMA_SPLIT = {'3': 3, '6': 6}.get(os.environ.get('DM_MFMA_SPLIT', '0'), 0)      # products per fp32 product: 0 = exact fp32
+
+
+_PACK_SPLIT_DEFAULT = [0]          # what pack_conv_weight(split=None) means right now (see split_packing): 0, 3 or 6
+
+
+def _products(split):
+    """False / None / 0 -> 0 (fp32 layout); True -> ops.MFMA_SPLIT or 3; 3 / 6 -> themselves."""
+    if split is True:
+        return MFMA_SPLIT or 3
+    split = int(split or 0)
+    assert split in (0, 3, 6)
+    return split
+
+
+class split_packing:
+    """Context: pack_conv_weight calls inside produce the bf16-split layout of ``on`` products (0 / 3 / 6) unless they
+    say otherwise.  The conv modules wrap their pack callbacks in it (mask_heads._Packed.get); a bare
+    ops.pack_conv_weight(w) -- tests, the deformable convolution's weights -- stays on the fp32 layout whatever
+    DM_MFMA_SPLIT says."""
+
+    def __init__(self, on):
+        self.on = _products(on)
+
+    def __enter__(self):
+        self.prev = _PACK_SPLIT_DEFAULT[0]
+        _PACK_SPLIT_DEFAULT[0] = self.on
+
+    def __exit__(self, *exc):
+        _PACK_SPLIT_DEFAULT[0] = self.prev
 
 
 def is_split(w_packed):
-    return bool(getattr(w_packed, '_dm_split', False))
+    """Products per fp32 product of a packed weight tensor: 0 (fp32 layout), 3 or 6."""
+    return int(getattr(w_packed, '_dm_split', 0) or 0)
 
 
-def packed_floats(cout, ksize, src_channels, split=False):
-    fn = lib().dm_conv_packed_floats_split if split else lib().dm_conv_packed_floats
-    n = fn(int(cout), int(ksize), len(src_channels), _int_array(src_channels))
+def packed_floats(cout, ksize, src_channels, split=0):
+    split = _products(split)
+    if split:
+        n = lib().dm_conv_packed_floats_split(int(cout), int(ksize), len(src_channels), _int_array(src_channels), split)
+    else:
+        n = lib().dm_conv_packed_floats(int(cout), int(ksize), len(src_channels), _int_array(src_channels))
     if n < 0:
         raise ValueError('bad conv packing request')
     return int(n)
@@ -296,7 +329,7 @@ def packed_floats(cout, ksize, src_channels, split=False):
 def pack_conv_weight(w, transpose_flip=False, src_channels=None, split=None):
     """OIHW -> [k*k][KQ][CoutP][4] (see include/dynamask_hip.h).  ``src_channels``:
     how the input channels split over the concat sources (default: one source).
-    ``split``: the bf16-split layout (default: ops.MFMA_SPLIT)."""
+    ``split``: the bf16-split layout (default: fp32, or what an enclosing ops.split_packing says)."""
     _chk(w, 'weight')
     cout, cin, kh, kw = w.shape
     assert kh == kw and kh in (1, 3)
@@ -305,11 +338,14 @@ def pack_conv_weight(w, transpose_flip=False, src_channels=None, split=None):
     if src_channels is None:
         src_channels = [rows]
     assert sum(src_channels) == rows
-    split = bool(MFMA_SPLIT) if split is None else bool(split)
+    split = _PACK_SPLIT_DEFAULT[0] if split is None else _products(split)
     wp = torch.empty((packed_floats(cols, kh, src_channels, split),), device=w.device, dtype=torch.float32)
-    fn = lib().dm_conv_pack_weight_split if split else lib().dm_conv_pack_weight
-    check(fn(_p(w), cout, cin, kh, 1 if transpose_flip else 0, len(src_channels),
-             _int_array(src_channels), _p(wp), _stream()), 'dm_conv_pack_weight')
+    if split:
+        check(lib().dm_conv_pack_weight_split(_p(w), cout, cin, kh, 1 if transpose_flip else 0, len(src_channels),
+                                              _int_array(src_channels), split, _p(wp), _stream()), 'dm_conv_pack_weight_split')
+    else:
+        check(lib().dm_conv_pack_weight(_p(w), cout, cin, kh, 1 if transpose_flip else 0, len(src_channels),
+                                        _int_array(src_channels), _p(wp), _stream()), 'dm_conv_pack_weight')
     wp._dm_split = split
     return wp
 
@@ -365,7 +401,7 @@ class PackPlan:
 
     def register(self, param, transpose_flip, src_channels, lo, hi, split=None):
         import weakref
-        split = bool(MFMA_SPLIT) if split is None else bool(split)
+        split = MFMA_SPLIT if split is None else _products(split)
         cout, cin_total, kh, kw = param.shape
         lo = 0 if lo is None else lo
         hi = cin_total if hi is None else hi
@@ -377,7 +413,7 @@ class PackPlan:
         out = torch.empty((packed_floats(cols, kh, src_channels, split),), device=param.device, dtype=torch.float32)
         out._dm_split = split
         plan = self._plan(param.device)
-        e = dict(param=weakref.ref(param), out=out, cout=cout, cin=cin, ks=kh, flip=(1 if transpose_flip else 0) | (2 if split else 0),
+        e = dict(param=weakref.ref(param), out=out, cout=cout, cin=cin, ks=kh, flip=(1 if transpose_flip else 0) | (2 if split == 3 else 4 if split == 6 else 0),
                  srcs=src_channels, ld=cin_total, c0=lo, ver=None, used=True, plan=plan)
         plan.entries.append(e)
         return e
@@ -487,7 +523,7 @@ def conv2d(srcs, w_packed, bias, cout, ksize, relu=False, out=None, out_ch_offse
         _chk(out, 'out')
         assert out.shape[0] == NB and out.shape[2] == H and out.shape[3] == W
     strides = (ctypes.c_longlong * len(srcs))(*[int(s.stride(0)) for s in srcs])
-    flags = (1 if relu else 0) | (2 if accumulate else 0) | (8 if _overlapped else 0) | (16 if split else 0)
+    flags = (1 if relu else 0) | (2 if accumulate else 0) | (8 if _overlapped else 0) | (16 if split == 3 else 32 if split == 6 else 0)
     if mask is not None:
         _chk(mask, 'mask')
         assert mask.shape == out.shape

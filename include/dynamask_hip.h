@@ -57,7 +57,7 @@ extern "C" {
 typedef void* dm_stream_t; /* hipStream_t */
 
 const char* dm_error_string(int code);
-/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient, dm_conv_pack_weight_batch, dm_mask_loss_stage; 15: dm_class_logits_up2x_fwd; 16: dm_conv2d_wgrad_slab / dm_conv2d_wgrad_scratch_floats; 17: dm_class_logits_bwd_slab / dm_class_logits_bwd_scratch_floats; 18: dm_reload_env_knobs, dm_roi_align_fwd_ws / dm_roi_align_workspace_bytes, dm_conv_pack_weight_split / dm_conv_packed_floats_split and flag bit 4 of dm_conv2d_fwd). */
+/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient, dm_conv_pack_weight_batch, dm_mask_loss_stage; 15: dm_class_logits_up2x_fwd; 16: dm_conv2d_wgrad_slab / dm_conv2d_wgrad_scratch_floats; 17: dm_class_logits_bwd_slab / dm_class_logits_bwd_scratch_floats; 18: dm_reload_env_knobs, dm_roi_align_fwd_ws / dm_roi_align_workspace_bytes, dm_conv_pack_weight_split / dm_conv_packed_floats_split and flag bits 4, 5 of dm_conv2d_fwd). */
 int dm_abi_version(void);
 /* Re-read the DM_ROI_* experiment knobs from the environment (they are otherwise read once, at the first launch, and
  * clamped to validated ranges).  For measurement tools that sweep settings inside one process; no knob changes a result. */
@@ -115,15 +115,17 @@ long long dm_conv_packed_floats(int Cout, int ksize, int num_srcs, const int* sr
 int dm_conv_pack_weight(const float* w_oihw, int Cout, int Cin, int ksize, int transpose_flip,
                         int num_srcs, const int* src_channels, float* w_packed, dm_stream_t stream);
 
-/* Opt-in bf16-split matrix mode (round 4; NOT the parity build).  dm_conv_pack_weight_split writes the weights as
- * (hi, lo) bf16 pairs -- [k*k][KQ][CoutP][16 bytes], every source padded to 16 channels, KQ = sum(roundup(Cs, 16)) / 4,
- * dm_conv_packed_floats_split() floats -- and dm_conv2d_fwd / dm_conv2d_fwd_masked called with flag bit 4 (16) in `relu`
- * take such a tensor: products become hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
- * (~2^-16 relative per product instead of exact fp32; 5.3x the fp32 matrix rate).  In a dm_pack_job, bit 1 (2) of
- * transpose_flip selects this layout.  No reference interface: the reference computes in fp32 throughout. */
-long long dm_conv_packed_floats_split(int Cout, int ksize, int num_srcs, const int* src_channels);
+/* Opt-in bf16-split matrix modes (round 4; NOT the parity build).  dm_conv_pack_weight_split writes every weight as
+ * 2 (products = 3) or 3 (products = 6) bf16 parts -- [k*k][KQ][CoutP][16 bytes], every source padded to 16 channels,
+ * KQ = sum(roundup(Cs, 16)) / 16 * 2 * parts, dm_conv_packed_floats_split() floats -- and dm_conv2d_fwd /
+ * dm_conv2d_fwd_masked called with flag bit 4 (16: products = 3) or bit 5 (32: products = 6) in `relu` take such a
+ * tensor: an fp32 product becomes 3 (hi*hi + hi*lo + lo*hi, ~2^-16 relative) or 6 (terms below 2^-24 dropped:
+ * fp32-level) v_mfma_f32_32x32x16_bf16 with fp32 accumulation, 5.3x / 2.7x the fp32 matrix rate.  In a dm_pack_job,
+ * bit 1 (2) / bit 2 (4) of transpose_flip select these layouts.  No reference interface: the reference computes in
+ * fp32 throughout. */
+long long dm_conv_packed_floats_split(int Cout, int ksize, int num_srcs, const int* src_channels, int products);
 int dm_conv_pack_weight_split(const float* w_oihw, int Cout, int Cin, int ksize, int transpose_flip,
-                              int num_srcs, const int* src_channels, float* w_packed, dm_stream_t stream);
+                              int num_srcs, const int* src_channels, int products, float* w_packed, dm_stream_t stream);
 
 /* All the packs of a training step in one launch (the weights change with every optimizer step).  A job is
  * dm_conv_pack_weight's arguments plus a window: the packed [Cout][Cin] tensor may be the input-channel slice

@@ -88,12 +88,13 @@ def mask_forward(sd, fpn_feats, rois, roi_labels, pre='mask_head.',
 
 def fcn_mask_head_forward(sd, x, pre='', num_convs=4, upsample='deconv', scale=2, carafe_cfg=None):
     """FCNMaskHead.forward -- mask_heads/fcn_mask_head.py:117-126."""
+    relu = F.relu
     for i in range(num_convs):
-        x = F.relu(F.conv2d(x, sd[f'{pre}convs.{i}.conv.weight'], sd[f'{pre}convs.{i}.conv.bias'],
-                            padding=1))
+        x = relu(F.conv2d(x, sd[f'{pre}convs.{i}.conv.weight'], sd[f'{pre}convs.{i}.conv.bias'],
+                          padding=1))
     if upsample == 'deconv':
-        x = F.relu(F.conv_transpose2d(x, sd[pre + 'upsample.weight'], sd[pre + 'upsample.bias'],
-                                      stride=scale))
+        x = relu(F.conv_transpose2d(x, sd[pre + 'upsample.weight'], sd[pre + 'upsample.bias'],
+                                    stride=scale))
     elif upsample == 'carafe':
         cfg = dict(up_kernel=5, up_group=1, encoder_kernel=3, encoder_dilation=1)
         cfg.update(carafe_cfg or {})
