@@ -33,6 +33,8 @@ struct RoiArgs {
   int order;           // forward tile / band kernels: 0 = workgroup b -> (RoI b / chunks, chunk b % chunks);
                        // 1 = XCD-aware (see roi_unit)
   int abl;             // ablation bits of the tile kernel (tools/micro/roi_tile_ablate.hip only, see DM_ABL)
+  int nt = 0;          // tile kernel: nontemporal output stores (experiment)
+  const float* sorted = nullptr;   // tile kernel: RoI records in processing order (roi_order_kernel), 8 floats each
 };
 
 // Ablations of the 14x14 tile kernel for the ceiling measurement (profiles/r03_roialign_ceiling.txt): the micro
@@ -635,10 +637,19 @@ __device__ __forceinline__ void roi_tile_fwd(const RoiArgs& a, const float* __re
           }
           if (DM_ABL(a, 4) && acc.x != 12345.678f) continue;      // (keeps the value live without the store)
           char* const oq = ob + (size_t)(4 * q) * PB;
-          *reinterpret_cast<float*>(oq + ot) = acc.x;
-          *reinterpret_cast<float*>(oq + PB + ot) = acc.y;
-          *reinterpret_cast<float*>(oq + 2 * PB + ot) = acc.z;
-          *reinterpret_cast<float*>(oq + 3 * PB + ot) = acc.w;
+          if (a.nt) {
+            // (experiment DM_ROI_NT14=1: the output streams past the caches, so that it does not evict the map planes
+            // the other workgroups of the XCD are staging from)
+            __builtin_nontemporal_store(acc.x, reinterpret_cast<float*>(oq + ot));
+            __builtin_nontemporal_store(acc.y, reinterpret_cast<float*>(oq + PB + ot));
+            __builtin_nontemporal_store(acc.z, reinterpret_cast<float*>(oq + 2 * PB + ot));
+            __builtin_nontemporal_store(acc.w, reinterpret_cast<float*>(oq + 3 * PB + ot));
+          } else {
+            *reinterpret_cast<float*>(oq + ot) = acc.x;
+            *reinterpret_cast<float*>(oq + PB + ot) = acc.y;
+            *reinterpret_cast<float*>(oq + 2 * PB + ot) = acc.z;
+            *reinterpret_cast<float*>(oq + 3 * PB + ot) = acc.w;
+          }
         }
       }
     }
@@ -664,6 +675,65 @@ __device__ __forceinline__ void roi_tile_fwd(const RoiArgs& a, const float* __re
   }
 }
 
+// Round 4: processing order of the RoIs.  With the RoIs as the caller hands them over (random positions and sizes) the
+// workgroups an XCD runs at any moment stage from all over its channel planes, 4 MB of L2 keep little of it, and
+// the launch fetches 160 MB from the fabric for 91 MB of maps (profiles/r04_roi_traffic.txt); walked by (level, 32-pixel
+// rows, x) neighbouring workgroups share their footprints: 93 MB fetched -- the whole launch moves 1.0 x its algorithmic
+// bytes -- and 56 -> 47 us with 32 channels per workgroup.  The keys are ranked by counting (N <= 1024; a first version
+// with ONE workgroup of 1024 threads took 17 us: one CU's vector ALU for N x N / 4 compares) and the RoIs written in that
+// order as 8-float records {batch, x1, y1, x2, y2, index,
+// level, 0}, one scalar load for the extraction's workgroups; it also writes levels_out.  The order changes no result.
+// NOT the default (DM_ROI_SORT=1): the ordering launch and the dependency behind it cost ~8 us, what the ordered
+// extraction gains (profiles/r04_roi_exp.txt (i)); a caller whose RoIs already come in such an order gets the 47 us.
+constexpr int kOrderMaxRois = 1024;
+
+// workgroup = 64 RoIs x 4 threads each; every workgroup holds all N keys in LDS (computing them costs less than a
+// second launch), a RoI's four threads each count a quarter of the keys below it
+__global__ __launch_bounds__(256) void roi_order_kernel(RoiArgs a, float* __restrict__ sorted) {
+  __shared__ unsigned keys[kOrderMaxRois];
+  const int tid = threadIdx.x;
+  auto key_of = [&](int t, float (&rec)[5], int& lvl) {
+    const float* r = a.rois + (size_t)t * 5;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) rec[i] = r[i];
+    lvl = (a.L > 1) ? roi_level(rec[1], rec[2], rec[3], rec[4], a.finest, a.L) : 0;
+    const float cy = 0.5f * (rec[2] + rec[4]), cx = 0.5f * (rec[1] + rec[3]);
+    const unsigned row = (unsigned)fminf(fmaxf(cy * (1.0f / 32.0f), 0.f), 1023.f);
+    const unsigned col = (unsigned)fminf(fmaxf(cx, 0.f), 65535.f);
+    const unsigned img = (unsigned)min(max((int)rec[0], 0), 3);                 // (beyond 4 images the order is only coarser)
+    return (img << 30) | ((unsigned)lvl << 26) | (row << 16) | col;
+  };
+  const int npad = (a.N + 3) & ~3;
+  for (int t = tid; t < npad; t += 256) {
+    float rec[5];
+    int lvl;
+    keys[t] = t < a.N ? key_of(t, rec, lvl) : 0xFFFFFFFFu;      // (padding keys: never below a real key)
+  }
+  __syncthreads();
+  const int t = blockIdx.x * 64 + (tid >> 2), part = tid & 3;
+  float rec[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  int lvl = 0;
+  unsigned key = 0xFFFFFFFFu;
+  if (t < a.N) key = key_of(t, rec, lvl);
+  const int n4 = npad >> 2;
+  const uint4* k4 = reinterpret_cast<const uint4*>(keys);
+  int rank = 0;
+  for (int j = part; j < n4; j += 4) {
+    const uint4 q = k4[j];
+    const int j0 = 4 * j;
+    rank += (q.x < key || (q.x == key && j0 < t)) + (q.y < key || (q.y == key && j0 + 1 < t)) +
+            (q.z < key || (q.z == key && j0 + 2 < t)) + (q.w < key || (q.w == key && j0 + 3 < t));
+  }
+  rank += __shfl_xor(rank, 1, 64);
+  rank += __shfl_xor(rank, 2, 64);
+  if (t < a.N && part == 0) {
+    if (a.levels) a.levels[t] = lvl;
+    float* o = sorted + (size_t)rank * 8;
+    reinterpret_cast<float4*>(o)[0] = make_float4(rec[0], rec[1], rec[2], rec[3]);
+    reinterpret_cast<float4*>(o)[1] = make_float4(rec[4], (float)t, (float)lvl, 0.f);
+  }
+}
+
 __global__ __launch_bounds__(256, 4) void roi_align_tile_kernel(RoiArgs a) {
   extern __shared__ __attribute__((aligned(16))) float4 lds4[];
   const int chunks = (a.C + a.CT - 1) / a.CT;
@@ -671,11 +741,19 @@ __global__ __launch_bounds__(256, 4) void roi_align_tile_kernel(RoiArgs a) {
   roi_unit(a, chunks, k, chunk);
   const int c0 = chunk * a.CT;
   const int c1 = min(c0 + a.CT, a.C);
-  const float* r = a.rois + (size_t)k * 5;
+  // (with a workspace the launcher has ordered the RoIs by level and position, roi_order_kernel: unit k of the grid is
+  // the k-th RoI of that order; its record carries the RoI's own index and its level)
+  const float* r = a.sorted ? a.sorted + (size_t)k * 8 : a.rois + (size_t)k * 5;
   const int b = (int)r[0];
   const float x1 = r[1], y1 = r[2], x2 = r[3], y2 = r[4];
-  const int lvl = (a.L > 1) ? roi_level(x1, y1, x2, y2, a.finest, a.L) : 0;
-  if (a.levels && chunk == 0 && threadIdx.x == 0) a.levels[k] = lvl;
+  int lvl;
+  if (a.sorted) {
+    k = (int)r[5];
+    lvl = (int)r[6];
+  } else {
+    lvl = (a.L > 1) ? roi_level(x1, y1, x2, y2, a.finest, a.L) : 0;
+    if (a.levels && chunk == 0 && threadIdx.x == 0) a.levels[k] = lvl;
+  }
   const bool bad_batch = (b < 0 || b >= a.B);
   int Hl = a.H[0], Wl = a.W[0];
   float sc = a.scale[0];
@@ -2163,6 +2241,10 @@ struct RoiKnobs {
   int nt;           // DM_ROI_NT: nontemporal stores in the units kernel
   int unit_wgs;     // DM_ROI_UNIT_WGS: workgroups per CU of the units kernel
   int abl;          // DM_ROI_ABL: ablation bits (tools/micro builds only)
+  int nt14;         // DM_ROI_NT14: nontemporal output stores in the tile kernel (experiment)
+  int sort;         // DM_ROI_SORT: 1 = order the RoIs by level and position when the caller passes a workspace (default 0: the
+                    // extraction alone drops from 56 to 47 us, the dependent ordering launch in front of it costs the 8 us back)
+  int sort_min;     // DM_ROI_SORT_MIN: fewest RoIs worth the extra launch (default 192)
 };
 RoiKnobs g_roi_knobs;
 bool g_roi_knobs_loaded = false;
@@ -2185,6 +2267,9 @@ void roi_load_knobs() {
   k.nt = env_int("DM_ROI_NT", 1, 0, 1);
   k.unit_wgs = env_int("DM_ROI_UNIT_WGS", 4, 1, 8);
   k.abl = env_int("DM_ROI_ABL", 0, 0, 7);
+  k.nt14 = env_int("DM_ROI_NT14", 0, 0, 1);
+  k.sort = env_int("DM_ROI_SORT", 0, 0, 1);
+  k.sort_min = env_int("DM_ROI_SORT_MIN", 192, 1, 1024);
   g_roi_knobs = k;
   g_roi_knobs_loaded = true;
 }
@@ -2282,6 +2367,23 @@ int roi_align_fwd_impl(const float* const* feats, const int* H, const int* W, co
     else DM_LAUNCH((roi_align_persist_kernel<3>), dim3(wgs), dim3(256), lds, (hipStream_t)stream, a, (const int*)plans, grid);
     return dm_check_launch();
   }
+  if (tile_ok && kn.sort && P * P >= 128 && workspace && N >= kn.sort_min && N <= kOrderMaxRois && workspace_bytes >= (long long)N * 32 &&
+      (((uintptr_t)workspace) & 15) == 0) {
+    // RoIs walked by level and position (roi_order_kernel), 32 channels per workgroup, XCD-aware chunk-major order
+    float* sorted = reinterpret_cast<float*>(workspace);
+    DM_LAUNCH(roi_order_kernel, dim3(dm_ceil_div(N, 64)), dim3(256), 0, (hipStream_t)stream, a, sorted);
+    int rco = dm_check_launch();
+    if (rco != DM_OK) return rco;
+    a.levels = nullptr;
+    a.sorted = sorted;
+    a.CT = kn.ct > 0 ? kn.ct : 32;
+    a.order = kn.order >= 0 ? kn.order : 1;
+    int chunks = dm_ceil_div(C, a.CT);
+    if (chunks % 8 != 0) a.order = 0;
+    a.nt = kn.nt14;
+    DM_LAUNCH(roi_align_tile_kernel, dim3(N * chunks), dim3(256), (kTileFloats4 + 64) * sizeof(float4), (hipStream_t)stream, a);
+    return dm_check_launch();
+  }
   if (tile_ok) {
     // 16 channels per workgroup in the XCD-aware order (roi_unit): XCD x walks the chunks c = x (mod 8) chunk-major,
     // so the planes it is staging from stay in its L2 across the RoIs that share them.  Same time as round 2's 32
@@ -2294,6 +2396,7 @@ int roi_align_fwd_impl(const float* const* feats, const int* H, const int* W, co
 #ifdef DM_ROI_ABLATE
     a.abl = kn.abl;
 #endif
+    a.nt = kn.nt14;
     DM_LAUNCH(roi_align_tile_kernel, dim3(N * chunks), dim3(256), (kTileFloats4 + 64) * sizeof(float4), (hipStream_t)stream, a);
     return dm_check_launch();
   }
@@ -2341,7 +2444,7 @@ extern "C" int dm_roi_align_fwd(const float* const* feats, const int* H, const i
 
 extern "C" long long dm_roi_align_workspace_bytes(int N, int P) {
   if (N <= 0 || P < 2 || P * P > 256) return 0;
-  return (long long)N * kPlanDwords * 4;
+  return roi_knobs().persist ? (long long)N * kPlanDwords * 4 : (long long)N * 32;      // plans (DM_ROI_PERSIST=1) | ordered RoI records
 }
 
 extern "C" int dm_roi_align_fwd_ws(const float* const* feats, const int* H, const int* W, const float* spatial_scales,

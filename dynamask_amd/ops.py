@@ -77,9 +77,11 @@ def _float_array(vals):
 
 
 # ------------------------------------------------------------------ RoIAlign
-# DM_ROI_PERSIST=1: route 14x14 / 7x7 extractions through dm_roi_align_fwd_ws (the library's own knob of the same name
-# selects the kernels there)
-ROI_PERSIST = os.environ.get('DM_ROI_PERSIST', '0') == '1'
+# DM_ROI_WORKSPACE=1: 14x14 / 7x7 extractions of 192 RoIs or more go through dm_roi_align_fwd_ws with a scratch buffer,
+# which the library's DM_ROI_SORT=1 (RoIs ordered by level and position on the device) or DM_ROI_PERSIST=1 (plan +
+# persistent kernels) then use: round 4's two measured-and-not-adopted paths, same results as dm_roi_align_fwd
+ROI_WORKSPACE = os.environ.get('DM_ROI_WORKSPACE', '0') == '1'
+ROI_WORKSPACE_MIN = int(os.environ.get('DM_ROI_SORT_MIN', '192'))
 
 
 def roi_align(feats, rois, output_size, spatial_scales, sampling_ratio=0, finest_scale=56.0, return_levels=False):
@@ -89,9 +91,10 @@ def roi_align(feats, rois, output_size, spatial_scales, sampling_ratio=0, finest
     N = rois.shape[0]
     out = torch.empty((N, C, output_size, output_size), device=rois.device, dtype=torch.float32)
     levels = torch.zeros((N,), device=rois.device, dtype=torch.int32) if return_levels else None
-    if ROI_PERSIST:
-        # round 4's plan + persistent kernels (measured slower than the tile kernel; kept as an A/B path, same bits):
-        # the workspace holds per-RoI geometry and stencil tables
+    if ROI_WORKSPACE and N >= ROI_WORKSPACE_MIN:
+        # 14x14 / 7x7 extraction with a workspace: the RoIs are first ordered by level and position (one extra launch:
+        # neighbouring workgroups then share their footprints in the L2; same results).  With DM_ROI_PERSIST=1 the
+        # workspace holds round 4's per-RoI plans instead (plan + persistent kernels: measured slower, kept as an A/B path).
         wsb = int(lib().dm_roi_align_workspace_bytes(N, output_size))
         ws = torch.empty(((wsb + 15) // 16 * 4,), device=rois.device, dtype=torch.int32) if wsb > 0 else None
         rc = lib().dm_roi_align_fwd_ws(_ptr_array(feats), _int_array([f.shape[2] for f in feats]),

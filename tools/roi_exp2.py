@@ -38,10 +38,10 @@ def cold_us(call, junk, iters=9):
 
 
 def setenv(env):
-    for k in ('DM_ROI_PERSIST', 'DM_ROI_ORDER', 'DM_ROI_CT'):
+    for k in ('DM_ROI_PERSIST', 'DM_ROI_SORT', 'DM_ROI_WORKSPACE', 'DM_ROI_ORDER', 'DM_ROI_CT', 'DM_ROI_NT14'):
         os.environ.pop(k, None)
     os.environ.update(env)
-    ops.ROI_PERSIST = env.get('DM_ROI_PERSIST', '0') == '1'
+    ops.ROI_WORKSPACE = (env.get('DM_ROI_SORT', '0') == '1' or env.get('DM_ROI_PERSIST', '0') == '1')
     _lib.lib().dm_reload_env_knobs()
 
 
@@ -71,7 +71,7 @@ junk = torch.empty(1 << 28, device=dev)
 for name, perm in orders.items():
     r = rois[perm].contiguous().to(dev)
     call = lambda: ops.roi_align(feats[:4], r, 14, scales)
-    for env in ({}, {'DM_ROI_CT': '32'}, {'DM_ROI_ORDER': '0'}, {'DM_ROI_CT': '32', 'DM_ROI_ORDER': '0'}, {'DM_ROI_PERSIST': '1'}):
+    for env in ({}, {'DM_ROI_NT14': '1'}, {'DM_ROI_CT': '32'}, {'DM_ROI_CT': '32', 'DM_ROI_NT14': '1'}, {'DM_ROI_ORDER': '0'}, {'DM_ROI_PERSIST': '1'}):
         setenv(env)
         us, _ = graph_us(call)
         cold = cold_us(call, junk)
