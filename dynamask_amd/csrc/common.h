@@ -79,6 +79,22 @@ __device__ __forceinline__ unsigned long long dm_fix36_mul(float g, float w16, f
   return ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo;
 }
 
+// |value| * 2^36 from t16 = value * 2^4 in four instructions: the high word is trunc(|t16|), the low word its fraction
+// * 2^32 (exact for a non-negative number: a subset of its mantissa bits; a negative one has no such split -- 1 - 2^-40
+// is not a float -- which is why the sign goes into the choice of ds_add_u64 / ds_sub_u64 instead: dm_fix36_accumulate).
+// |value| < 2^27; the fraction below 2^-36 is truncated towards zero, as in dm_fix36_mul.
+__device__ __forceinline__ unsigned long long dm_fix36_abs16(float t16) {
+  const float m = __builtin_fabsf(t16);
+  const unsigned hi = (unsigned)m;
+  const unsigned lo = (unsigned)(__builtin_amdgcn_fractf(m) * 4294967296.0f);
+  return ((unsigned long long)hi << 32) | (unsigned long long)lo;
+}
+__device__ __forceinline__ void dm_fix36_accumulate(unsigned long long* cell, float t16) {
+  const unsigned long long mag = dm_fix36_abs16(t16);
+  if (t16 < 0.f) atomicSub(cell, mag);
+  else atomicAdd(cell, mag);
+}
+
 __device__ __forceinline__ unsigned long long dm_to_fx(float v) {
   const long long q = __builtin_isfinite(v) ? __double2ll_rn((double)v * DM_FX_ONE) : (1LL << 62);
   return (unsigned long long)q;

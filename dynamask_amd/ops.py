@@ -1033,12 +1033,58 @@ def pack_dcn_colgrad_weight(weight):
     return pack_conv_weight(dcn_weight_permute(weight.contiguous(), cout, c, True))        # [(tap,ci)][co]
 
 
-def deform_conv_backward_data(x, offset, weight, grad_out, deform_groups, side=None, w_colgrad=None):
-    """(grad_x, grad_offset) of DCNv1 3x3: column gradient = W^T . dY as a 1x1 conv, then the coordinate
-    gradient and col2im over it.  ``w_colgrad``: ``pack_dcn_colgrad_weight(weight)`` if the caller caches it.
-    ``side``: a second stream -- the coordinate gradient (bound by its gathers) then
-    runs there, beside col2im (bound by LDS atomics) on the caller's stream; both only read the column gradient."""
+# DM_DCN_FUSED=1: the one-kernel data gradient (csrc/dcn_bwd_fused.hip) where it applies; default: column-gradient GEMM,
+# coordinate gradient and col2im as three kernels -- both forms are bound by the same LDS scatter and measure alike
+# 
+DCN_BWD_FUSED = [os.environ.get('DM_DCN_FUSED', '0') == '1']
+
+
+def dcn_bwd_fused_ok(x_shape, cout, deform_groups):
+    """True where the one-kernel data gradient applies (dm_dcn_bwd_data_fused_supported) and is wanted: not in
+    deterministic mode -- a sample displaced beyond the staged rows adds to grad_x with float atomics."""
+    NB, C, H, W = x_shape
+    return bool(DCN_BWD_FUSED[0] and not DETERMINISTIC[0]
+                and lib().dm_dcn_bwd_data_fused_supported(C, cout, H, W, deform_groups))
+
+
+def pack_dcn_bwd_weight(weight, deform_groups):
+    """DCN weight [Cout, C, 3, 3] in the register layout of dm_dcn_bwd_data_fused (per group, 16-channel block and
+    tap pair: the 32 x Cout slice of W^T as one MFMA A operand per two output channels)."""
+    weight = _chk_src(weight.contiguous())
+    cout, c = weight.shape[0], weight.shape[1]
+    n = lib().dm_dcn_bwd_pack_floats(c, cout, deform_groups)
+    assert n > 0, 'dm_dcn_bwd_pack: unsupported shape'
+    out = torch.empty((n,), device=weight.device, dtype=torch.float32)
+    check(lib().dm_dcn_bwd_pack(_p(weight), cout, c, deform_groups, _p(out), _stream()), 'dm_dcn_bwd_pack')
+    return out
+
+
+def deform_conv_backward_data_fused(x, offset, grad_out, w_fused, deform_groups):
+    """(grad_x, grad_offset) of DCNv1 3x3 in one launch, no column-gradient matrix (csrc/dcn_bwd_fused.hip)."""
+    for t, nm in ((x, 'x'), (offset, 'offset'), (grad_out, 'grad_out'), (w_fused, 'w_fused')):
+        _chk(t, nm)
     NB, C, H, W = x.shape
+    cout = grad_out.shape[1]
+    assert grad_out.shape == (NB, cout, H, W) and offset.shape == (NB, 18 * deform_groups, H, W)
+    assert w_fused.numel() == lib().dm_dcn_bwd_pack_floats(C, cout, deform_groups)
+    gx = torch.empty_like(x)
+    goff = torch.empty_like(offset)
+    check(lib().dm_dcn_bwd_data_fused(_p(x), _p(offset), _p(grad_out), _p(w_fused), NB, C, cout, H, W, deform_groups,
+                                      _p(gx), _p(goff), _stream()), 'dm_dcn_bwd_data_fused')
+    return gx, goff
+
+
+def deform_conv_backward_data(x, offset, weight, grad_out, deform_groups, side=None, w_colgrad=None, w_fused=None):
+    """(grad_x, grad_offset) of DCNv1 3x3.  Where ``dcn_bwd_fused_ok``: one kernel (``w_fused``:
+    ``pack_dcn_bwd_weight(weight, deform_groups)`` if the caller caches it).  Otherwise column gradient = W^T . dY as
+    a 1x1 conv, then the coordinate gradient and col2im over it (``w_colgrad``: ``pack_dcn_colgrad_weight(weight)``);
+    ``side``: a second stream -- the coordinate gradient (bound by its gathers) then runs there, beside col2im (bound
+    by LDS atomics) on the caller's stream; both only read the column gradient."""
+    NB, C, H, W = x.shape
+    if dcn_bwd_fused_ok(x.shape, grad_out.shape[1], deform_groups):
+        if w_fused is None:
+            w_fused = pack_dcn_bwd_weight(weight, deform_groups)
+        return deform_conv_backward_data_fused(x, offset, grad_out, w_fused, deform_groups)
     if w_colgrad is None:
         w_colgrad = pack_dcn_colgrad_weight(weight)
     colgrad = conv2d(grad_out, w_colgrad, None, 9 * C, 1)                      # W^T . dY

@@ -516,6 +516,24 @@ int dm_deform_col2im(const float* colgrad, const float* offset, int NB, int C, i
 int dm_dcn_weight_permute(const float* src, float* dst, int Cout, int C, int to_colmajor, int accumulate,
                           dm_stream_t stream);
 
+/* (ABI 19) The data gradient of DCNv1 3x3 in ONE kernel (csrc/dcn_bwd_fused.hip): grad_x and grad_offset from grad_out
+ * without the [9C x HW] column-gradient matrix the reference materialises (deform_conv_cuda.cpp:262-374: columns =
+ * W^T . gradOut, deformable_col2im_coord, deformable_col2im).  A workgroup owns (image, deformable group); the column
+ * gradient of (tap, pixel, 16 channels) lives in one MFMA tile's accumulator registers, the coordinate gradient and the
+ * col2im scatter (64-bit fixed-point LDS atomics into a ring of rows of the 16 planes) are taken from there.
+ * dm_dcn_bwd_data_fused_supported: 1 where the kernel applies (Cout 64 or 128, (C / deform_groups) % 16 == 0, W % 4 == 0,
+ * the staging fits 160 KB of LDS), else 0 -- callers then take dm_conv2d_fwd + dm_deform_col2im_coord.
+ * w_packed: dm_dcn_bwd_pack of the [Cout, C, 3, 3] weight (dm_dcn_bwd_pack_floats floats).  grad_x is zero-filled and
+ * written by the call; grad_offset is overwritten.  Samples displaced by more than R/2 rows (R = 4, knob DM_DCN_FUSED_R)
+ * leave the staged ring: they read x from memory and add to grad_x with float atomics -- correct, slower, and the only
+ * case in which the sum order of grad_x depends on timing. */
+int dm_dcn_bwd_data_fused_supported(int C, int Cout, int H, int W, int deform_groups);
+long long dm_dcn_bwd_pack_floats(int C, int Cout, int deform_groups);
+int dm_dcn_bwd_pack(const float* weight, int Cout, int C, int deform_groups, float* packed, dm_stream_t stream);
+int dm_dcn_bwd_data_fused(const float* x, const float* offset, const float* grad_out, const float* w_packed, int NB,
+                          int C, int Cout, int H, int W, int deform_groups, float* grad_x, float* grad_offset,
+                          dm_stream_t stream);
+
 /* SGD(momentum, weight decay) step on a flat fp32 buffer; grad_scale folds the
  * 1/world_size of the gradient all-reduce (apis/train.py:75-79 DDP averaging). */
 int dm_sgd_momentum_step(float* params, const float* grads, float* momentum_buf, long long count, float lr,

@@ -17,3 +17,21 @@ e0.record()
 for _ in range(10): ops.deform_col2im(cg, off, (N, C, S, S), 1, out=gx)
 e1.record(); torch.cuda.synchronize()
 print(f'col2im 64 ch @56x56 x256: {e0.elapsed_time(e1) / 10:.3f} ms  checksum {gx.double().sum().item():.6f} {gx.double().abs().sum().item():.6f}', flush=True)
+# the offsets of the benchmark's training step (a zero-initialised offset conv: every interior pixel links with its neighbour)
+for sigma in (0.0, 0.3):
+    off0 = torch.randn(N, 18, S, S, device=dev) * sigma
+    for _ in range(3): ops.deform_col2im(cg, off0, (N, C, S, S), 1, out=gx)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10): ops.deform_col2im(cg, off0, (N, C, S, S), 1, out=gx)
+    e1.record(); torch.cuda.synchronize()
+    print(f'   offsets sigma {sigma}: {e0.elapsed_time(e1) / 10:.3f} ms  checksum {gx.double().sum().item():.6f} {gx.double().abs().sum().item():.6f}', flush=True)
+for (C2, S2) in ((128, 28), (256, 14)):
+    cg2 = torch.randn(N, 9 * C2, S2, S2, device=dev)
+    off2 = torch.zeros(N, 36, S2, S2, device=dev)
+    for _ in range(3): ops.deform_col2im(cg2, off2, (N, C2, S2, S2), 2)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10): ops.deform_col2im(cg2, off2, (N, C2, S2, S2), 2)
+    e1.record(); torch.cuda.synchronize()
+    print(f'col2im {C2} ch @{S2}x{S2} x256, zero offsets: {e0.elapsed_time(e1) / 10:.3f} ms', flush=True)

@@ -110,3 +110,20 @@ if 'wgrad' in cases:
         ms = timed(lambda: ops.conv2d_wgrad(dy, x, ks, dw=dw))
         fl = 2.0 * N * S * S * cout * cin * ks * ks
         print(f'conv2d_wgrad {cout}x{cin}x{ks}x{ks} @{S}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s  ({(dy.numel() + x.numel()) * 4 / ms / 1e9:.2f} TB/s of operands)', flush=True)
+if 'wgradcat' in cases:      # the concat weight gradients (feat, semantic, 2 coordinate planes) per source, and the slab reduce's share
+    for cout, cs, S in ((128, (128, 128, 2), 28), (64, (64, 64, 2), 56), (256, (256, 256, 2), 14)):
+        dy = torch.randn(N, cout, S, S, generator=g).to(dev)
+        srcs = [torch.randn(N, c, S, S, generator=g).to(dev) for c in cs]
+        dw = torch.zeros(cout, sum(cs), 1, 1, device=dev)
+        fl = 2.0 * N * S * S * cout * sum(cs)
+        ms = timed(lambda: ops.conv2d_wgrad(dy, srcs, 1, dw=dw))
+        print(f'concat wgrad {cout}x{sum(cs)} @{S}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s', flush=True)
+        for s in srcs:
+            d1 = torch.zeros(cout, s.shape[1], 1, 1, device=dev)
+            ms = timed(lambda: ops.conv2d_wgrad(dy, s, 1, dw=d1))
+            print(f'     source of {s.shape[1]:3d} channels alone: {ms:.3f} ms', flush=True)
+        for slab in (False,):
+            ops.WGRAD_SLAB[0] = slab
+            ms = timed(lambda: ops.conv2d_wgrad(dy, srcs, 1, dw=dw))
+            print(f'     atomics instead of slabs: {ms:.3f} ms', flush=True)
+            ops.WGRAD_SLAB[0] = True
