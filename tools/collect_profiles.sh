@@ -13,7 +13,6 @@ stats() {  # stats <dir> <dest>: copy the kernel_stats.csv of a rocprofv3 --stat
 }
 python3 bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.stderr
 tail -1 $out/${tag}_bench.json | cut -c1-200
-python3 bench.py --end-to-end > $out/${tag}_bench_end_to_end.json 2>> $out/${tag}_bench.stderr
 # the N > 1 launch path rehearsed on the one GPU (both ranks on cuda:0, gloo), and the training step as the headline
 DM_BENCH_REHEARSAL=1 python3 bench.py --gpus 2 --steps 10 --warmup 2 --cpu-sample 0 > $out/${tag}_bench_rehearsal_gpus2.json 2>> $out/${tag}_bench.stderr
 python3 bench.py --leg train --steps 8 --warmup 4 --cpu-sample 0 > $out/${tag}_bench_leg_train.json 2>> $out/${tag}_bench.stderr
@@ -26,6 +25,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_head -- python
 stats $out/prof_head $out/${tag}_headline_kernel_stats.csv
 TP_STEPS=6 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_train -- python3 tools/train_probe.py > /dev/null 2>&1
 stats $out/prof_train $out/${tag}_train_step_kernel_stats.csv
+# the same step on ONE stream (no side streams): per-kernel times without co-running kernels
+rm -rf $out/prof_serial
+DM_TRAIN_SIDE_STREAM=0 TP_STEPS=6 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_serial -- python3 tools/train_probe.py > /dev/null 2>&1
+stats $out/prof_serial $out/${tag}_train_step_serial_kernel_stats.csv
 # training-step timeline: busy time per queue, what runs alone, the gaps of the chain's queue
 rm -rf $out/prof_tl
 TP_STEPS=6 rocprofv3 --kernel-trace --output-format csv -d $out/prof_tl -- python3 tools/train_probe.py > /dev/null 2>&1
@@ -49,4 +52,8 @@ python3 tools/conv1_exp.py > $out/${tag}_conv1_exp.txt 2>&1
 python3 tools/coord_exp.py > $out/${tag}_coord_exp.txt 2>&1
 python3 tools/dcn_offsets_exp.py > $out/${tag}_dcn_offsets_exp.txt 2>&1
 python3 tools/small_n.py > $out/${tag}_small_n.txt 2>&1
+python3 tools/col2im_exp.py > $out/${tag}_col2im_exp.txt 2>&1
+python3 tools/dcn_fused_probe.py > $out/${tag}_dcn_fused_probe.txt 2>&1
+python3 tools/op_probe.py wgradcat wgrad > $out/${tag}_wgrad_probe.txt 2>&1
+bash tools/dcn_stamps.sh > $out/${tag}_dcn_fused_stamps.txt 2>&1
 echo "all done"
