@@ -202,3 +202,103 @@ def test_two_rank_rehearsal_line_carries_the_training_step_at_top_level():
 def test_bench_leg_train_is_an_option_of_the_command_line():
     r = _run_bench(['--help'], {})
     assert r.returncode == 0 and '--leg' in r.stdout and 'train' in r.stdout
+
+
+# ---------------------------------------------------------------- the whole mask-path step over two ranks
+def _whole_step_worker(rank, world, port, q, steps):
+    """shard -> forward + loss + backward -> all-reduce of the flat gradient -> SGD, with the product's own plumbing
+    (registry-built DynaMaskRoIHead as the parameter holder, dist.mask_path_parameters, FlatParamGroup, shard_images)
+    and the ORACLE as the arithmetic: the product's kernels are HIP-only and refuse CPU tensors, the collective and the
+    optimiser bookkeeping around them are the same code on either device (the fused SGD kernel is replaced by its torch
+    restatement, as in the test above)."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(3)
+    if world > 1:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'tests', 'golden'))
+    sys.path.insert(0, root)
+    import golden_inputs as gi
+    from oracle import ref_model
+    from dynamask_amd import ops, registry, roi_head, losses, mask_heads, roi_extractors  # noqa: F401
+    from dynamask_amd.dist import FlatParamGroup, mask_path_parameters, shard_images
+    ops.sgd_momentum_step_ = _torch_sgd_
+
+    def build():
+        cfg = dict(type='DynaMaskRoIHead', mask_roi_extractor=dict(type='SingleRoIExtractor', **gi.MASK_ROI_EXTRACTOR_CFG),
+                   mask_head=dict(type='DynaMaskHead', **gi.MASK_HEAD_CFG),
+                   train_cfg=registry.ConfigDict(flops=[0.23, 0.62, 1.01, 1.4], Lambda=0.3, mask_size=28),
+                   test_cfg=registry.ConfigDict(mask_thr_binary=0.5))
+        m = registry.build_head(cfg)
+        m.load_state_dict({**gi.head_state(), **gi.mask_pre_state()}, strict=True)
+        return m.train()
+
+    hi = gi.head_inputs()
+    n = hi['rois'].shape[0]
+    U = torch.rand(n, 4, generator=torch.Generator().manual_seed(9))
+    tg = gi.head_targets(n)
+
+    def shard_loss(model, images):
+        """the mask loss of one rank's images: its own RoIs, its own BatchNorm statistics, its own normaliser
+        (mmdet/apis/train.py:75-79: one DDP replica)"""
+        sd = {**dict(model.named_buffers()), **dict(model.named_parameters())}
+        keep = torch.isin(hi['rois'][:, 0].long(), torch.tensor(images))
+        rois = hi['rois'][keep].clone()
+        remap = {b: i for i, b in enumerate(images)}
+        rois[:, 0] = torch.tensor([remap[int(b)] for b in rois[:, 0]], dtype=torch.float32)
+        feats = [f[images] for f in hi['feats']]
+        loss, _, ind, _ = ref_model.mask_forward_train(sd, feats, rois, hi['labels'][keep], [t[keep] for t in tg], U[keep])
+        return loss, ind
+
+    model = build()
+    grp = FlatParamGroup(mask_path_parameters(model))
+    mine = shard_images(2, rank, world)
+    assert len(mine) == 2 // world
+    # the reference run of this test: ONE process, both shards one after the other, gradients averaged, torch.optim.SGD
+    ref = build()
+    opt = torch.optim.SGD(mask_path_parameters(ref), lr=0.02, momentum=0.9, weight_decay=1e-4)
+    for it in range(steps):
+        grp.zero_grad()
+        loss, ind = shard_loss(model, mine)
+        loss.backward()
+        grp.all_reduce_async()
+        grp.sgd_step(lr=0.02, momentum=0.9, weight_decay=1e-4)
+        opt.zero_grad()
+        for r in range(2):
+            lr_, _ = shard_loss(ref, [r])
+            (lr_ / 2).backward()
+        opt.step()
+        if world == 2:
+            worst = max(float((p.detach() - pr.detach()).abs().max()) for p, pr in zip(mask_path_parameters(model), mask_path_parameters(ref)))
+            scale = max(float(pr.detach().abs().max()) for pr in mask_path_parameters(ref))
+            assert worst <= 1e-6 * max(scale, 1.0), (it, worst)
+    flat = grp.flat_param.detach().clone()
+    if world > 1:
+        both = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        assert torch.equal(both[0], both[1])          # the same bits on both ranks after every update
+    q.put((rank, float(flat.double().sum()), [int(i) for i in ind]))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_whole_mask_path_step_world2_gloo_equals_one_process_over_both_shards():
+    """Two gloo ranks, one image each: forward + DynaCrossEntropyLoss + backward through extractor, MaskPre, selector and
+    the four-stage head, all-reduce of the flat 4.16 M-float gradient, momentum SGD -- for two steps.  After every step
+    the parameters equal (1e-6) those of one process that ran both shards with their own BatchNorm statistics and loss
+    normalisers and averaged the gradients (the DDP semantics of mmdet/apis/train.py:75-79), and both ranks hold the
+    same bits.  The arithmetic is the oracle's (tests may use it); every line of dist.py on the path is the product's."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_whole_step_worker, args=(r, 2, port, q, 2)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted(q.get(timeout=900) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert outs[0][1] == outs[1][1]
