@@ -246,7 +246,7 @@ class MaskHeadFn(torch.autograd.Function):
         # HOST ISSUE ORDER (round 3).  A step is ~350 launches; the host needs 3.5 ms to issue the forward's.  Round 2
         # issued them in program order -- selector branch, semantic branches, the ~45 weight packs of forward and
         # backward, the second stream's half of the head -- and the main stream's first convolution reached the GPU
-        # 3.9 ms into the step (profiles/r03_train_timeline_before.txt: the chain's queue empty for 3.4 of its first
+        # 3.9 ms into the step (round 3's timeline before this change, docs/HISTORY.md: the chain's queue empty for 3.4 of its first
         # 3.9 ms).  Now what the chain needs first is issued first: the forward's packs, the instance convs of both
         # halves, then the semantic branches (needed at the first fusion conv), the stages, and only then what has
         # slack until the loss or the backward (selector branch in roi_head.py, the backward's packs below).  Work

@@ -173,18 +173,18 @@ def test_flat_group_survives_grad_set_to_none_world1_and_world2():
 
 
 # ---------------------------------------------------------------- what the N > 1 bench line carries
-TOP_LEVEL_TRAIN_KEYS = ('train_ms_per_step', 'train_img_per_s', 'train_imgs_per_gpu', 'allreduce_alone_ms', 'collective',
+TOP_LEVEL_TRAIN_KEYS = ('train_ms_per_step', 'train_img_per_s', 'train_imgs_per_gpu', 'allreduce_alone_ms', 'allreduce_exposed_ms', 'collective',
                         'infer_ms_per_roi_batch', 'infer_img_per_s', 'inference_100dets_ms')
 
 
 def test_two_rank_rehearsal_line_carries_the_training_step_at_top_level():
     """the driver's SCALE record keeps only the top-level keys of the line, so the training-step
-    figures (the unit of the north star's scaling curve) must be there at every N.  profiles/r03_bench_rehearsal_gpus2.json
+    figures (the unit of the north star's scaling curve) must be there at every N.  profiles/r04_bench_rehearsal_gpus2.json
     is the line `DM_BENCH_REHEARSAL=1 python bench.py --gpus 2` printed on the one-GPU box this round
     (tools/collect_profiles.sh); bench.py's source must name the same keys."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(root, 'profiles', 'r03_bench_rehearsal_gpus2.json')) as f:
+    with open(os.path.join(root, 'profiles', 'r04_bench_rehearsal_gpus2.json')) as f:
         line = [l for l in f.read().splitlines() if l.startswith('{')]
     assert len(line) == 1
     out = json.loads(line[0])
