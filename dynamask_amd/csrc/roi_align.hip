@@ -37,11 +37,13 @@ struct RoiArgs {
   const float* sorted = nullptr;   // tile kernel: RoI records in processing order (roi_order_kernel), 8 floats each
 };
 
-// Ablations of the 14x14 tile kernel for the ceiling measurement (profiles/r03_roialign_ceiling.txt): the micro
-// benchmark compiles THIS file with DM_ROI_ABLATE defined and switches phases off at run time (bit 1: no global
-// loads, 2: one tap instead of the stencil, 4: no output stores); in the library the condition is the constant false.
+// Ablations of the 14x14 tile kernel for the ceiling measurement (profiles/r04_roialign_ceiling.txt): the micro
+// benchmark compiles THIS file once per variant with DM_ROI_ABLATE = the variant's bits (1: no global loads, 2: one tap
+// instead of the stencil, 4: no output stores) -- compile-time constants: round 3 switched them at run time, and those
+// uniform branches in the batch loop are exactly what makes the compiler serialise the loads (the harness
+// read 80 us for the 55 us kernel).  In the library the condition is the constant false.
 #ifdef DM_ROI_ABLATE
-#define DM_ABL(a, bit) (((a).abl & (bit)) != 0)
+#define DM_ABL(a, bit) (((DM_ROI_ABLATE) & (bit)) != 0)
 #else
 #define DM_ABL(a, bit) false
 #endif
@@ -1491,7 +1493,7 @@ __device__ __forceinline__ void roi_pipe_fwd(const RoiArgs& a, const float* __re
     const int gx = min(tg.fx0 + x, tg.xmax);
     voff[i] = (unsigned)(__mul24(q * 4, (int)plane) + __mul24(gy, Wl) + gx) * 4u;       // bytes; H * W <= 2^23 (launcher)
 #ifdef DM_ROI_STAMPS
-    if (a.abl & 1) voff[i] = (unsigned)(__mul24(q * 4, (int)plane) + idx) * 4u;      // timing only: contiguous 256 B per wave-instruction
+    if (DM_ABL(a, 1)) voff[i] = (unsigned)(__mul24(q * 4, (int)plane) + idx) * 4u;      // timing only: contiguous 256 B per wave-instruction
 #endif
   }
   float pf[IPT][4];
@@ -1606,7 +1608,7 @@ __device__ __forceinline__ void roi_pipe_fwd(const RoiArgs& a, const float* __re
   auto sample = [&](int nq) {
     if (!active) return;
 #ifdef DM_ROI_STAMPS
-    if (a.abl & 4) {      // timing only: one tap
+    if (DM_ABL(a, 4)) {      // timing only: one tap
       for (int j = 0; j < kPipeMaxQ; ++j) res[j] = lds[__mul24(min(qs + j * QS, nq - 1), plane_px) + base];
       return;
     }
@@ -1654,7 +1656,7 @@ __device__ __forceinline__ void roi_pipe_fwd(const RoiArgs& a, const float* __re
   auto store = [&](int cb, int nq) {
     if (!active) return;
 #ifdef DM_ROI_STAMPS
-    if ((a.abl & 2) && res[0].x != 12345.678f) return;      // timing only: no output stores
+    if (DM_ABL(a, 2) && res[0].x != 12345.678f) return;      // timing only: no output stores
 #endif
     char* const ob = reinterpret_cast<char*>(a.out + ((size_t)k * a.C + cb) * PP);
     const unsigned ot = (unsigned)bin << 2;

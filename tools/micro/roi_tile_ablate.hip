@@ -1,14 +1,16 @@
 // Ceiling measurement of the 14x14 multi-level RoIAlign kernel (reproducible evidence).
-// Compiles the LIBRARY's roi_align.hip with DM_ROI_ABLATE, so the kernel timed here is the product kernel plus three
-// run-time switches (DM_ABL in roi_align.hip): bit 1 = no global loads (the staging commits register garbage), bit 2 =
-// one LDS tap per output instead of the merged stencil, bit 4 = no output stores.  Workload = bench.py's: FPN maps of a
+// Compiles the LIBRARY's roi_align.hip with -DDM_ROI_ABLATE=<variant>, ONE BINARY PER VARIANT (tools/roi_ceiling.sh builds
+// eight): the ablation bits are compile-time constants (DM_ABL in roi_align.hip), variant 0 is the product kernel
+// instruction for instruction.  Bit 1 = no global loads (the staging commits register garbage), bit 2 = one LDS tap per
+// output instead of the merged stencil, bit 4 = no output stores.  Workload = bench.py's: FPN maps of a
 // 1333x800 image (P2..P5, 256 channels, random), the 512 RoIs of synth.make_rois(seed=1) (rois_512_1333x800.txt).
 //
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Idynamask_amd/csrc tools/micro/roi_tile_ablate.hip -o gpurun_out/roi_tile_ablate
-//   gpurun_out/roi_tile_ablate tools/micro/rois_512_1333x800.txt            # all variants, 14x14
-//   ROI_ABL_ONLY=3 gpurun_out/roi_tile_ablate ...                            # one variant (for rocprofv3 --pmc passes)
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Idynamask_amd/csrc -DDM_ROI_ABLATE=3 tools/micro/roi_tile_ablate.hip -o gpurun_out/roi_tile_ablate_3
+//   gpurun_out/roi_tile_ablate_3 tools/micro/rois_512_1333x800.txt          # that variant, 14x14
 //   ROI_P=7 ...                                                              # the 7x7 bbox extraction
-#define DM_ROI_ABLATE 1
+#ifndef DM_ROI_ABLATE
+#define DM_ROI_ABLATE 0
+#endif
 #include "../../dynamask_amd/csrc/roi_align.hip"
 
 #include <cstdio>
@@ -81,15 +83,12 @@ int main(int argc, char** argv) {
          map_bytes / 1e6, foot / 1e6, alg / 1e6);
   const char* names[8] = {"full kernel", "no global loads", "one tap (no stencil)", "no loads, one tap", "no stores",
                           "no loads, no stores", "one tap, no stores", "no loads, one tap, no stores"};
-  const int only = getenv("ROI_ABL_ONLY") ? atoi(getenv("ROI_ABL_ONLY")) : -1;
   const int reps = getenv("ROI_REPS") ? atoi(getenv("ROI_REPS")) : 50;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  double full_us = 0;
-  for (int v = 0; v < 8; ++v) {
-    if (only >= 0 && v != only) continue;
-    setenv("DM_ROI_ABL", std::to_string(v).c_str(), 1);
+  {
+    const int v = DM_ROI_ABLATE;
     for (int i = 0; i < 5; ++i) dm_roi_align_fwd(feats, H, W, scales, 4, B, C, d_rois, N, P, 0, 56.f, d_out, nullptr, nullptr);
     CK(hipDeviceSynchronize());
     float best = 1e30f, sum = 0;
@@ -104,10 +103,8 @@ int main(int argc, char** argv) {
       sum += ms / reps;
     }
     const double us = best * 1e3;
-    if (v == 0) full_us = us;
     printf("abl=%d  %-30s  %7.1f us (best of 5 x %d back-to-back launches; mean %.1f)  %6.2f TB/s algorithmic%s\n", v, names[v], us,
            reps, sum / 5 * 1e3, alg / us / 1e6, v ? "" : "  <- the product kernel");
-    if (v && full_us > 0) printf("        saves %.1f us of %.1f\n", full_us - us, full_us);
   }
   return 0;
 }
