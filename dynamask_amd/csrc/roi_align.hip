@@ -411,7 +411,9 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiArgs a) {
 // setup 0.8 us, staging round trip ~1.8 us under load, 0.7 us of sampling per batch; PMC:
 // VALU 35 % / LDS 25 % busy, L2 hit rate of the staging reads ~32 % (174 MB leave the L2
 // per launch for 91 MB of maps: short unaligned row segments over-fetch 64-byte sectors).
-constexpr int kTileFloats4 = 2048;   // float4 words of the staging buffer (32 KB): 4 workgroups share a CU   // float4 words of LDS per workgroup (48 KB = 2 buffers of 1536 pixel-quads): 3 workgroups per CU
+constexpr int kTileFloats4 = 2048;   // float4 words of the staging buffer (32 KB): 4 workgroups share a CU (round 4 tried 1920
+                                     // words + __launch_bounds__(256, 5), 96 VGPRs: FIVE per CU measured 57.0 vs 55.6 us at 512 RoIs,
+                                     // 22.2 vs 20.7 at 129 -- the launch is bound by its fabric traffic, 261 MB at the copy rate)   // float4 words of LDS per workgroup (48 KB = 2 buffers of 1536 pixel-quads): 3 workgroups per CU
 
 struct TileGeom {
   int fy0, fx0, FH, pitch;   // tile origin (feature pixel), rows, columns
