@@ -4,7 +4,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DYNAMASK_HIP_LIB') or os.path.join(_HERE, 'libdynamask_hip.so')      # override: kernel experiments
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -26,6 +26,8 @@ SIGNATURES = {
     'dm_conv_pack_weight_split': ([_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp, _vp], _c_int),
     'dm_conv_pack_weight_batch': ([_vp, _c_int, _vp], _c_int),
     'dm_conv2d_fwd': ([_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp], _c_int),
+    'dm_conv2d_fwd_ws': ([_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp, ctypes.c_longlong, _vp], _c_int),
+    'dm_conv2d_splitk_floats': ([_c_int, _c_int, _c_int, _c_int, _c_int], ctypes.c_longlong),
     'dm_conv2d_fwd_masked': ([_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _vp], _c_int),
     'dm_point_sample_fwd': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_float, _vp, _vp], _c_int),
     'dm_class_logits_fwd': ([_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp], _c_int),

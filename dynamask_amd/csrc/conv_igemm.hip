@@ -50,6 +50,12 @@ struct ConvArgs {
   int shuffle;    // deconv 2x2/s2 epilogue: packed cout = phase*shuffle + co, stored at (2y+dy, 2x+dx)
   const float* mask = nullptr;   // same layout as out: outputs whose mask value is not > 0 are stored as 0 (a ReLU adjoint)
   int off32 = 0;     // every source spans < 4 GB: a pixel's offset inside a source fits 32 bits (the 1x1 builds' branch-free staging)
+  // split-K (round 4; launches of few workgroups -- the <= 100-RoI inference calls): blockIdx.y = split, which walks
+  // kchunks chunks of the K loop from chunk split * kchunks and stores its bare sums to ws + split * ws_stride
+  // ([NB][Cout][HW]); conv_splitk_reduce_kernel adds the splits in index order and applies bias / accumulate / ReLU / mask
+  float* ws = nullptr;
+  long long ws_floats = 0, ws_stride = 0;
+  int ksplit = 1, kchunks = 0;
 };
 
 // CK input channels per chunk (multiple of 8); MAXPOS = plane positions per thread (3x3)
@@ -148,6 +154,19 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
   const int q0 = a.q_begin + n_tile * TN;
   const int HW = a.HW, W = a.W, H = a.H;
   const int plane = a.plane;
+  int k_skip = 0, k_left = 0x7fffffff;         // split-K: chunks to pass over, chunks to walk
+  // the epilogue's destination and modes (locals: writing to the argument struct would copy all of it to scratch)
+  float* e_out = a.out;
+  const float* e_bias = a.bias;
+  const float* e_mask = a.mask;
+  int e_relu = a.relu, e_oct = a.out_ch_total, e_oco = a.out_ch_offset;
+  if (a.ksplit > 1) {
+    const int sp = blockIdx.y;
+    e_out = a.ws + (size_t)sp * a.ws_stride;
+    e_bias = nullptr; e_mask = nullptr; e_relu = 0;
+    e_oct = a.Cout; e_oco = 0;
+    k_skip = sp * a.kchunks; k_left = a.kchunks;
+  }
 
   // ---- tile geometry (uniform) -------------------------------------------
   const int qlast = min(q0 + TN, a.Q) - 1;
@@ -237,7 +256,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
   int cs = 0, cc0 = 0, ckq = 0;   // current source, channel offset in it, global quad index of the chunk
   int curC = a.src_c[0];          // channels of the current source (kept in a register: a.src_c[cs] is a scalar load from the
                                   // argument block, and its s_waitcnt lgkmcnt(0) in the K loop also waits for the LDS)
-  auto chunk_valid = [&]() { return cs < a.num_srcs; };
+  auto chunk_valid = [&]() { return cs < a.num_srcs && k_left > 0; };
   auto chunk_advance = [&]() {
     const int ckv = min(CK, curC - cc0);
     ckq += SPLIT ? NWC : ((ckv + 7) / 8) * 2;      // (SPLIT: every source is padded to whole 16-channel chunks)
@@ -412,6 +431,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
     }
   };
 
+  for (; k_skip > 0 && cs < a.num_srcs; --k_skip) chunk_advance();      // (split-K: this split's first chunk)
   if (chunk_valid()) prefetch();
   while (chunk_valid()) {
     const int ckv_cur = min(CK, curC - cc0);
@@ -419,6 +439,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
     commit();
     __syncthreads();
     chunk_advance();
+    --k_left;
     if (chunk_valid()) prefetch();
 
     // ---- MFMA over the committed chunk ---------------------------------------
@@ -513,10 +534,10 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
     float* pj[WN];
 #pragma unroll
     for (int j = 0; j < WN; ++j)
-      pj[j] = a.out + ((size_t)col_n[j] * a.out_ch_total + a.out_ch_offset) * HW + col_p[j];
+      pj[j] = e_out + ((size_t)col_n[j] * e_oct + e_oco) * HW + col_p[j];
     const int co_lane = m0 + wave_m * WM * 32 + 4 * hi;
     const size_t off_lane = (size_t)co_lane * HW;
-    const bool relu = a.relu & 1;
+    const bool relu = e_relu & 1;
     // all bias values first: a load inside the store loop puts an s_waitcnt vmcnt(0) -- which also
     // waits for the stores issued so far -- in front of every output row
     float bias_r[WM][16];
@@ -524,11 +545,11 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
     for (int i = 0; i < WM; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) bias_r[i][r] = 0.f;
-    if (a.bias) {
+    if (e_bias) {
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bias_r[i][r] = a.bias[min(co_lane + i * 32 + (r & 3) + 8 * (r >> 2), a.Cout - 1)];
+        for (int r = 0; r < 16; ++r) bias_r[i][r] = e_bias[min(co_lane + i * 32 + (r & 3) + 8 * (r >> 2), a.Cout - 1)];
       // land them all here: otherwise the compiler waits for each value at its use, with counts that
       // include the stores issued meanwhile
 #pragma unroll
@@ -536,7 +557,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
 #pragma unroll
         for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(bias_r[i][r]));
     }
-    const ptrdiff_t mask_off = a.mask ? a.mask - a.out : 0;
+    const ptrdiff_t mask_off = e_mask ? e_mask - e_out : 0;
     // full: the workgroup's tile lies inside the output (every cout row and every pixel column exists) -- uniform, and then
     // no store is predicated: the row and column tests cost an exec-mask sequence each, 600 scalar instructions per wave in
     // front of the 64 stores of a K = 64 GEMM (SQ counters: 4.8 SALU per MFMA on 64 -> 576 @56^2)
@@ -570,17 +591,17 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
     using T = std::true_type;
     using F = std::false_type;
     if (KS == 1 && full) {
-      if (a.mask) {
-        if (a.relu & 2) store_all(T{}, F{}, T{}, T{});
+      if (e_mask) {
+        if (e_relu & 2) store_all(T{}, F{}, T{}, T{});
         else store_all(F{}, F{}, T{}, T{});
-      } else if (a.relu & 2) store_all(T{}, F{}, F{}, T{});
-      else if (a.relu & 4) store_all(F{}, T{}, F{}, T{});
+      } else if (e_relu & 2) store_all(T{}, F{}, F{}, T{});
+      else if (e_relu & 4) store_all(F{}, T{}, F{}, T{});
       else store_all(F{}, F{}, F{}, T{});
-    } else if (a.mask) {
-      if (a.relu & 2) store_all(T{}, F{}, T{}, F{});
+    } else if (e_mask) {
+      if (e_relu & 2) store_all(T{}, F{}, T{}, F{});
       else store_all(F{}, F{}, T{}, F{});
-    } else if (a.relu & 2) store_all(T{}, F{}, F{}, F{});
-    else if (a.relu & 4) store_all(F{}, T{}, F{}, F{});
+    } else if (e_relu & 2) store_all(T{}, F{}, F{}, F{});
+    else if (e_relu & 4) store_all(F{}, T{}, F{}, F{});
     else store_all(F{}, F{}, F{}, F{});
   } else {
     // deconv 2x2/s2: packed cout = phase * shuffle + oc, stored at (2y+dy, 2x+dx)
@@ -599,13 +620,13 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
           const int phase = co / a.shuffle;
           const int oc = co - phase * a.shuffle;
           const int dy = phase >> 1, dx = phase & 1;
-          const float b = a.bias ? a.bias[oc] : 0.f;
+          const float b = e_bias ? e_bias[oc] : 0.f;
 #pragma unroll
           for (int j = 0; j < WN; ++j) {
             if (col_ok[j]) {
               float v = acc[i][j][r] + b;
-              if (a.relu & 1) v = fmaxf(v, 0.f);
-              a.out[(((size_t)col_n[j] * a.shuffle + oc) * (2 * H) + 2 * sy[j] + dy) * (2 * W) + 2 * sx[j] + dx] = v;
+              if (e_relu & 1) v = fmaxf(v, 0.f);
+              e_out[(((size_t)col_n[j] * a.shuffle + oc) * (2 * H) + 2 * sy[j] + dy) * (2 * W) + 2 * sx[j] + dx] = v;
             }
           }
         }
@@ -621,11 +642,11 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
         float v = acct[j][i] + __shfl_xor(acct[j][i], 32, 64);
         const int co = m0 + TM + i;
         if (hi == 0 && co < a.Cout && col_ok[j]) {
-          if (a.bias) v += a.bias[co];
-          float* op = a.out + ((size_t)col_n[j] * a.out_ch_total + a.out_ch_offset + co) * HW + col_p[j];
-          if (a.relu & 2) v += *op;
-          if (a.relu & 1) v = fmaxf(v, 0.f);
-          if (a.mask && !(a.mask[op - a.out] > 0.f)) v = 0.f;
+          if (e_bias) v += e_bias[co];
+          float* op = e_out + ((size_t)col_n[j] * e_oct + e_oco + co) * HW + col_p[j];
+          if (e_relu & 2) v += *op;
+          if (e_relu & 1) v = fmaxf(v, 0.f);
+          if (e_mask && !(e_mask[op - e_out] > 0.f)) v = 0.f;
           *op = v;
         }
       }
@@ -762,6 +783,28 @@ int packed_words_split(int nsrc, const int* src_c, int parts) {
   return kq;
 }
 
+// out = epilogue(sum over the splits, in index order): the conv kernel's own epilogue arithmetic (bias, accumulate, ReLU,
+// mask -- in that order) on the bare sums of a split-K launch.  ws: [splits][NB][Cout][HW]; out / mask: [NB][out_ch_total][HW].
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __restrict__ ws, int splits, long long stride, int NB,
+                                                                int Cout, int HW, const float* __restrict__ bias, int flags,
+                                                                float* __restrict__ out, int out_ch_total, int out_ch_offset,
+                                                                const float* __restrict__ mask) {
+  const long long total = (long long)NB * Cout * HW;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long nc = e / HW;
+    const int p = (int)(e - nc * HW);
+    const int n = (int)(nc / Cout), co = (int)(nc - (long long)n * Cout);
+    float v = ws[e];
+    for (int s = 1; s < splits; ++s) v += ws[(size_t)s * stride + e];
+    if (bias) v += bias[co];
+    const size_t o = ((size_t)n * out_ch_total + out_ch_offset + co) * HW + p;
+    if (flags & 2) v += out[o];
+    if (flags & 1) v = fmaxf(v, 0.f);
+    if (mask) v = (mask[o] > 0.f) ? v : 0.f;
+    out[o] = v;
+  }
+}
+
 template <int KS, int WGM, int WGN, int WM, int WN, int CK, int MAXPOS, int TAIL = 0, int SPLIT = 0>
 int launch_conv_mp(ConvArgs& a, hipStream_t st) {
   constexpr int TM = WGM * WM * 32;
@@ -777,6 +820,35 @@ int launch_conv_mp(ConvArgs& a, hipStream_t st) {
     const int rc = dm_ensure_lds_limit(reinterpret_cast<const void*>(&conv_igemm_kernel<KS, WGM, WGN, WM, WN, CK, MAXPOS, TAIL, SPLIT>),
                                        128 * 1024, raised);
     if (rc != DM_OK) return rc;
+  }
+  // ---- split-K for launches that leave most of the chip idle (a caller-provided workspace, one launch per call)
+  a.ksplit = 1;
+  if (a.ws && a.shuffle == 0 && a.q_begin == 0) {
+    constexpr int CKS = SPLIT ? 16 : CK;
+    int chunks = 0;
+    for (int s_ = 0; s_ < a.num_srcs; ++s_) chunks += dm_ceil_div(a.src_c[s_], CKS);
+    const int wgs = a.MT * NTiles, cus = dm_num_cus();
+    const long long per = (long long)a.NB * a.Cout * a.HW;
+    int S = min(min(8, (3 * cus) / max(wgs, 1)), chunks / 4);
+    if (per > 0) S = (int)min((long long)S, a.ws_floats / per);
+    if (S >= 2) {
+      a.kchunks = dm_ceil_div(chunks, S);
+      a.ksplit = dm_ceil_div(chunks, a.kchunks);
+      a.ws_stride = per;
+    }
+  }
+  if (a.ksplit > 1) {
+    const float* bias = a.bias;
+    const float* mask = a.mask;
+    float* out = a.out;
+    const int flags = a.relu, oct = a.out_ch_total, oco = a.out_ch_offset;
+    DM_LAUNCH((conv_igemm_kernel<KS, WGM, WGN, WM, WN, CK, MAXPOS, TAIL, SPLIT>), dim3(a.MT * NTiles, a.ksplit), dim3(NT), lds_bytes, st, a);
+    int rc = dm_check_launch();
+    if (rc != DM_OK) return rc;
+    const long long total = a.ws_stride;
+    DM_LAUNCH(conv_splitk_reduce_kernel, dim3((unsigned)min((long long)4096, (total + 255) / 256)), dim3(256), 0, st, a.ws, a.ksplit,
+              a.ws_stride, a.NB, a.Cout, a.HW, bias, flags, out, oct, oco, mask);
+    return dm_check_launch();
   }
   DM_LAUNCH((conv_igemm_kernel<KS, WGM, WGN, WM, WN, CK, MAXPOS, TAIL, SPLIT>), dim3(a.MT * NTiles), dim3(NT), lds_bytes, st, a);
   return dm_check_launch();
@@ -889,7 +961,8 @@ extern "C" int dm_conv_pack_weight_batch(const dm_pack_job* jobs_device, int num
 static int conv2d_launch(const float* const* srcs, const int* src_channels, const long long* src_batch_strides,
                          int num_srcs, int NB, int H, int W,
                          const float* w_packed, const float* bias, int Cout, int ksize, int relu, float* out,
-                         int out_ch_total, int out_ch_offset, const float* mask, dm_stream_t stream);
+                         int out_ch_total, int out_ch_offset, const float* mask, dm_stream_t stream, float* ws = nullptr,
+                         long long ws_floats = 0);
 
 extern "C" int dm_conv2d_fwd(const float* const* srcs, const int* src_channels, const long long* src_batch_strides,
                              int num_srcs, int NB, int H, int W,
@@ -897,6 +970,29 @@ extern "C" int dm_conv2d_fwd(const float* const* srcs, const int* src_channels, 
                              int out_ch_total, int out_ch_offset, dm_stream_t stream) {
   return conv2d_launch(srcs, src_channels, src_batch_strides, num_srcs, NB, H, W, w_packed, bias, Cout, ksize, relu, out,
                        out_ch_total, out_ch_offset, nullptr, stream);
+}
+
+// (ABI 20) dm_conv2d_fwd with a caller-owned workspace: launches of few workgroups split their K loop over up to eight
+// workgroups per tile (bare sums to the workspace, added in split order by a second kernel: the same bits every run; they
+// differ from the unsplit sum in rounding only).  dm_conv2d_splitk_floats: the workspace that lets this shape split as far
+// as it wants to (0: the launch would not split).
+extern "C" long long dm_conv2d_splitk_floats(int NB, int H, int W, int Cout, int ksize) {
+  if (NB <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+  const long long px = (long long)NB * H * W;
+  // tiles of the smallest configuration the launcher would pick: 128 couts x 32 pixels (3x3, Cout > 64), else >= 64 x 128
+  const long long wgs = (ksize == 3 && Cout > 64) ? dm_ceil_div(Cout, 128) * dm_ceil_div(px, 32)
+                                                   : dm_ceil_div(Cout, 128) * dm_ceil_div(px, 128);
+  if (wgs * 2 > 3LL * dm_num_cus()) return 0;
+  return 8LL * NB * Cout * H * W;
+}
+
+extern "C" int dm_conv2d_fwd_ws(const float* const* srcs, const int* src_channels, const long long* src_batch_strides,
+                                int num_srcs, int NB, int H, int W,
+                                const float* w_packed, const float* bias, int Cout, int ksize, int relu, float* out,
+                                int out_ch_total, int out_ch_offset, float* workspace, long long workspace_floats,
+                                dm_stream_t stream) {
+  return conv2d_launch(srcs, src_channels, src_batch_strides, num_srcs, NB, H, W, w_packed, bias, Cout, ksize, relu, out,
+                       out_ch_total, out_ch_offset, nullptr, stream, workspace, workspace_floats);
 }
 
 extern "C" int dm_conv2d_fwd_masked(const float* const* srcs, const int* src_channels, const long long* src_batch_strides,
@@ -911,7 +1007,8 @@ extern "C" int dm_conv2d_fwd_masked(const float* const* srcs, const int* src_cha
 static int conv2d_launch(const float* const* srcs, const int* src_channels, const long long* src_batch_strides,
                          int num_srcs, int NB, int H, int W,
                          const float* w_packed, const float* bias, int Cout, int ksize, int relu, float* out,
-                         int out_ch_total, int out_ch_offset, const float* mask, dm_stream_t stream) {
+                         int out_ch_total, int out_ch_offset, const float* mask, dm_stream_t stream, float* ws,
+                         long long ws_floats) {
   if (!srcs || !src_channels || num_srcs < 1 || num_srcs > DM_MAX_SOURCES || !w_packed || !out) return DM_ERR_INVALID_ARG;
   if (NB < 0 || H <= 0 || W <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3)) return DM_ERR_INVALID_ARG;
   if (out_ch_offset < 0 || out_ch_offset + Cout > out_ch_total) return DM_ERR_INVALID_ARG;
@@ -938,6 +1035,8 @@ static int conv2d_launch(const float* const* srcs, const int* src_channels, cons
   a.shuffle = 0;
   a.q_begin = 0;
   a.mask = mask;
+  a.ws = (ws && ws_floats > 0) ? ws : nullptr;
+  a.ws_floats = ws_floats;
   a.off32 = 1;
   for (int s = 0; s < num_srcs; ++s)
     if ((long long)NB * a.src_bs[s] * 4 >= (1LL << 32)) a.off32 = 0;

@@ -505,6 +505,25 @@ class overlapped_streams:
         _overlapped -= 1
 
 
+# DM_CONV_SPLITK=0: no split-K for small inference launches (the sums of one launch, in one order, whatever the RoI count)
+CONV_SPLITK = [os.environ.get('DM_CONV_SPLITK', '1') == '1']
+_SPLITK_DEPTH = [0]
+
+
+class splitk_scope:
+    """Inside this scope ``conv2d`` may split the K loop of a launch that would leave most of the chip idle
+    (dm_conv2d_fwd_ws): entered by the inference entry points of the RoI head only -- a training forward keeps one
+    association of its sums whatever the RoI count (its golden tests pin gradients behind ReLU kinks and pool ties)."""
+
+    def __enter__(self):
+        _SPLITK_DEPTH[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _SPLITK_DEPTH[0] -= 1
+        return False
+
+
 def conv2d(srcs, w_packed, bias, cout, ksize, relu=False, out=None, out_ch_offset=0, accumulate=False, mask=None):
     """Fused concat(srcs) -> conv(ksize, same) -> +bias -> ReLU.  ``mask`` (same shape as ``out``): outputs where it
     is not > 0 are stored as 0 -- the ReLU adjoint of a data gradient, fused into the epilogue."""
@@ -535,6 +554,16 @@ def conv2d(srcs, w_packed, bias, cout, ksize, relu=False, out=None, out_ch_offse
                                         _p(mask), _stream())
         check(rc, 'dm_conv2d_fwd_masked')
         return out
+    if CONV_SPLITK[0] and _SPLITK_DEPTH[0] > 0 and not accumulate:
+        # the <= 100-RoI inference calls: a launch of few workgroups splits its K loop (dm_conv2d_fwd_ws)
+        nws = int(lib().dm_conv2d_splitk_floats(NB, H, W, cout, ksize))
+        if nws > 0:
+            ws = torch.empty((nws,), device=out.device, dtype=torch.float32)
+            rc = lib().dm_conv2d_fwd_ws(_ptr_array(srcs), _int_array([s.shape[1] for s in srcs]), strides, len(srcs), NB, H, W,
+                                        _p(w_packed), _p(bias), cout, ksize, flags, _p(out), out.shape[1], out_ch_offset,
+                                        _p(ws), nws, _stream())
+            check(rc, 'dm_conv2d_fwd_ws')
+            return out
     rc = lib().dm_conv2d_fwd(_ptr_array(srcs), _int_array([s.shape[1] for s in srcs]), strides, len(srcs), NB, H, W,
                              _p(w_packed), _p(bias), cout, ksize, flags, _p(out), out.shape[1], out_ch_offset, _stream())
     check(rc, 'dm_conv2d_fwd')

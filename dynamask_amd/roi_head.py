@@ -175,6 +175,10 @@ class DynaMaskRoIHead(nn.Module):
             ins_feats = train_path.roi_extract_train(self.mask_roi_extractor, x, rois)
             ips, dps = train_path.mask_head_forward_train(self.mask_head, ins_feats, x, rois, roi_labels, between=_between)
             return dict(stage_instance_preds=ips, stage_detail_preds=dps)
+        with ops.splitk_scope():           # inference: launches of few workgroups may split their K loop
+            return self._mask_forward_infer(x, rois, roi_labels, last_stage)
+
+    def _mask_forward_infer(self, x, rois, roi_labels, last_stage=None):
         n = rois.shape[0]
         n_streams = self.num_streams if n >= self.stream_split_min else 1
         if n_streams <= 1:

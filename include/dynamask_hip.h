@@ -57,7 +57,7 @@ extern "C" {
 typedef void* dm_stream_t; /* hipStream_t */
 
 const char* dm_error_string(int code);
-/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient, dm_conv_pack_weight_batch, dm_mask_loss_stage; 15: dm_class_logits_up2x_fwd; 16: dm_conv2d_wgrad_slab / dm_conv2d_wgrad_scratch_floats; 17: dm_class_logits_bwd_slab / dm_class_logits_bwd_scratch_floats; 18: dm_reload_env_knobs, dm_roi_align_fwd_ws / dm_roi_align_workspace_bytes, dm_conv_pack_weight_split / dm_conv_packed_floats_split and flag bits 4, 5 of dm_conv2d_fwd). */
+/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient, dm_conv_pack_weight_batch, dm_mask_loss_stage; 15: dm_class_logits_up2x_fwd; 16: dm_conv2d_wgrad_slab / dm_conv2d_wgrad_scratch_floats; 17: dm_class_logits_bwd_slab / dm_class_logits_bwd_scratch_floats; 18: dm_reload_env_knobs, dm_roi_align_fwd_ws / dm_roi_align_workspace_bytes, dm_conv_pack_weight_split / dm_conv_packed_floats_split and flag bits 4, 5 of dm_conv2d_fwd; 19: dm_dcn_bwd_data_fused and its pack; 20: dm_conv2d_fwd_ws / dm_conv2d_splitk_floats). */
 int dm_abi_version(void);
 /* Re-read the DM_ROI_* experiment knobs from the environment (they are otherwise read once, at the first launch, and
  * clamped to validated ranges).  For measurement tools that sweep settings inside one process; no knob changes a result. */
@@ -166,6 +166,18 @@ int dm_conv2d_fwd(const float* const* srcs, const int* src_channels, const long 
                   int num_srcs, int NB, int H, int W,
                   const float* w_packed, const float* bias, int Cout, int ksize, int relu, float* out,
                   int out_ch_total, int out_ch_offset, dm_stream_t stream);
+/* (ABI 20) dm_conv2d_fwd with a caller-owned workspace, for the calls of real inference (the reference runs the head on at
+ * most 100 RoIs, dynamask_roi_head.py:132-135): a launch that would leave most of the chip idle splits its K loop over up
+ * to eight workgroups per tile; the splits store bare sums to the workspace ([split][NB][Cout][HW]) and a second kernel
+ * adds them in split order and applies bias / accumulate / ReLU.  The same bits every run; they differ from dm_conv2d_fwd's
+ * in rounding only (another association of the same products).  dm_conv2d_splitk_floats: the workspace with which this
+ * shape splits as far as it wants to, 0 when it would not split (then call dm_conv2d_fwd). */
+long long dm_conv2d_splitk_floats(int NB, int H, int W, int Cout, int ksize);
+int dm_conv2d_fwd_ws(const float* const* srcs, const int* src_channels, const long long* src_batch_strides,
+                     int num_srcs, int NB, int H, int W, const float* w_packed, const float* bias, int Cout, int ksize,
+                     int relu, float* out, int out_ch_total, int out_ch_offset, float* workspace,
+                     long long workspace_floats, dm_stream_t stream);
+
 /* dm_conv2d_fwd whose epilogue also applies a ReLU adjoint: outputs where `mask` (same layout, channel count and
  * channel offset as `out`) is not > 0 are stored as 0.  Used for data gradients: the mask is the activation the
  * gradient flows into, so the separate mask pass (read gradient + activation, write gradient) disappears. */

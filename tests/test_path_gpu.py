@@ -311,9 +311,50 @@ def _dyn_case(seed=3, n=37):
     return feats, rois, labels, exits
 
 
-def test_dynamic_exit_rows_are_bit_identical_to_the_fixed_path():
+@pytest.fixture
+def no_splitk():
+    """Launches of few workgroups split their K loop in the inference entry points (dm_conv2d_fwd_ws): another
+    association of the same products per RoI COUNT.  Tests of bitwise row identity across RoI counts switch it off."""
+    from dynamask_amd import ops
+    was = ops.CONV_SPLITK[0]
+    ops.CONV_SPLITK[0] = False
+    yield
+    ops.CONV_SPLITK[0] = was
+
+
+def test_small_inference_calls_split_k_and_stay_within_rounding_of_the_unsplit_sums():
+    """dm_conv2d_fwd_ws: at the detection counts of real inference the 14 x 14 convolutions are a few
+    workgroups walking K = 2304 alone; with split-K the same call must give the unsplit logits up to the rounding of
+    another association (1e-5 of the logit scale), the same bits on every run, and the oracle's within 1e-4."""
+    from dynamask_amd import ops
+    feats, rois, labels, _ = _dyn_case(seed=21, n=9)
+    m = _roi_head()
+    m.num_streams = 1
+    fd = [_dev(f) for f in feats]
+    assert ops.CONV_SPLITK[0]
+    with torch.no_grad():
+        a = m._mask_forward(fd, _dev(rois), _dev(labels))['stage_instance_preds']
+        b = m._mask_forward(fd, _dev(rois), _dev(labels))['stage_instance_preds']
+        ops.CONV_SPLITK[0] = False
+        try:
+            c = m._mask_forward(fd, _dev(rois), _dev(labels))['stage_instance_preds']
+        finally:
+            ops.CONV_SPLITK[0] = True
+        sd = {**gi.head_state(), **gi.mask_pre_state()}
+        ips, _ = ref_model.mask_forward(sd, feats, rois, labels)
+    differs = False
+    for k in range(4):
+        assert torch.equal(a[k], b[k])
+        scale = float(c[k].abs().max())
+        assert float((a[k] - c[k]).abs().max()) <= 1e-5 * max(scale, 1.0), k
+        differs = differs or not torch.equal(a[k], c[k])
+        _close(a[k], ips[k])
+    assert differs, 'nine RoIs did not split any launch: the test exercises nothing'
+
+
+def test_dynamic_exit_rows_are_bit_identical_to_the_fixed_path(no_splitk):
     """RoIs never interact inside the head: RoI j leaving at exit e must carry exactly the
-    logits the all-exits path computes for it at e (bitwise)."""
+    logits the all-exits path computes for it at e (bitwise; split-K off: see ``no_splitk``)."""
     feats, rois, labels, exits = _dyn_case()
     m = _roi_head()
     m.num_streams = 1
@@ -633,9 +674,10 @@ def test_polygon_mask_targets_other_sizes(size):
     assert 0.05 < ref.mean() < 0.95
 
 
-def test_bucketed_inference_graphs_replay_the_eager_launch_sequence():
+def test_bucketed_inference_graphs_replay_the_eager_launch_sequence(no_splitk):
     """DynaMaskRoIHead.enable_inference_graphs(): simple_test_mask_logits through a HIP graph per bucket of detection
-    counts (16 / 32 / 64 / 100, padded with empty boxes) gives the bits of the eager call, captures once per bucket
+    counts (16 / 32 / 64 / 100, padded with empty boxes) gives the bits of the eager call (with split-K off: a bucket
+    pads the RoI count, and the split of a launch depends on it -- ``no_splitk``), captures once per bucket
     and map storage, follows a parameter update, and leaves counts above the largest bucket to the eager path."""
     from dynamask_amd import ops, synth
     m = _roi_head().eval()
