@@ -56,6 +56,7 @@ struct ConvArgs {
   float* ws = nullptr;
   long long ws_floats = 0, ws_stride = 0;
   int ksplit = 1, kchunks = 0;
+  int want_split = 0;        // host side: the launcher's choice of splits for this launch (0: launch_conv_mp decides)
 };
 
 // CK input channels per chunk (multiple of 8); MAXPOS = plane positions per thread (3x3)
@@ -829,7 +830,7 @@ int launch_conv_mp(ConvArgs& a, hipStream_t st) {
     for (int s_ = 0; s_ < a.num_srcs; ++s_) chunks += dm_ceil_div(a.src_c[s_], CKS);
     const int wgs = a.MT * NTiles, cus = dm_num_cus();
     const long long per = (long long)a.NB * a.Cout * a.HW;
-    int S = min(min(8, (3 * cus) / max(wgs, 1)), chunks / 4);
+    int S = a.want_split > 0 ? min(a.want_split, chunks / 4) : min(min(8, (3 * cus) / max(wgs, 1)), chunks / 4);
     if (per > 0) S = (int)min((long long)S, a.ws_floats / per);
     if (S >= 2) {
       a.kchunks = dm_ceil_div(chunks, S);
@@ -980,8 +981,13 @@ extern "C" long long dm_conv2d_splitk_floats(int NB, int H, int W, int Cout, int
   if (NB <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
   const long long px = (long long)NB * H * W;
   // tiles of the smallest configuration the launcher would pick: 128 couts x 32 pixels (3x3, Cout > 64), else >= 64 x 128
-  const long long wgs = (ksize == 3 && Cout > 64) ? dm_ceil_div(Cout, 128) * dm_ceil_div(px, 32)
-                                                   : dm_ceil_div(Cout, 128) * dm_ceil_div(px, 128);
+  const long long wgs = (long long)dm_ceil_div(Cout, 128) * dm_ceil_div(px, 128);
+  if (ksize == 3 && Cout > 64) {
+    // 128 x 128 tiles, two or three workgroups per CU: split while the tiles do not fill half a round of slots
+    const long long slots = 3LL * dm_num_cus();
+    if (wgs * 2 > slots) return 0;
+    return min(8LL, slots / wgs) * NB * Cout * H * W;
+  }
   if (wgs * 2 > 3LL * dm_num_cus()) return 0;
   return 8LL * NB * Cout * H * W;
 }
@@ -1079,6 +1085,16 @@ static int conv2d_launch(const float* const* srcs, const int* src_channels, cons
       // tile-per-CU (16 RoIs of 14 x 14: 0.175 -> 0.077 ms, 100 RoIs: 0.322 -> 0.275 ms).
       {
         const int wgs = MT * NTiles, cus = dm_num_cus();
+        // with a workspace: the 128 x 128 tiles (the efficient build) and as many K splits as fill ONE round of slots
+        // (100 RoIs of 14 x 14: 306 tiles x 2 splits on 768 slots; the 128 x 32 tiles without a split: 0.233 ms)
+        if (a.ws && wgs < slots) {
+          const long long per = (long long)NB * Cout * H * W;
+          const int S = (int)min((long long)min(8, slots / wgs), per > 0 ? a.ws_floats / per : 0LL);
+          if (S >= 2) {
+            a.want_split = S;
+            return launch_conv<3, 2, 2, 2, 2, 8>(a, st);
+          }
+        }
         if (tail_mode && (wgs * 10 <= cus * 7 || (wgs > cus && wgs * 20 <= cus * 29))) return launch_conv<3, 4, 1, 1, 1, 8>(a, st);
       }
       if (tail_mode && !(relu & 8) && full_rounds >= 1 && rem > 0 && rem * 5 <= 3 * slots) {
