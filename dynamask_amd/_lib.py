@@ -4,7 +4,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DYNAMASK_HIP_LIB') or os.path.join(_HERE, 'libdynamask_hip.so')      # override: kernel experiments
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -33,6 +33,8 @@ SIGNATURES = {
     'dm_class_logits_fwd': ([_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp], _c_int),
     'dm_class_logits_up2x_fwd': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp], _c_int),
     'dm_deform_conv_fwd': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _vp, _vp], _c_int),
+    'dm_deform_conv_fwd_ws': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _vp, _vp, ctypes.c_longlong, _vp], _c_int),
+    'dm_deform_conv_splitk_floats': ([_c_int, _c_int, _c_int, _c_int, _c_int], ctypes.c_longlong),
     'dm_upsample2x_bilinear_fwd': ([_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp], _c_int),
     'dm_boundary_merge': ([_vp, _vp, _c_int, _c_int, _vp], _c_int),
     'dm_deconv_pack_weight': ([_vp, _c_int, _c_int, _vp, _vp], _c_int),

@@ -830,8 +830,22 @@ int launch_conv_mp(ConvArgs& a, hipStream_t st) {
     for (int s_ = 0; s_ < a.num_srcs; ++s_) chunks += dm_ceil_div(a.src_c[s_], CKS);
     const int wgs = a.MT * NTiles, cus = dm_num_cus();
     const long long per = (long long)a.NB * a.Cout * a.HW;
-    int S = a.want_split > 0 ? min(a.want_split, chunks / 4) : min(min(8, (3 * cus) / max(wgs, 1)), chunks / 4);
-    if (per > 0) S = (int)min((long long)S, a.ws_floats / per);
+    int Smax = a.want_split > 0 ? min(a.want_split, chunks / 4) : min(min(8, (3 * cus) / max(wgs, 1)), chunks / 4);
+    if (per > 0) Smax = (int)min((long long)Smax, a.ws_floats / per);
+    // worth it?  A launch of one round walks its chunks one after the other at ~2.1 us (3x3) / ~1.5 us (1x1) per chunk
+    // whatever the RoI count (tools/small_n.py: conv14 64-71 us for 32 chunks, fuse14 50 us for 33); S splits save
+    // (1 - 1/S) of that and cost a second launch (~5 us) that reads S and writes one copy of the output at ~4 TB/s.
+    // (Without this test the 1x1 convolutions of the 28 x 28 / 56 x 56 stages split too: 17.7 reduce launches of 15.7 us
+    // each per 100-detection call, more than the splits saved.)
+    int S = 1;
+    {
+      const double chain_us = chunks * (KS == 3 ? 2.1 : 1.5), out_mb = (double)per * 4e-6;
+      double best = 8.0;                               // at least 8 us of net gain
+      for (int c = 2; c <= Smax; ++c) {
+        const double g = chain_us * (1.0 - 1.0 / c) - (5.0 + (c + 1) * out_mb * 0.25);
+        if (g > best) { best = g; S = c; }
+      }
+    }
     if (S >= 2) {
       a.kchunks = dm_ceil_div(chunks, S);
       a.ksplit = dm_ceil_div(chunks, a.kchunks);

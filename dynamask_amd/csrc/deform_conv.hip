@@ -29,6 +29,11 @@ struct DcnArgs {
   int q_begin = 0;   // first flat pixel of this launch (Q is its end)
   float* out;
   int MT;
+  // split-K (round 4, the <= 100-RoI inference calls): blockIdx.y = split, which walks channels [split * kchan, + kchan)
+  // and stores bare sums to ws + split * ws_stride ([NB][Cout][HW]); dcn_splitk_reduce_kernel adds the splits in order
+  float* ws = nullptr;
+  long long ws_stride = 0, ws_floats = 0;
+  int ksplit = 1, kchan = 0;
 };
 
 // One bilinear sample from its two row pairs.  Spelled as an explicit fma chain so that every kernel
@@ -51,6 +56,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void deform_conv_kernel(DcnArgs a) {
   static_assert(NT % TN == 0, "threads must tile the pixel columns");
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  // split-K: this workgroup's channel range and destination (see DcnArgs)
+  const int kc_begin = (a.ksplit > 1) ? (int)blockIdx.y * a.kchan : 0;
+  const int kc_end = (a.ksplit > 1) ? min(a.C, kc_begin + a.kchan) : a.C;
+  float* const e_out = (a.ksplit > 1) ? a.ws + (size_t)blockIdx.y * a.ws_stride : a.out;
+  const int e_relu = (a.ksplit > 1) ? 0 : a.relu;
   dm_f32x4* ldsA = reinterpret_cast<dm_f32x4*>(lds);           // [9][2][TM]
   dm_f32x4* ldsB = reinterpret_cast<dm_f32x4*>(lds) + A_F4;    // [2][9][TN]
 
@@ -234,19 +244,19 @@ __global__ __launch_bounds__(WGM* WGN * 64) void deform_conv_kernel(DcnArgs a) {
   };
 
   // prologue: chunk 0 entirely in registers
-  cur_group = 0;
-  load_params(0);
-  prefetch_a(0);
-  issue_quad(0, 0);
+  cur_group = kc_begin / cpg;
+  load_params(cur_group);
+  prefetch_a(kc_begin);
+  issue_quad(kc_begin, 0);
 #pragma unroll
   for (int t = 0; t < MAXT; ++t) rb0[t] = combine(t);
-  issue_quad(0, 1);
+  issue_quad(kc_begin, 1);
 
-  for (int c0 = 0; c0 < a.C; c0 += CK) {
+  for (int c0 = kc_begin; c0 < kc_end; c0 += CK) {
     commit();
     __syncthreads();
     const int cn = c0 + CK;
-    const bool more = cn < a.C;
+    const bool more = cn < kc_end;
     if (more) {
       const int group = cn / cpg;    // CK divides cpg (checked on the host)
       if (group != cur_group) {
@@ -273,10 +283,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void deform_conv_kernel(DcnArgs a) {
   {
     float* pj[WN];
 #pragma unroll
-    for (int j = 0; j < WN; ++j) pj[j] = a.out + (size_t)col_n[j] * a.Cout * HW + col_p[j];
+    for (int j = 0; j < WN; ++j) pj[j] = e_out + (size_t)col_n[j] * a.Cout * HW + col_p[j];
     const int co_lane = m0 + wave_m * WM * 32 + 4 * hi;
     const size_t off_lane = (size_t)co_lane * HW;
-    const bool relu = a.relu != 0;
+    const bool relu = e_relu != 0;
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -323,6 +333,11 @@ __global__ __launch_bounds__(256, 2) void deform_conv_lds_kernel(DcnArgs a) {
   constexpr int A_PER_T = AS_F4 / NT;             // 3
   constexpr int X_PER_T = 4;                      // float4 per thread for 2 images x 8 planes (H*W <= 256)
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  // split-K: this workgroup's channel range and destination (see DcnArgs)
+  const int kc_begin = (a.ksplit > 1) ? (int)blockIdx.y * a.kchan : 0;
+  const int kc_end = (a.ksplit > 1) ? min(a.C, kc_begin + a.kchan) : a.C;
+  float* const e_out = (a.ksplit > 1) ? a.ws + (size_t)blockIdx.y * a.ws_stride : a.out;
+  const int e_relu = (a.ksplit > 1) ? 0 : a.relu;
   dm_f32x4* ldsA = reinterpret_cast<dm_f32x4*>(lds);                 // [2][AS_F4]
   dm_f32x4* ldsB = ldsA + 2 * AS_F4;                                 // [2][BS_F4]
   dm_f32x4* ldsX = ldsB + 2 * BS_F4;                                 // [2 buffers][2 image slots][2 quads][H*W] float4
@@ -512,20 +527,20 @@ __global__ __launch_bounds__(256, 2) void deform_conv_lds_kernel(DcnArgs a) {
   };
 
   // prologue: planes of chunk 0, weights and gathered pixels of step 0, loads of step 1 in flight
-  int cur_group = 0;
-  load_params(0);
-  load_x(0);
-  load_a(0, 0);
+  int cur_group = kc_begin / cpg;
+  load_params(cur_group);
+  load_x(kc_begin);
+  load_a(kc_begin, 0);
   store_x(0);
   store_a(0);
-  load_a(0, 1);
+  load_a(kc_begin, 1);
   __syncthreads();
   gather3(0, 0, 0);
   __syncthreads();
   int slot = 0;                                   // ring slot of the current step
-  for (int c0 = 0, buf = 0; c0 < a.C; c0 += 8, buf ^= 1) {
+  for (int c0 = kc_begin, buf = 0; c0 < kc_end; c0 += 8, buf ^= 1) {
     const int cn = c0 + 8;
-    const bool more = cn < a.C;
+    const bool more = cn < kc_end;
     // step 0: MFMAs of taps 0..2; fills taps 3..5
     if (more) load_x(cn);
     store_a(slot ^ 1);
@@ -560,10 +575,10 @@ __global__ __launch_bounds__(256, 2) void deform_conv_lds_kernel(DcnArgs a) {
   {
     float* pj[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) pj[j] = a.out + (size_t)col_n[j] * a.Cout * HW + col_p[j];
+    for (int j = 0; j < 2; ++j) pj[j] = e_out + (size_t)col_n[j] * a.Cout * HW + col_p[j];
     const int co_lane = m0 + wave_m * 64 + 4 * hi;
     const size_t off_lane = (size_t)co_lane * HW;
-    const bool relu = a.relu != 0;
+    const bool relu = e_relu != 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -606,6 +621,11 @@ __global__ __launch_bounds__(256, 2) void deform_conv_band_kernel(DcnArgs a, int
   constexpr int A_F4 = 9 * 2 * TM;                       // float4 of one chunk's weights: [tap][quad][cout]
   constexpr int A_PER_T = (A_F4 + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  // split-K: this workgroup's channel range and destination (see DcnArgs)
+  const int kc_begin = (a.ksplit > 1) ? (int)blockIdx.y * a.kchan : 0;
+  const int kc_end = (a.ksplit > 1) ? min(a.C, kc_begin + a.kchan) : a.C;
+  float* const e_out = (a.ksplit > 1) ? a.ws + (size_t)blockIdx.y * a.ws_stride : a.out;
+  const int e_relu = (a.ksplit > 1) ? 0 : a.relu;
   dm_f32x4* ldsA = reinterpret_cast<dm_f32x4*>(lds);
   dm_f32x4* ldsX = reinterpret_cast<dm_f32x4*>(lds) + A_F4;      // [2 quads][BR * W] float4: the 4 channels of a quad at a band pixel
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -711,16 +731,16 @@ __global__ __launch_bounds__(256, 2) void deform_conv_band_kernel(DcnArgs a, int
   };
   struct __attribute__((packed, aligned(4))) F2 { float a, b; };      // (the slow pass's global row pairs)
 
-  int cur_group = 0;
-  load_params(0);
-  load_a(0);
-  load_x(0);
-  for (int c0 = 0; c0 < a.C; c0 += 8) {
+  int cur_group = kc_begin / cpg;
+  load_params(cur_group);
+  load_a(kc_begin);
+  load_x(kc_begin);
+  for (int c0 = kc_begin; c0 < kc_end; c0 += 8) {
     __syncthreads();                   // the previous chunk's operand reads are done
     store_ax();
     __syncthreads();
     const int cn = c0 + 8;
-    if (cn < a.C) {
+    if (cn < kc_end) {
       load_a(cn);
       load_x(cn);
     }
@@ -809,7 +829,7 @@ __global__ __launch_bounds__(256, 2) void deform_conv_band_kernel(DcnArgs a, int
         }
       }
     }
-    if (cn < a.C) {
+    if (cn < kc_end) {
       const int group = cn / cpg;      // 8 divides cpg (host)
       if (group != cur_group) {
         cur_group = group;
@@ -821,8 +841,8 @@ __global__ __launch_bounds__(256, 2) void deform_conv_band_kernel(DcnArgs a, int
   {
     const int p = p0 + wave_n * 32 + l31;
     if (p < HW) {
-      float* po = a.out + (size_t)n * a.Cout * HW + p;
-      const bool relu = a.relu != 0;
+      float* po = e_out + (size_t)n * a.Cout * HW + p;
+      const bool relu = e_relu != 0;
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -838,14 +858,64 @@ __global__ __launch_bounds__(256, 2) void deform_conv_band_kernel(DcnArgs a, int
   }
 }
 
+// out = relu?(sum over the splits, in index order) of a split-K launch (ws: [splits][NB * Cout * HW])
+__global__ __launch_bounds__(256) void dcn_splitk_reduce_kernel(const float* __restrict__ ws, int splits, long long stride,
+                                                               long long total, int relu, float* __restrict__ out) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    float v = ws[e];
+    for (int s_ = 1; s_ < splits; ++s_) v += ws[(size_t)s_ * stride + e];
+    out[e] = relu ? fmaxf(v, 0.f) : v;
+  }
+}
+
+// Split-K for a launch of ``wgs`` workgroups on ``slots`` slots (caller-owned workspace of ws_floats floats): a workgroup
+// walks its chunks of 8 channels one after the other at ~3.5 us each whatever the RoI count (tools/small_n.py: dcn14 105-115 us
+// for 32 chunks at 8-16 RoIs); S splits save (1 - 1/S) of that and cost a second launch that reads S and writes one copy of
+// the output.  Sets a.ksplit / kchan / ws_stride; a.ksplit stays 1 when it does not pay.
+static void dcn_choose_split(DcnArgs& a, long long wgs, long long slots, long long ws_floats) {
+  a.ksplit = 1;
+  // (only calls of a handful of RoIs: from ~32 on the workgroups are bound by what they share -- every one streams its
+  // cout tile's weights from L2 -- and more of them gain nothing: the full head at 32 / 64 / 100 RoIs measured 1-2 % slower
+  // with the split, 13 % / 3 % faster at 8 / 16)
+  if (!a.ws || a.q_begin != 0 || wgs <= 0 || a.NB > 24) return;
+  const int chunks = a.C / 8;
+  const long long per = (long long)a.NB * a.Cout * a.HW;
+  long long Smax = min(min(8LL, slots / wgs), (long long)chunks / 2);
+  if (per > 0) Smax = min(Smax, ws_floats / per);
+  const double chain_us = chunks * 3.5, out_mb = (double)per * 4e-6;
+  double best = 8.0;
+  int S = 1;
+  for (int c = 2; c <= Smax; ++c) {
+    const double g = chain_us * (1.0 - 1.0 / c) - (5.0 + (c + 1) * out_mb * 0.25);
+    if (g > best) { best = g; S = c; }
+  }
+  if (S >= 2) {
+    const int per_split = dm_ceil_div(chunks, S);
+    a.kchan = per_split * 8;
+    a.ksplit = dm_ceil_div(chunks, per_split);
+    a.ws_stride = per;
+  }
+}
+
+static int dcn_finish_split(const DcnArgs& a, int relu, float* out, hipStream_t st) {
+  if (a.ksplit <= 1) return dm_check_launch();
+  int rc = dm_check_launch();
+  if (rc != DM_OK) return rc;
+  const long long total = a.ws_stride;
+  DM_LAUNCH(dcn_splitk_reduce_kernel, dim3((unsigned)min((long long)4096, (total + 255) / 256)), dim3(256), 0, st, a.ws, a.ksplit,
+            a.ws_stride, total, relu, out);
+  return dm_check_launch();
+}
+
 template <int WM, int WGM, int XR>
 int launch_dcn_band(DcnArgs& a, hipStream_t st) {
   const int BR = 16;
   if (8 * BR * a.W / 4 > XR * 256 || a.H < BR) return DM_ERR_UNSUPPORTED;      // the staging registers must cover the band planes
   const int tiles = dm_ceil_div(a.HW, (4 / WGM) * 32);
   const size_t lds_bytes = 16 * (size_t)(9 * 2 * WM * WGM * 32) + 4 * (size_t)8 * BR * a.W;
-  DM_LAUNCH((deform_conv_band_kernel<WM, WGM, XR>), dim3((unsigned)(a.NB * tiles)), dim3(256), lds_bytes, st, a, tiles, BR);
-  return dm_check_launch();
+  dcn_choose_split(a, (long long)a.NB * tiles, 2LL * dm_num_cus(), a.ws_floats);
+  DM_LAUNCH((deform_conv_band_kernel<WM, WGM, XR>), dim3((unsigned)(a.NB * tiles), (unsigned)a.ksplit), dim3(256), lds_bytes, st, a, tiles, BR);
+  return dcn_finish_split(a, a.relu, a.out, st);
 }
 
 template <int WGM, int WGN, int WM, int WN>
@@ -860,15 +930,42 @@ int launch_dcn(DcnArgs& a, hipStream_t st) {
   if (lds_bytes > 64 * 1024 &&
       dm_ensure_lds_limit(reinterpret_cast<const void*>(&deform_conv_kernel<WGM, WGN, WM, WN>), (int)lds_bytes, attr_set) != DM_OK)
     return DM_ERR_LAUNCH;
-  DM_LAUNCH((deform_conv_kernel<WGM, WGN, WM, WN>), dim3(a.MT * NTiles), dim3(NT), lds_bytes, st, a);
-  return dm_check_launch();
+  dcn_choose_split(a, (long long)a.MT * NTiles, (NT == 256 ? 2LL : 1LL) * dm_num_cus(), a.ws_floats);
+  DM_LAUNCH((deform_conv_kernel<WGM, WGN, WM, WN>), dim3(a.MT * NTiles, a.ksplit), dim3(NT), lds_bytes, st, a);
+  return dcn_finish_split(a, a.relu, a.out, st);
 }
 
 }  // namespace
 
+static int deform_conv_fwd_impl(const float* x, const float* offset, int NB, int C, int H, int W,
+                                const float* w_packed, int Cout, int deform_groups, int relu, float* out, float* ws,
+                                long long ws_floats, dm_stream_t stream);
+
 extern "C" int dm_deform_conv_fwd(const float* x, const float* offset, int NB, int C, int H, int W,
                                   const float* w_packed, int Cout, int deform_groups, int relu, float* out,
                                   dm_stream_t stream) {
+  return deform_conv_fwd_impl(x, offset, NB, C, H, W, w_packed, Cout, deform_groups, relu, out, nullptr, 0, stream);
+}
+
+// (ABI 21) dm_deform_conv_fwd with a caller-owned workspace: a launch that leaves most of the chip idle (the <= 100-RoI
+// inference calls) splits its channel loop over up to eight workgroups per tile; a second kernel adds the splits in index
+// order (+ ReLU).  Same bits every run; they differ from dm_deform_conv_fwd's by the association of the channel sums.
+extern "C" long long dm_deform_conv_splitk_floats(int NB, int C, int H, int W, int Cout) {
+  if (NB <= 0 || C < 32 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+  const long long wgs = (long long)dm_ceil_div(Cout, 128) * dm_ceil_div((long long)NB * H * W, 128);
+  if (wgs * 2 > 2LL * dm_num_cus()) return 0;
+  return 8LL * NB * Cout * H * W;
+}
+
+extern "C" int dm_deform_conv_fwd_ws(const float* x, const float* offset, int NB, int C, int H, int W,
+                                     const float* w_packed, int Cout, int deform_groups, int relu, float* out,
+                                     float* workspace, long long workspace_floats, dm_stream_t stream) {
+  return deform_conv_fwd_impl(x, offset, NB, C, H, W, w_packed, Cout, deform_groups, relu, out, workspace, workspace_floats, stream);
+}
+
+static int deform_conv_fwd_impl(const float* x, const float* offset, int NB, int C, int H, int W,
+                                const float* w_packed, int Cout, int deform_groups, int relu, float* out, float* ws,
+                                long long ws_floats, dm_stream_t stream) {
   if (!x || !offset || !w_packed || !out) return DM_ERR_INVALID_ARG;
   if (NB < 0 || C <= 0 || H <= 0 || W <= 0 || Cout <= 0 || deform_groups <= 0 || C % deform_groups != 0)
     return DM_ERR_INVALID_ARG;
@@ -880,6 +977,8 @@ extern "C" int dm_deform_conv_fwd(const float* x, const float* offset, int NB, i
   a.x = x; a.offset = offset; a.NB = NB; a.C = C; a.H = H; a.W = W; a.HW = H * W; a.Q = NB * H * W;
   a.wp = w_packed; a.Cout = Cout; a.CoutP = dm_conv_packed_cout(Cout); a.KQ = (C + 7) / 8 * 2; a.dg = deform_groups;
   a.relu = relu & 1; a.out = out;
+  a.ws = (ws && ws_floats > 0) ? ws : nullptr;
+  a.ws_floats = a.ws ? ws_floats : 0;
   hipStream_t st = (hipStream_t)stream;
   // 8-wave workgroups: 4 threads share a pixel column, so a thread owns <= 3 taps
   // (a 256-cout tile would gather each sample once but needs > 256 VGPRs: it spills)
@@ -940,8 +1039,9 @@ extern "C" int dm_deform_conv_fwd(const float* x, const float* offset, int NB, i
       a.Q = Q;
       return launch_dcn<2, 2, 1, 1>(a, st);
     }
-    DM_LAUNCH(deform_conv_lds_kernel, dim3(a.MT * NTiles), dim3(256), lds_bytes, st, a);
-    return dm_check_launch();
+    dcn_choose_split(a, (long long)a.MT * NTiles, slots, a.ws_floats);
+    DM_LAUNCH(deform_conv_lds_kernel, dim3(a.MT * NTiles, a.ksplit), dim3(256), lds_bytes, st, a);
+    return dcn_finish_split(a, a.relu, a.out, st);
   }
   if (Cout > 64 && (long long)dm_ceil_div(a.CoutP, 128) * dm_ceil_div(a.Q, 64) * 20 <= (long long)dm_num_cus() * 9)
     return launch_dcn<2, 2, 1, 1>(a, st);                 // same rule for the 128 x 64 tiles (28 x 28, 8 RoIs: 0.081 -> 0.056 ms)

@@ -582,6 +582,14 @@ def deform_conv(x, offset, w_packed, cout, deform_groups, relu=False, out=None):
     else:
         _chk(out, 'out')
         assert tuple(out.shape) == (NB, cout, H, W)
+    if CONV_SPLITK[0] and _SPLITK_DEPTH[0] > 0:
+        nws = int(lib().dm_deform_conv_splitk_floats(NB, C, H, W, cout))
+        if nws > 0:
+            ws = torch.empty((nws,), device=out.device, dtype=torch.float32)
+            check(lib().dm_deform_conv_fwd_ws(_p(x), _p(offset), NB, C, H, W, _p(w_packed), cout, deform_groups,
+                                              (1 if relu else 0) | (8 if _overlapped else 0), _p(out), _p(ws), nws, _stream()),
+                  'dm_deform_conv_fwd_ws')
+            return out
     check(lib().dm_deform_conv_fwd(_p(x), _p(offset), NB, C, H, W, _p(w_packed), cout, deform_groups,
                                    (1 if relu else 0) | (8 if _overlapped else 0), _p(out), _stream()), 'dm_deform_conv_fwd')
     return out

@@ -57,7 +57,7 @@ extern "C" {
 typedef void* dm_stream_t; /* hipStream_t */
 
 const char* dm_error_string(int code);
-/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient, dm_conv_pack_weight_batch, dm_mask_loss_stage; 15: dm_class_logits_up2x_fwd; 16: dm_conv2d_wgrad_slab / dm_conv2d_wgrad_scratch_floats; 17: dm_class_logits_bwd_slab / dm_class_logits_bwd_scratch_floats; 18: dm_reload_env_knobs, dm_roi_align_fwd_ws / dm_roi_align_workspace_bytes, dm_conv_pack_weight_split / dm_conv_packed_floats_split and flag bits 4, 5 of dm_conv2d_fwd; 19: dm_dcn_bwd_data_fused and its pack; 20: dm_conv2d_fwd_ws / dm_conv2d_splitk_floats). */
+/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient, dm_conv_pack_weight_batch, dm_mask_loss_stage; 15: dm_class_logits_up2x_fwd; 16: dm_conv2d_wgrad_slab / dm_conv2d_wgrad_scratch_floats; 17: dm_class_logits_bwd_slab / dm_class_logits_bwd_scratch_floats; 18: dm_reload_env_knobs, dm_roi_align_fwd_ws / dm_roi_align_workspace_bytes, dm_conv_pack_weight_split / dm_conv_packed_floats_split and flag bits 4, 5 of dm_conv2d_fwd; 19: dm_dcn_bwd_data_fused and its pack; 20: dm_conv2d_fwd_ws / dm_conv2d_splitk_floats; 21: dm_deform_conv_fwd_ws / dm_deform_conv_splitk_floats). */
 int dm_abi_version(void);
 /* Re-read the DM_ROI_* experiment knobs from the environment (they are otherwise read once, at the first launch, and
  * clamped to validated ranges).  For measurement tools that sweep settings inside one process; no knob changes a result. */
@@ -232,6 +232,14 @@ int dm_class_logits_up2x_fwd(const float* x, int N, int C, int H, int W, const f
 int dm_deform_conv_fwd(const float* x, const float* offset, int NB, int C, int H, int W,
                        const float* w_packed, int Cout, int deform_groups, int relu, float* out,
                        dm_stream_t stream);
+/* (ABI 21) dm_deform_conv_fwd with a caller-owned workspace: a launch that leaves most of the chip idle (the <= 100-RoI
+ * inference calls) splits its channel loop over up to eight workgroups per tile; a second kernel adds the splits in index
+ * order (+ ReLU).  Same bits every run; they differ from dm_deform_conv_fwd's by the association of the channel sums.
+ * dm_deform_conv_splitk_floats: the workspace with which this shape may split as far as it wants to (0: it would not). */
+long long dm_deform_conv_splitk_floats(int NB, int C, int H, int W, int Cout);
+int dm_deform_conv_fwd_ws(const float* x, const float* offset, int NB, int C, int H, int W, const float* w_packed, int Cout,
+                          int deform_groups, int relu, float* out, float* workspace, long long workspace_floats,
+                          dm_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * K11  x2 bilinear upsampling.
