@@ -40,6 +40,7 @@ if 'check' in what:
                                           (2, 128, 128, 28, 2, 0.7, None), (2, 128, 128, 28, 2, 4.0, None), (2, 32, 64, 12, 2, 1.0, 10),
                                           (1, 16, 64, 8, 1, 1.0, 6), (2, 64, 128, 20, 4, 1.5, 14), (16, 64, 64, 56, 2, 0.3, None)):
         x, off, go, w = both(N, C, Cout, S, dg, sigma, H)
+        ops.DCN_BWD_FUSED[0] = True               # (opt-in by default: DM_DCN_FUSED=1)
         assert ops.dcn_bwd_fused_ok(x.shape, Cout, dg), (x.shape, Cout, dg)
         ops.DCN_BWD_FUSED[0] = False
         gx0, goff0 = ops.deform_conv_backward_data(x, off, w, go, dg)
