@@ -559,3 +559,52 @@ def test_deform_conv_band_kernel_odd_shapes(ops, N, C, Cout, H, W):
     ref = F.relu(ref_ops.deform_conv2d(x, off, w, 1, 1, 1, 2))
     out = ops.deform_conv(_dev(x), _dev(off), ops.pack_conv_weight(_dev(w)), Cout, 2, relu=True)
     _close(out, ref)
+
+
+# ------------------------------------------------------------------ split-K entry points (round 4)
+@pytest.mark.parametrize('N,cins,cout,S,ks', [(3, [256], 256, 14, 3), (9, [256, 256, 2], 256, 14, 1), (5, [256], 36, 14, 3),
+                                              (2, [128], 128, 28, 3), (1, [64], 64, 56, 3), (4, [256], 126, 14, 1)])
+def test_conv2d_split_k_vs_oracle_and_unsplit(ops, N, cins, cout, S, ks):
+    """dm_conv2d_fwd_ws: a launch of few workgroups splits its K loop (bare sums to a workspace, fixed-order reduce with
+    bias + ReLU).  Against F.conv2d, against the unsplit launch (another association of the same products: 1e-5 of the
+    scale), the same bits on every run, concat sources, the 36-cout tail build and an out_ch_offset destination."""
+    srcs = [torch.randn(N, c, S, S, generator=_g(700 + i)) for i, c in enumerate(cins)]
+    cin = sum(cins)
+    w = torch.randn(cout, cin, ks, ks, generator=_g(710)) / (cin * ks * ks) ** 0.5
+    b = torch.randn(cout, generator=_g(711))
+    ref = F.relu(F.conv2d(torch.cat(srcs, 1), w, b, padding=ks // 2))
+    wq = ops.pack_conv_weight(_dev(w), src_channels=cins)
+    ds = [_dev(t) for t in srcs]
+    plain = ops.conv2d(ds, wq, _dev(b), cout, ks, relu=True)
+    assert int(ops.lib().dm_conv2d_splitk_floats(N, S, S, cout, ks)) > 0
+    with ops.splitk_scope():
+        a = ops.conv2d(ds, wq, _dev(b), cout, ks, relu=True)
+        a2 = ops.conv2d(ds, wq, _dev(b), cout, ks, relu=True)
+        wide = torch.full((N, cout + 3, S, S), -7.0).cuda()
+        ops.conv2d(ds, wq, _dev(b), cout, ks, relu=True, out=wide, out_ch_offset=2)
+    _close(a, ref)
+    assert torch.equal(a, a2)
+    assert torch.equal(wide[:, 2:2 + cout], a) and float(wide[:, :2].max()) == -7.0 and float(wide[:, -1].min()) == -7.0
+    scale = float(plain.abs().max())
+    assert float((a - plain).abs().max()) <= 1e-5 * max(scale, 1.0)
+
+
+@pytest.mark.parametrize('N,C,S', [(3, 256, 14), (16, 256, 14), (5, 128, 28), (2, 64, 56)])
+def test_deform_conv_split_k_vs_oracle_and_unsplit(ops, N, C, S):
+    """dm_deform_conv_fwd_ws: the three DCN forward kernels with a channel range per split (calls of up to 24 RoIs)."""
+    x = torch.randn(N, C, S, S, generator=_g(720))
+    w = torch.randn(C, C, 3, 3, generator=_g(721)) / (9 * C) ** 0.5
+    off = torch.randn(N, 36, S, S, generator=_g(722)) * 1.5
+    off[0, :, 0, 0] = 30.0
+    ref = F.relu(ref_ops.deform_conv2d(x, off, w, 1, 1, 1, 2))
+    wq = ops.pack_conv_weight(_dev(w))
+    plain = ops.deform_conv(_dev(x), _dev(off), wq, C, 2, relu=True)
+    assert int(ops.lib().dm_deform_conv_splitk_floats(N, C, S, S, C)) > 0
+    with ops.splitk_scope():
+        a = ops.deform_conv(_dev(x), _dev(off), wq, C, 2, relu=True)
+        a2 = ops.deform_conv(_dev(x), _dev(off), wq, C, 2, relu=True)
+    _close(a, ref)
+    assert torch.equal(a, a2)
+    assert not torch.equal(a, plain), 'the call did not split: the test exercises nothing'
+    scale = float(plain.abs().max())
+    assert float((a - plain).abs().max()) <= 1e-5 * max(scale, 1.0)
