@@ -546,7 +546,8 @@ int dm_dcn_weight_permute(const float* src, float* dst, int Cout, int C, int to_
  * w_packed: dm_dcn_bwd_pack of the [Cout, C, 3, 3] weight (dm_dcn_bwd_pack_floats floats).  grad_x is zero-filled and
  * written by the call; grad_offset is overwritten.  Samples displaced by more than R/2 rows (R = 4, knob DM_DCN_FUSED_R)
  * leave the staged ring: they read x from memory and add to grad_x with float atomics -- correct, slower, and the only
- * case in which the sum order of grad_x depends on timing. */
+ * case in which the sum order of grad_x depends on timing.  A non-finite column gradient poisons (NaN) the rows of its
+ * grad_x plane that are still in the ring or yet to come (rows already written keep their values). */
 int dm_dcn_bwd_data_fused_supported(int C, int Cout, int H, int W, int deform_groups);
 long long dm_dcn_bwd_pack_floats(int C, int Cout, int deform_groups);
 int dm_dcn_bwd_pack(const float* weight, int Cout, int C, int deform_groups, float* packed, dm_stream_t stream);

@@ -316,6 +316,27 @@ def test_dcn_data_gradient_in_one_kernel_rejects_what_it_cannot_stage(ops):
     assert gx.shape == x.shape and goff.shape == off.shape
 
 
+def test_dcn_data_gradient_in_one_kernel_propagates_non_finite_gradients(ops):
+    """A non-finite output gradient makes the column gradients of its pixel non-finite for every input channel
+    (W^T . dY): the fused kernel has no fixed-point value for them and must poison the planes they scatter into -- every
+    plane of that image, from the rows still in the ring on -- and leave the other image's bits alone."""
+    g = _g(95)
+    N, C, S, dg = 2, 64, 16, 2
+    x = torch.randn(N, C, S, S, generator=g)
+    off = torch.randn(N, 18 * dg, S, S, generator=g) * 0.5
+    w = torch.randn(C, C, 3, 3, generator=g) / (9 * C) ** 0.5
+    go = torch.randn(N, C, S, S, generator=g)
+    wf = ops.pack_dcn_bwd_weight(_dev(w), dg)
+    gx0, goff0 = ops.deform_conv_backward_data_fused(_dev(x), _dev(off), _dev(go), wf, dg)
+    bad = go.clone()
+    bad[1, 7, 5, 9] = float('inf')
+    gx1, goff1 = ops.deform_conv_backward_data_fused(_dev(x), _dev(off), _dev(bad), wf, dg)
+    # (rows of a plane that left the ring before the bad pixel's band are already written: the poison covers the rest)
+    assert torch.isnan(gx1[1]).flatten(1).any(dim=1).all() and torch.isnan(gx1[1, :, 4:]).all()
+    assert torch.equal(gx1[0], gx0[0]) and torch.equal(goff1[0], goff0[0])
+    assert torch.isfinite(gx0).all() and torch.isfinite(goff0).all()
+
+
 def test_fixed_point_scatter_accumulators_propagate_non_finite_gradients(ops):
     """The LDS accumulators of the DCN col2im and the point-sample adjoint are 64-bit fixed point; a NaN or
     Inf gradient has no fixed-point value and must show up as NaN in the plane it belongs to (a diverged step

@@ -608,3 +608,38 @@ def test_deform_conv_split_k_vs_oracle_and_unsplit(ops, N, C, S):
     assert not torch.equal(a, plain), 'the call did not split: the test exercises nothing'
     scale = float(plain.abs().max())
     assert float((a - plain).abs().max()) <= 1e-5 * max(scale, 1.0)
+
+
+# ------------------------------------------------------------------ the opt-in RoIAlign paths of round 4
+@pytest.mark.parametrize('knob', ['DM_ROI_SORT', 'DM_ROI_PERSIST'])
+@pytest.mark.parametrize('P,n', [(14, 300), (7, 260), (14, 1)])
+def test_roi_align_opt_in_workspace_paths_match_the_default(ops, knob, P, n):
+    """dm_roi_align_fwd_ws with DM_ROI_SORT=1 (RoIs ranked by level and position on the device, outputs written back to
+    their own rows) or DM_ROI_PERSIST=1 (plan + persistent kernels): measured and not the default, but entry
+    points of the library -- the ordered path must give the default's bits and levels, the persistent one the oracle's
+    values (it merges wide stencils at run time: another association, < 1e-6)."""
+    import os
+    from dynamask_amd import synth
+    feats = [_dev(f) for f in synth.make_fpn(2, 320, 448, 32, seed=40)[:4]]
+    rois = synth.make_rois(2, (n + 1) // 2, 320, 448, seed=41)[:n].contiguous()
+    scales = (0.25, 0.125, 0.0625, 0.03125)
+    ref, lv_ref = ops.roi_align(feats, _dev(rois), P, scales, return_levels=True)
+    was = (ops.ROI_WORKSPACE, ops.ROI_WORKSPACE_MIN)
+    os.environ[knob] = '1'
+    os.environ['DM_ROI_SORT_MIN'] = '1'
+    try:
+        ops.lib().dm_reload_env_knobs()
+        ops.ROI_WORKSPACE, ops.ROI_WORKSPACE_MIN = True, 1
+        out, lv = ops.roi_align(feats, _dev(rois), P, scales, return_levels=True)
+        out2, _ = ops.roi_align(feats, _dev(rois), P, scales, return_levels=True)
+    finally:
+        del os.environ[knob]
+        del os.environ['DM_ROI_SORT_MIN']
+        ops.lib().dm_reload_env_knobs()
+        ops.ROI_WORKSPACE, ops.ROI_WORKSPACE_MIN = was
+    assert torch.equal(lv, lv_ref)
+    assert torch.equal(out, out2)
+    if knob == 'DM_ROI_SORT':
+        assert torch.equal(out, ref)
+    else:
+        _close(out, ref, atol=2e-6, rtol=2e-6)
