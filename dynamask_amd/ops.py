@@ -554,7 +554,7 @@ def conv2d(srcs, w_packed, bias, cout, ksize, relu=False, out=None, out_ch_offse
                                         _p(mask), _stream())
         check(rc, 'dm_conv2d_fwd_masked')
         return out
-    if CONV_SPLITK[0] and _SPLITK_DEPTH[0] > 0 and not accumulate:
+    if CONV_SPLITK[0] and _SPLITK_DEPTH[0] > 0 and not accumulate and not split:      # (exact fp32 kernels only)
         # the <= 100-RoI inference calls: a launch of few workgroups splits its K loop (dm_conv2d_fwd_ws)
         nws = int(lib().dm_conv2d_splitk_floats(NB, H, W, cout, ksize))
         if nws > 0:
