@@ -643,3 +643,34 @@ def test_roi_align_opt_in_workspace_paths_match_the_default(ops, knob, P, n):
         assert torch.equal(out, ref)
     else:
         _close(out, ref, atol=2e-6, rtol=2e-6)
+
+
+def test_split_k_entry_points_with_a_workspace_smaller_than_they_ask_for(ops):
+    """The C ABI takes whatever workspace the caller owns: with room for two splits instead of eight a call splits in two,
+    with room for less than two it runs unsplit -- the result stays the oracle's either way."""
+    import ctypes
+    from dynamask_amd.ops import _p, _ptr_array, _int_array, _stream
+    N, C, S = 4, 256, 14
+    x = torch.randn(N, C, S, S, generator=_g(730)).cuda()
+    w = torch.randn(C, C, 3, 3, generator=_g(731)) / (9 * C) ** 0.5
+    b = torch.randn(C, generator=_g(732)).cuda()
+    ref = F.relu(F.conv2d(x.cpu(), w, b.cpu(), padding=1))
+    wq = ops.pack_conv_weight(w.cuda())
+    per = N * C * S * S
+    strides = (ctypes.c_longlong * 1)(int(x.stride(0)))
+    for room in (2 * per, per + 7, 0):
+        out = torch.empty_like(x)
+        ws = torch.empty((max(room, 1),), device='cuda')
+        rc = ops.lib().dm_conv2d_fwd_ws(_ptr_array([x]), _int_array([C]), strides, 1, N, S, S, _p(wq), _p(b), C, 3, 1, _p(out), C, 0,
+                                        _p(ws) if room else None, room, _stream())
+        assert rc == 0
+        _close(out, ref)
+    off = (torch.randn(N, 36, S, S, generator=_g(733)) * 1.2).cuda()
+    dref = F.relu(ref_ops.deform_conv2d(x.cpu(), off.cpu(), w, 1, 1, 1, 2))
+    for room in (2 * per, per + 7, 0):
+        out = torch.empty_like(x)
+        ws = torch.empty((max(room, 1),), device='cuda')
+        rc = ops.lib().dm_deform_conv_fwd_ws(_p(x), _p(off), N, C, S, S, _p(wq), C, 2, 1, _p(out), _p(ws) if room else None, room,
+                                             _stream())
+        assert rc == 0
+        _close(out, dref)
