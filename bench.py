@@ -585,6 +585,22 @@ def main():
                 result['roofline_roialign']['traffic_source'] = src
             except Exception:
                 pass
+        # the committed rocprofv3 per-kernel average of the same kernel (tools/pmc_probe.py alternates it with the
+        # convolution: the maps are not cache-warm as in the graph of 20) -- a number from a file, labelled as such
+        stats = os.path.join(ROOT, 'profiles', 'r04_roofline_kernel_stats.csv')
+        if os.path.exists(stats):
+            try:
+                import csv
+                for row in csv.DictReader(open(stats)):
+                    if 'roi_align_tile_kernel' in row['Name']:
+                        us = float(row['AverageNs']) / 1e3
+                        result['roofline_roialign']['us_per_launch_rocprof_committed'] = us
+                        result['roofline_roialign']['frac_rocprof_committed'] = nbytes / (us * 1e-6) / 1e9 / PEAK_HBM_GBS
+                        result['roofline_roialign']['rocprof_source'] = ('profiles/r04_roofline_kernel_stats.csv (rocprofv3 --kernel-trace '
+                                                                        '--stats over tools/pmc_probe.py), not measured in this run')
+                        break
+            except Exception:
+                pass
         extra = {}
         # ---- opt-in bf16-split matrix modes (DM_MFMA_SPLIT = 3 / 6; csrc/conv_igemm.hip): NEVER the headline -- the
         # headline computes in exact fp32 like the reference.  The same step with the implicit-GEMM convolutions on

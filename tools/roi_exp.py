@@ -55,7 +55,7 @@ if which in ('14', 'all'):
     # the other shapes the kernel serves: 7x7 at 1000 proposals (bbox branch), odd counts, one level, 2 images
     props = synth.make_rois(1, 1000, 800, 1333, seed=31).to(dev)
     call7 = lambda: ops.roi_align(feats[:4], props, 7, [1 / 4, 1 / 8, 1 / 16, 1 / 32])
-    sweep('roialign7 1000 RoIs', call7, [{}, {'DM_ROI_PERSIST': '1'}])
+    sweep('roialign7 1000 RoIs', call7, [{}, {'DM_ROI_CT': '32'}, {'DM_ROI_CT': '64'}, {'DM_ROI_CT': '128'}, {'DM_ROI_CT': '256'}, {'DM_ROI_PERSIST': '1'}])
     r129 = synth.make_rois(1, 129, 800, 1333, seed=5).to(dev)
     call129 = lambda: ops.roi_align(feats[:4], r129, 14, [1 / 4, 1 / 8, 1 / 16, 1 / 32])
     sweep('roialign14 129 RoIs', call129, [{}, {'DM_ROI_SORT': '1', 'DM_ROI_SORT_MIN': '1'}, {'DM_ROI_PERSIST': '1'}])
