@@ -455,11 +455,13 @@ class PackPlan:
         todo = [(e, p) for e, p in live if e['used'] and e['ver'] != self._ver(p)]
         if not todo:
             return
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError('PackPlan: a kernel-layout weight is stale inside a HIP-graph capture (the refresh uploads '
-                               'a job table: run the path once eagerly before capturing it)')
         with torch.cuda.device(plan.device):
             ids = tuple((id(e), p.data_ptr()) for e, p in todo)
+            if ids != plan.table_ids and torch.cuda.is_current_stream_capturing():
+                # (with the job table already on the device the refresh is one launch and is captured like any other:
+                # a captured training step repacks its weights on every replay)
+                raise RuntimeError('PackPlan: a kernel-layout weight is stale inside a HIP-graph capture and its job table '
+                                   'is not on the device yet (the upload cannot be captured: run the path once eagerly first)')
             if ids != plan.table_ids:
                 arr = (PackJob * len(todo))()
                 for j, (e, p) in zip(arr, todo):
