@@ -24,7 +24,11 @@
 //   (Only with such samples does the sum order of grad_x depend on timing; DM_DETERMINISTIC callers keep the
 //   three-kernel path.)
 //
-// Next band's grad_out and x rows are fetched into registers before the band's MFMAs and committed behind the barrier.
+// The lanes run one instruction stream (a switched-off corner adds 0 to a cell of its own pixel: the MFMAs of the NEXT unit
+// are issued between this unit's channel steps and need the exec mask full, their B values read one step ahead); the next
+// band's grad_out and x rows are only touched into L2 while a band computes and staged behind the barrier.
+// Measured: at parity with the three-kernel path -- both are bound by the LDS scatter -- hence opt-in
+// (DM_DCN_FUSED=1).
 #include <type_traits>
 
 #include "common.h"
