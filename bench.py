@@ -563,10 +563,10 @@ def main():
         _, lv = ops.roi_align(feats[:4], rois, 14, [1 / 4, 1 / 8, 1 / 16, 1 / 32], return_levels=True)
         nbytes = roialign_algorithmic_bytes(rois_c, lv.cpu().long(), [tuple(f.shape[2:]) for f in feats_c[:4]])
         ach_r = nbytes / (ms_r * 1e-3) / 1e9
-        result['roofline_roialign'] = {'kernel': 'roi_align_tile_kernel (one launch; LDS-staged channel-quad tiles, merged stencils; P2..P5 -> [512,256,14,14]); '
-                                                 'ms_per_launch = 20 launches replayed back to back as one HIP graph / 20 (maps + output stay in the '
-                                                 'Infinity Cache), median of 7 replays; ms_per_launch_single = replay of a graph of two launches minus '
-                                                 'a graph of one (medians of 15): one launch with one predecessor; rocprofv3 per-kernel averages: '
+        result['roofline_roialign'] = {'kernel': 'roi_order_kernel + roi_align_tile_kernel (one dm_roi_align_fwd_ws call: RoIs ranked by level and position on the device, then LDS-staged channel-quad tiles, merged stencils; P2..P5 -> [512,256,14,14]); '
+                                                 'ms_per_launch = 20 calls (both kernels each) replayed back to back as one HIP graph / 20 (maps + output stay in the '
+                                                 'Infinity Cache), median of 7 replays; ms_per_launch_single = replay of a graph of two calls minus '
+                                                 'a graph of one (medians of 15): one call with one predecessor; rocprofv3 per-kernel averages: '
                                                  'profiles/r04_roofline_kernel_stats.csv', 'bound': 'hbm',
                                        'achieved': ach_r, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                        'frac': ach_r / PEAK_HBM_GBS, 'traffic': None, 'ms_per_launch': ms_r,
@@ -591,14 +591,18 @@ def main():
         if os.path.exists(stats):
             try:
                 import csv
+                parts = {}
                 for row in csv.DictReader(open(stats)):
-                    if 'roi_align_tile_kernel' in row['Name']:
-                        us = float(row['AverageNs']) / 1e3
-                        result['roofline_roialign']['us_per_launch_rocprof_committed'] = us
-                        result['roofline_roialign']['frac_rocprof_committed'] = nbytes / (us * 1e-6) / 1e9 / PEAK_HBM_GBS
-                        result['roofline_roialign']['rocprof_source'] = ('profiles/r04_roofline_kernel_stats.csv (rocprofv3 --kernel-trace '
-                                                                        '--stats over tools/pmc_probe.py), not measured in this run')
-                        break
+                    for kname in ('roi_align_tile_kernel', 'roi_order_kernel'):
+                        if kname in row['Name']:
+                            parts[kname] = float(row['AverageNs']) / 1e3
+                if 'roi_align_tile_kernel' in parts:
+                    us = sum(parts.values())               # the call = the ordering kernel (if it ran) + the extraction
+                    result['roofline_roialign']['us_per_launch_rocprof_committed'] = us
+                    result['roofline_roialign']['us_per_kernel_rocprof_committed'] = parts
+                    result['roofline_roialign']['frac_rocprof_committed'] = nbytes / (us * 1e-6) / 1e9 / PEAK_HBM_GBS
+                    result['roofline_roialign']['rocprof_source'] = ('profiles/r04_roofline_kernel_stats.csv (rocprofv3 --kernel-trace '
+                                                                    '--stats over tools/pmc_probe.py), not measured in this run')
             except Exception:
                 pass
         extra = {}

@@ -687,14 +687,17 @@ __device__ __forceinline__ void roi_tile_fwd(const RoiArgs& a, const float* __re
 // with ONE workgroup of 1024 threads took 17 us: one CU's vector ALU for N x N / 4 compares) and the RoIs written in that
 // order as 8-float records {batch, x1, y1, x2, y2, index,
 // level, 0}, one scalar load for the extraction's workgroups; it also writes levels_out.  The order changes no result.
-// NOT the default (DM_ROI_SORT=1): the ordering launch and the dependency behind it cost ~8 us, what the ordered
-// extraction gains (profiles/r04_roi_exp.txt (i)); a caller whose RoIs already come in such an order gets the 47 us.
+// The default for 192 RoIs or more when the caller passes a workspace (DM_ROI_SORT=0: off): with the first ordering kernel
+// (64 RoIs x 4 threads, 7.2 us) the launch and the dependency behind it cost what the ordered extraction gains; with 16
+// threads per RoI and unique keys it takes 5 us and the pair runs in 50.7 us against 57 (profiles/r04_roi_exp.txt (l)).
 constexpr int kOrderMaxRois = 1024;
 
-// workgroup = 64 RoIs x 4 threads each; every workgroup holds all N keys in LDS (computing them costs less than a
-// second launch), a RoI's four threads each count a quarter of the keys below it
+// workgroup = 16 RoIs x 16 threads each; every workgroup holds all N keys in LDS (computing them costs less than a
+// second launch), a RoI's sixteen threads each count a sixteenth of the keys below it.  The keys carry the RoI's index in
+// their low ten bits: unique, one compare per key.  (64 RoIs x 4 threads with index tie-breaks: 7.2 us for 512 RoIs.)
+constexpr int kOrderTpr = 16;                      // threads per RoI
 __global__ __launch_bounds__(256) void roi_order_kernel(RoiArgs a, float* __restrict__ sorted) {
-  __shared__ unsigned keys[kOrderMaxRois];
+  __shared__ __attribute__((aligned(16))) unsigned keys[kOrderMaxRois];
   const int tid = threadIdx.x;
   auto key_of = [&](int t, float (&rec)[5], int& lvl) {
     const float* r = a.rois + (size_t)t * 5;
@@ -702,10 +705,10 @@ __global__ __launch_bounds__(256) void roi_order_kernel(RoiArgs a, float* __rest
     for (int i = 0; i < 5; ++i) rec[i] = r[i];
     lvl = (a.L > 1) ? roi_level(rec[1], rec[2], rec[3], rec[4], a.finest, a.L) : 0;
     const float cy = 0.5f * (rec[2] + rec[4]), cx = 0.5f * (rec[1] + rec[3]);
-    const unsigned row = (unsigned)fminf(fmaxf(cy * (1.0f / 32.0f), 0.f), 1023.f);
-    const unsigned col = (unsigned)fminf(fmaxf(cx, 0.f), 65535.f);
+    const unsigned row = (unsigned)fminf(fmaxf(cy * (1.0f / 32.0f), 0.f), 127.f);            // 32-pixel rows, 7 bits
+    const unsigned col = (unsigned)fminf(fmaxf(cx * (1.0f / 8.0f), 0.f), 511.f);             // 8-pixel columns, 9 bits
     const unsigned img = (unsigned)min(max((int)rec[0], 0), 3);                 // (beyond 4 images the order is only coarser)
-    return (img << 30) | ((unsigned)lvl << 26) | (row << 16) | col;
+    return (img << 30) | ((unsigned)lvl << 26) | (row << 19) | (col << 10) | (unsigned)t;     // t < 1024: unique keys
   };
   const int npad = (a.N + 3) & ~3;
   for (int t = tid; t < npad; t += 256) {
@@ -714,22 +717,20 @@ __global__ __launch_bounds__(256) void roi_order_kernel(RoiArgs a, float* __rest
     keys[t] = t < a.N ? key_of(t, rec, lvl) : 0xFFFFFFFFu;      // (padding keys: never below a real key)
   }
   __syncthreads();
-  const int t = blockIdx.x * 64 + (tid >> 2), part = tid & 3;
+  const int t = blockIdx.x * (256 / kOrderTpr) + tid / kOrderTpr, part = tid % kOrderTpr;
   float rec[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
   int lvl = 0;
-  unsigned key = 0xFFFFFFFFu;
+  unsigned key = 0u;
   if (t < a.N) key = key_of(t, rec, lvl);
   const int n4 = npad >> 2;
   const uint4* k4 = reinterpret_cast<const uint4*>(keys);
   int rank = 0;
-  for (int j = part; j < n4; j += 4) {
+  for (int j = part; j < n4; j += kOrderTpr) {
     const uint4 q = k4[j];
-    const int j0 = 4 * j;
-    rank += (q.x < key || (q.x == key && j0 < t)) + (q.y < key || (q.y == key && j0 + 1 < t)) +
-            (q.z < key || (q.z == key && j0 + 2 < t)) + (q.w < key || (q.w == key && j0 + 3 < t));
+    rank += (q.x < key) + (q.y < key) + (q.z < key) + (q.w < key);
   }
-  rank += __shfl_xor(rank, 1, 64);
-  rank += __shfl_xor(rank, 2, 64);
+#pragma unroll
+  for (int m = 1; m < kOrderTpr; m <<= 1) rank += __shfl_xor(rank, m, 64);
   if (t < a.N && part == 0) {
     if (a.levels) a.levels[t] = lvl;
     float* o = sorted + (size_t)rank * 8;
@@ -2246,8 +2247,8 @@ struct RoiKnobs {
   int unit_wgs;     // DM_ROI_UNIT_WGS: workgroups per CU of the units kernel
   int abl;          // DM_ROI_ABL: ablation bits (tools/micro builds only)
   int nt14;         // DM_ROI_NT14: nontemporal output stores in the tile kernel (experiment)
-  int sort;         // DM_ROI_SORT: 1 = order the RoIs by level and position when the caller passes a workspace (default 0: the
-                    // extraction alone drops from 56 to 47 us, the dependent ordering launch in front of it costs the 8 us back)
+  int sort;         // DM_ROI_SORT: 1 (default) = order the RoIs by level and position when the caller passes a workspace: the
+                    // extraction drops from 57 to 47 us, the ordering launch in front of it costs 4-5 back (50.7 us in a graph of 20)
   int sort_min;     // DM_ROI_SORT_MIN: fewest RoIs worth the extra launch (default 192)
 };
 RoiKnobs g_roi_knobs;
@@ -2272,7 +2273,7 @@ void roi_load_knobs() {
   k.unit_wgs = env_int("DM_ROI_UNIT_WGS", 4, 1, 8);
   k.abl = env_int("DM_ROI_ABL", 0, 0, 7);
   k.nt14 = env_int("DM_ROI_NT14", 0, 0, 1);
-  k.sort = env_int("DM_ROI_SORT", 0, 0, 1);
+  k.sort = env_int("DM_ROI_SORT", 1, 0, 1);
   k.sort_min = env_int("DM_ROI_SORT_MIN", 192, 1, 1024);
   g_roi_knobs = k;
   g_roi_knobs_loaded = true;
@@ -2375,7 +2376,7 @@ int roi_align_fwd_impl(const float* const* feats, const int* H, const int* W, co
       (((uintptr_t)workspace) & 15) == 0) {
     // RoIs walked by level and position (roi_order_kernel), 32 channels per workgroup, XCD-aware chunk-major order
     float* sorted = reinterpret_cast<float*>(workspace);
-    DM_LAUNCH(roi_order_kernel, dim3(dm_ceil_div(N, 64)), dim3(256), 0, (hipStream_t)stream, a, sorted);
+    DM_LAUNCH(roi_order_kernel, dim3(dm_ceil_div(N, 256 / kOrderTpr)), dim3(256), 0, (hipStream_t)stream, a, sorted);
     int rco = dm_check_launch();
     if (rco != DM_OK) return rco;
     a.levels = nullptr;

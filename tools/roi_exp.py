@@ -36,7 +36,7 @@ def sweep(name, call, settings, ref=None):
         for k in ('DM_ROI_PERSIST', 'DM_ROI_SORT', 'DM_ROI_SORT_MIN', 'DM_ROI_NT14', 'DM_ROI_WORKSPACE', 'DM_ROI_WPC', 'DM_ROI_ORDER', 'DM_ROI_CT', 'DM_ROI_BAND_ORDER', 'DM_ROI_UNITS', 'DM_ROI_NT', 'DM_ROI_UNIT_WGS'):
             os.environ.pop(k, None)
         os.environ.update(env)
-        ops.ROI_WORKSPACE = (env.get('DM_ROI_SORT', '0') == '1' or env.get('DM_ROI_PERSIST', '0') == '1')
+        ops.ROI_WORKSPACE = (env.get('DM_ROI_SORT', '1') == '1' or env.get('DM_ROI_PERSIST', '0') == '1')
         ops.ROI_WORKSPACE_MIN = int(env.get('DM_ROI_SORT_MIN', '192'))
         _lib.lib().dm_reload_env_knobs()
         us, out = graph_us(call)
@@ -50,7 +50,7 @@ if which in ('14', 'all'):
     feats = [f.to(dev) for f in synth.make_fpn(1, 800, 1333, 256, seed=0)]
     rois = synth.make_rois(1, 512, 800, 1333, seed=1).to(dev)
     call = lambda: ops.roi_align(feats[:4], rois, 14, [1 / 4, 1 / 8, 1 / 16, 1 / 32])
-    sets = [{}, {'DM_ROI_CT': '32'}, {'DM_ROI_NT14': '1'}, {'DM_ROI_ORDER': '0'}, {'DM_ROI_SORT': '1'}, {'DM_ROI_SORT': '1', 'DM_ROI_CT': '16'}, {'DM_ROI_PERSIST': '1'}, {}]
+    sets = [{}, {'DM_ROI_SORT': '0'}, {'DM_ROI_SORT': '0', 'DM_ROI_CT': '32'}, {'DM_ROI_NT14': '1'}, {'DM_ROI_ORDER': '0'}, {'DM_ROI_CT': '16'}, {'DM_ROI_PERSIST': '1'}, {}]
     sweep('roialign14 512 RoIs', call, sets)
     # the other shapes the kernel serves: 7x7 at 1000 proposals (bbox branch), odd counts, one level, 2 images
     props = synth.make_rois(1, 1000, 800, 1333, seed=31).to(dev)
@@ -58,7 +58,7 @@ if which in ('14', 'all'):
     sweep('roialign7 1000 RoIs', call7, [{}, {'DM_ROI_CT': '32'}, {'DM_ROI_CT': '64'}, {'DM_ROI_CT': '128'}, {'DM_ROI_CT': '256'}, {'DM_ROI_PERSIST': '1'}])
     r129 = synth.make_rois(1, 129, 800, 1333, seed=5).to(dev)
     call129 = lambda: ops.roi_align(feats[:4], r129, 14, [1 / 4, 1 / 8, 1 / 16, 1 / 32])
-    sweep('roialign14 129 RoIs', call129, [{}, {'DM_ROI_SORT': '1', 'DM_ROI_SORT_MIN': '1'}, {'DM_ROI_PERSIST': '1'}])
+    sweep('roialign14 129 RoIs', call129, [{'DM_ROI_SORT': '0'}, {'DM_ROI_SORT_MIN': '1'}, {'DM_ROI_PERSIST': '1'}])
     # slivers and large grids: clipped boxes along the image border (grids up to 15), everything on ONE level
     g = torch.Generator().manual_seed(7)
     n = 64
@@ -69,9 +69,9 @@ if which in ('14', 'all'):
     sl[n // 2:, 4] = sl[n // 2:, 2] + 4 + torch.rand(n // 2, generator=g) * 60
     sl = sl.to(dev)
     calls = lambda: ops.roi_align(feats[:4], sl, 14, [1 / 4, 1 / 8, 1 / 16, 1 / 32])
-    sweep('roialign14 64 slivers', calls, [{}, {'DM_ROI_SORT': '1', 'DM_ROI_SORT_MIN': '1'}, {'DM_ROI_PERSIST': '1'}])
+    sweep('roialign14 64 slivers', calls, [{'DM_ROI_SORT': '0'}, {'DM_ROI_SORT_MIN': '1'}, {'DM_ROI_PERSIST': '1'}])
     call1 = lambda: ops.roi_align([feats[1]], sl, 14, [1 / 8])
-    sweep('roialign14 64 slivers on P3 only', call1, [{}, {'DM_ROI_SORT': '1', 'DM_ROI_SORT_MIN': '1'}, {'DM_ROI_PERSIST': '1'}])
+    sweep('roialign14 64 slivers on P3 only', call1, [{'DM_ROI_SORT': '0'}, {'DM_ROI_SORT_MIN': '1'}, {'DM_ROI_PERSIST': '1'}])
 if which in ('56', 'all'):
     for B, per in ((1, 128), (2, 128)):
         feats = [f.to(dev) for f in synth.make_fpn(B, 800, 1333, 256, seed=10)]

@@ -41,7 +41,7 @@ def setenv(env):
     for k in ('DM_ROI_PERSIST', 'DM_ROI_SORT', 'DM_ROI_WORKSPACE', 'DM_ROI_ORDER', 'DM_ROI_CT', 'DM_ROI_NT14'):
         os.environ.pop(k, None)
     os.environ.update(env)
-    ops.ROI_WORKSPACE = (env.get('DM_ROI_SORT', '0') == '1' or env.get('DM_ROI_PERSIST', '0') == '1')
+    ops.ROI_WORKSPACE = (env.get('DM_ROI_SORT', '1') == '1' or env.get('DM_ROI_PERSIST', '0') == '1')
     _lib.lib().dm_reload_env_knobs()
 
 

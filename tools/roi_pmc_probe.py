@@ -4,7 +4,7 @@ import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from dynamask_amd import ops, synth
-ops.ROI_WORKSPACE = (os.environ.get('DM_ROI_SORT', '0') == '1' or os.environ.get('DM_ROI_PERSIST', '0') == '1')
+ops.ROI_WORKSPACE = (os.environ.get('DM_ROI_SORT', '1') == '1' or os.environ.get('DM_ROI_PERSIST', '0') == '1')
 dev = torch.device('cuda')
 it = int(os.environ.get('PROBE_ITERS', '10'))
 feats = [f.to(dev) for f in synth.make_fpn(1, 800, 1333, 256, seed=0)]
