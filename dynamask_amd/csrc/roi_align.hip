@@ -1441,7 +1441,8 @@ __global__ __launch_bounds__(256, 4) void roi_align_units_kernel(RoiArgs a, int 
 // ---------------------------------------------------------------------------
 // Round 4: the pipelined forward kernel for small output grids (P * P <= 256).
 //
-// What the tile kernel above measured (profiles/r04_roialign_ceiling.txt): 73.7 us per launch of which 40.7 us remain
+// What the tile kernel above measured in round 3 (its ceiling file is in git history; profiles/r04_roialign_ceiling.txt
+// repeats the measurement on the current kernel: 55.7 us, 37.2 with everything off): 73.7 us per launch of which 40.7 us remain
 // with its loads, its stencils and its stores all switched off -- 8192 workgroups (RoI x 16 channels) that each decode
 // the RoI, derive level, geometry, staging offsets and the stencil table for 3136 outputs: 20.8 M vector and 15.7 M
 // scalar instructions per launch (one per 2.5 cycles per SIMD for the whole 40 us) where the stencils need 4 M.
@@ -2393,7 +2394,7 @@ int roi_align_fwd_impl(const float* const* feats, const int* H, const int* W, co
     // 16 channels per workgroup in the XCD-aware order (roi_unit): XCD x walks the chunks c = x (mod 8) chunk-major,
     // so the planes it is staging from stay in its L2 across the RoIs that share them.  Same time as round 2's 32
     // channels in launch order (16 .. 256 channels swept at 128 .. 2048 RoIs), 29 % fewer bytes fetched from
-    // the fabric (FETCH_SIZE 113.6 -> 81.2 MB per launch, profiles/r04_roialign_ceiling.txt).
+    // the fabric (FETCH_SIZE 113.6 -> 81.2 MB per launch, round 3's ceiling measurement).
     a.CT = kn.ct > 0 ? kn.ct : 16;
     a.order = kn.order >= 0 ? kn.order : 1;
     int chunks = dm_ceil_div(C, a.CT);
