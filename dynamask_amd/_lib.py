@@ -117,6 +117,7 @@ class PackJob(ctypes.Structure):
 
 
 _LIB = None
+_PROXY = None       # hazard.wrap_lib(_LIB), handed out while the stream-hazard tracker is on (DM_HAZARD, hazard.ENABLED)
 
 
 class DynaMaskLibraryError(RuntimeError):
@@ -144,6 +145,12 @@ def lib():
         if L.dm_abi_version() != ABI_VERSION:
             raise DynaMaskLibraryError('libdynamask_hip.so ABI version mismatch: rebuild')
         _LIB = L
+    from . import hazard
+    if hazard.ENABLED[0]:
+        global _PROXY
+        if _PROXY is None:
+            _PROXY = hazard.wrap_lib(_LIB)
+        return _PROXY
     return _LIB
 
 

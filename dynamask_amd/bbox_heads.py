@@ -209,6 +209,8 @@ class BBoxHeadFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_cls, g_reg):
         head, acts = ctx.head, ctx.acts
+        from . import hazard
+        hazard.engine_handoff(g_cls, g_reg)
         n = acts[0].shape[0]
         pg = {}
 

@@ -18,6 +18,8 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import hazard
+
 
 class FlatParamGroup:
     """Re-homes ``params`` into one flat buffer (``p.data`` and ``p.grad`` become
@@ -86,6 +88,7 @@ class FlatParamGroup:
         copied: whatever tensor autograd or ``module.zero_grad(set_to_none=True)`` left in
         ``p.grad`` belongs to the step that has just ended."""
         self.flat_grad.zero_()
+        hazard.touch('FlatParamGroup.zero_grad', writes=[self.flat_grad])
         for p, view in self._views():
             if p.grad is None or p.grad.data_ptr() != view.data_ptr():
                 p.grad = view
@@ -124,6 +127,7 @@ class FlatParamGroup:
         if self._stream is not None:
             self._stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._stream):
+                hazard.touch('all_reduce', writes=[self.flat_grad])
                 self._work = dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
             self._work = dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)

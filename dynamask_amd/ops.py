@@ -8,6 +8,7 @@ import ctypes
 
 import torch
 
+from . import hazard
 from ._lib import check, lib
 
 
@@ -61,11 +62,18 @@ def _chk_src(t):
 
 
 def _p(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+    if t is None:
+        return ctypes.c_void_p(0)
+    if hazard.ENABLED[0]:
+        hazard.note_ptr(t)          # (DM_HAZARD: the tracker learns which tensor the pointer came from)
+    return ctypes.c_void_p(t.data_ptr())
 
 
 def _ptr_array(tensors):
-    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    if hazard.ENABLED[0]:
+        hazard.note_ptr_array(arr, tensors)
+    return arr
 
 
 def _int_array(vals):
@@ -477,6 +485,8 @@ class PackPlan:
                 plan.table = host.to(plan.device)
                 plan.table_ids = ids
                 self.uploads += 1
+            if hazard.ENABLED[0]:       # the device-side job table hides what this launch reads and writes
+                hazard.touch('dm_conv_pack_weight_batch', reads=[p for _, p in todo], writes=[e['out'] for e, _ in todo])
             check(lib().dm_conv_pack_weight_batch(_p(plan.table), len(todo), _stream()), 'dm_conv_pack_weight_batch')
             self.launches += 1
             plan.event = torch.cuda.current_stream(plan.device).record_event()

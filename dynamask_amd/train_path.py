@@ -16,7 +16,7 @@ import os
 
 import torch
 
-from . import ops
+from . import hazard, ops
 
 # maps of at least this many pixels keep the DCN column matrix from the forward for the weight gradient (56 x 56 and, since the
 # leaf work was dealt over three side streams, 28 x 28: 20.09 -> 20.00 ms per step over three runs each; all three: 20.2)
@@ -33,7 +33,10 @@ def side_stream(dev, which='leaf'):
     if dev.type != 'cuda' or os.environ.get('DM_TRAIN_SIDE_STREAM', '1') == '0':
         return None
     from . import streams
-    return streams.side(dev, _SIDE_STREAMS[which])
+    st = streams.side(dev, _SIDE_STREAMS[which])
+    if hazard.ENABLED[0]:
+        hazard.name_stream(st, f'side{_SIDE_STREAMS[which]}')
+    return st
 
 
 def _join_caller_after_backward(dev):
@@ -133,6 +136,7 @@ class RoIExtractFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (rois,) = ctx.saved_tensors
+        hazard.engine_handoff(g)
         output_size, scales, sr, fs, shapes = ctx.cfg
         grads = ops.roi_align_backward(g.contiguous(), shapes, rois, output_size, scales, sr, fs)
         return (None, None, None, None, None, *grads)
@@ -392,6 +396,7 @@ class MaskHeadFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         head, sv, feats, rois, labels = ctx.head, ctx.saved, ctx.feats, ctx.rois, ctx.labels
+        hazard.engine_handoff(*grads)
         dev = rois.device
         n_st = len(head.stages) + 1
         g_ips = [g.contiguous() if g is not None else None for g in grads[:n_st]]
@@ -598,6 +603,7 @@ class MaskPreFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         mp = ctx.mp
+        hazard.engine_handoff(g)
         x, y1, m1, v1, p1, y2, m2, v2, p2, h = ctx.sv
         n = x.shape[0]
         pg = {}
@@ -650,6 +656,7 @@ class GumbelSelectFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_hot, _g_idx):
         (y,) = ctx.saved_tensors
+        hazard.engine_handoff(g_hot)
         return ops.gumbel_select_backward(y, g_hot.contiguous(), ctx.t), None, None
 
 
@@ -681,6 +688,7 @@ class FCNMaskHeadFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         head, acts, u, aux = ctx.head, ctx.acts, ctx.u, ctx.aux
+        hazard.engine_handoff(g)
         pg = {}
 
         def params_bwd(conv, dy, xin, ks):
