@@ -110,3 +110,28 @@ def test_fcn_head_state_dict_keys():
         h.load_state_dict(ref, strict=True)
     with pytest.raises(ValueError):
         registry.build_head(dict(type='FCNMaskHead', upsample_cfg=dict(type='bogus', scale_factor=2)))
+
+
+def test_library_contains_no_packed_fp32_instructions(tmp_path):
+    """Round 5: a compiler-generated ``v_pk_fma_f32 ... op_sel:[0,1,0]`` dropped a product in lane 48 when four queues
+    shared the CUs (dynamask_amd/build.py ``FLAGS``; profiles/r05_race_hunt.txt).  The library is built without packed
+    fp32 operations; this disassembles the gfx950 code objects of the built .so and fails on any of them."""
+    import glob
+    import shutil
+    import subprocess
+    from dynamask_amd import _lib
+    objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    if not os.path.exists(objdump) or not os.path.exists(_lib.LIB_PATH):
+        pytest.skip('llvm-objdump or the built library is not here')
+    so = shutil.copy(_lib.LIB_PATH, tmp_path / 'lib.so')
+    subprocess.run([objdump, '--offloading', str(so)], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=tmp_path)
+    objs = glob.glob(str(tmp_path / 'lib.so.*gfx950*'))
+    assert objs, 'no gfx950 code object found in the library'
+    bad = 0
+    total = 0
+    for o in objs:
+        out = subprocess.run([objdump, '-d', o], check=True, capture_output=True, text=True).stdout
+        total += out.count('v_mfma_f32')
+        bad += sum(out.count(op) for op in ('v_pk_fma_f32', 'v_pk_mul_f32', 'v_pk_add_f32'))
+    assert total > 1000, 'the disassembly does not look like the operator library'
+    assert bad == 0, f'{bad} packed fp32 instructions in the library: build with dynamask_amd.build.FLAGS'

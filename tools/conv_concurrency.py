@@ -16,7 +16,8 @@ side = streams.side(dev, 0)
 noise_x = torch.randn(256, 64, 56, 56, device=dev)
 noise_w = ops.pack_conv_weight(torch.randn(64, 64, 3, 3, device=dev) * 0.05)
 noise_g = torch.randn(256, 64, 56, 56, device=dev)
-shapes = [(256, 256, 256, 14, 3), (256, 514, 256, 14, 1), (128, 64, 64, 56, 3), (256, 128, 128, 28, 1)]
+shapes = [(256, 256, 256, 14, 3), (256, 514, 256, 14, 1), (128, 64, 64, 56, 3), (256, 128, 128, 28, 1), (256, 256, 2, 14, 1), (256, 128, 2, 28, 1),
+          (256, 64, 2, 56, 1), (256, 36, 256, 14, 3), (256, 126, 256, 14, 1)]
 modes = [0] + ([3, 6] if hasattr(ops, 'split_packing') else [])
 for split in modes:
     for (n, cin, cout, s, ks) in shapes:

@@ -86,8 +86,17 @@ if args.hazard:
 ref_loss, ref = one_pass()
 differ = {}
 n_diff = 0
+distinct = [ref]
+seq = [0]
 for rep in range(1, args.reps):
     loss, g = one_pass()
+    for k, d in enumerate(distinct):
+        if torch.equal(g, d):
+            seq.append(k)
+            break
+    else:
+        distinct.append(g)
+        seq.append(len(distinct) - 1)
     if torch.equal(g, ref) and torch.equal(loss, ref_loss):
         continue
     n_diff += 1
@@ -99,9 +108,14 @@ for rep in range(1, args.reps):
             e = differ.setdefault(names.get(id(p), '?'), [0, 0.0])
             e[0] += 1
             e[1] = max(e[1], d)
+            if e[0] <= 3:
+                dd = (g[off:off + k] - ref[off:off + k]).view(p.shape[0], -1)
+                nz = dd.nonzero()
+                print(f'   pass {rep}: {names.get(id(p))} {tuple(p.shape)}: {nz.shape[0]} elements differ; rows {sorted(set(nz[:, 0].tolist()))[:20]} '
+                      f'cols {sorted(set(nz[:, 1].tolist()))[:40]}; labels count of those rows {[int((labels == r).sum()) for r in sorted(set(nz[:, 0].tolist()))[:20]]}')
         off += k
 print(f'mode: split={ops.MFMA_SPLIT if hasattr(ops, "MFMA_SPLIT") else 0} deterministic={ops.DETERMINISTIC[0]} '
       f'side_streams={os.environ.get("DM_TRAIN_SIDE_STREAM", "1")} leaf_alt={os.environ.get("DM_LEAF_ALT", "1")} perturb={args.perturb}')
-print(f'{n_diff} of {args.reps - 1} repeated passes differ from the first')
+print(f'{n_diff} of {args.reps - 1} repeated passes differ from the first; {len(distinct)} distinct results, sequence {"".join(chr(65 + min(k, 25)) for k in seq)}')
 for n, (c, d) in sorted(differ.items()):
     print(f'  {n}: differs in {c} passes, max |diff| {d:.3e}')
