@@ -30,7 +30,6 @@ IMG_H, IMG_W = 800, 1333
 ROIS_PER_IMG = 512
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
-PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA
 
 
 def build_head(dev):
@@ -606,46 +605,6 @@ def main():
             except Exception:
                 pass
         extra = {}
-        # ---- opt-in bf16-split matrix modes (DM_MFMA_SPLIT = 3 / 6; csrc/conv_igemm.hip): NEVER the headline -- the
-        # headline computes in exact fp32 like the reference.  The same step with the implicit-GEMM convolutions on
-        # the bf16 matrix cores (3 or 6 bf16 products per fp32 product, fp32 accumulation; deformable convolutions stay
-        # on fp32), as a replayed HIP graph like the headline; error against this run's exact-fp32 output.
-        split_report = {}
-        exact_out = eager_step()['stage_instance_preds'][1].clone()
-        for products in (3, 6):
-            try:
-                ops.MFMA_SPLIT = products
-                with torch.no_grad():
-                    for _ in range(2):
-                        so = eager_step()
-                    torch.cuda.synchronize()
-                    gs = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gs):
-                        so = eager_step()
-                    t_s = time_kernel_median(gs.replay, iters=15, warmup=3)
-                    err = float((so['stage_instance_preds'][1] - exact_out).abs().max())
-                    conv_s = head.mask_head.instance_convs[0].conv
-                    wps = conv_s.packed([256])
-                    ms_s = sorted(time_kernel(lambda: ops.conv2d(x, wps, b, 256, 3, relu=True), iters=10, warmup=2) for _ in range(5))[2]
-                split_report[str(products)] = {
-                    'ms_per_step': t_s, 'img_per_s': 1e3 / t_s, 'max_abs_err_vs_exact_fp32_step': err,
-                    'logit_scale': float(exact_out.abs().max()),
-                    'conv3x3_ms_per_launch': ms_s, 'conv3x3_fp32_equivalent_tflops': flops / (ms_s * 1e-3) / 1e12,
-                    'conv3x3_frac_of_fp32_mfma_peak': flops / (ms_s * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                    'conv3x3_frac_of_bf16_mfma_peak': products * flops / (ms_s * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS}
-            except Exception as e:      # noqa: BLE001
-                split_report[str(products)] = {'error': str(e)}
-            finally:
-                ops.MFMA_SPLIT = 0
-        extra['split_mfma'] = dict(split_report, what='opt-in bf16-split MFMA modes of the implicit-GEMM convolutions, not the headline '
-                                   '(dtype of the headline stays f32 on exact fp32 MFMA); 3 = hi*hi + hi*lo + lo*hi (~2^-16 per product), '
-                                   '6 = fp32-level; tests under the modes: DESIGN section 4 "bf16-split"')
-        if 'ms_per_step' in split_report.get('3', {}):
-            result['split_mfma_ms_per_step'] = split_report['3']['ms_per_step']
-            result['split_mfma_max_abs_err_vs_exact'] = split_report['3']['max_abs_err_vs_exact_fp32_step']
-        if 'ms_per_step' in split_report.get('6', {}):
-            result['split6_mfma_ms_per_step'] = split_report['6']['ms_per_step']
-            result['split6_mfma_max_abs_err_vs_exact'] = split_report['6']['max_abs_err_vs_exact_fp32_step']
         # ---- the reference's real inference shape (dynamask_roi_head.py:117-158, tools/benchmark.py:63-89): <= 100
         # detections per image, every exit to 112x112 + boundary merge, through the product's bucketed HIP-graph
         # replay (graphs.py); the eager figures beside it
@@ -721,17 +680,6 @@ def main():
             dt_cpu, cores, out_cpu = cpu_baseline(sd, feats_c, rois_c, labels_c, args.cpu_sample, reps=6)
             gpu = eager_step()      # not the graph: its packed-weight buffers predate the training leg
             err = float((gpu['stage_instance_preds'][1][:args.cpu_sample, 0].cpu() - out_cpu[0]).abs().max())
-            for products in (3, 6):
-                try:
-                    ops.MFMA_SPLIT = products
-                    so = eager_step()
-                    e_s = float((so['stage_instance_preds'][1][:args.cpu_sample, 0].cpu() - out_cpu[0]).abs().max())
-                    result['split_mfma_max_abs_err_vs_oracle' if products == 3 else 'split6_mfma_max_abs_err_vs_oracle'] = e_s
-                    extra['split_mfma'][str(products)]['max_abs_err_vs_oracle'] = e_s
-                except Exception:      # noqa: BLE001
-                    pass
-                finally:
-                    ops.MFMA_SPLIT = 0
             torch.set_num_threads(1)
             n1 = min(8, args.cpu_sample)
             dt1, _, _ = cpu_baseline(sd, feats_c, rois_c, labels_c, n1)

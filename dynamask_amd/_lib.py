@@ -4,7 +4,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DYNAMASK_HIP_LIB') or os.path.join(_HERE, 'libdynamask_hip.so')      # override: kernel experiments
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -22,8 +22,6 @@ SIGNATURES = {
     'dm_conv_packed_cout': ([_c_int], _c_int),
     'dm_conv_packed_floats': ([_c_int, _c_int, _c_int, _vp], ctypes.c_longlong),
     'dm_conv_pack_weight': ([_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp], _c_int),
-    'dm_conv_packed_floats_split': ([_c_int, _c_int, _c_int, _vp, _c_int], ctypes.c_longlong),
-    'dm_conv_pack_weight_split': ([_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp, _vp], _c_int),
     'dm_conv_pack_weight_batch': ([_vp, _c_int, _vp], _c_int),
     'dm_conv2d_fwd': ([_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp], _c_int),
     'dm_conv2d_fwd_ws': ([_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp, ctypes.c_longlong, _vp], _c_int),
@@ -63,10 +61,6 @@ SIGNATURES = {
     'dm_deform_coord_grad': ([_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp], _c_int),
     'dm_deform_col2im': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp], _c_int),
     'dm_dcn_weight_permute': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp], _c_int),
-    'dm_dcn_bwd_data_fused_supported': ([_c_int, _c_int, _c_int, _c_int, _c_int], _c_int),
-    'dm_dcn_bwd_pack_floats': ([_c_int, _c_int, _c_int], ctypes.c_longlong),
-    'dm_dcn_bwd_pack': ([_vp, _c_int, _c_int, _c_int, _vp, _vp], _c_int),
-    'dm_dcn_bwd_data_fused': ([_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp], _c_int),
     'dm_bn_relu_maxpool_bwd': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_float, _vp, _vp, _vp, _vp, _vp, _vp], _c_int),
     'dm_rle_scratch_ints': ([_c_int, _c_int, _c_int], ctypes.c_longlong),
     'dm_rle_encode_canvas': ([_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp], _c_int),

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libdynamask_hip.so')
-SOURCES = ['api_misc.hip', 'roi_align.hip', 'conv_igemm.hip', 'deform_conv.hip', 'pointwise.hip', 'carafe.hip', 'mask_pre.hip', 'backward.hip', 'rle.hip', 'bbox.hip', 'fc_gemm.hip', 'bbox_train.hip', 'polygon.hip', 'dcn_bwd_fused.hip']
+SOURCES = ['api_misc.hip', 'roi_align.hip', 'conv_igemm.hip', 'deform_conv.hip', 'pointwise.hip', 'carafe.hip', 'mask_pre.hip', 'backward.hip', 'rle.hip', 'bbox.hip', 'fc_gemm.hip', 'bbox_train.hip', 'polygon.hip']
 
 
 # Product-wide compile flags (beside -O3 -fPIC -std=c++17 --offload-arch=gfx950).

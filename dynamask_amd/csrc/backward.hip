@@ -581,8 +581,7 @@ static void launch_slab_reduce(const WgradArgs& a, int slabs, int splits, int Jt
 }
 
 static int launch_wgrad3_narrow(const WgradArgs& g, hipStream_t st) {
-  static const bool off = getenv("DM_WGRAD_NARROW_OFF") != nullptr;          // A/B switch
-  if (off || g.Cout > 36 || (g.W & 1) || g.W < 8 || g.H < 1) return 1;
+  if (g.Cout > 36 || (g.W & 1) || g.W < 8 || g.H < 1) return 1;
   if (((uintptr_t)g.dy | (uintptr_t)g.x) & 7u) return 1;
   if ((g.dy_bs | g.x_bs) & 1LL) return 1;
   const bool tail = g.Cout > 32;
@@ -2077,9 +2076,8 @@ static int point_sample_bwd_impl(const float* grad_out, int B, int C, int H, int
   if (!grad_out || !rois || !grad_feat || B <= 0 || C <= 0 || H <= 0 || W <= 0 || N < 0 || S <= 0) return DM_ERR_INVALID_ARG;
   if (N == 0) return DM_OK;
   constexpr int CT = 4;
-  static const int v1_env = getenv("DM_PSB_V1") ? atoi(getenv("DM_PSB_V1")) : 0;      // A/B switch: 1 = the scatter kernel
   const size_t glds = sizeof(float) * ((size_t)CT * S * S + 4 * (size_t)S + 3 * ((size_t)W + 4) + 3 * ((size_t)H + 4));
-  if (!v1_env && glds <= 64 * 1024 && S <= 128 && (long long)H * W * W < (1LL << 32)) {      // (2 S threads build the tables; cell * TW < 2^32)
+  if (glds <= 64 * 1024 && S <= 128 && (long long)H * W * W < (1LL << 32)) {      // (2 S threads build the tables; cell * TW < 2^32)
     DM_LAUNCH(point_sample_bwd_gather_kernel<CT>, dim3((unsigned)dm_ceil_div(C, CT), (unsigned)N), dim3(256), glds,
               (hipStream_t)stream, grad_out, B, C, H, W, rois, N, S, spatial_scale, grad_feat, fx);
     return dm_check_launch();
@@ -2111,8 +2109,7 @@ static int class_logits_bwd_impl(const float* x, int N, int C, int HW, const flo
     return DM_ERR_INVALID_ARG;
   if (N < 0 || C <= 0 || HW <= 0 || num_classes <= 0) return DM_ERR_INVALID_ARG;
   if (N == 0) return DM_OK;
-  static const bool v1_env = getenv("DM_CLB_V1") != nullptr;      // A/B switch
-  if (!v1_env && (HW & 3) == 0 && HW <= 1024 && ((((uintptr_t)x | (uintptr_t)grad_x | (uintptr_t)grad_inst | (uintptr_t)grad_det) & 15) == 0)) {
+  if ((HW & 3) == 0 && HW <= 1024 && ((((uintptr_t)x | (uintptr_t)grad_x | (uintptr_t)grad_inst | (uintptr_t)grad_det) & 15) == 0)) {
     constexpr int CPW = 4;
     if (HW <= 256)
       DM_LAUNCH((class_logits_bwd_wave_kernel<CPW, 1>), dim3((unsigned)dm_ceil_div(C, 4 * CPW), N), dim3(256), 0, (hipStream_t)stream, x, N, C, HW,
@@ -2174,8 +2171,7 @@ extern "C" int dm_deform_im2col(const float* x, const float* offset, int NB, int
   {
     // LDS-plane build: H*W a multiple of 4 and CT | C/deform_groups planes that fit 64 KB
     const int HW = H * W, cpg = C / deform_groups;
-    static const int v1_env = getenv("DM_IM2COL_V1") ? atoi(getenv("DM_IM2COL_V1")) : 0;      // A/B knob
-    if (!v1_env && HW % 4 == 0) {
+    if (HW % 4 == 0) {
       const dim3 block(256);
 #define DM_IM2COL(CTV)                                                                                              \
   if (cpg % CTV == 0 && (size_t)CTV * HW * 4 <= 64 * 1024) {                                                        \
@@ -2208,14 +2204,13 @@ extern "C" int dm_deform_coord_grad(const float* colgrad, const float* x, const 
   {
     // LDS-staged build: 8 | channels per group, W >= 2, H * W < 65536; a band of BRows rows (<= 224 pixels: 8 items per
     // thread) with DCN_COORD_HALO rows staged either side
-    static const bool v1_env = getenv("DM_COORD_V1") != nullptr;      // A/B switch
     const int cpg = C / deform_groups;
     const int BRows = max(1, min(H, 224 / W));
     const int XR = min(H, BRows + 2 * DCN_COORD_HALO);
     const int bands = dm_ceil_div(H, BRows);
     const int slots = 2 * (XR + 2) * (W + 2);
     const size_t lds = (size_t)2 * slots * 16;
-    if (!v1_env && cpg % 8 == 0 && W >= 2 && W <= 224 && H * W < (1 << 20) && 9 * BRows * W <= 2048 && slots <= 2048 &&
+    if (cpg % 8 == 0 && W >= 2 && W <= 224 && H * W < (1 << 20) && 9 * BRows * W <= 2048 && slots <= 2048 &&
         lds <= 64 * 1024 && (long long)NB * deform_groups * bands <= 0x7fffffffLL) {
       const dim3 grid((unsigned)(NB * deform_groups * bands));
       if (slots <= 2 * 512)

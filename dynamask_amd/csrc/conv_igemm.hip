@@ -70,53 +70,16 @@ struct ConvArgs {
 // chunks spill 35-55 dwords at 168 and lose a third of their rate; with 16-channel chunks (half the
 // prefetch registers) they fit without scratch, and three per CU beats the longer chunk: the DCN
 // column-gradient GEMMs 1.56 -> 1.20, 0.94 -> 0.78, 0.75 -> 0.67 ms, fusion 130->64 @56^2 0.56 -> 0.45 ms.
-// SPLIT (round 4, opt-in: DM_MFMA_SPLIT=3 | 6, flag bits 4 / 5 of dm_conv2d_fwd): the same tile, staging and epilogue on
-// the bf16 matrix cores.  SPLIT = the number of bf16 PARTS an fp32 value is cut into:
-//   2 parts  x = hi + lo      (hi = bf16(x), lo = bf16(x - hi): 16 significant bits), a product is hi*hi + hi*lo + lo*hi
-//            -- THREE v_mfma_f32_32x32x16_bf16, ~2^-16 relative per product (lo*lo dropped);
-//   3 parts  x = hi + mid + lo (24 significant bits), a product is hh + hm + mh + hl + lh + mm -- SIX MFMAs, the dropped
-//            terms are below 2^-24: fp32-level accuracy, sums differ from the exact fp32 chain only in their rounding.
-// fp32 accumulation in both.  One bf16 MFMA covers 16 channels in 32 cycles against 2 in 64 for v_mfma_f32_32x32x2_f32:
-// 16 x 32 / (3 x 64) = 5.3 x (6 products: 2.7 x) the fp32 matrix rate.  K is walked in chunks of 16 channels; a "word"
-// (16 bytes) holds 8 consecutive channels of one (cout | pixel) as bf16, and the 2 * SPLIT words of a chunk are
-// (channels 0-7 | 8-15) x (parts): the LDS images keep the fp32 builds' indexing with word = quad.  Weights are split once
-// at pack time (dm_conv_pack_weight_split, sources padded to 16 channels), activations when a thread commits its
-// prefetched floats to LDS.  NOT the parity build: inf * 0 / NaN propagation differs (inf splits into inf + NaN).
-typedef __bf16 dm_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 dm_bf16x2 __attribute__((ext_vector_type(2)));
-typedef float dm_f32x2 __attribute__((ext_vector_type(2)));
-
-// 8 floats -> NP words of 8 bf16: word p holds part p of each (part 0 = bf16(x), part p = bf16 of what is left)
-template <int NP>
-__device__ __forceinline__ void dm_split8(const dm_f32x4& q0, const dm_f32x4& q1, dm_f32x4 (&out)[NP]) {
-  dm_bf16x8 w[NP];
-#pragma unroll
-  for (int e = 0; e < 8; e += 2) {
-    float a = e < 4 ? q0[e] : q1[e - 4], b = e < 4 ? q0[e + 1] : q1[e - 3];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const dm_bf16x2 pb = __builtin_convertvector(dm_f32x2{a, b}, dm_bf16x2);
-      w[p][e] = pb[0];
-      w[p][e + 1] = pb[1];
-      a -= (float)pb[0];
-      b -= (float)pb[1];
-    }
-  }
-#pragma unroll
-  for (int p = 0; p < NP; ++p) out[p] = __builtin_bit_cast(dm_f32x4, w[p]);
-}
-
-template <int KS, int WGM, int WGN, int WM, int WN, int CK, int MAXPOS, int TAIL = 0, int SPLIT = 0>
-__global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && WM == 2 && WN == 2 && MAXPOS == 1) || (KS == 1 && CK == 16) || SPLIT == 2 || (SPLIT == 3 && KS == 1) ? 3 : (SPLIT == 3 ? 2 : 1)) void conv_igemm_kernel(ConvArgs a) {
+template <int KS, int WGM, int WGN, int WM, int WN, int CK, int MAXPOS, int TAIL = 0>
+__global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && WM == 2 && WN == 2 && MAXPOS == 1) || (KS == 1 && CK == 16) ? 3 : 1) void conv_igemm_kernel(ConvArgs a) {
   static_assert(TAIL == 0 || (TAIL == 4 && WGM == 1), "tail rows need a single cout tile");
-  static_assert(SPLIT == 0 || ((SPLIT == 2 || SPLIT == 3) && CK == 16 && TAIL == 0), "the bf16-split builds walk K in 16-channel chunks");
   constexpr int TM = WGM * WM * 32;
   constexpr int TMA = TM + TAIL;              // rows of the LDS A image
   constexpr int TN = WGN * WN * 32;
   constexpr int NT = WGM * WGN * 64;
   constexpr int TAPS = KS * KS;
   constexpr int NQ = CK / 4;                      // channel quads per chunk (what a thread prefetches of a pixel)
-  constexpr int NWC = SPLIT ? 2 * SPLIT : NQ;     // 16-byte words per chunk and (cout | pixel) in LDS and in the packed weights
+  constexpr int NWC = NQ;                         // 16-byte words per chunk and (cout | pixel) in LDS and in the packed weights
   constexpr int A_F4 = TAPS * NWC * TMA;          // float4 slots of the A chunk
   constexpr int A_PER_T = (A_F4 + NT - 1) / NT;
   constexpr int B1_PER_T = (NQ * TN + NT - 1) / NT;   // 1x1: float4 slots per thread
@@ -197,9 +160,9 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
       const int x = p - y * W;
       const int seg = n - n0;
       const int r = (seg == 0) ? (y - y00 + 1) : (rows0 + 2) + (seg - 1) * (H + 2) + (y + 1);
-      lane_base[wn] = (r - 1) * Wp + x + (SPLIT ? SPLIT * hi : hi) * plane;      // (SPLIT: lane half = channels 8 hi .. 8 hi + 7 = words SPLIT * hi ..)
+      lane_base[wn] = (r - 1) * Wp + x + hi * plane;
     } else {
-      lane_base[wn] = j + (SPLIT ? SPLIT * hi : hi) * plane;
+      lane_base[wn] = j + hi * plane;
     }
   }
 
@@ -260,7 +223,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
   auto chunk_valid = [&]() { return cs < a.num_srcs && k_left > 0; };
   auto chunk_advance = [&]() {
     const int ckv = min(CK, curC - cc0);
-    ckq += SPLIT ? NWC : ((ckv + 7) / 8) * 2;      // (SPLIT: every source is padded to whole 16-channel chunks)
+    ckq += ((ckv + 7) / 8) * 2;
     cc0 += CK;
     if (cc0 >= curC) {
       cs++;
@@ -287,7 +250,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
   // issue the global loads of the chunk at (cs, cc0, ckq) into registers
   auto prefetch = [&]() {
     const int ckv = min(CK, curC - cc0);
-    const int nq = SPLIT ? NWC : ((ckv + 7) / 8) * 2;    // quads (words) of this chunk present in the packed weights
+    const int nq = ((ckv + 7) / 8) * 2;    // quads of this chunk present in the packed weights
     // the chunk's part of an address is uniform (ckq, cc0); the thread's part is fixed for the K loop
     // (per source for B) and kept in a register: no 64-bit multiplies per load next to the MFMAs
     const float* abase = a.wq + (size_t)ckq * a.CoutP * 4;
@@ -310,8 +273,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
       const int qw = __builtin_amdgcn_readfirstlane(tid / TN);
 #pragma unroll
       for (int i = 0; i < B1_PER_T; ++i) {
-        // (SPLIT: a thread stages the two quads of one 8-channel half -- it converts them to one hi and one lo word)
-        const float* rq = rp + (size_t)((SPLIT ? qw * 2 + i : qw + i * (NT / TN)) * 4) * HW;
+        const float* rq = rp + (size_t)((qw + i * (NT / TN)) * 4) * HW;
 #pragma unroll
         for (int e = 0; e < 4; ++e) rb[i][e] = rq[(size_t)e * HW + b_off32];
       }
@@ -371,7 +333,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
       const float* gp = sp + b_off[0];
 #pragma unroll
       for (int i = 0; i < B1_PER_T; ++i) {
-        const int qd = SPLIT ? (tid / TN) * 2 + i : tid / TN + i * (NT / TN);
+        const int qd = tid / TN + i * (NT / TN);
         dm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -389,32 +351,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
       const int idx = tid + i * NT;
       if (idx < A_F4) ldsA[idx] = ra[i];
     }
-    if (SPLIT) {
-      // fp32 -> SPLIT bf16 words per 8-channel half: [channels 0-7: part 0 .. ][channels 8-15: part 0 .. ] of the thread's pixel(s)
-      constexpr int NP = SPLIT ? SPLIT : 1;
-      if (KS == 3) {
-#pragma unroll
-        for (int k = 0; k < MAXPOS; ++k) {
-          const int pos = tid + k * NT;
-          if (pos < plane) {
-#pragma unroll
-            for (int h8 = 0; h8 < 2; ++h8) {
-              dm_f32x4 wd[NP];
-              dm_split8<NP>(rb[k * NQ + 2 * h8], rb[k * NQ + 2 * h8 + 1], wd);
-#pragma unroll
-              for (int p_ = 0; p_ < NP; ++p_) ldsB[(NP * h8 + p_) * plane + pos] = wd[p_];
-            }
-          }
-        }
-      } else {
-        static_assert(!SPLIT || KS == 3 || (B1_PER_T == 2 && NT / TN == 2), "1x1 split build: two quads (one half) per thread");
-        const int h8 = tid / TN;
-        dm_f32x4 wd[NP];
-        dm_split8<NP>(rb[0], rb[B1_PER_T > 1 ? 1 : 0], wd);
-#pragma unroll
-        for (int p_ = 0; p_ < NP; ++p_) ldsB[(NP * h8 + p_) * plane + (tid % TN)] = wd[p_];
-      }
-    } else if (KS == 3) {
+    if (KS == 3) {
 #pragma unroll
       for (int k = 0; k < MAXPOS; ++k) {
         const int pos = tid + k * NT;
@@ -447,42 +384,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
     // Operand fragments are double-buffered in registers: the ds_reads of step s+1 are
     // issued before the 4 x WM x WN MFMAs of step s, so LDS latency never stalls the
     // matrix pipe (the compiler alone re-uses one register set and issues them late).
-    if (SPLIT) {
-      // one step per tap: the chunk's 16 channels are ONE k of v_mfma_f32_32x32x16_bf16 (lane half hi = channels 8 hi ..)
-      constexpr int NP = SPLIT ? SPLIT : 1;
-      auto load_frag = [&](int tap, dm_f32x4 (*av)[NP], dm_f32x4 (*bv)[NP]) {
-        const int tapoff = (KS == 3) ? ((tap / 3) * Wp + (tap % 3)) : 0;
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-          for (int p_ = 0; p_ < NP; ++p_) av[i][p_] = ldsA[(tap * NWC + NP * hi + p_) * TMA + (wave_m * WM + i) * 32 + l31];
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-          for (int p_ = 0; p_ < NP; ++p_) bv[j][p_] = ldsB[p_ * plane + lane_base[j] + tapoff];
-      };
-      dm_f32x4 av[2][WM][NP], bv[2][WN][NP];
-      load_frag(0, av[0], bv[0]);
-#pragma unroll
-      for (int st = 0; st < TAPS; ++st) {
-        const int cur = st & 1;
-        if (st + 1 < TAPS) load_frag(st + 1, av[cur ^ 1], bv[cur ^ 1]);
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-          for (int j = 0; j < WN; ++j) {
-            // part products with pa + pb <= NP - 1 (2 parts: 3 of them, 3 parts: 6), smallest terms first
-#pragma unroll
-            for (int sum = NP - 1; sum >= 0; --sum)
-#pragma unroll
-              for (int pa = 0; pa <= sum; ++pa) {
-                const int pb = sum - pa;
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dm_bf16x8, av[cur][i][pa]),
-                                                                    __builtin_bit_cast(dm_bf16x8, bv[cur][j][pb]), acc[i][j], 0, 0, 0);
-              }
-          }
-      }
-    } else {
+    {
       constexpr int NG = NQ / 2;
       constexpr int STEPS = TAPS * NG;
       auto load_frag = [&](int st, dm_f32x4* av, dm_f32x4* bv) {
@@ -704,58 +606,13 @@ __device__ __forceinline__ void pack_weight_body(const PackArgs& p, int ld, int 
   }
 }
 
-// bf16-split layout (SPLIT builds): [tap][KQ][colsP][16 bytes], sources padded to 16 channels, KQ = sum of
-// roundup(Cs, 16) / 16 * 2 NP words; word 2 NP b + NP h + part of a source's 16-channel block b holds channels
-// 16 b + 8 h .. + 7 of one produced channel as bf16 (part 0 = bf16(w), part p = bf16 of the remainder).  One thread per
-// (tap, half block, col).
-template <int NP>
-__device__ __forceinline__ void pack_weight_split_body(const PackArgs& p, int ld, int c0) {
-  const int HB = p.KQ / NP;                     // 8-channel halves
-  const long long total = (long long)p.kk * HB * p.colsP;
-  dm_f32x4* out = reinterpret_cast<dm_f32x4*>(p.wq);
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const int col = (int)(idx % p.colsP);
-    const int hb = (int)(idx / p.colsP % HB);
-    const int tap = (int)(idx / ((long long)p.colsP * HB));
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      int pc = hb * 8 + e, row = -1, base = 0;
-      for (int s = 0; s < p.nsrc; ++s) {
-        const int padded = (p.src_c[s] + 15) / 16 * 16;
-        if (pc < padded) {
-          if (pc < p.src_c[s]) row = base + pc;
-          break;
-        }
-        pc -= padded;
-        base += p.src_c[s];
-      }
-      float x = 0.f;
-      if (row >= 0 && col < p.cols) {
-        if (!p.flip) x = p.w[((size_t)col * ld + c0 + row) * p.kk + tap];
-        else x = p.w[((size_t)row * ld + c0 + col) * p.kk + (p.kk - 1 - tap)];
-      }
-      v[e] = x;
-    }
-    dm_f32x4 wd[NP];
-    dm_split8<NP>(dm_f32x4{v[0], v[1], v[2], v[3]}, dm_f32x4{v[4], v[5], v[6], v[7]}, wd);
-    const size_t w0 = ((size_t)tap * p.KQ + NP * hb) * p.colsP + col;
-#pragma unroll
-    for (int p_ = 0; p_ < NP; ++p_) out[w0 + (size_t)p_ * p.colsP] = wd[p_];
-  }
-}
-
 __global__ void pack_weight_kernel(PackArgs p) { pack_weight_body(p, p.Cin, 0); }
-template <int NP>
-__global__ void pack_weight_split_kernel(PackArgs p) { pack_weight_split_body<NP>(p, p.Cin, 0); }
 
 // Every pack of a training step in ONE launch (blockIdx.y = job): ~45 weight tensors change with every optimizer
 // step, and a launch per tensor cost the host 1.3 ms of the 3.7 ms it needs to issue a forward pass.
 __global__ void pack_weight_batch_kernel(const dm_pack_job* __restrict__ jobs) {
   const dm_pack_job j = jobs[blockIdx.y];
   PackArgs p;
-  const int split = (j.transpose_flip & 2) ? 2 : (j.transpose_flip & 4) ? 3 : 0;      // bits 1 / 2 of transpose_flip: the bf16-split layouts (parts)
   p.w = j.w; p.wq = j.w_packed; p.Cout = j.Cout; p.Cin = j.Cin; p.kk = j.ksize * j.ksize; p.flip = (j.transpose_flip & 1) ? 1 : 0;
   p.rows = p.flip ? j.Cout : j.Cin;
   p.cols = p.flip ? j.Cin : j.Cout;
@@ -764,23 +621,15 @@ __global__ void pack_weight_batch_kernel(const dm_pack_job* __restrict__ jobs) {
   p.KQ = 0;
   for (int s = 0; s < DM_MAX_SOURCES; ++s) {
     p.src_c[s] = s < j.num_srcs ? j.src_channels[s] : 0;
-    if (s < j.num_srcs) p.KQ += split ? (j.src_channels[s] + 15) / 16 * 2 * split : (j.src_channels[s] + 7) / 8 * 2;
+    if (s < j.num_srcs) p.KQ += (j.src_channels[s] + 7) / 8 * 2;
   }
   p.deconv = 0;
-  if (split == 2) pack_weight_split_body<2>(p, j.ld, j.c0);
-  else if (split == 3) pack_weight_split_body<3>(p, j.ld, j.c0);
-  else pack_weight_body(p, j.ld, j.c0);
+  pack_weight_body(p, j.ld, j.c0);
 }
 
 int packed_quads(int nsrc, const int* src_c) {
   int kq = 0;
   for (int s = 0; s < nsrc; ++s) kq += (src_c[s] + 7) / 8 * 2;
-  return kq;
-}
-
-int packed_words_split(int nsrc, const int* src_c, int parts) {
-  int kq = 0;
-  for (int s = 0; s < nsrc; ++s) kq += (src_c[s] + 15) / 16 * 2 * parts;
   return kq;
 }
 
@@ -806,26 +655,19 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __
   }
 }
 
-template <int KS, int WGM, int WGN, int WM, int WN, int CK, int MAXPOS, int TAIL = 0, int SPLIT = 0>
+template <int KS, int WGM, int WGN, int WM, int WN, int CK, int MAXPOS, int TAIL = 0>
 int launch_conv_mp(ConvArgs& a, hipStream_t st) {
   constexpr int TM = WGM * WM * 32;
   constexpr int TN = WGN * WN * 32;
   constexpr int NT = WGM * WGN * 64;
   const int NTiles = dm_ceil_div(a.Q - a.q_begin, TN);
-  constexpr int NWC = SPLIT ? 2 * SPLIT : CK / 4;
+  constexpr int NWC = CK / 4;
   const size_t lds_bytes = 16 * ((size_t)KS * KS * NWC * (TM + TAIL) + (size_t)NWC * a.plane);
-  if (lds_bytes > 64 * 1024) {
-    // (the bf16-split build of wide maps: 9 taps x 4 words x 64 couts + a two-position plane = 66.5 KB at 56 x 56)
-    if (!SPLIT || lds_bytes > 128 * 1024) return DM_ERR_UNSUPPORTED;
-    static bool raised[DM_MAX_DEVICES] = {false};
-    const int rc = dm_ensure_lds_limit(reinterpret_cast<const void*>(&conv_igemm_kernel<KS, WGM, WGN, WM, WN, CK, MAXPOS, TAIL, SPLIT>),
-                                       128 * 1024, raised);
-    if (rc != DM_OK) return rc;
-  }
+  if (lds_bytes > 64 * 1024) return DM_ERR_UNSUPPORTED;
   // ---- split-K for launches that leave most of the chip idle (a caller-provided workspace, one launch per call)
   a.ksplit = 1;
   if (a.ws && a.shuffle == 0 && a.q_begin == 0) {
-    constexpr int CKS = SPLIT ? 16 : CK;
+    constexpr int CKS = CK;
     int chunks = 0;
     for (int s_ = 0; s_ < a.num_srcs; ++s_) chunks += dm_ceil_div(a.src_c[s_], CKS);
     const int wgs = a.MT * NTiles, cus = dm_num_cus();
@@ -857,7 +699,7 @@ int launch_conv_mp(ConvArgs& a, hipStream_t st) {
     const float* mask = a.mask;
     float* out = a.out;
     const int flags = a.relu, oct = a.out_ch_total, oco = a.out_ch_offset;
-    DM_LAUNCH((conv_igemm_kernel<KS, WGM, WGN, WM, WN, CK, MAXPOS, TAIL, SPLIT>), dim3(a.MT * NTiles, a.ksplit), dim3(NT), lds_bytes, st, a);
+    DM_LAUNCH((conv_igemm_kernel<KS, WGM, WGN, WM, WN, CK, MAXPOS, TAIL>), dim3(a.MT * NTiles, a.ksplit), dim3(NT), lds_bytes, st, a);
     int rc = dm_check_launch();
     if (rc != DM_OK) return rc;
     const long long total = a.ws_stride;
@@ -865,11 +707,11 @@ int launch_conv_mp(ConvArgs& a, hipStream_t st) {
               a.ws_stride, a.NB, a.Cout, a.HW, bias, flags, out, oct, oco, mask);
     return dm_check_launch();
   }
-  DM_LAUNCH((conv_igemm_kernel<KS, WGM, WGN, WM, WN, CK, MAXPOS, TAIL, SPLIT>), dim3(a.MT * NTiles), dim3(NT), lds_bytes, st, a);
+  DM_LAUNCH((conv_igemm_kernel<KS, WGM, WGN, WM, WN, CK, MAXPOS, TAIL>), dim3(a.MT * NTiles), dim3(NT), lds_bytes, st, a);
   return dm_check_launch();
 }
 
-template <int KS, int WGM, int WGN, int WM, int WN, int CK, int TAIL = 0, int SPLIT = 0>
+template <int KS, int WGM, int WGN, int WM, int WN, int CK, int TAIL = 0>
 int launch_conv(ConvArgs& a, hipStream_t st) {
   constexpr int TM = WGM * WM * 32;
   constexpr int TN = WGN * WN * 32;
@@ -880,16 +722,14 @@ int launch_conv(ConvArgs& a, hipStream_t st) {
     const int nsegmax = dm_ceil_div(TN - 1, a.HW) + 1;
     const int rmax = dm_ceil_div(TN - 1, a.W) + 1 + 2 * nsegmax;
     a.plane = rmax * a.Wp;
-    if (a.plane <= NT) return launch_conv_mp<KS, WGM, WGN, WM, WN, CK, 1, TAIL, SPLIT>(a, st);
-    if (a.plane <= 2 * NT) return launch_conv_mp<KS, WGM, WGN, WM, WN, CK, 2, TAIL, SPLIT>(a, st);
-    if constexpr (SPLIT == 0) {
-      if (a.plane <= 4 * NT) return launch_conv_mp<KS, WGM, WGN, WM, WN, CK, 4, TAIL, SPLIT>(a, st);
-    }
+    if (a.plane <= NT) return launch_conv_mp<KS, WGM, WGN, WM, WN, CK, 1, TAIL>(a, st);
+    if (a.plane <= 2 * NT) return launch_conv_mp<KS, WGM, WGN, WM, WN, CK, 2, TAIL>(a, st);
+    if (a.plane <= 4 * NT) return launch_conv_mp<KS, WGM, WGN, WM, WN, CK, 4, TAIL>(a, st);
     return DM_ERR_UNSUPPORTED;
   }
   a.Wp = 0;
   a.plane = TN;
-  return launch_conv_mp<KS, WGM, WGN, WM, WN, CK, 1, TAIL, SPLIT>(a, st);
+  return launch_conv_mp<KS, WGM, WGN, WM, WN, CK, 1, TAIL>(a, st);
 }
 
 int run_pack(PackArgs& p, hipStream_t st) {
@@ -928,41 +768,6 @@ extern "C" int dm_conv_pack_weight(const float* w_oihw, int Cout, int Cin, int k
   p.KQ = packed_quads(num_srcs, src_channels);
   p.deconv = 0;
   return run_pack(p, (hipStream_t)stream);
-}
-
-extern "C" long long dm_conv_packed_floats_split(int Cout, int ksize, int num_srcs, const int* src_channels, int products) {
-  if (Cout <= 0 || ksize <= 0 || num_srcs < 1 || num_srcs > DM_MAX_SOURCES || !src_channels) return -1;
-  if (products != 3 && products != 6) return -1;
-  return (long long)ksize * ksize * packed_words_split(num_srcs, src_channels, products == 3 ? 2 : 3) * dm_conv_packed_cout(Cout) * 4;
-}
-
-extern "C" int dm_conv_pack_weight_split(const float* w_oihw, int Cout, int Cin, int ksize, int transpose_flip,
-                                         int num_srcs, const int* src_channels, int products, float* w_packed,
-                                         dm_stream_t stream) {
-  if (!w_oihw || !w_packed || Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3)) return DM_ERR_INVALID_ARG;
-  if (products != 3 && products != 6) return DM_ERR_INVALID_ARG;
-  const int parts = products == 3 ? 2 : 3;
-  if (num_srcs < 1 || num_srcs > DM_MAX_SOURCES || !src_channels) return DM_ERR_INVALID_ARG;
-  PackArgs p;
-  p.w = w_oihw; p.wq = w_packed; p.Cout = Cout; p.Cin = Cin; p.kk = ksize * ksize; p.flip = transpose_flip ? 1 : 0;
-  p.rows = transpose_flip ? Cout : Cin;
-  p.cols = transpose_flip ? Cin : Cout;
-  p.colsP = dm_conv_packed_cout(p.cols);
-  p.nsrc = num_srcs;
-  int sum = 0;
-  for (int s = 0; s < DM_MAX_SOURCES; ++s) {
-    p.src_c[s] = s < num_srcs ? src_channels[s] : 0;
-    if (s < num_srcs && src_channels[s] <= 0) return DM_ERR_INVALID_ARG;
-    sum += p.src_c[s];
-  }
-  if (sum != p.rows) return DM_ERR_INVALID_ARG;
-  p.KQ = packed_words_split(num_srcs, src_channels, parts);
-  p.deconv = 0;
-  const long long total = (long long)p.kk * (p.KQ / parts) * p.colsP;
-  const int blocks = (int)min((long long)dm_ceil_div(total, 256), 4096LL);
-  if (parts == 2) DM_LAUNCH(pack_weight_split_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
-  else DM_LAUNCH(pack_weight_split_kernel<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
-  return dm_check_launch();
 }
 
 extern "C" int dm_conv_pack_weight_batch(const dm_pack_job* jobs_device, int num_jobs, dm_stream_t stream) {
@@ -1046,9 +851,8 @@ static int conv2d_launch(const float* const* srcs, const int* src_channels, cons
     }
   }
   a.num_srcs = num_srcs;
-  // flag bit 4 / bit 5: w_packed is the 3-product / 6-product bf16-split layout (dm_conv_pack_weight_split)
-  const int split = (relu & 16) ? 2 : (relu & 32) ? 3 : 0;
-  a.KQ = split ? packed_words_split(num_srcs, src_channels, split) : packed_quads(num_srcs, src_channels);
+  if (relu & ~15) return DM_ERR_INVALID_ARG;      // (bits 4, 5 selected the bf16-split layouts of ABI 18-21: removed)
+  a.KQ = packed_quads(num_srcs, src_channels);
   a.NB = NB; a.H = H; a.W = W; a.HW = H * W; a.Q = NB * H * W;
   a.wq = w_packed; a.bias = bias; a.Cout = Cout; a.CoutP = dm_conv_packed_cout(Cout);
   a.relu = relu & 3; a.out = out; a.out_ch_total = out_ch_total; a.out_ch_offset = out_ch_offset;
@@ -1065,15 +869,6 @@ static int conv2d_launch(const float* const* srcs, const int* src_channels, cons
   // below); accumulating launches read the destination and keep the default policy
   if (!(relu & 2) && (long long)NB * Cout * H * W * 4 > (192LL << 20)) a.relu |= 4;
   hipStream_t st = (hipStream_t)stream;
-  if (split == 2) {
-    // 64 couts x 128 pixels, four waves of 32 x 64, three workgroups per CU (53 KB of LDS at 3x3): see the kernel's header
-    if (ksize == 3) return launch_conv<3, 2, 2, 1, 2, 16, 0, 2>(a, st);
-    return launch_conv<1, 2, 2, 1, 2, 16, 0, 2>(a, st);
-  }
-  if (split == 3) {
-    if (ksize == 3) return launch_conv<3, 2, 2, 1, 2, 16, 0, 3>(a, st);      // (80 KB of LDS at 3x3: two workgroups per CU)
-    return launch_conv<1, 2, 2, 1, 2, 16, 0, 3>(a, st);
-  }
   if (ksize == 3) {
     if (Cout > 64) {
       // 128 x 128 tiles run two or three to a CU: a launch is a sequence of rounds of 512 / 768 workgroups,
@@ -1127,16 +922,10 @@ static int conv2d_launch(const float* const* srcs, const int* src_channels, cons
     if (Cout > 32) return launch_conv<3, 1, 4, 2, 1, 8>(a, st);
     return launch_conv<3, 1, 4, 1, 1, 8>(a, st);
   }
-  int v = 0;                                                   // DM_CONV1_VARIANT: the other tilings tools/conv1_exp.py times
-  if (const char* e = getenv("DM_CONV1_VARIANT")) v = atoi(e);
-  if (Cout > 64) return v == 1 ? launch_conv<1, 2, 2, 2, 2, 32>(a, st) : launch_conv<1, 2, 2, 2, 2, 16>(a, st);
+  if (Cout > 64) return launch_conv<1, 2, 2, 2, 2, 16>(a, st);
   if (Cout > 32) {
     // 64 couts x 128 px as 4 waves of 32 x 64: 0.437 -> 0.379 ms on 576 -> 64 @56^2 x 128 RoIs, 0.098 -> 0.089 ms on
-    // 64 -> 64 x 256 (profiles/r03_conv1_exp.txt); same bits as the 64 x 256 tiling (v = 5), one k order per output.
-    if (v == 1) return launch_conv<1, 1, 4, 2, 2, 32>(a, st);
-    if (v == 3) return launch_conv<1, 2, 2, 1, 2, 32>(a, st);
-    if (v == 4) return launch_conv<1, 1, 4, 2, 1, 32>(a, st);
-    if (v == 5) return launch_conv<1, 1, 4, 2, 2, 16>(a, st);
+    // 64 -> 64 x 256 (the other tilings tried: docs/HISTORY.md, round 3); one k order per output.
     return launch_conv<1, 2, 2, 1, 2, 16>(a, st);
   }
   return launch_conv<1, 1, 4, 1, 1, 32>(a, st);

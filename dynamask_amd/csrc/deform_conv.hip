@@ -992,9 +992,8 @@ static int deform_conv_fwd_impl(const float* x, const float* offset, int NB, int
     // large maps: gather in the consuming wave from an LDS band of 16 rows (the 8 band planes of a chunk must fit the
     // 7 float4 per thread of the widest staging build: W <= 56).
     // Every launch size of an eligible shape takes this kernel (rows must not depend on the batch).
-    static const bool band_off = getenv("DM_DCN_BAND_OFF") != nullptr;      // A/B switch
     const int max_rows = (W - 1 + 128 + W - 1) / W;                         // rows a 128-pixel tile can span
-    if (!band_off && H >= 16 && (W & 3) == 0 && 8 * 16 * W / 4 <= 7 * 256 && (16 - max_rows) / 2 >= DCN_NEAR_ROWS && a.HW > 256 &&
+    if (H >= 16 && (W & 3) == 0 && 8 * 16 * W / 4 <= 7 * 256 && (16 - max_rows) / 2 >= DCN_NEAR_ROWS && a.HW > 256 &&
         a.HW < 65536 && (a.CoutP == 64 || a.CoutP == 128) && Cout > 32) {
       const bool narrow = 8 * 16 * W / 4 <= 4 * 256;                        // band planes fit 4 float4 per thread
       // a handful of RoIs (real inference): the launch is bound by the time of one workgroup -- one cout tile per

@@ -166,10 +166,6 @@ __global__ __launch_bounds__(256) void fc_reduce_kernel(const float* __restrict_
 // with one workgroup per tile those layers were a chain of 32 dependent staging round trips (0.105 ms);
 // long K (12544) coarser, or the partial slabs would cost more traffic than the operands.
 static inline int fc_seg(int K) {
-  if (const char* e = getenv("DM_FC_SEG")) {          // experiments
-    const int v = atoi(e);
-    if (v > 0 && K > 4096) return (v + 31) / 32 * 32;
-  }
   return K <= 4096 ? 256 : 1024;
 }
 

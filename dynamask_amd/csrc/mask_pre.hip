@@ -228,9 +228,8 @@ extern "C" int dm_bn_relu_maxpool_fwd(const float* x, int NB, int C, int H, int 
   if (NB == 0) return DM_OK;
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
   const size_t total = (size_t)NB * C * OH * OW;
-  static const int rows_off = getenv("DM_BN_POOL_V1") ? atoi(getenv("DM_BN_POOL_V1")) : 0;      // A/B switch
   const int pblocks = dm_ceil_div(OH * OW, 1024);
-  if (!rows_off && !(W & 1) && W >= 4 && OH * OW < 65536 && (long long)NB * C * pblocks < 0x7fffffffLL && (((uintptr_t)x) & 7) == 0) {
+  if (!(W & 1) && W >= 4 && OH * OW < 65536 && (long long)NB * C * pblocks < 0x7fffffffLL && (((uintptr_t)x) & 7) == 0) {
     const unsigned m_ow = 0xFFFFFFFFu / (unsigned)OW + 1u;      // OW >= 2; o * OW < 2^32
     DM_LAUNCH(bn_relu_maxpool_rows_kernel, dim3((unsigned)(NB * C * pblocks)), dim3(256), 0, (hipStream_t)stream, x, pblocks, C, H, W,
               mean, var, gamma, beta, eps, out, OH, OW, m_ow);
@@ -680,9 +679,8 @@ extern "C" int dm_bn_relu_maxpool_bwd(const float* x, int NB, int C, int H, int 
   hipStream_t st = (hipStream_t)stream;
   int rc;
   const size_t plane_lds = ((size_t)H * W + 2 * (size_t)OH * OW) * 4;
-  static const int fused_off = getenv("DM_BN_BWD_V1") ? atoi(getenv("DM_BN_BWD_V1")) : 0;      // A/B switch: 1 = the three-kernel form
   // (a workgroup per (channel, split): needs enough channels to fill the chip -- 256 x 16 x 28 x 28 measured 0.082 vs 0.055 ms)
-  if (!fused_off && scratch && NB >= kBnSplits && C * kBnSplits >= 4 * dm_num_cus() && (H * W) % 4 == 0 && plane_lds <= 64 * 1024) {
+  if (scratch && NB >= kBnSplits && C * kBnSplits >= 4 * dm_num_cus() && (H * W) % 4 == 0 && plane_lds <= 64 * 1024) {
     DM_LAUNCH(maxpool_relu_bwd_sums_kernel, dim3(C, kBnSplits), dim3(256), plane_lds, st, x, NB, C, H, W, mean, var, gamma, beta,
               eps, grad_out, grad_x, OH, OW, scratch);
     rc = dm_check_launch();

@@ -734,8 +734,7 @@ extern "C" int dm_point_sample_fwd(const float* feat, int B, int C, int H, int W
                                    float spatial_scale, float* out, dm_stream_t stream) {
   if (!feat || !rois || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0 || N < 0 || S <= 0) return DM_ERR_INVALID_ARG;
   if (N == 0) return DM_OK;
-  static const int ct_env = getenv("DM_PS_CT") ? atoi(getenv("DM_PS_CT")) : 0;      // experiments
-  const int CT = ct_env > 0 ? ct_env : 16;
+  const int CT = 16;
   const int chunks = dm_ceil_div(C, CT);
   const long long pos_blocks = ((long long)N * S * S + 255) / 256;
   if (pos_blocks * chunks > 0x7fffffffLL) return DM_ERR_UNSUPPORTED;

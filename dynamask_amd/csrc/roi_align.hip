@@ -33,7 +33,6 @@ struct RoiArgs {
   int order;           // forward tile / band kernels: 0 = workgroup b -> (RoI b / chunks, chunk b % chunks);
                        // 1 = XCD-aware (see roi_unit)
   int abl;             // ablation bits of the tile kernel (tools/micro/roi_tile_ablate.hip only, see DM_ABL)
-  int nt = 0;          // tile kernel: nontemporal output stores (experiment)
   const float* sorted = nullptr;   // tile kernel: RoI records in processing order (roi_order_kernel), 8 floats each
 };
 
@@ -46,18 +45,6 @@ struct RoiArgs {
 #define DM_ABL(a, bit) (((DM_ROI_ABLATE) & (bit)) != 0)
 #else
 #define DM_ABL(a, bit) false
-#endif
-
-// Per-workgroup phase stamps of the pipelined kernel (tools/roi_stamps.py builds THIS file with DM_ROI_STAMPS and reads
-// them back; in the library the macro expands to nothing).  Slot s of workgroup b: stamps[b * 32 + s] = s_memtime.
-#ifdef DM_ROI_STAMPS
-#define DM_STAMP(a, s)                                                                                        \
-  do {                                                                                                        \
-    if ((a).gfeat[0] && threadIdx.x == 0 && (s) < 32)                                                         \
-      reinterpret_cast<unsigned long long*>((a).gfeat[0])[(size_t)blockIdx.x * 32 + (s)] = __builtin_amdgcn_s_memtime(); \
-  } while (0)
-#else
-#define DM_STAMP(a, s) do { } while (0)
 #endif
 
 // Which (RoI, channel chunk) a workgroup of the forward tile / band kernels takes.
@@ -641,19 +628,10 @@ __device__ __forceinline__ void roi_tile_fwd(const RoiArgs& a, const float* __re
           }
           if (DM_ABL(a, 4) && acc.x != 12345.678f) continue;      // (keeps the value live without the store)
           char* const oq = ob + (size_t)(4 * q) * PB;
-          if (a.nt) {
-            // (experiment DM_ROI_NT14=1: the output streams past the caches, so that it does not evict the map planes
-            // the other workgroups of the XCD are staging from)
-            __builtin_nontemporal_store(acc.x, reinterpret_cast<float*>(oq + ot));
-            __builtin_nontemporal_store(acc.y, reinterpret_cast<float*>(oq + PB + ot));
-            __builtin_nontemporal_store(acc.z, reinterpret_cast<float*>(oq + 2 * PB + ot));
-            __builtin_nontemporal_store(acc.w, reinterpret_cast<float*>(oq + 3 * PB + ot));
-          } else {
-            *reinterpret_cast<float*>(oq + ot) = acc.x;
-            *reinterpret_cast<float*>(oq + PB + ot) = acc.y;
-            *reinterpret_cast<float*>(oq + 2 * PB + ot) = acc.z;
-            *reinterpret_cast<float*>(oq + 3 * PB + ot) = acc.w;
-          }
+          *reinterpret_cast<float*>(oq + ot) = acc.x;
+          *reinterpret_cast<float*>(oq + PB + ot) = acc.y;
+          *reinterpret_cast<float*>(oq + 2 * PB + ot) = acc.z;
+          *reinterpret_cast<float*>(oq + 3 * PB + ot) = acc.w;
         }
       }
     }
@@ -1105,1149 +1083,11 @@ __global__ __launch_bounds__(256, WPC) void roi_align_band_kernel(RoiArgs a) {
   }
 }
 
-// ---------------------------------------------------------------------------
-// Forward kernel for larger output grids, round 3: the same LDS tile format, staging and merged stencils as the band
-// kernel, reorganised around UNITS of equal size.
-//
-// What the band kernel measured (tools/roi_exp.py, 128 RoIs on P2 -> [128,256,56,56], 411 MB written): 284 us =
-// 1.45 TB/s, and 378 us for twice the RoIs -- the launch ends in a long tail.  A workgroup there owns (RoI, channel
-// quad) and walks the RoI's bands one after the other, each a dependent global -> LDS round trip: a 100 x 100-pixel
-// footprint is 7 such trips, the widest RoIs (bins of 3.6 feature pixels, 5 x 5 merged stencils, footprints wider
-// than the buffer allows for even one output row) fell to the per-sample global path, and whichever workgroups got
-// those RoIs were still running when everything else had finished.
-//
-// Here the work is cut into units = (RoI, tile of output rows x columns, channel quad) whose footprint fills the
-// 32 KB staging buffer at most once -- wide RoIs are cut into column blocks as well, so every RoI goes through LDS --
-// and a fixed number of persistent workgroups (4 per CU) takes unit u = workgroup + i * workgroups.  Every
-// workgroup derives the unit table itself: the tile counts of all RoIs (a function of the RoI's geometry alone, so
-// every workgroup finds the same) and their prefix sums in LDS; a binary search maps a unit to its RoI.  Units are
-// numbered tile-major, channel quads innermost: the workgroups running at any moment write neighbouring pieces of
-// one output region (the chunk-major order, which would share staged planes through the L2, measured 40 % slower).
-// A thread owns 4 neighbouring output columns and stores 16 bytes per channel (sampling grids up to 2 x 2), or one
-// output bin where the 5 x 5 stencils of large RoIs make reading, not writing, the bulk of the work.
-// Same products in the same order as the band kernel: the two give the same bits.
-constexpr int kUnitMaxRois = 2047;      // prefix sums are 16-bit (at most 64 x 16 tiles per RoI)
-
-struct UnitGeom {
-  int Hl, Wl;
-  const float* fimg;
-  float sw, sh, bw, bh, inv_count;
-  int gh, gw, G, pad;
-  int mode;            // 0: zero fill, 1: LDS tiles, 2: per-sample global path (footprint beyond any tile)
-  int ncb, gpb, R, nb; // column blocks, 4-column groups per block, output rows per band, bands
-  int lvl;
-};
-
-__device__ __forceinline__ void unit_geom(const RoiArgs& a, int k, UnitGeom& g) {
-  const float* r = a.rois + (size_t)k * 5;
-  const int b = (int)r[0];
-  const float x1 = r[1], y1 = r[2], x2 = r[3], y2 = r[4];
-  g.lvl = (a.L > 1) ? roi_level(x1, y1, x2, y2, a.finest, a.L) : 0;
-  g.Hl = a.H[0];
-  g.Wl = a.W[0];
-  float sc = a.scale[0];
-  const float* flvl = a.feat[0];
-#pragma unroll
-  for (int l = 1; l < DM_MAX_LEVELS; ++l)
-    if (g.lvl == l) {
-      g.Hl = a.H[l];
-      g.Wl = a.W[l];
-      sc = a.scale[l];
-      flvl = a.feat[l];
-    }
-  g.sw = x1 * sc - 0.5f;
-  g.sh = y1 * sc - 0.5f;
-  const float rw = (x2 * sc - 0.5f) - g.sw, rh = (y2 * sc - 0.5f) - g.sh;
-  const int P = a.P;
-  g.bh = rh / (float)P;
-  g.bw = rw / (float)P;
-  g.gh = a.sr > 0 ? a.sr : (int)ceilf(rh / (float)P);
-  g.gw = a.sr > 0 ? a.sr : (int)ceilf(rw / (float)P);
-  g.inv_count = 1.0f / (float)max(g.gh * g.gw, 1);
-  const bool bad_batch = (b < 0 || b >= a.B);
-  g.fimg = flvl + (bad_batch ? 0 : (size_t)b * a.C * g.Hl * g.Wl);
-  g.ncb = 1; g.gpb = P >> 2; g.R = P; g.nb = 1; g.G = 0; g.pad = 1;
-  if (g.gh <= 0 || g.gw <= 0 || bad_batch) { g.mode = 0; return; }
-  const int Gm = max(g.gh, g.gw);
-  const bool merged = Gm <= 4 && g.bh <= (float)g.gh && g.bw <= (float)g.gw;
-  g.G = merged ? Gm : 0;
-  g.pad = merged ? Gm : 1;
-  const float abh = fmaxf(fabsf(g.bh), 1e-6f), abw = fmaxf(fabsf(g.bw), 1e-6f);
-  const int groups = P >> 2;
-  // fewest column blocks whose tiles still hold >= 4 output rows (or the whole height); else the tallest on offer
-  int best_R = 0, best_ncb = 1;
-  for (int ncb = 1; ncb <= groups; ncb = (ncb < 4 ? ncb * 2 : ncb + 3)) {
-    const int gpb = (groups + ncb - 1) / ncb;
-    const int pitch = (int)floorf((float)(4 * gpb) * abw) + g.pad + 3;       // >= the widest block's tile (see unit_tile)
-    const int fh_max = kTileFloats4 / pitch;
-    const int R = (int)fminf((float)P, floorf((float)(fh_max - g.pad - 2) / abh));
-    if (R > best_R) { best_R = R; best_ncb = ncb; }
-    if (R >= min(P, 4)) break;
-  }
-  if (best_R < 1) { g.mode = 2; return; }
-  g.mode = 1;
-  g.ncb = best_ncb;
-  g.gpb = (groups + best_ncb - 1) / best_ncb;
-  g.ncb = (groups + g.gpb - 1) / g.gpb;          // blocks that actually hold columns
-  g.R = best_R;
-  g.nb = (P + best_R - 1) / best_R;
-}
-
-// one entry of a unit's stencil table: {L, W0 .. WG} (rows carry the 1 / (gh * gw) of the average)
-template <int GG>
-__device__ __forceinline__ void unit_table_entry(float start, float bin, int g, int p, int size, float fac, float* e) {
-  int L;
-  float Wt[GG + 1];
-  axis_stencil<GG>(start, bin, g, p, size, L, Wt);
-  e[0] = __int_as_float(L);
-#pragma unroll
-  for (int r = 0; r <= GG; ++r) e[1 + r] = fac == 1.0f ? Wt[r] : Wt[r] * fac;
-}
-
-// sampling of one unit: PXI = 4 (a thread owns 4 neighbouring columns, 16-byte stores) or 1
-template <int G, int PXI>
-__device__ __forceinline__ void unit_sample(const RoiArgs& a, const UnitGeom& g, int k, int cq, int ph0, int R, int pw0,
-                                            int Cw, int fy0, int fx0, int FH, int pitch, const float4* __restrict__ lds,
-                                            const float* __restrict__ tab, int nt) {
-  constexpr int S = G + 1;
-  const int P = a.P, PP = P * P;
-  const int tid = threadIdx.x;
-  const int ipr = Cw / PXI;                      // items per output row
-  float* obase = a.out + ((size_t)k * a.C + cq) * PP;
-  for (int it = tid; it < R * ipr; it += 256) {
-    const int pr = it / ipr, ci = it - pr * ipr;
-    const int ph = ph0 + pr, pl = ci * PXI;       // pl: first column of the item inside the block
-    float4 acc[PXI];
-    if (G > 0) {
-      const float* ey = tab + pr * 8;
-      const int Ly = __float_as_int(ey[0]);
-      const int rowbase = min(max(Ly - fy0, 0), FH - S) * pitch;
-#pragma unroll
-      for (int j = 0; j < PXI; ++j) {
-        const float* ex = tab + (64 + pl + j) * 8;
-        const int Lx = __float_as_int(ex[0]);
-        const float4* tq = lds + rowbase + min(max(Lx - fx0, 0), pitch - S);
-        float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int r = 0; r < S; ++r) {
-          const float4* tr = tq + r * pitch;
-#pragma unroll
-          for (int c = 0; c < S; ++c) {
-            const float4 v = tr[c];
-            const float wv = ey[1 + r] * ex[1 + c];
-            s4.x += wv * v.x;
-            s4.y += wv * v.y;
-            s4.z += wv * v.z;
-            s4.w += wv * v.w;
-          }
-        }
-        acc[j] = s4;
-        if (PXI > 1) __builtin_amdgcn_sched_barrier(0);      // one column's taps at a time: 4 x 9 float4 in flight spill
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < PXI; ++j) {
-        const int pw = pw0 + pl + j;
-        float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int iy = 0; iy < g.gh; ++iy) {
-          int lo, hi;
-          float yl_w, yh_w;
-          axis_sample(g.sh, g.bh, g.gh, ph, iy, g.Hl, lo, hi, yl_w, yh_w);
-          const int yo = min(max(lo - fy0, 0), FH - 2) * pitch;
-          yl_w *= g.inv_count;
-          yh_w *= g.inv_count;
-          for (int ix = 0; ix < g.gw; ++ix) {
-            float xl_w, xh_w;
-            axis_sample(g.sw, g.bw, g.gw, pw, ix, g.Wl, lo, hi, xl_w, xh_w);
-            const int xo = min(max(lo - fx0, 0), pitch - 2);
-            const float4* tp = lds + yo + xo;
-            const float4 v1 = tp[0], v2 = tp[1], v3 = tp[pitch], v4 = tp[pitch + 1];
-            const float w0 = yl_w * xl_w, w1 = yl_w * xh_w, w2 = yh_w * xl_w, w3 = yh_w * xh_w;
-            s4.x += w0 * v1.x + w1 * v2.x + w2 * v3.x + w3 * v4.x;
-            s4.y += w0 * v1.y + w1 * v2.y + w2 * v3.y + w3 * v4.y;
-            s4.z += w0 * v1.z + w1 * v2.z + w2 * v3.z + w3 * v4.z;
-            s4.w += w0 * v1.w + w1 * v2.w + w2 * v3.w + w3 * v4.w;
-          }
-        }
-        acc[j] = s4;
-      }
-    }
-    float* o = obase + ph * P + pw0 + pl;
-    if (PXI == 4) {
-      const dm_f32x4 o0 = {acc[0].x, acc[PXI > 1 ? 1 : 0].x, acc[PXI > 2 ? 2 : 0].x, acc[PXI > 3 ? 3 : 0].x};
-      const dm_f32x4 o1 = {acc[0].y, acc[PXI > 1 ? 1 : 0].y, acc[PXI > 2 ? 2 : 0].y, acc[PXI > 3 ? 3 : 0].y};
-      const dm_f32x4 o2 = {acc[0].z, acc[PXI > 1 ? 1 : 0].z, acc[PXI > 2 ? 2 : 0].z, acc[PXI > 3 ? 3 : 0].z};
-      const dm_f32x4 o3 = {acc[0].w, acc[PXI > 1 ? 1 : 0].w, acc[PXI > 2 ? 2 : 0].w, acc[PXI > 3 ? 3 : 0].w};
-      if (nt) {
-        __builtin_nontemporal_store(o0, reinterpret_cast<dm_f32x4*>(o));
-        __builtin_nontemporal_store(o1, reinterpret_cast<dm_f32x4*>(o + PP));
-        __builtin_nontemporal_store(o2, reinterpret_cast<dm_f32x4*>(o + 2 * (size_t)PP));
-        __builtin_nontemporal_store(o3, reinterpret_cast<dm_f32x4*>(o + 3 * (size_t)PP));
-      } else {
-        *reinterpret_cast<dm_f32x4*>(o) = o0;
-        *reinterpret_cast<dm_f32x4*>(o + PP) = o1;
-        *reinterpret_cast<dm_f32x4*>(o + 2 * (size_t)PP) = o2;
-        *reinterpret_cast<dm_f32x4*>(o + 3 * (size_t)PP) = o3;
-      }
-    } else {
-      o[0] = acc[0].x;
-      o[PP] = acc[0].y;
-      o[2 * (size_t)PP] = acc[0].z;
-      o[3 * (size_t)PP] = acc[0].w;
-    }
-  }
-}
-
-__global__ __launch_bounds__(256, 4) void roi_align_units_kernel(RoiArgs a, int nt) {
-  extern __shared__ __attribute__((aligned(16))) float4 lds4[];     // staging tile, stencil table, unit prefix sums
-  float* tab = reinterpret_cast<float*>(lds4 + kTileFloats4);       // [2][64][8]: rows of the band, columns of the block
-  unsigned short* pre = reinterpret_cast<unsigned short*>(lds4 + kTileFloats4 + kBandTabFloats4);   // [N + 1]
-  __shared__ int wsum[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int P = a.P, PP = P * P;
-  const int quads = a.C >> 2;
-  // ---- tiles per RoI and their exclusive prefix sums (every workgroup computes the same table)
-  int run = 0;
-  for (int base = 0; base < a.N; base += 256) {
-    const int k = base + tid;
-    int cnt = 0;
-    if (k < a.N) {
-      UnitGeom g;
-      unit_geom(a, k, g);
-      cnt = g.nb * g.ncb;
-      if (a.levels && blockIdx.x == 0) a.levels[k] = g.lvl;
-    }
-    int inc = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int up = __shfl_up(inc, d);
-      if (lane >= d) inc += up;
-    }
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    int off = run;
-    for (int w = 0; w < wave; ++w) off += wsum[w];
-    if (k < a.N) pre[k] = (unsigned short)(off + inc - cnt);
-    run += wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    __syncthreads();
-  }
-  if (tid == 0) pre[a.N] = (unsigned short)run;
-  __syncthreads();
-  const long long total = (long long)run * quads;
-
-  constexpr int IPT = (kTileFloats4 + 255) / 256;
-  for (long long u = blockIdx.x; u < total; u += gridDim.x) {
-    const int slot = (int)(u / quads);
-    const int cq = (int)(u - (long long)slot * quads) * 4;           // first channel of the unit's quad
-    int lo = 0, hi = a.N;                                             // largest k with pre[k] <= slot
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if ((int)pre[mid] <= slot) lo = mid; else hi = mid;
-    }
-    const int k = lo;
-    const int local = slot - (int)pre[k];
-    UnitGeom g;
-    unit_geom(a, k, g);
-    if (g.mode != 1) {
-      // degenerate RoI -> zeros; footprint beyond any tile (wider than ~2000 feature pixels per 4 output columns) ->
-      // per-sample global path
-      for (int pos = tid; pos < PP; pos += 256) {
-        const int ph = pos / P, pw = pos - ph * P;
-        if (g.mode == 0) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) a.out[((size_t)k * a.C + cq + c) * PP + pos] = 0.f;
-        } else {
-          roi_bin_generic<false>(a, g.fimg, nullptr, g.Hl, g.Wl, g.sh, g.sw, g.bh, g.bw, g.gh, g.gw, g.inv_count, ph, pw, k,
-                                 cq, cq + 4);
-        }
-      }
-      continue;
-    }
-    const int band = local / g.ncb, cb = local - band * g.ncb;
-    const int ph0 = band * g.R, R = min(g.R, P - ph0);
-    const int pw0 = cb * g.gpb * 4, Cw = min(g.gpb * 4, P - pw0);
-    // tile: first / last low tap of the unit's rows and columns (the expressions of axis_sample at their extremes)
-    const float yf = g.sh + (float)ph0 * g.bh + 0.5f * g.bh / (float)g.gh;
-    const float yl = g.sh + (float)(ph0 + R - 1) * g.bh + ((float)(g.gh - 1) + 0.5f) * g.bh / (float)g.gh;
-    const float xf = g.sw + (float)pw0 * g.bw + 0.5f * g.bw / (float)g.gw;
-    const float xl = g.sw + (float)(pw0 + Cw - 1) * g.bw + ((float)(g.gw - 1) + 0.5f) * g.bw / (float)g.gw;
-    const int fy0 = min((int)fmaxf(fminf(yf, yl), 0.f), g.Hl - 1);
-    const int ylast = min((int)fmaxf(fmaxf(yf, yl), 0.f), g.Hl - 1);
-    const int fx0 = min((int)fmaxf(fminf(xf, xl), 0.f), g.Wl - 1);
-    const int xlast = min((int)fmaxf(fmaxf(xf, xl), 0.f), g.Wl - 1);
-    const int FH = ylast + g.pad - fy0 + 1, pitch = xlast + g.pad - fx0 + 1;
-    const int ymax = min(ylast + 1, g.Hl - 1), xmax = min(xlast + 1, g.Wl - 1);
-    const int plane_px = FH * pitch;
-    if (plane_px > kTileFloats4) {
-      // cannot happen by the bounds of unit_geom; kept so that a rounding surprise costs time, not memory safety
-      for (int pos = tid; pos < R * Cw; pos += 256) {
-        const int pr = pos / Cw;
-        roi_bin_generic<false>(a, g.fimg, nullptr, g.Hl, g.Wl, g.sh, g.sw, g.bh, g.bw, g.gh, g.gw, g.inv_count, ph0 + pr,
-                               pw0 + pos - pr * Cw, k, cq, cq + 4);
-      }
-      continue;
-    }
-    // ---- stencil table of the unit's rows and columns, then the tile of this channel quad
-    const size_t plane = (size_t)g.Hl * g.Wl;
-    const unsigned m_pitch = 0xFFFFFFFFu / (unsigned)pitch + 1u;
-    const char* b0 = reinterpret_cast<const char*>(g.fimg + (size_t)cq * plane);
-    const char* b1 = b0 + plane * 4;
-    const char* b2 = b1 + plane * 4;
-    const char* b3 = b2 + plane * 4;
-    if (g.G > 0 && tid < 128) {
-      const bool xa = tid >= 64;
-      const int p = xa ? tid - 64 : tid;
-      if (p < (xa ? Cw : R)) {
-        const float st = xa ? g.sw : g.sh, bn = xa ? g.bw : g.bh;
-        const int gg = xa ? g.gw : g.gh, pp = (xa ? pw0 : ph0) + p, sz = xa ? g.Wl : g.Hl;
-        float* e = tab + tid * 8;
-        const float fac = xa ? 1.0f : g.inv_count;
-        if (g.G == 1) unit_table_entry<1>(st, bn, gg, pp, sz, fac, e);
-        else if (g.G == 2) unit_table_entry<2>(st, bn, gg, pp, sz, fac, e);
-        else if (g.G == 3) unit_table_entry<3>(st, bn, gg, pp, sz, fac, e);
-        else unit_table_entry<4>(st, bn, gg, pp, sz, fac, e);
-      }
-    }
-    float pf[IPT][4];
-#pragma unroll
-    for (int i = 0; i < IPT; ++i) {
-      const int idx = tid + i * 256;
-      const int idc = idx < plane_px ? idx : 0;
-      const int rr = (int)__umulhi((unsigned)idc, m_pitch);
-      const int xx = idc - rr * pitch;
-      const int gy = min(fy0 + rr, ymax), gx = min(fx0 + xx, xmax);
-      const int vo = (gy * g.Wl + gx) * 4;
-      pf[i][0] = *reinterpret_cast<const float*>(b0 + vo);
-      pf[i][1] = *reinterpret_cast<const float*>(b1 + vo);
-      pf[i][2] = *reinterpret_cast<const float*>(b2 + vo);
-      pf[i][3] = *reinterpret_cast<const float*>(b3 + vo);
-    }
-#pragma unroll
-    for (int i = 0; i < IPT; ++i)
-      if (tid + i * 256 < plane_px) lds4[tid + i * 256] = make_float4(pf[i][0], pf[i][1], pf[i][2], pf[i][3]);
-    __syncthreads();
-#define DM_UNIT(GG, PX) unit_sample<GG, PX>(a, g, k, cq, ph0, R, pw0, Cw, fy0, fx0, FH, pitch, lds4, tab, nt)
-    if (g.G == 1) DM_UNIT(1, 4);
-    else if (g.G == 2) DM_UNIT(2, 4);
-    else if (g.G == 3) DM_UNIT(3, 1);
-    else if (g.G == 4) DM_UNIT(4, 1);
-    else DM_UNIT(0, 1);
-#undef DM_UNIT
-    // LDS-only barrier (the stores just issued need no acknowledgement before the next unit stages)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  }
-}
-
-// ---------------------------------------------------------------------------
-// Round 4: the pipelined forward kernel for small output grids (P * P <= 256).
-//
-// What the tile kernel above measured in round 3 (its ceiling file is in git history; profiles/r04_roialign_ceiling.txt
-// repeats the measurement on the current kernel: 55.7 us, 37.2 with everything off): 73.7 us per launch of which 40.7 us remain
-// with its loads, its stencils and its stores all switched off -- 8192 workgroups (RoI x 16 channels) that each decode
-// the RoI, derive level, geometry, staging offsets and the stencil table for 3136 outputs: 20.8 M vector and 15.7 M
-// scalar instructions per launch (one per 2.5 cycles per SIMD for the whole 40 us) where the stencils need 4 M.
-// This kernel keeps the tile format, the staging and the merged stencils (same products in the same order: same
-// bits) and changes the skeleton:
-//   * a workgroup owns a RoI and CT = 64 channels (16 channel quads): the setup is paid once per 12 544 outputs;
-//   * the channel batches are software-pipelined inside the workgroup: batch i + 1 is fetched into registers before
-//     batch i is sampled, and batch i's results stay in registers until the top of the next round, so that the
-//     stores are OLDER than the loads the next commit waits for (vmcnt retires in issue order: stores issued
-//     behind the fetch would make every commit wait for their acknowledgement);
-//   * sampling grids above 3 x 3 (clipped slivers, a few per cent of the RoIs) take a run-time (gh+1) x (gw+1)
-//     merged stencil read from the LDS table instead of the per-sample path: no RoI is a tail;
-//   * 7 x 7 extraction: 5 channel quads are sampled side by side (thread = bin x quad slot) instead of 49 lanes of 256.
-constexpr int kPipeTabStride = 20;            // {L, W0 .. W16, pad}: run-time stencils up to 16 x 16 (grids up to 15)
-constexpr int kPipeTabFloats4 = 2 * 16 * kPipeTabStride / 4;
-
-// G: 1 .. 3: static merged stencil (G + 1)^2; 0: run-time merged stencil (gh + 1) x (gw + 1)
-// kPipeMaxQ: channel quads a thread samples per batch (their results stay in registers)
-template <int G, int kPipeMaxQ>
-__device__ __forceinline__ void roi_pipe_fwd(const RoiArgs& a, const float* __restrict__ fimg, int Hl, int Wl, float sh,
-                                             float sw, float bh, float bw, int gh, int gw, float inv_count, int k,
-                                             int c0, int c1, const TileGeom tg, float4* __restrict__ lds) {
-  constexpr int kBufPx = kTileFloats4;
-  constexpr int S = G + 1;
-  constexpr int IPT = (kBufPx + 255) / 256;      // items per thread and batch: 8
-  const int tid = threadIdx.x;
-  const int P = a.P, PP = P * P;
-  // thread = (bin, quad slot): P = 14 -> one slot (196 of 256 lanes), P = 7 -> five slots (245 lanes)
-  const int QS = 256 / PP;
-  const int qs = (int)__umulhi((unsigned)tid, 0xFFFFFFFFu / (unsigned)PP + 1u);       // tid / PP
-  const int bin = tid - qs * PP;
-  const bool active = qs < QS;
-  const int ph = (int)__umulhi((unsigned)bin, 0xFFFFFFFFu / (unsigned)P + 1u);        // bin / P (P >= 2)
-  const int pw = bin - ph * P;
-  const int plane_px = tg.FH * tg.pitch;              // <= kBufPx (checked by the caller)
-  const int NQ = min(min(kPipeMaxQ * QS, kBufPx / plane_px), (c1 - c0) >> 2);      // quads per batch
-
-  // ---- staging (as roi_tile_fwd): item = one tile pixel of one channel quad, LDS slot = item index
-  const size_t plane = (size_t)Hl * Wl;
-  unsigned voff[IPT];
-  const unsigned m_plane = 0xFFFFFFFFu / (unsigned)plane_px + 1u;
-  const unsigned m_pitch = 0xFFFFFFFFu / (unsigned)tg.pitch + 1u;
-#pragma unroll
-  for (int i = 0; i < IPT; ++i) {
-    const int idx = tid + i * 256;
-    const int idc = idx < NQ * plane_px ? idx : 0;
-    const int q = (int)__umulhi((unsigned)idc, m_plane);
-    const int rem = idc - __mul24(q, plane_px);
-    const int r = (int)__umulhi((unsigned)rem, m_pitch);
-    const int x = rem - __mul24(r, tg.pitch);
-    const int gy = min(tg.fy0 + r, tg.ymax);
-    const int gx = min(tg.fx0 + x, tg.xmax);
-    voff[i] = (unsigned)(__mul24(q * 4, (int)plane) + __mul24(gy, Wl) + gx) * 4u;       // bytes; H * W <= 2^23 (launcher)
-#ifdef DM_ROI_STAMPS
-    if (DM_ABL(a, 1)) voff[i] = (unsigned)(__mul24(q * 4, (int)plane) + idx) * 4u;      // timing only: contiguous 256 B per wave-instruction
-#endif
-  }
-  float pf[IPT][4];
-  auto fetch = [&](int cb, int nq) {
-    const int live = nq * plane_px;
-    const int ngr = (live + 255) >> 8;
-    const char* b0 = reinterpret_cast<const char*>(fimg + (size_t)cb * plane);
-    const char* b1 = b0 + plane * 4;
-    const char* b2 = b1 + plane * 4;
-    const char* b3 = b2 + plane * 4;
-#pragma unroll
-    for (int i = 0; i < IPT; ++i) {
-      if (i >= ngr) continue;
-      const unsigned vo = (tid + i * 256 < live) ? voff[i] : 0u;
-      pf[i][0] = *reinterpret_cast<const float*>(b0 + vo);
-      pf[i][1] = *reinterpret_cast<const float*>(b1 + vo);
-      pf[i][2] = *reinterpret_cast<const float*>(b2 + vo);
-      pf[i][3] = *reinterpret_cast<const float*>(b3 + vo);
-    }
-  };
-  auto commit = [&](int nq) {
-    const int ngr = (nq * plane_px + 255) >> 8;
-    // Every load of the fetch has to be back here anyway; saying so once, unconditionally, also tells the compiler
-    // that nothing is pending afterwards.  Without it, it cannot prove that the groups a fetch skipped (i >= ngr)
-    // are the groups this commit skips, assumes a load into pf[i] may still be in flight at the NEXT fetch, and puts
-    // an s_waitcnt vmcnt(0) in front of every group of loads there: eight dependent round trips per batch (first
-    // build of this kernel: 90 us at 64 channels per workgroup, 182 us at 256).
-    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) only (expcnt 7, lgkmcnt 15: not waited for)
-    float4* dst = lds + tid;
-#pragma unroll
-    for (int i = 0; i < IPT; ++i)
-      if (i < ngr) dst[i * 256] = make_float4(pf[i][0], pf[i][1], pf[i][2], pf[i][3]);
-  };
-
-  int nq_cur = NQ;
-  // (the RoI's coordinates are in, nothing else was loaded; said explicitly because the stencil variants are branches
-  // of one kernel and the compiler otherwise carries "a load into pf[i] may be pending" from one variant's loop into
-  // the next variant's first fetch, where it costs a vmcnt(0) between the groups of loads: see commit())
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  DM_STAMP(a, 1);
-  fetch(c0, nq_cur);      // the first batch is on its way while the stencil table is built
-  DM_STAMP(a, 2);
-
-  // ---- stencil table: one entry per output row and per output column, behind the staging buffer
-  float* tab = reinterpret_cast<float*>(lds + kTileFloats4);
-  int base = 0;
-  float W[G > 0 ? S * S : 1];
-  const int Gm = max(gh, gw);
-  if (G > 0) {
-    if (tid < 2 * P) {
-      const bool xa = tid >= P;
-      const int p = xa ? tid - P : tid;
-      int L;
-      float Wt[(G > 0 ? G : 1) + 1];
-      axis_stencil<(G > 0 ? G : 1)>(xa ? sw : sh, xa ? bw : bh, xa ? gw : gh, p, xa ? Wl : Hl, L, Wt);
-      float* e = tab + tid * 8;
-      e[0] = __int_as_float(L);
-#pragma unroll
-      for (int r = 0; r <= (G > 0 ? G : 1); ++r) e[1 + r] = xa ? Wt[r] : Wt[r] * inv_count;
-    }
-  } else {
-    // run-time form of axis_stencil: the same sums in the same order (a sample adds its low weight to cell d and its
-    // high weight to cell d + 1; the static form adds zeros elsewhere), accumulated in the thread's own table entry
-    if (tid < 2 * P) {
-      const bool xa = tid >= P;
-      const int p = xa ? tid - P : tid;
-      const float st = xa ? sw : sh, bn = xa ? bw : bh;
-      const int g = xa ? gw : gh, size = xa ? Wl : Hl;
-      float* e = tab + tid * kPipeTabStride;
-      int L = 0x7fffffff;
-      for (int i = 0; i < g; ++i) {
-        int lo, hi;
-        float wl, wh;
-        axis_sample(st, bn, g, p, i, size, lo, hi, wl, wh);
-        if (wl != 0.f || wh != 0.f) L = min(L, lo);
-      }
-      if (L == 0x7fffffff) L = 0;
-      e[0] = __int_as_float(L);
-      for (int r = 0; r <= g + 1; ++r) e[1 + r] = 0.f;
-      for (int i = 0; i < g; ++i) {
-        int lo, hi;
-        float wl, wh;
-        axis_sample(st, bn, g, p, i, size, lo, hi, wl, wh);
-        if (wl != 0.f || wh != 0.f) {
-          const int d = min(max(lo - L, 0), g - 1);       // 0 .. g-1 (samples are <= 1 pixel apart)
-          e[1 + d] += wl;
-          e[2 + d] += wh;
-        }
-      }
-      if (!xa)
-        for (int r = 0; r <= g; ++r) e[1 + r] *= inv_count;
-    }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (LDS only: the fetch stays in flight)
-  const float* ey = tab + ph * (G > 0 ? 8 : kPipeTabStride);
-  const float* ex = tab + (P + pw) * (G > 0 ? 8 : kPipeTabStride);
-  {
-    const int Sg = (G > 0 ? G : Gm) + 1;
-    const int Ly = __float_as_int(ey[0]), Lx = __float_as_int(ex[0]);
-    base = min(max(Ly - tg.fy0, 0), tg.FH - Sg) * tg.pitch + min(max(Lx - tg.fx0, 0), tg.pitch - Sg);
-  }
-  if (G > 0) {
-#pragma unroll
-    for (int r = 0; r < S; ++r)
-#pragma unroll
-      for (int c = 0; c < S; ++c) W[G > 0 ? r * S + c : 0] = ey[1 + r] * ex[1 + c];
-  }
-
-  float4 res[kPipeMaxQ];
-#pragma unroll
-  for (int j = 0; j < kPipeMaxQ; ++j) res[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto sample = [&](int nq) {
-    if (!active) return;
-#ifdef DM_ROI_STAMPS
-    if (DM_ABL(a, 4)) {      // timing only: one tap
-      for (int j = 0; j < kPipeMaxQ; ++j) res[j] = lds[__mul24(min(qs + j * QS, nq - 1), plane_px) + base];
-      return;
-    }
-#endif
-#pragma unroll
-    for (int j = 0; j < kPipeMaxQ; ++j) {
-      const int q = qs + j * QS;
-      if (q >= nq) continue;
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4* tq = lds + __mul24(q, plane_px) + base;
-      if (G > 0) {
-#pragma unroll
-        for (int r = 0; r < S; ++r) {
-          const float4* tr = tq + r * tg.pitch;
-#pragma unroll
-          for (int c = 0; c < S; ++c) {
-            const float4 v = tr[c];
-            const float wv = W[G > 0 ? r * S + c : 0];
-            acc.x += wv * v.x;
-            acc.y += wv * v.y;
-            acc.z += wv * v.z;
-            acc.w += wv * v.w;
-          }
-          // (the scheduler otherwise hoists the reads of all four quads -- 4 x 16 float4 at S = 4 -- and spills)
-          if (S >= 4 && (r & 1)) __builtin_amdgcn_sched_barrier(0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      } else {
-        for (int r = 0; r <= gh; ++r) {
-          const float wy = ey[1 + r];
-          const float4* tr = tq + r * tg.pitch;
-          for (int c = 0; c <= gw; ++c) {
-            const float4 v = tr[c];
-            const float wv = wy * ex[1 + c];
-            acc.x += wv * v.x;
-            acc.y += wv * v.y;
-            acc.z += wv * v.z;
-            acc.w += wv * v.w;
-          }
-        }
-      }
-      res[j] = acc;
-    }
-  };
-  auto store = [&](int cb, int nq) {
-    if (!active) return;
-#ifdef DM_ROI_STAMPS
-    if (DM_ABL(a, 2) && res[0].x != 12345.678f) return;      // timing only: no output stores
-#endif
-    char* const ob = reinterpret_cast<char*>(a.out + ((size_t)k * a.C + cb) * PP);
-    const unsigned ot = (unsigned)bin << 2;
-    const size_t PB = (size_t)PP * 4;
-#pragma unroll
-    for (int j = 0; j < kPipeMaxQ; ++j) {
-      const int q = qs + j * QS;
-      if (q >= nq) continue;
-      char* const oq = ob + (size_t)(4 * q) * PB;
-      *reinterpret_cast<float*>(oq + ot) = res[j].x;
-      *reinterpret_cast<float*>(oq + PB + ot) = res[j].y;
-      *reinterpret_cast<float*>(oq + 2 * PB + ot) = res[j].z;
-      *reinterpret_cast<float*>(oq + 3 * PB + ot) = res[j].w;
-    }
-  };
-
-  DM_STAMP(a, 3);
-  commit(nq_cur);
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  DM_STAMP(a, 4);
-  int cb = c0, cb_prev = c0, nq_prev = 0;
-  int stamp = 5;
-  (void)stamp;
-  for (;;) {
-    const int cbn = cb + 4 * nq_cur;
-    const int nq_next = min(NQ, (c1 - cbn) >> 2);
-    // (nothing is in flight here -- the last commit waited for its fetch and for the older stores -- but the compiler
-    // sees a path from a fetch around the commit to this point, see commit(); this wait is free and says so)
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    if (nq_prev > 0) store(cb_prev, nq_prev);      // the previous batch's results: older than the fetch below
-    if (nq_next > 0) fetch(cbn, nq_next);
-    DM_STAMP(a, stamp);          // stores + fetch issued
-    sample(nq_cur);
-    DM_STAMP(a, stamp + 1);      // sampled
-    cb_prev = cb;
-    nq_prev = nq_cur;
-    if (nq_next <= 0) break;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave has read the buffer
-    DM_STAMP(a, stamp + 2);      // barrier passed
-    commit(nq_next);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    DM_STAMP(a, stamp + 3);      // committed (fetch landed) + barrier
-    stamp += 4;
-    cb = cbn;
-    nq_cur = nq_next;
-  }
-  store(cb_prev, nq_prev);
-  DM_STAMP(a, 31);
-}
-
-// ---------------------------------------------------------------------------
-// Round 4, second step: plan + persistent kernel.
-//
-// What the stamps of the pipelined kernel showed (tools/roi_stamps.py, profiles/r04_roi_stamps.txt): of a workgroup's
-// 22 000 cycles (RoI x 32 channels) 6 100 pass before its first fetch is issued -- kernel arguments, the RoI's five
-// floats, level, geometry, eight staging offsets: a chain of dependent round trips and ~500 instructions during which
-// the workgroup holds its LDS and registers and moves nothing -- another 2 800 between its first fetch and its first
-// sample and 1 800 behind its last one; with loads, stencils and stores all ablated the launch still takes 40 us.
-// So the per-RoI arithmetic moves into a pre-pass (roi_plan_kernel: one 64-thread workgroup per RoI writes level,
-// tile geometry, staging constants and the 2 P stencil-table entries: 2.6 KB per RoI), and the extraction becomes a
-// PERSISTENT kernel: a workgroup walks units (RoI x CT channels) u = b, b + grid, ...; the header of unit i + 1 is
-// loaded (scalar loads) while unit i runs, and the batch pipeline of roi_pipe_fwd runs ACROSS units -- the first
-// batch of unit i + 1 is in flight while the last batch of unit i is sampled, its table entries arrive with it.
-// Units whose stencil is not a static 2x2 .. 5x5 one (grids above 4: clipped slivers) are left out of the pipeline and
-// done afterwards, synchronously (roi_unit_sync).
-constexpr int kPlanHdr = 16;                                   // dwords
-constexpr int kPlanDwords = kPlanHdr + 2 * 16 * kPipeTabStride;      // 656 dwords = 2624 bytes per RoI
-enum { kPlanMode = 0, kPlanLvl, kPlanB, kPlanGh, kPlanGw, kPlanFy0, kPlanFx0, kPlanFH, kPlanPitch, kPlanYmax, kPlanXmax,
-       kPlanPx, kPlanMPlane, kPlanMPitch, kPlanHl, kPlanWl };
-// mode: 0 = zeros (empty grid / bad batch index), 1 .. 4 = static merged stencil of that grid, 5 = run-time merged
-// stencil (grids 5 .. 15), 6 = the tile kernel's per-sample path or the direct path
-
-__global__ __launch_bounds__(64) void roi_plan_kernel(RoiArgs a, int* __restrict__ plans) {
-  const int k = blockIdx.x;
-  const int tid = threadIdx.x;
-  const float* r = a.rois + (size_t)k * 5;
-  const int b = (int)r[0];
-  const float x1 = r[1], y1 = r[2], x2 = r[3], y2 = r[4];
-  const int lvl = (a.L > 1) ? roi_level(x1, y1, x2, y2, a.finest, a.L) : 0;
-  if (a.levels && tid == 0) a.levels[k] = lvl;
-  const bool bad_batch = (b < 0 || b >= a.B);
-  int Hl = a.H[0], Wl = a.W[0];
-  float sc = a.scale[0];
-#pragma unroll
-  for (int l = 1; l < DM_MAX_LEVELS; ++l)
-    if (lvl == l) {
-      Hl = a.H[l];
-      Wl = a.W[l];
-      sc = a.scale[l];
-    }
-  const float sw = x1 * sc - 0.5f, sh = y1 * sc - 0.5f;
-  const float ew = x2 * sc - 0.5f, eh = y2 * sc - 0.5f;
-  const float rw = ew - sw, rh = eh - sh;
-  const int P = a.P;
-  const float bh = rh / (float)P, bw = rw / (float)P;
-  const int gh = a.sr > 0 ? a.sr : (int)ceilf(rh / (float)P);
-  const int gw = a.sr > 0 ? a.sr : (int)ceilf(rw / (float)P);
-  const float inv_count = 1.0f / (float)max(gh * gw, 1);
-  int* h = plans + (size_t)k * kPlanDwords;
-  int mode = 6;
-  int fy0 = 0, fx0 = 0, FH = 1, pitch = 1, ymax = 0, xmax = 0;
-  if (gh <= 0 || gw <= 0 || bad_batch) {
-    mode = 0;
-  } else {
-    const float yf = sh + 0.5f * bh / (float)gh;
-    const float yl = sh + (float)(P - 1) * bh + ((float)(gh - 1) + 0.5f) * bh / (float)gh;
-    const float xf = sw + 0.5f * bw / (float)gw;
-    const float xl = sw + (float)(P - 1) * bw + ((float)(gw - 1) + 0.5f) * bw / (float)gw;
-    const int G = max(gh, gw);
-    const bool near = bh <= (float)gh && bw <= (float)gw;
-    fy0 = min((int)fmaxf(fminf(yf, yl), 0.f), Hl - 1);
-    fx0 = min((int)fmaxf(fminf(xf, xl), 0.f), Wl - 1);
-    const int ylast = min((int)fmaxf(fmaxf(yf, yl), 0.f), Hl - 1);
-    const int xlast = min((int)fmaxf(fmaxf(xf, xl), 0.f), Wl - 1);
-    ymax = min(ylast + 1, Hl - 1);
-    xmax = min(xlast + 1, Wl - 1);
-    if (near && G <= 15) {
-      FH = ylast + G - fy0 + 1;
-      pitch = xlast + G - fx0 + 1;
-      if (FH * pitch <= kTileFloats4) mode = G <= 4 ? G : 5;
-    }
-    if (mode != 6 && tid < 2 * P) {
-      // stencil-table entry of one output row / column: the run-time form of axis_stencil (same sums, same order)
-      const bool xa = tid >= P;
-      const int p = xa ? tid - P : tid;
-      const float st = xa ? sw : sh, bn = xa ? bw : bh;
-      const int g = xa ? gw : gh, size = xa ? Wl : Hl;
-      float* e = reinterpret_cast<float*>(h + kPlanHdr) + tid * kPipeTabStride;
-      int L = 0x7fffffff;
-      for (int i = 0; i < g; ++i) {
-        int lo, hi;
-        float wl, wh;
-        axis_sample(st, bn, g, p, i, size, lo, hi, wl, wh);
-        if (wl != 0.f || wh != 0.f) L = min(L, lo);
-      }
-      if (L == 0x7fffffff) L = 0;
-      float Wt[17];
-#pragma unroll
-      for (int rr = 0; rr < 17; ++rr) Wt[rr] = 0.f;
-      for (int i = 0; i < g; ++i) {
-        int lo, hi;
-        float wl, wh;
-        axis_sample(st, bn, g, p, i, size, lo, hi, wl, wh);
-        if (wl != 0.f || wh != 0.f) {
-          const int d = min(max(lo - L, 0), g - 1);
-#pragma unroll
-          for (int rr = 0; rr < 16; ++rr) {
-            if (rr == d) Wt[rr] += wl;
-            if (rr == d) Wt[rr + 1] += wh;
-          }
-        }
-      }
-      e[0] = __int_as_float(L);
-#pragma unroll
-      for (int rr = 0; rr < 17; ++rr) e[1 + rr] = xa ? Wt[rr] : Wt[rr] * inv_count;
-    }
-  }
-  if (tid == 0) {
-    const int px = FH * pitch;
-    h[kPlanMode] = mode;
-    h[kPlanLvl] = lvl;
-    h[kPlanB] = bad_batch ? 0 : b;
-    h[kPlanGh] = gh;
-    h[kPlanGw] = gw;
-    h[kPlanFy0] = fy0;
-    h[kPlanFx0] = fx0;
-    h[kPlanFH] = FH;
-    h[kPlanPitch] = pitch;
-    h[kPlanYmax] = ymax;
-    h[kPlanXmax] = xmax;
-    h[kPlanPx] = px;
-    h[kPlanMPlane] = (int)(0xFFFFFFFFu / (unsigned)max(px, 1) + 1u);
-    h[kPlanMPitch] = (int)(0xFFFFFFFFu / (unsigned)max(pitch, 1) + 1u);
-    h[kPlanHl] = Hl;
-    h[kPlanWl] = Wl;
-  }
-}
-
-// one unit (RoI k, channels c0 .. c1), synchronously, with the batches pipelined inside the unit (roi_pipe_fwd)
-template <int MAXQ, bool ONLY_SPECIAL>
-__device__ __forceinline__ void roi_unit_sync(const RoiArgs& a, int k, int c0, int c1, float4* __restrict__ lds4) {
-  const float* r = a.rois + (size_t)k * 5;
-  const int b = (int)r[0];
-  const float x1 = r[1], y1 = r[2], x2 = r[3], y2 = r[4];
-  const int lvl = (a.L > 1) ? roi_level(x1, y1, x2, y2, a.finest, a.L) : 0;
-  const bool bad_batch = (b < 0 || b >= a.B);
-  int Hl = a.H[0], Wl = a.W[0];
-  float sc = a.scale[0];
-  const float* flvl = a.feat[0];
-#pragma unroll
-  for (int l = 1; l < DM_MAX_LEVELS; ++l)
-    if (lvl == l) {
-      Hl = a.H[l];
-      Wl = a.W[l];
-      sc = a.scale[l];
-      flvl = a.feat[l];
-    }
-  const float sw = x1 * sc - 0.5f, sh = y1 * sc - 0.5f;
-  const float ew = x2 * sc - 0.5f, eh = y2 * sc - 0.5f;
-  const float rw = ew - sw, rh = eh - sh;
-  const int P = a.P, PP = P * P;
-  const float bh = rh / (float)P, bw = rw / (float)P;
-  const int gh = a.sr > 0 ? a.sr : (int)ceilf(rh / (float)P);
-  const int gw = a.sr > 0 ? a.sr : (int)ceilf(rw / (float)P);
-  const float inv_count = 1.0f / (float)max(gh * gw, 1);
-  const float* fimg = flvl + (bad_batch ? 0 : (size_t)b * a.C * Hl * Wl);
-  if (gh <= 0 || gw <= 0 || bad_batch) {
-    for (int i = threadIdx.x; i < (c1 - c0) * PP; i += blockDim.x) a.out[((size_t)k * a.C + c0) * PP + i] = 0.f;
-    return;
-  }
-  const float yf = sh + 0.5f * bh / (float)gh;
-  const float yl = sh + (float)(P - 1) * bh + ((float)(gh - 1) + 0.5f) * bh / (float)gh;
-  const float xf = sw + 0.5f * bw / (float)gw;
-  const float xl = sw + (float)(P - 1) * bw + ((float)(gw - 1) + 0.5f) * bw / (float)gw;
-  const int G = max(gh, gw);
-  const bool near = bh <= (float)gh && bw <= (float)gw;      // samples <= 1 pixel apart (always true for the adaptive grid)
-  TileGeom tg;
-  tg.fy0 = min((int)fmaxf(fminf(yf, yl), 0.f), Hl - 1);
-  tg.fx0 = min((int)fmaxf(fminf(xf, xl), 0.f), Wl - 1);
-  const int ylast = min((int)fmaxf(fmaxf(yf, yl), 0.f), Hl - 1);     // last low tap
-  const int xlast = min((int)fmaxf(fmaxf(xf, xl), 0.f), Wl - 1);
-  tg.ymax = min(ylast + 1, Hl - 1);
-  tg.xmax = min(xlast + 1, Wl - 1);
-  if (near && G <= 15) {
-    tg.FH = ylast + G - tg.fy0 + 1;          // G cells past the last low tap
-    tg.pitch = xlast + G - tg.fx0 + 1;
-    if (tg.FH * tg.pitch <= kTileFloats4) {
-#define DM_ROI_PIPE(GG) roi_pipe_fwd<GG, MAXQ>(a, fimg, Hl, Wl, sh, sw, bh, bw, gh, gw, inv_count, k, c0, c1, tg, lds4)
-      if (!ONLY_SPECIAL && G == 1) DM_ROI_PIPE(1);
-      else if (!ONLY_SPECIAL && G == 2) DM_ROI_PIPE(2);
-      else if (!ONLY_SPECIAL && G == 3) DM_ROI_PIPE(3);
-      else DM_ROI_PIPE(0);
-#undef DM_ROI_PIPE
-      return;
-    }
-  }
-  {
-    // samples more than a pixel apart (a fixed sampling ratio on a large RoI), grids above 15, or a merged tile
-    // that does not fit: the tile kernel's per-sample path on its own tile (one cell past the last low tap)
-    const bool merged = G <= 4 && near;
-    const int pad = merged ? G : 1;
-    tg.FH = ylast + pad - tg.fy0 + 1;
-    tg.pitch = xlast + pad - tg.fx0 + 1;
-    if (!merged && tg.FH * tg.pitch <= kTileFloats4) {
-      roi_tile_fwd<0>(a, fimg, Hl, Wl, sh, sw, bh, bw, gh, gw, inv_count, k, c0, c1, tg, lds4);
-      return;
-    }
-  }
-  for (int pos = threadIdx.x; pos < PP; pos += blockDim.x) {
-    const int ph = pos / P;
-    const int pw = pos - ph * P;
-    roi_bin_generic<false>(a, fimg, nullptr, Hl, Wl, sh, sw, bh, bw, gh, gw, inv_count, ph, pw, k, c0, c1);
-  }
-}
-
-// virtual unit v -> (RoI, chunk); false if v names no unit.  order 1: units are dealt round-robin to the 8 XCDs
-// (v % 8, kept by a workgroup's stride); with 8 or more chunks XCD x takes the chunks c = x (mod 8) chunk-major (as
-// roi_unit), with 1, 2 or 4 chunks it takes chunk x % chunks for the RoIs k = x / chunks (mod 8 / chunks).
-__device__ __forceinline__ bool roi_persist_unit(const RoiArgs& a, int chunks, int v, int& k, int& chunk) {
-  if (a.order == 1 && chunks < 8) {
-    const int x = v & 7, j = v >> 3;
-    const int per = 8 / chunks;
-    chunk = x & (chunks - 1);
-    k = j * per + x / chunks;
-  } else if (a.order == 1) {
-    const int x = v & 7, j = v >> 3;
-    const int lc = j / a.N;
-    k = j - lc * a.N;
-    chunk = lc * 8 + x;
-  } else {
-    k = v / chunks;
-    chunk = v - k * chunks;
-  }
-  return k < a.N && chunk < chunks;
-}
-
-template <int WPC>
-__global__ __launch_bounds__(256, WPC) void roi_align_persist_kernel(RoiArgs a, const int* __restrict__ plans, int vtotal) {
-  extern __shared__ __attribute__((aligned(16))) float4 lds4[];
-  constexpr int MAXQ = 4;
-  constexpr int kBufPx = kTileFloats4;
-  constexpr int IPT = (kBufPx + 255) / 256;
-  float4* const lds = lds4;
-  const int tid = threadIdx.x;
-  const int P = a.P, PP = P * P;
-  const int chunks = (a.C + a.CT - 1) / a.CT;
-  const int stride = gridDim.x;
-  // ---- thread -> (bin, first quad q0, quad step): the quads of a batch this thread samples are q0 + j * qstep.
-  //  * PP >= 64 (14x14): the threads below nfull = PP rounded down to whole waves own one bin each and walk the batch's
-  //    quads; the PP - nfull bins left (4 of 196) would keep a whole wave busy for four lanes: their (bin, quad) pairs
-  //    are dealt over the lanes of ONE wave instead (lane = bin + TB * quad), which then runs the stencil once, not
-  //    once per quad
-  //  * PP < 64 (7x7): 256 / PP quad slots side by side (thread = bin + PP * slot)
-  int bin, q0, qstep, QB;             // QB: quads a batch may hold per MAXQ rounds of this mapping
-  bool active;
-  if (PP >= 64) {
-    const int nfull = PP & ~63;
-    QB = MAXQ;
-    if (tid < nfull) {
-      bin = tid; q0 = 0; qstep = 1; active = true;
-    } else {
-      const int tail = PP - nfull;
-      int TB = 1;
-      while (TB < tail) TB <<= 1;
-      const int l = tid - nfull;
-      bin = nfull + (l & (TB - 1));
-      q0 = l / TB;
-      qstep = 64 / TB;
-      active = l < 64 && (l & (TB - 1)) < tail && tail > 0;
-      if (!active) bin = 0;
-    }
-  } else {
-    const int QS = 256 / PP;
-    const int qsl = (int)__umulhi((unsigned)tid, 0xFFFFFFFFu / (unsigned)PP + 1u);
-    bin = tid - qsl * PP;
-    q0 = qsl; qstep = QS; active = qsl < QS;
-    QB = MAXQ * QS;
-    if (!active) bin = 0;
-  }
-  const int ph = (int)__umulhi((unsigned)bin, 0xFFFFFFFFu / (unsigned)P + 1u);
-  const int pw = bin - ph * P;
-  const unsigned PB = (unsigned)PP * 4u;
-  const unsigned ot = ((unsigned)bin << 2) + (unsigned)q0 * 4u * PB;      // lane part of a store offset (< 2^31: C * PP * 4 per RoI is checked by the launcher)
-  const unsigned qadv = (unsigned)qstep * 4u * PB;
-
-  // ---- header of a unit's RoI: 16 dwords by scalar loads
-  struct Hdr { int mode, b, fy0, fx0, FH, pitch, ymax, xmax, px, Hl, Wl, lvl; unsigned m_plane, m_pitch; };
-  auto load_hdr = [&](int k, Hdr& h) {
-    const int* p = plans + (size_t)k * kPlanDwords;
-    h.mode = p[kPlanMode]; h.lvl = p[kPlanLvl]; h.b = p[kPlanB];
-    h.fy0 = p[kPlanFy0]; h.fx0 = p[kPlanFx0]; h.FH = p[kPlanFH]; h.pitch = p[kPlanPitch];
-    h.ymax = p[kPlanYmax]; h.xmax = p[kPlanXmax]; h.px = p[kPlanPx];
-    h.m_plane = (unsigned)p[kPlanMPlane]; h.m_pitch = (unsigned)p[kPlanMPitch];
-    h.Hl = p[kPlanHl]; h.Wl = p[kPlanWl];
-  };
-  // next unit of this workgroup behind virtual index v whose stencil is static (or vtotal): its header in h
-  auto next_normal = [&](int v, int& k, int& chunk, Hdr& h) {
-    for (v += stride; v < vtotal; v += stride) {
-      if (!roi_persist_unit(a, chunks, v, k, chunk)) continue;
-      load_hdr(k, h);
-      if (h.mode >= 1 && h.mode <= 4) return v;
-    }
-    return vtotal;
-  };
-
-  // ---- fetch side (unit F)
-  unsigned voff[IPT];                // byte offset of the thread's items inside a batch (0 for items past the batch)
-  float pf[IPT][4];
-  int kF = 0;
-  const char* fbase = nullptr;       // first channel plane of the next batch to fetch
-  size_t planeF = 0;                 // H * W of unit F's level
-  int pxF = 1, NQF = 1, cF = 0, c1F = 0, ngrF = 0;   // tile pixels, quads per batch, next channel, end of the chunk, groups of 256 items per batch
-  char* obF = nullptr;               // output of unit F's RoI: a.out + k * C * PP
-  int pitchF = 1, fy0F = 0, fx0F = 0, FHF = 1, GF = 1;
-  auto setup_fetch = [&](int k, int chunk, const Hdr& h) {
-    kF = k;
-    planeF = (size_t)h.Hl * h.Wl;
-    pxF = h.px;
-    pitchF = h.pitch; fy0F = h.fy0; fx0F = h.fx0; FHF = h.FH; GF = h.mode;
-    const int c0 = chunk * a.CT;
-    c1F = min(c0 + a.CT, a.C);
-    cF = c0;
-    // every batch of the unit holds the same number of quads (the largest count the buffer and the result registers
-    // allow that divides the chunk): the items a thread fetches are then the same in every batch and their
-    // "past the batch" test is part of the offsets below, not of every fetch
-    const int nqu = (c1F - c0) >> 2;
-    NQF = min(min(QB, kBufPx / pxF), nqu);
-    while (nqu % NQF != 0) --NQF;
-    ngrF = (NQF * pxF + 255) >> 8;
-    const float* flvl = a.feat[0];
-#pragma unroll
-    for (int l = 1; l < DM_MAX_LEVELS; ++l)
-      if (h.lvl == l) flvl = a.feat[l];
-    fbase = reinterpret_cast<const char*>(flvl + ((size_t)h.b * a.C + c0) * planeF);
-    obF = reinterpret_cast<char*>(a.out + (size_t)k * a.C * PP);
-#pragma unroll
-    for (int i = 0; i < IPT; ++i) {
-      const int idx = tid + i * 256;
-      const int idc = idx < NQF * pxF ? idx : 0;
-      const int q = (int)__umulhi((unsigned)idc, h.m_plane);
-      const int rem = idc - __mul24(q, pxF);
-      const int r = (int)__umulhi((unsigned)rem, h.m_pitch);
-      const int x = rem - __mul24(r, h.pitch);
-      const int gy = min(h.fy0 + r, h.ymax);
-      const int gx = min(h.fx0 + x, h.xmax);
-      voff[i] = (unsigned)(__mul24(q * 4, (int)planeF) + __mul24(gy, h.Wl) + gx) * 4u;
-    }
-  };
-  // (the thread's table entries of a unit -- {L, W0 .. W4} of its row and of its column -- are loaded right in front of
-  // the commit that waits for the unit's first fetch: loaded WITH that fetch they are twelve more live registers during
-  // the sampling of the previous unit's last batch, and the compiler copies them into place at the end of the branch
-  // that loads them, i.e. waits for them before the fetch is even issued)
-  auto load_table = [&](float (&tb)[12]) {
-    const float* ey = reinterpret_cast<const float*>(plans + (size_t)kF * kPlanDwords + kPlanHdr) + ph * kPipeTabStride;
-    const float* ex = reinterpret_cast<const float*>(plans + (size_t)kF * kPlanDwords + kPlanHdr) + (P + pw) * kPipeTabStride;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      tb[i] = ey[i];
-      tb[6 + i] = ex[i];
-    }
-  };
-  auto fetch = [&]() {       // the next NQF quads from fbase on; advances fbase / cF
-    const char* b0 = fbase;
-    const char* b1 = b0 + planeF * 4;
-    const char* b2 = b1 + planeF * 4;
-    const char* b3 = b2 + planeF * 4;
-#pragma unroll
-    for (int i = 0; i < IPT; ++i) {
-      if (i >= ngrF) continue;
-      pf[i][0] = *reinterpret_cast<const float*>(b0 + voff[i]);
-      pf[i][1] = *reinterpret_cast<const float*>(b1 + voff[i]);
-      pf[i][2] = *reinterpret_cast<const float*>(b2 + voff[i]);
-      pf[i][3] = *reinterpret_cast<const float*>(b3 + voff[i]);
-    }
-    fbase += (size_t)(4 * NQF) * planeF * 4;
-    cF += 4 * NQF;
-  };
-  auto commit = [&](int ngr) {
-    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): see roi_pipe_fwd
-    float4* dst = lds + tid;
-#pragma unroll
-    for (int i = 0; i < IPT; ++i)
-      if (i < ngr) dst[i * 256] = make_float4(pf[i][0], pf[i][1], pf[i][2], pf[i][3]);
-  };
-
-  // ---- sample side (unit S) and the results in flight (unit R)
-  int GS = 1, pxS = 1, pitchS = 1, base = 0;
-  float W[25];
-  auto weights = [&](const float (&tb)[12]) {           // unit F becomes unit S: the thread's stencil from its table entries
-    GS = GF; pxS = pxF; pitchS = pitchF;
-    const int S = GF + 1;
-    const int Ly = __float_as_int(tb[0]), Lx = __float_as_int(tb[6]);
-    base = min(max(Ly - fy0F, 0), FHF - S) * pitchF + min(max(Lx - fx0F, 0), pitchF - S);
-#pragma unroll
-    for (int r = 0; r < 5; ++r)
-#pragma unroll
-      for (int c = 0; c < 5; ++c) W[r * 5 + c] = tb[1 + r] * tb[7 + c];
-  };
-  float4 res[MAXQ];
-#pragma unroll
-  for (int j = 0; j < MAXQ; ++j) res[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto sample = [&](int nq) {
-    if (!active) return;
-#define DM_TAPS(S_)                                                                 \
-    _Pragma("unroll") for (int j = 0; j < MAXQ; ++j) {                               \
-      const int q = q0 + j * qstep;                                                 \
-      if (q >= nq) continue;                                                        \
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);                                 \
-      const float4* tq = lds + __mul24(q, pxS) + base;                              \
-      _Pragma("unroll") for (int r = 0; r < S_; ++r) {                              \
-        const float4* tr = tq + r * pitchS;                                         \
-        _Pragma("unroll") for (int c = 0; c < S_; ++c) {                            \
-          const float4 v = tr[c];                                                   \
-          const float wv = W[r * 5 + c];                                            \
-          acc.x += wv * v.x;                                                        \
-          acc.y += wv * v.y;                                                        \
-          acc.z += wv * v.z;                                                        \
-          acc.w += wv * v.w;                                                        \
-        }                                                                           \
-        if (S_ >= 4 && (r & 1)) __builtin_amdgcn_sched_barrier(0);                  \
-      }                                                                             \
-      __builtin_amdgcn_sched_barrier(0);                                            \
-      res[j] = acc;                                                                 \
-    }
-    if (GS == 1) { DM_TAPS(2) }
-    else if (GS == 2) { DM_TAPS(3) }
-    else if (GS == 3) { DM_TAPS(4) }
-    else { DM_TAPS(5) }
-#undef DM_TAPS
-  };
-  char* obR = nullptr;             // first output plane of the results held in res
-  int nqR = 0;
-  auto store = [&]() {
-    if (!active || nqR <= 0) return;
-    // uniform plane bases + one 32-bit lane offset per quad (a 64-bit lane address per store was 3 VALU instructions each)
-    char* const o0 = obR;
-    char* const o1 = o0 + PB;
-    char* const o2 = o1 + PB;
-    char* const o3 = o2 + PB;
-    unsigned off = ot;
-#pragma unroll
-    for (int j = 0; j < MAXQ; ++j) {
-      const int q = q0 + j * qstep;
-      if (q < nqR) {
-        *reinterpret_cast<float*>(o0 + off) = res[j].x;
-        *reinterpret_cast<float*>(o1 + off) = res[j].y;
-        *reinterpret_cast<float*>(o2 + off) = res[j].z;
-        *reinterpret_cast<float*>(o3 + off) = res[j].w;
-      }
-      off += qadv;
-    }
-  };
-
-  // ---- phase 1: the pipeline over this workgroup's units with static stencils
-  {
-    int kN = 0, chunkN = 0;
-    Hdr hN;
-    DM_STAMP(a, 0);
-    int vN = next_normal((int)blockIdx.x - stride, kN, chunkN, hN);
-    DM_STAMP(a, 1);
-    if (vN < vtotal) {
-      __builtin_amdgcn_s_waitcnt(0x0F70);
-      setup_fetch(kN, chunkN, hN);
-      DM_STAMP(a, 2);
-      int nq_cur = NQF;
-      char* ob_cur = obF + (size_t)cF * PB;
-      int ngr_cur = ngrF;
-      fetch();
-      {
-        float tb0[12];
-        load_table(tb0);
-        vN = next_normal(vN, kN, chunkN, hN);          // the header behind it: on its way while this unit runs
-        commit(ngr_cur);
-        weights(tb0);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      DM_STAMP(a, 3);
-      int stamp = 4;
-      (void)stamp;
-      for (;;) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);        // (nothing in flight: see roi_pipe_fwd)
-        store();                                   // the previous batch's results: older than the fetch below
-        DM_STAMP(a, stamp);            // stores issued
-        // the next batch: of unit F, or the first of the next unit
-        bool more = cF < c1F;
-        bool switched = false;
-        if (!more && vN < vtotal) {
-          setup_fetch(kN, chunkN, hN);
-          switched = true;
-          more = true;
-        }
-        char* ob_next = obF + (size_t)cF * PB;
-        const int nq_next = NQF, ngr_next = ngrF;
-        if (more) fetch();
-        if (switched) vN = next_normal(vN, kN, chunkN, hN);
-        DM_STAMP(a, stamp + 1);        // next batch set up and its fetch issued
-        sample(nq_cur);
-        DM_STAMP(a, stamp + 2);        // sampled
-        obR = ob_cur;
-        nqR = nq_cur;
-        if (!more) break;
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave has read the buffer
-        if (switched) {
-          float tbn[12];
-          load_table(tbn);
-          commit(ngr_next);
-          weights(tbn);
-        } else {
-          commit(ngr_next);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        DM_STAMP(a, stamp + 3);        // barrier, fetch landed, committed, barrier
-        if (stamp < 24) stamp += 4;
-        nq_cur = nq_next;
-        ob_cur = ob_next;
-      }
-      store();
-    }
-    DM_STAMP(a, 30);
-  }
-  // ---- phase 2: the units left out (zeros, run-time stencils, per-sample path), one after the other
-  for (int v = blockIdx.x; v < vtotal; v += stride) {
-    int k, chunk;
-    if (!roi_persist_unit(a, chunks, v, k, chunk)) continue;
-    const int mode = plans[(size_t)k * kPlanDwords + kPlanMode];
-    if (mode >= 1 && mode <= 4) continue;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // the buffer is free
-    const int c0 = chunk * a.CT;
-    roi_unit_sync<MAXQ, true>(a, k, c0, min(c0 + a.CT, a.C), lds4);
-  }
-  DM_STAMP(a, 31);
-}
-
-// Experiment knobs of the forward launchers, read from the environment ONCE (first launch) and clamped to the ranges
-// the kernels were validated for; dm_reload_env_knobs() re-reads them (tools/roi_exp.py sweeps settings in one process).
-// None of them changes a result.
+// The two knobs of the forward launchers, read from the environment ONCE (first launch) and clamped;
+// dm_reload_env_knobs() re-reads them (tools that sweep settings in one process).  Neither changes a result.
+// (Rounds 3-4 had eleven: chunk size, workgroup orders, nontemporal stores, the units / plan / persistent kernels.  What
+// they measured is in docs/HISTORY.md and profiles/r04_roi_*; the settings that won are the constants below.)
 struct RoiKnobs {
-  int persist;      // DM_ROI_PERSIST: 1 = plan + persistent kernel when the caller passes a workspace (default 0: measured slower)
-  int wpc;          // DM_ROI_WPC: persistent workgroups per CU, 3 (default) or 4
-  int ct;           // DM_ROI_CT: channels per workgroup / unit of the P <= 16 kernels (0 = the kernel's default)
-  int order;        // DM_ROI_ORDER: -1 = default (1: XCD-aware), 0 = launch order
-  int band_order;   // DM_ROI_BAND_ORDER: 56x56 band kernel, 0 (default) .. 8
-  int units;        // DM_ROI_UNITS: 1 = persistent-units 56x56 kernel
-  int nt;           // DM_ROI_NT: nontemporal stores in the units kernel
-  int unit_wgs;     // DM_ROI_UNIT_WGS: workgroups per CU of the units kernel
-  int abl;          // DM_ROI_ABL: ablation bits (tools/micro builds only)
-  int nt14;         // DM_ROI_NT14: nontemporal output stores in the tile kernel (experiment)
   int sort;         // DM_ROI_SORT: 1 (default) = order the RoIs by level and position when the caller passes a workspace: the
                     // extraction drops from 57 to 47 us, the ordering launch in front of it costs 4-5 back (50.7 us in a graph of 20)
   int sort_min;     // DM_ROI_SORT_MIN: fewest RoIs worth the extra launch (default 192)
@@ -2264,16 +1104,6 @@ int env_int(const char* name, int dflt, int lo, int hi) {
 
 void roi_load_knobs() {
   RoiKnobs k;
-  k.persist = env_int("DM_ROI_PERSIST", 0, 0, 1);
-  k.wpc = env_int("DM_ROI_WPC", 3, 3, 4);
-  k.ct = env_int("DM_ROI_CT", 0, 0, 256) & ~3;
-  k.order = env_int("DM_ROI_ORDER", -1, -1, 1);
-  k.band_order = env_int("DM_ROI_BAND_ORDER", 0, 0, 8);
-  k.units = env_int("DM_ROI_UNITS", 0, 0, 1);
-  k.nt = env_int("DM_ROI_NT", 1, 0, 1);
-  k.unit_wgs = env_int("DM_ROI_UNIT_WGS", 4, 1, 8);
-  k.abl = env_int("DM_ROI_ABL", 0, 0, 7);
-  k.nt14 = env_int("DM_ROI_NT14", 0, 0, 1);
   k.sort = env_int("DM_ROI_SORT", 1, 0, 1);
   k.sort_min = env_int("DM_ROI_SORT_MIN", 192, 1, 1024);
   g_roi_knobs = k;
@@ -2311,11 +1141,6 @@ int fill_args(RoiArgs& a, const int* H, const int* W, const float* spatial_scale
 
 }  // namespace
 
-#ifdef DM_ROI_STAMPS
-static float* g_roi_stamp_buffer = nullptr;
-extern "C" void dm_roi_stamp_buffer(void* p) { g_roi_stamp_buffer = reinterpret_cast<float*>(p); }
-#endif
-
 extern "C" int dm_reload_env_knobs(void) {
   roi_load_knobs();
   return DM_OK;
@@ -2341,38 +1166,6 @@ int roi_align_fwd_impl(const float* const* feats, const int* H, const int* W, co
   const RoiKnobs& kn = roi_knobs();
   bool tile_ok = P * P <= 256 && P >= 2 && C % 4 == 0;
   for (int l = 0; l < num_levels; ++l) tile_ok = tile_ok && (long long)H[l] * W[l] <= (1 << 23);   // 32-bit staging offsets
-  if (tile_ok && kn.persist && workspace && workspace_bytes >= (long long)N * kPlanDwords * 4) {
-    // DM_ROI_PERSIST=1 (round 4's experiment, measured SLOWER than the tile kernel: 71 us against 55 us at the bench
-    // shape, DESIGN section 4 "RoIAlign, round 4"): the per-RoI arithmetic once in roi_plan_kernel, then persistent
-    // workgroups that pipeline the channel batches across units of RoI x CT channels.
-    a.CT = kn.ct > 0 ? kn.ct : 32;
-    a.order = kn.order >= 0 ? kn.order : 1;
-    const int chunks = dm_ceil_div(C, a.CT);
-    int grid = N * chunks;                  // virtual units (roi_persist_unit)
-    if (a.order == 1 && chunks < 8) {
-      if (8 % chunks != 0) a.order = 0;
-      else grid = dm_ceil_div(N, 8 / chunks) * 8;
-    } else if (a.order == 1 && chunks % 8 != 0) {
-      a.order = 0;
-    }
-    const size_t lds = (kTileFloats4 + kPipeTabFloats4) * sizeof(float4);
-#ifdef DM_ROI_STAMPS
-    a.gfeat[0] = g_roi_stamp_buffer;
-    a.abl = kn.abl;
-#endif
-    int* plans = reinterpret_cast<int*>(workspace);
-    DM_LAUNCH(roi_plan_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, a, plans);
-    int rcp = dm_check_launch();
-    if (rcp != DM_OK) return rcp;
-    a.levels = nullptr;                   // (written by the plan kernel)
-    int wgs = kn.wpc * dm_num_cus();
-    wgs -= wgs % 8;                        // a workgroup's units keep their b % 8
-    if (wgs > grid) wgs = grid;
-    if (wgs < 1) wgs = 1;
-    if (kn.wpc >= 4) DM_LAUNCH((roi_align_persist_kernel<4>), dim3(wgs), dim3(256), lds, (hipStream_t)stream, a, (const int*)plans, grid);
-    else DM_LAUNCH((roi_align_persist_kernel<3>), dim3(wgs), dim3(256), lds, (hipStream_t)stream, a, (const int*)plans, grid);
-    return dm_check_launch();
-  }
   if (tile_ok && kn.sort && P * P >= 128 && workspace && N >= kn.sort_min && N <= kOrderMaxRois && workspace_bytes >= (long long)N * 32 &&
       (((uintptr_t)workspace) & 15) == 0) {
     // RoIs walked by level and position (roi_order_kernel), 32 channels per workgroup, XCD-aware chunk-major order
@@ -2382,11 +1175,10 @@ int roi_align_fwd_impl(const float* const* feats, const int* H, const int* W, co
     if (rco != DM_OK) return rco;
     a.levels = nullptr;
     a.sorted = sorted;
-    a.CT = kn.ct > 0 ? kn.ct : 32;
-    a.order = kn.order >= 0 ? kn.order : 1;
+    a.CT = 32;
+    a.order = 1;
     int chunks = dm_ceil_div(C, a.CT);
     if (chunks % 8 != 0) a.order = 0;
-    a.nt = kn.nt14;
     DM_LAUNCH(roi_align_tile_kernel, dim3(N * chunks), dim3(256), (kTileFloats4 + 64) * sizeof(float4), (hipStream_t)stream, a);
     return dm_check_launch();
   }
@@ -2395,34 +1187,22 @@ int roi_align_fwd_impl(const float* const* feats, const int* H, const int* W, co
     // so the planes it is staging from stay in its L2 across the RoIs that share them.  Same time as round 2's 32
     // channels in launch order (16 .. 256 channels swept at 128 .. 2048 RoIs), 29 % fewer bytes fetched from
     // the fabric (FETCH_SIZE 113.6 -> 81.2 MB per launch, round 3's ceiling measurement).
-    a.CT = kn.ct > 0 ? kn.ct : 16;
-    a.order = kn.order >= 0 ? kn.order : 1;
+    a.CT = 16;
+    a.order = 1;
     int chunks = dm_ceil_div(C, a.CT);
     if (chunks % 8 != 0) a.order = 0;
-#ifdef DM_ROI_ABLATE
-    a.abl = kn.abl;
-#endif
-    a.nt = kn.nt14;
     DM_LAUNCH(roi_align_tile_kernel, dim3(N * chunks), dim3(256), (kTileFloats4 + 64) * sizeof(float4), (hipStream_t)stream, a);
     return dm_check_launch();
   }
   bool band_ok = P > 16 && P <= 64 && C % 4 == 0;
   for (int l = 0; l < num_levels; ++l) band_ok = band_ok && (long long)H[l] * W[l] <= (1 << 23) && W[l] < (1 << 20);      // (the band kernel packs a map column into 20 bits)
-  if (band_ok && (P & 3) == 0 && N <= kUnitMaxRois && (((uintptr_t)out) & 15) == 0 && kn.units) {
-    // A/B switch DM_ROI_UNITS=1: the persistent-units kernel of round 3 (measured slower)
-    const int wgs = kn.unit_wgs * dm_num_cus();
-    const size_t lds = (size_t)(kTileFloats4 + kBandTabFloats4) * sizeof(float4) + (((size_t)N + 1) * 2 + 15) / 16 * 16;
-    DM_LAUNCH(roi_align_units_kernel, dim3(wgs), dim3(256), lds, (hipStream_t)stream, a, kn.nt);
-    return dm_check_launch();
-  }
   if (band_ok) {
     // one channel quad per workgroup (swept 4 .. 32 at 128 RoIs on P2: 0.32 / 0.45 / 0.79 / 1.5 ms): the
     // bands of a large RoI are a long chain of dependent staging round trips, so the parallelism has to
     // come from the number of workgroups
     a.CT = 4;            // (roi_band_fwd is written for exactly one quad)
     const int chunks = dm_ceil_div(C, a.CT);
-    a.order = kn.band_order;      // experiments: 0 = full-height bands, 1 = XCD-aware chunk-major, 2 + d = bands of 1 / (d + 1) of the height
-    if (a.order == 1 && chunks % 8 != 0) a.order = 0;
+    a.order = 0;                  // full-height bands in launch order (XCD-aware chunk-major and shorter bands measured slower, round 4)
     // (a 28 KB tile with five workgroups per CU -- 96 VGPRs, 92 bytes of scratch -- measured slower: 202 vs 188 us)
     DM_LAUNCH((roi_align_band_kernel<kTileFloats4, 4>), dim3(N * chunks), dim3(256),
               (kTileFloats4 + kBandTabFloats4) * sizeof(float4), (hipStream_t)stream, a);
@@ -2450,7 +1230,7 @@ extern "C" int dm_roi_align_fwd(const float* const* feats, const int* H, const i
 
 extern "C" long long dm_roi_align_workspace_bytes(int N, int P) {
   if (N <= 0 || P < 2 || P * P > 256) return 0;
-  return roi_knobs().persist ? (long long)N * kPlanDwords * 4 : (long long)N * 32;      // plans (DM_ROI_PERSIST=1) | ordered RoI records
+  return (long long)N * 32;      // ordered RoI records (roi_order_kernel)
 }
 
 extern "C" int dm_roi_align_fwd_ws(const float* const* feats, const int* H, const int* W, const float* spatial_scales,

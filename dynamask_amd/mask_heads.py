@@ -28,25 +28,21 @@ class _Packed:
     def __init__(self):
         self._c = {}
 
-    def get(self, key, param, fn, job=None, split=None):
+    def get(self, key, param, fn, job=None):
         """``job`` = (transpose_flip, src_channels | None, lo | None, hi | None): the pack is dm_conv_pack_weight of
         the parameter itself (or of its input-channel window lo:hi); such packs of contiguous device parameters are
-        registered with ops.PACK_PLAN and refreshed together in one launch.  Anything else goes through ``fn``.
-        ``split``: False for consumers that only take the fp32 layout (the deformable convolution); default: the
-        layout ops.MFMA_SPLIT selects (a pack is cached per layout)."""
-        split = ops.MFMA_SPLIT if split is None else ops._products(split)
-        key = (key, split)
+        registered with ops.PACK_PLAN and refreshed together in one launch.  Anything else goes through ``fn``."""
         if job is not None and param.is_cuda and param.dim() == 4 and param.is_contiguous():
             e = self._c.get(key)
             if e is None or e[0] != 'plan' or e[1]['param']() is not param:
-                e = ('plan', ops.PACK_PLAN.register(param, *job, split=split))
+                e = ('plan', ops.PACK_PLAN.register(param, *job))
                 self._c[key] = e
             with torch.no_grad():
                 return ops.PACK_PLAN.get(e[1])
         ver = (param.data_ptr(), param._version, param.device, ops.WEIGHT_EPOCH[0])
         e = self._c.get(key)
         if e is None or e[0] != ver:
-            with torch.no_grad(), ops.split_packing(split):
+            with torch.no_grad():
                 e = (ver, fn(param.detach().contiguous()))
             self._c[key] = e
         return e[1]
@@ -113,7 +109,7 @@ class DeformConv2dPack(nn.Module):
 
     def forward(self, x, relu=False):
         offset = self.conv_offset.run(x)
-        wp = self._pk.get('w', self.weight, lambda t: ops.pack_conv_weight(t, split=False), job=(False, None, None, None), split=False)
+        wp = self._pk.get('w', self.weight, ops.pack_conv_weight, job=(False, None, None, None))
         return ops.deform_conv(x, offset, wp, self.out_channels, self.deform_groups, relu=relu)
 
 
@@ -241,7 +237,7 @@ class DynaMaskHead(nn.Module):
             stage.fuse_conv[0].packed([c, stage.semantic_transform_in.out_channels, 2])
             dcn.conv_offset.packed([c])
             if fused_dcn is None or fused_dcn[i]:
-                dcn._pk.get('w', dcn.weight, lambda t: ops.pack_conv_weight(t, split=False), job=(False, None, None, None), split=False)
+                dcn._pk.get('w', dcn.weight, ops.pack_conv_weight, job=(False, None, None, None))
             stage.fuse_transform_out.packed([dcn.out_channels])
 
     def pred_sizes(self, last_stage=None):

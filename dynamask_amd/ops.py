@@ -87,7 +87,7 @@ def _float_array(vals):
 # ------------------------------------------------------------------ RoIAlign
 # 14x14 / 7x7 extractions of 192 RoIs or more go through dm_roi_align_fwd_ws with a scratch buffer (DM_ROI_WORKSPACE=0: never):
 # the library orders the RoIs by level and position on the device first (DM_ROI_SORT, default on: 57 -> 50.7 us for 512 RoIs,
-# the same bits) or, with DM_ROI_PERSIST=1, runs round 4's plan + persistent kernels (measured slower, an A/B path)
+# the same bits)
 ROI_WORKSPACE = os.environ.get('DM_ROI_WORKSPACE', '1') == '1'
 ROI_WORKSPACE_MIN = int(os.environ.get('DM_ROI_SORT_MIN', '192'))
 
@@ -101,8 +101,7 @@ def roi_align(feats, rois, output_size, spatial_scales, sampling_ratio=0, finest
     levels = torch.zeros((N,), device=rois.device, dtype=torch.int32) if return_levels else None
     if ROI_WORKSPACE and N >= ROI_WORKSPACE_MIN:
         # 14x14 / 7x7 extraction with a workspace: the RoIs are first ordered by level and position (one extra launch:
-        # neighbouring workgroups then share their footprints in the L2; same results).  With DM_ROI_PERSIST=1 the
-        # workspace holds round 4's per-RoI plans instead (plan + persistent kernels: measured slower, kept as an A/B path).
+        # neighbouring workgroups then share their footprints in the L2; same results).
         wsb = int(lib().dm_roi_align_workspace_bytes(N, output_size))
         ws = torch.empty(((wsb + 15) // 16 * 4,), device=rois.device, dtype=torch.int32) if wsb > 0 else None
         rc = lib().dm_roi_align_fwd_ws(_ptr_array(feats), _int_array([f.shape[2] for f in feats]),
@@ -285,62 +284,16 @@ def packed_cout(cout):
     return lib().dm_conv_packed_cout(int(cout))
 
 
-# Opt-in bf16-split matrix modes of the implicit-GEMM convolutions (DM_MFMA_SPLIT=3: three bf16 products per fp32 product,
-# ~2^-16 relative per product; 6: six, fp32-level accuracy; NOT the parity build -- see csrc/conv_igemm.hip).  While it is set, the conv modules'
-# packs (mask_heads._Packed, the pack plan) are produced in the split layout and marked; conv2d follows the mark.  Deformable convolutions, weight
-# gradients and fully connected layers stay on exact fp32.
-MFMA_SPLIT = {'3': 3, '6': 6}.get(os.environ.get('DM_MFMA_SPLIT', '0'), 0)      # products per fp32 product: 0 = exact fp32
-
-
-_PACK_SPLIT_DEFAULT = [0]          # what pack_conv_weight(split=None) means right now (see split_packing): 0, 3 or 6
-
-
-def _products(split):
-    """False / None / 0 -> 0 (fp32 layout); True -> ops.MFMA_SPLIT or 3; 3 / 6 -> themselves."""
-    if split is True:
-        return MFMA_SPLIT or 3
-    split = int(split or 0)
-    assert split in (0, 3, 6)
-    return split
-
-
-class split_packing:
-    """Context: pack_conv_weight calls inside produce the bf16-split layout of ``on`` products (0 / 3 / 6) unless they
-    say otherwise.  The conv modules wrap their pack callbacks in it (mask_heads._Packed.get); a bare
-    ops.pack_conv_weight(w) -- tests, the deformable convolution's weights -- stays on the fp32 layout whatever
-    DM_MFMA_SPLIT says."""
-
-    def __init__(self, on):
-        self.on = _products(on)
-
-    def __enter__(self):
-        self.prev = _PACK_SPLIT_DEFAULT[0]
-        _PACK_SPLIT_DEFAULT[0] = self.on
-
-    def __exit__(self, *exc):
-        _PACK_SPLIT_DEFAULT[0] = self.prev
-
-
-def is_split(w_packed):
-    """Products per fp32 product of a packed weight tensor: 0 (fp32 layout), 3 or 6."""
-    return int(getattr(w_packed, '_dm_split', 0) or 0)
-
-
-def packed_floats(cout, ksize, src_channels, split=0):
-    split = _products(split)
-    if split:
-        n = lib().dm_conv_packed_floats_split(int(cout), int(ksize), len(src_channels), _int_array(src_channels), split)
-    else:
-        n = lib().dm_conv_packed_floats(int(cout), int(ksize), len(src_channels), _int_array(src_channels))
+def packed_floats(cout, ksize, src_channels):
+    n = lib().dm_conv_packed_floats(int(cout), int(ksize), len(src_channels), _int_array(src_channels))
     if n < 0:
         raise ValueError('bad conv packing request')
     return int(n)
 
 
-def pack_conv_weight(w, transpose_flip=False, src_channels=None, split=None):
+def pack_conv_weight(w, transpose_flip=False, src_channels=None):
     """OIHW -> [k*k][KQ][CoutP][4] (see include/dynamask_hip.h).  ``src_channels``:
-    how the input channels split over the concat sources (default: one source).
-    ``split``: the bf16-split layout (default: fp32, or what an enclosing ops.split_packing says)."""
+    how the input channels split over the concat sources (default: one source)."""
     _chk(w, 'weight')
     cout, cin, kh, kw = w.shape
     assert kh == kw and kh in (1, 3)
@@ -349,15 +302,9 @@ def pack_conv_weight(w, transpose_flip=False, src_channels=None, split=None):
     if src_channels is None:
         src_channels = [rows]
     assert sum(src_channels) == rows
-    split = _PACK_SPLIT_DEFAULT[0] if split is None else _products(split)
-    wp = torch.empty((packed_floats(cols, kh, src_channels, split),), device=w.device, dtype=torch.float32)
-    if split:
-        check(lib().dm_conv_pack_weight_split(_p(w), cout, cin, kh, 1 if transpose_flip else 0, len(src_channels),
-                                              _int_array(src_channels), split, _p(wp), _stream()), 'dm_conv_pack_weight_split')
-    else:
-        check(lib().dm_conv_pack_weight(_p(w), cout, cin, kh, 1 if transpose_flip else 0, len(src_channels),
-                                        _int_array(src_channels), _p(wp), _stream()), 'dm_conv_pack_weight')
-    wp._dm_split = split
+    wp = torch.empty((packed_floats(cols, kh, src_channels),), device=w.device, dtype=torch.float32)
+    check(lib().dm_conv_pack_weight(_p(w), cout, cin, kh, 1 if transpose_flip else 0, len(src_channels),
+                                    _int_array(src_channels), _p(wp), _stream()), 'dm_conv_pack_weight')
     return wp
 
 
@@ -410,9 +357,8 @@ class PackPlan:
             p = self.plans[idx] = _DevicePlan(torch.device('cuda', idx))
         return p
 
-    def register(self, param, transpose_flip, src_channels, lo, hi, split=None):
+    def register(self, param, transpose_flip, src_channels, lo, hi):
         import weakref
-        split = MFMA_SPLIT if split is None else _products(split)
         cout, cin_total, kh, kw = param.shape
         lo = 0 if lo is None else lo
         hi = cin_total if hi is None else hi
@@ -421,10 +367,9 @@ class PackPlan:
         cols = cin if transpose_flip else cout
         src_channels = [rows] if src_channels is None else list(src_channels)
         assert sum(src_channels) == rows and kh == kw and kh in (1, 3) and len(src_channels) <= 4
-        out = torch.empty((packed_floats(cols, kh, src_channels, split),), device=param.device, dtype=torch.float32)
-        out._dm_split = split
+        out = torch.empty((packed_floats(cols, kh, src_channels),), device=param.device, dtype=torch.float32)
         plan = self._plan(param.device)
-        e = dict(param=weakref.ref(param), out=out, cout=cout, cin=cin, ks=kh, flip=(1 if transpose_flip else 0) | (2 if split == 3 else 4 if split == 6 else 0),
+        e = dict(param=weakref.ref(param), out=out, cout=cout, cin=cin, ks=kh, flip=1 if transpose_flip else 0,
                  srcs=src_channels, ld=cin_total, c0=lo, ver=None, used=True, plan=plan)
         plan.entries.append(e)
         return e
@@ -549,15 +494,14 @@ def conv2d(srcs, w_packed, bias, cout, ksize, relu=False, out=None, out_ch_offse
     for s in srcs:
         assert s.shape[0] == NB and s.shape[2] == H and s.shape[3] == W
     cin = sum(s.shape[1] for s in srcs)
-    split = is_split(w_packed)
-    assert w_packed.numel() == packed_floats(cout, ksize, [s.shape[1] for s in srcs], split), 'weights packed for other sources'
+    assert w_packed.numel() == packed_floats(cout, ksize, [s.shape[1] for s in srcs]), 'weights packed for other sources'
     if out is None:
         out = torch.empty((NB, cout, H, W), device=srcs[0].device, dtype=torch.float32)
     else:
         _chk(out, 'out')
         assert out.shape[0] == NB and out.shape[2] == H and out.shape[3] == W
     strides = (ctypes.c_longlong * len(srcs))(*[int(s.stride(0)) for s in srcs])
-    flags = (1 if relu else 0) | (2 if accumulate else 0) | (8 if _overlapped else 0) | (16 if split == 3 else 32 if split == 6 else 0)
+    flags = (1 if relu else 0) | (2 if accumulate else 0) | (8 if _overlapped else 0)
     if mask is not None:
         _chk(mask, 'mask')
         assert mask.shape == out.shape
@@ -566,7 +510,7 @@ def conv2d(srcs, w_packed, bias, cout, ksize, relu=False, out=None, out_ch_offse
                                         _p(mask), _stream())
         check(rc, 'dm_conv2d_fwd_masked')
         return out
-    if CONV_SPLITK[0] and _SPLITK_DEPTH[0] > 0 and not accumulate and not split:      # (exact fp32 kernels only)
+    if CONV_SPLITK[0] and _SPLITK_DEPTH[0] > 0 and not accumulate:
         # the <= 100-RoI inference calls: a launch of few workgroups splits its K loop (dm_conv2d_fwd_ws)
         nws = int(lib().dm_conv2d_splitk_floats(NB, H, W, cout, ksize))
         if nws > 0:
@@ -1082,58 +1026,13 @@ def pack_dcn_colgrad_weight(weight):
     return pack_conv_weight(dcn_weight_permute(weight.contiguous(), cout, c, True))        # [(tap,ci)][co]
 
 
-# DM_DCN_FUSED=1: the one-kernel data gradient (csrc/dcn_bwd_fused.hip) where it applies; default: column-gradient GEMM,
-# coordinate gradient and col2im as three kernels -- both forms are bound by the same LDS scatter and measure alike
-# 
-DCN_BWD_FUSED = [os.environ.get('DM_DCN_FUSED', '0') == '1']
-
-
-def dcn_bwd_fused_ok(x_shape, cout, deform_groups):
-    """True where the one-kernel data gradient applies (dm_dcn_bwd_data_fused_supported) and is wanted: not in
-    deterministic mode -- a sample displaced beyond the staged rows adds to grad_x with float atomics."""
-    NB, C, H, W = x_shape
-    return bool(DCN_BWD_FUSED[0] and not DETERMINISTIC[0]
-                and lib().dm_dcn_bwd_data_fused_supported(C, cout, H, W, deform_groups))
-
-
-def pack_dcn_bwd_weight(weight, deform_groups):
-    """DCN weight [Cout, C, 3, 3] in the register layout of dm_dcn_bwd_data_fused (per group, 16-channel block and
-    tap pair: the 32 x Cout slice of W^T as one MFMA A operand per two output channels)."""
-    weight = _chk_src(weight.contiguous())
-    cout, c = weight.shape[0], weight.shape[1]
-    n = lib().dm_dcn_bwd_pack_floats(c, cout, deform_groups)
-    assert n > 0, 'dm_dcn_bwd_pack: unsupported shape'
-    out = torch.empty((n,), device=weight.device, dtype=torch.float32)
-    check(lib().dm_dcn_bwd_pack(_p(weight), cout, c, deform_groups, _p(out), _stream()), 'dm_dcn_bwd_pack')
-    return out
-
-
-def deform_conv_backward_data_fused(x, offset, grad_out, w_fused, deform_groups):
-    """(grad_x, grad_offset) of DCNv1 3x3 in one launch, no column-gradient matrix (csrc/dcn_bwd_fused.hip)."""
-    for t, nm in ((x, 'x'), (offset, 'offset'), (grad_out, 'grad_out'), (w_fused, 'w_fused')):
-        _chk(t, nm)
+def deform_conv_backward_data(x, offset, weight, grad_out, deform_groups, side=None, w_colgrad=None):
+    """(grad_x, grad_offset) of DCNv1 3x3: column gradient = W^T . dY as a 1x1 conv, then the coordinate gradient and
+    col2im over it (``w_colgrad``: ``pack_dcn_colgrad_weight(weight)``); ``side``: a second stream -- the coordinate
+    gradient (bound by its gathers) then runs there, beside col2im (bound by LDS atomics) on the caller's stream; both
+    only read the column gradient.  (Round 4's one-kernel form measured at parity -- both are bound by the LDS scatter --
+    and was removed in round 5: docs/HISTORY.md.)"""
     NB, C, H, W = x.shape
-    cout = grad_out.shape[1]
-    assert grad_out.shape == (NB, cout, H, W) and offset.shape == (NB, 18 * deform_groups, H, W)
-    assert w_fused.numel() == lib().dm_dcn_bwd_pack_floats(C, cout, deform_groups)
-    gx = torch.empty_like(x)
-    goff = torch.empty_like(offset)
-    check(lib().dm_dcn_bwd_data_fused(_p(x), _p(offset), _p(grad_out), _p(w_fused), NB, C, cout, H, W, deform_groups,
-                                      _p(gx), _p(goff), _stream()), 'dm_dcn_bwd_data_fused')
-    return gx, goff
-
-
-def deform_conv_backward_data(x, offset, weight, grad_out, deform_groups, side=None, w_colgrad=None, w_fused=None):
-    """(grad_x, grad_offset) of DCNv1 3x3.  Where ``dcn_bwd_fused_ok``: one kernel (``w_fused``:
-    ``pack_dcn_bwd_weight(weight, deform_groups)`` if the caller caches it).  Otherwise column gradient = W^T . dY as
-    a 1x1 conv, then the coordinate gradient and col2im over it (``w_colgrad``: ``pack_dcn_colgrad_weight(weight)``);
-    ``side``: a second stream -- the coordinate gradient (bound by its gathers) then runs there, beside col2im (bound
-    by LDS atomics) on the caller's stream; both only read the column gradient."""
-    NB, C, H, W = x.shape
-    if dcn_bwd_fused_ok(x.shape, grad_out.shape[1], deform_groups):
-        if w_fused is None:
-            w_fused = pack_dcn_bwd_weight(weight, deform_groups)
-        return deform_conv_backward_data_fused(x, offset, grad_out, w_fused, deform_groups)
     if w_colgrad is None:
         w_colgrad = pack_dcn_colgrad_weight(weight)
     colgrad = conv2d(grad_out, w_colgrad, None, 9 * C, 1)                      # W^T . dY

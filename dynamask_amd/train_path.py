@@ -327,8 +327,8 @@ class MaskHeadFn(torch.autograd.Function):
                     f2 = ops.conv2d([col], dcn._pk.get('w_cm', dcn.weight, _pack_dcn_colmajor), None, dcn.out_channels, 1,
                                     relu=True, out=st['f2'][lo:hi])
                 else:
-                    f2 = ops.deform_conv(f1, off, dcn._pk.get('w', dcn.weight, lambda t: ops.pack_conv_weight(t, split=False),
-                                                              job=(False, None, None, None), split=False), dcn.out_channels,
+                    f2 = ops.deform_conv(f1, off, dcn._pk.get('w', dcn.weight, ops.pack_conv_weight, job=(False, None, None, None)),
+                                         dcn.out_channels,
                                          dcn.deform_groups, relu=True, out=st['f2'][lo:hi])
                 stage.fuse_transform_out.run(f2, relu=True, out=tail, out_ch_offset=0)
                 if st['up'] is not None:

@@ -11,18 +11,14 @@
  *     What the library does keep, per device and only as a cache: the device's
  *     compute-unit count and "this kernel's dynamic-LDS limit has been raised"
  *     flags (hipFuncSetAttribute once per device).  A few knobs are read from
- *     the environment on first use.  Tuning knobs that never change results,
- *     only tile / split / order choices: DM_CONV_TAIL, DM_DCN_TAIL, DM_WGRAD_WGS, DM_ROI_PIPE (0 = round 3's
- *     RoIAlign tile kernel instead of the pipelined one: same bits), DM_ROI_PERSIST, DM_ROI_WPC, DM_ROI_CT,
- *     DM_ROI_ORDER, DM_ROI_BAND_ORDER, DM_ROI_UNITS (the
- *     persistent-units RoIAlign of round 3: same bits as the band kernel), DM_ROI_NT, DM_ROI_UNIT_WGS
- *     (the DM_ROI_* set is read once and clamped; dm_reload_env_knobs() re-reads it),
- *     DM_CONV1_VARIANT (other tilings of the 1x1 GEMM: same products in the same order), DM_PS_CT.
- *     A/B switches that select an older kernel or another split for the same
- *     operation (same mathematics; sums may differ in the last bits):
- *     DM_WGRAD_NARROW_OFF, DM_DCN_BAND_OFF, DM_IM2COL_V1, DM_FC_SEG, DM_COORD_V1 (the first-generation
- *     coordinate-gradient kernel), DM_BN_BWD_V1 / DM_BN_POOL_V1 (MaskPre's BatchNorm + pool block as first written), DM_PSB_V1 (the
- *     scatter form of dm_point_sample_bwd).
+ *     the environment on first use, six in all, none of which changes what is
+ *     computed: DM_CONV_TAIL / DM_DCN_TAIL (0: no separate launch for the last,
+ *     underfull round of workgroups), DM_WGRAD_WGS (split-K workgroups of the
+ *     weight gradients), DM_ROI_SORT / DM_ROI_SORT_MIN (the RoI ordering launch of
+ *     dm_roi_align_fwd_ws; re-read by dm_reload_env_knobs()), DM_CONV_SPLITK is the
+ *     host binding's.  (Rounds 2-4 had twenty more -- first-generation kernels and
+ *     rejected variants kept for A/B timing; their measurements are in
+ *     docs/HISTORY.md and profiles/, the kernels are gone.)
  *     Calls from several host threads are safe (a race only repeats an
  *     idempotent attribute call);
  *   - LDS scatter-accumulators (dm_deform_col2im_coord, the scatter form of
@@ -57,7 +53,7 @@ extern "C" {
 typedef void* dm_stream_t; /* hipStream_t */
 
 const char* dm_error_string(int code);
-/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient, dm_conv_pack_weight_batch, dm_mask_loss_stage; 15: dm_class_logits_up2x_fwd; 16: dm_conv2d_wgrad_slab / dm_conv2d_wgrad_scratch_floats; 17: dm_class_logits_bwd_slab / dm_class_logits_bwd_scratch_floats; 18: dm_reload_env_knobs, dm_roi_align_fwd_ws / dm_roi_align_workspace_bytes, dm_conv_pack_weight_split / dm_conv_packed_floats_split and flag bits 4, 5 of dm_conv2d_fwd; 19: dm_dcn_bwd_data_fused and its pack; 20: dm_conv2d_fwd_ws / dm_conv2d_splitk_floats; 21: dm_deform_conv_fwd_ws / dm_deform_conv_splitk_floats). */
+/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient, dm_conv_pack_weight_batch, dm_mask_loss_stage; 15: dm_class_logits_up2x_fwd; 16: dm_conv2d_wgrad_slab / dm_conv2d_wgrad_scratch_floats; 17: dm_class_logits_bwd_slab / dm_class_logits_bwd_scratch_floats; 18: dm_reload_env_knobs, dm_roi_align_fwd_ws / dm_roi_align_workspace_bytes, dm_conv_pack_weight_split / dm_conv_packed_floats_split and flag bits 4, 5 of dm_conv2d_fwd; 19: dm_dcn_bwd_data_fused and its pack; 20: dm_conv2d_fwd_ws / dm_conv2d_splitk_floats; 21: dm_deform_conv_fwd_ws / dm_deform_conv_splitk_floats; 22: the bf16-split layouts (dm_conv_pack_weight_split, dm_conv_packed_floats_split, flag bits 4 / 5 of dm_conv2d_fwd) and the one-kernel DCN data gradient (dm_dcn_bwd_*) REMOVED -- measured, never the parity path, see docs/HISTORY.md). */
 int dm_abi_version(void);
 /* Re-read the DM_ROI_* experiment knobs from the environment (they are otherwise read once, at the first launch, and
  * clamped to validated ranges).  For measurement tools that sweep settings inside one process; no knob changes a result. */
@@ -86,8 +82,7 @@ int dm_roi_align_fwd(const float* const* feats, const int* H, const int* W, cons
  * 14x14 extraction of 192 .. 1024 RoIs a first kernel ranks the RoIs by (image, level, 32-pixel row, column) into the
  * workspace and the extraction walks them in that order -- workgroups that run side by side then share their footprints
  * in the XCD's L2 (fabric traffic 261 -> 193 MB per 512 RoIs, 57 -> 50.7 us with the ranking kernel) -- and writes every
- * RoI's rows where dm_roi_align_fwd writes them: the same bits (knob DM_ROI_SORT, default 1).  DM_ROI_PERSIST=1 selects
- * round 4's plan + persistent kernels instead (measured slower; values equal up to the association of wide stencils).
+ * RoI's rows where dm_roi_align_fwd writes them: the same bits (knob DM_ROI_SORT, default 1).
  * A null / too small workspace falls back to dm_roi_align_fwd's kernels. */
 long long dm_roi_align_workspace_bytes(int N, int P);
 int dm_roi_align_fwd_ws(const float* const* feats, const int* H, const int* W, const float* spatial_scales,
@@ -117,18 +112,6 @@ int dm_conv_packed_cout(int Cout);
 long long dm_conv_packed_floats(int Cout, int ksize, int num_srcs, const int* src_channels);
 int dm_conv_pack_weight(const float* w_oihw, int Cout, int Cin, int ksize, int transpose_flip,
                         int num_srcs, const int* src_channels, float* w_packed, dm_stream_t stream);
-
-/* Opt-in bf16-split matrix modes (round 4; NOT the parity build).  dm_conv_pack_weight_split writes every weight as
- * 2 (products = 3) or 3 (products = 6) bf16 parts -- [k*k][KQ][CoutP][16 bytes], every source padded to 16 channels,
- * KQ = sum(roundup(Cs, 16)) / 16 * 2 * parts, dm_conv_packed_floats_split() floats -- and dm_conv2d_fwd /
- * dm_conv2d_fwd_masked called with flag bit 4 (16: products = 3) or bit 5 (32: products = 6) in `relu` take such a
- * tensor: an fp32 product becomes 3 (hi*hi + hi*lo + lo*hi, ~2^-16 relative) or 6 (terms below 2^-24 dropped:
- * fp32-level) v_mfma_f32_32x32x16_bf16 with fp32 accumulation, 5.3x / 2.7x the fp32 matrix rate.  In a dm_pack_job,
- * bit 1 (2) / bit 2 (4) of transpose_flip select these layouts.  No reference interface: the reference computes in
- * fp32 throughout. */
-long long dm_conv_packed_floats_split(int Cout, int ksize, int num_srcs, const int* src_channels, int products);
-int dm_conv_pack_weight_split(const float* w_oihw, int Cout, int Cin, int ksize, int transpose_flip,
-                              int num_srcs, const int* src_channels, int products, float* w_packed, dm_stream_t stream);
 
 /* All the packs of a training step in one launch (the weights change with every optimizer step).  A job is
  * dm_conv_pack_weight's arguments plus a window: the packed [Cout][Cin] tensor may be the input-channel slice
@@ -161,7 +144,7 @@ int dm_conv_pack_weight_batch(const dm_pack_job* jobs_device, int num_jobs, dm_s
  *            for gradient sums in the backward); bit 3: the caller overlaps this
  *            launch with work on another stream (a scheduling hint: the 3x3
  *            kernel then does not split off its last round of workgroups;
- *            results are the same bits either way)
+ *            results are the same bits either way); any other bit: DM_ERR_INVALID_ARG
  * out      : written at channels [out_ch_offset, out_ch_offset+Cout) of a
  *            tensor [NB, out_ch_total, H, W]
  * ------------------------------------------------------------------------- */
@@ -537,25 +520,6 @@ int dm_deform_coord_grad(const float* colgrad, const float* x, const float* offs
 int dm_deform_col2im(const float* colgrad, const float* offset, int NB, int C, int H, int W, int deform_groups,
                      float* grad_x, dm_stream_t stream);
 int dm_dcn_weight_permute(const float* src, float* dst, int Cout, int C, int to_colmajor, int accumulate,
-                          dm_stream_t stream);
-
-/* (ABI 19) The data gradient of DCNv1 3x3 in ONE kernel (csrc/dcn_bwd_fused.hip): grad_x and grad_offset from grad_out
- * without the [9C x HW] column-gradient matrix the reference materialises (deform_conv_cuda.cpp:262-374: columns =
- * W^T . gradOut, deformable_col2im_coord, deformable_col2im).  A workgroup owns (image, deformable group); the column
- * gradient of (tap, pixel, 16 channels) lives in one MFMA tile's accumulator registers, the coordinate gradient and the
- * col2im scatter (64-bit fixed-point LDS atomics into a ring of rows of the 16 planes) are taken from there.
- * dm_dcn_bwd_data_fused_supported: 1 where the kernel applies (Cout 64 or 128, (C / deform_groups) % 16 == 0, W % 4 == 0,
- * the staging fits 160 KB of LDS), else 0 -- callers then take dm_conv2d_fwd + dm_deform_col2im_coord.
- * w_packed: dm_dcn_bwd_pack of the [Cout, C, 3, 3] weight (dm_dcn_bwd_pack_floats floats).  grad_x is zero-filled and
- * written by the call; grad_offset is overwritten.  Samples displaced by more than R/2 rows (R = 4, knob DM_DCN_FUSED_R)
- * leave the staged ring: they read x from memory and add to grad_x with float atomics -- correct, slower, and the only
- * case in which the sum order of grad_x depends on timing.  A non-finite column gradient poisons (NaN) the rows of its
- * grad_x plane that are still in the ring or yet to come (rows already written keep their values). */
-int dm_dcn_bwd_data_fused_supported(int C, int Cout, int H, int W, int deform_groups);
-long long dm_dcn_bwd_pack_floats(int C, int Cout, int deform_groups);
-int dm_dcn_bwd_pack(const float* weight, int Cout, int C, int deform_groups, float* packed, dm_stream_t stream);
-int dm_dcn_bwd_data_fused(const float* x, const float* offset, const float* grad_out, const float* w_packed, int NB,
-                          int C, int Cout, int H, int W, int deform_groups, float* grad_x, float* grad_offset,
                           dm_stream_t stream);
 
 /* SGD(momentum, weight decay) step on a flat fp32 buffer; grad_scale folds the

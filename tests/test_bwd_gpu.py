@@ -272,71 +272,6 @@ def test_deform_coord_grad_with_samples_far_from_their_pixel(ops, N, C, S, sigma
     _close(gx, x.grad, atol=1e-4, rtol=1e-4)
 
 
-@pytest.mark.parametrize('N,C,H,W,dg,sigma', [(1, 64, 56, 56, 2, 0.8), (1, 64, 24, 56, 2, 0.0), (1, 128, 28, 28, 2, 1.5), (1, 64, 12, 8, 4, 3.0),
-                                              (1, 128, 12, 28, 2, 6.0), (2, 64, 10, 12, 1, 1.0)])
-def test_dcn_data_gradient_in_one_kernel_vs_oracle(ops, N, C, H, W, dg, sigma):
-    """dm_dcn_bwd_data_fused (csrc/dcn_bwd_fused.hip): grad_x and grad_offset without the column-gradient matrix, the
-    column gradient of (tap, pixel, 16 channels) living in one MFMA tile's registers.  Against autograd of the oracle
-    (deform_conv_cuda.cpp:262-374, deform_conv_cuda_kernel.cu:145-188, 279-465): zero offsets (every sample on the
-    pixel grid), offsets inside the staged ring, offsets of many rows (the far path: global loads and float atomics),
-    a plane smaller than one band, four deformable groups; and against the three-kernel path of the same library."""
-    assert ops.lib().dm_dcn_bwd_data_fused_supported(C, C, H, W, dg) == 1
-    x = torch.randn(N, C, H, W, generator=_g(470), requires_grad=True)
-    w = torch.randn(C, C, 3, 3, generator=_g(471)) / (9 * C) ** 0.5
-    off = (torch.randn(N, 18 * dg, H, W, generator=_g(472)) * sigma).requires_grad_(True)
-    y = ref_ops.deform_conv2d(x, off, w, 1, 1, 1, dg)
-    go = torch.randn(y.shape, generator=_g(473))
-    y.backward(go)
-    wf = ops.pack_dcn_bwd_weight(_dev(w), dg)
-    gx, goff = ops.deform_conv_backward_data_fused(_dev(x.detach()), _dev(off.detach()), _dev(go), wf, dg)
-    _close(goff, off.grad, atol=1e-4, rtol=1e-4)
-    _close(gx, x.grad, atol=1e-4, rtol=1e-4)
-    was = ops.DCN_BWD_FUSED[0]
-    ops.DCN_BWD_FUSED[0] = False
-    try:
-        gx3, goff3 = ops.deform_conv_backward_data(_dev(x.detach()), _dev(off.detach()), _dev(w), _dev(go), dg)
-    finally:
-        ops.DCN_BWD_FUSED[0] = was
-    _close(gx, gx3, atol=2e-5, rtol=2e-5)
-    _close(goff, goff3, atol=2e-5, rtol=2e-5)
-    # the coordinate gradient adds its channel blocks in a fixed order: the same bits every run
-    _, goff_again = ops.deform_conv_backward_data_fused(_dev(x.detach()), _dev(off.detach()), _dev(go), wf, dg)
-    assert torch.equal(goff, goff_again)
-
-
-def test_dcn_data_gradient_in_one_kernel_rejects_what_it_cannot_stage(ops):
-    lib = ops.lib()
-    assert lib.dm_dcn_bwd_data_fused_supported(256, 256, 14, 14, 2) == 0        # Cout 256: the A operand would not fit the registers
-    assert lib.dm_dcn_bwd_data_fused_supported(64, 64, 14, 14, 2) == 0          # W % 4 != 0
-    assert lib.dm_dcn_bwd_data_fused_supported(24, 64, 16, 16, 1) == 0          # channels per group not a multiple of 16
-    x = torch.zeros(1, 256, 14, 14).cuda()
-    off = torch.zeros(1, 36, 14, 14).cuda()
-    assert not ops.dcn_bwd_fused_ok(x.shape, 256, 2)
-    gx, goff = ops.deform_conv_backward_data(x, off, torch.zeros(256, 256, 3, 3).cuda(), torch.zeros_like(x), 2)      # falls back
-    assert gx.shape == x.shape and goff.shape == off.shape
-
-
-def test_dcn_data_gradient_in_one_kernel_propagates_non_finite_gradients(ops):
-    """A non-finite output gradient makes the column gradients of its pixel non-finite for every input channel
-    (W^T . dY): the fused kernel has no fixed-point value for them and must poison the planes they scatter into -- every
-    plane of that image, from the rows still in the ring on -- and leave the other image's bits alone."""
-    g = _g(95)
-    N, C, S, dg = 2, 64, 16, 2
-    x = torch.randn(N, C, S, S, generator=g)
-    off = torch.randn(N, 18 * dg, S, S, generator=g) * 0.5
-    w = torch.randn(C, C, 3, 3, generator=g) / (9 * C) ** 0.5
-    go = torch.randn(N, C, S, S, generator=g)
-    wf = ops.pack_dcn_bwd_weight(_dev(w), dg)
-    gx0, goff0 = ops.deform_conv_backward_data_fused(_dev(x), _dev(off), _dev(go), wf, dg)
-    bad = go.clone()
-    bad[1, 7, 5, 9] = float('inf')
-    gx1, goff1 = ops.deform_conv_backward_data_fused(_dev(x), _dev(off), _dev(bad), wf, dg)
-    # (rows of a plane that left the ring before the bad pixel's band are already written: the poison covers the rest)
-    assert torch.isnan(gx1[1]).flatten(1).any(dim=1).all() and torch.isnan(gx1[1, :, 4:]).all()
-    assert torch.equal(gx1[0], gx0[0]) and torch.equal(goff1[0], goff0[0])
-    assert torch.isfinite(gx0).all() and torch.isfinite(goff0).all()
-
-
 def test_fixed_point_scatter_accumulators_propagate_non_finite_gradients(ops):
     """The LDS accumulators of the DCN col2im and the point-sample adjoint are 64-bit fixed point; a NaN or
     Inf gradient has no fixed-point value and must show up as NaN in the plane it belongs to (a diverged step

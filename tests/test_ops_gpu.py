@@ -610,39 +610,53 @@ def test_deform_conv_split_k_vs_oracle_and_unsplit(ops, N, C, S):
     assert float((a - plain).abs().max()) <= 1e-5 * max(scale, 1.0)
 
 
-# ------------------------------------------------------------------ the opt-in RoIAlign paths of round 4
-@pytest.mark.parametrize('knob', ['DM_ROI_SORT', 'DM_ROI_PERSIST'])
-@pytest.mark.parametrize('P,n', [(14, 300), (7, 260), (14, 1)])
-def test_roi_align_opt_in_workspace_paths_match_the_default(ops, knob, P, n):
-    """dm_roi_align_fwd_ws with DM_ROI_SORT=1 (RoIs ranked by level and position on the device, outputs written back to
-    their own rows) or DM_ROI_PERSIST=1 (plan + persistent kernels): measured and not the default, but entry
-    points of the library -- the ordered path must give the default's bits and levels, the persistent one the oracle's
-    values (it merges wide stencils at run time: another association, < 1e-6)."""
-    import os
+# ------------------------------------------------------------------ the ordered RoI walk (default from 192 RoIs on)
+@pytest.mark.parametrize('P,n', [(14, 192), (14, 300), (14, 513), (14, 1024), (7, 260), (14, 1)])
+def test_roi_align_ordered_walk_gives_the_bits_and_levels_of_the_unordered_kernel(ops, P, n):
+    """dm_roi_align_fwd_ws (the default for 14 x 14 extractions of 192 .. 1024 RoIs): roi_order_kernel ranks the RoIs by
+    (image, level, position) and the tile kernel walks them in that order, writing every RoI's rows where
+    dm_roi_align_fwd writes them.  Compared with the UNORDERED kernel (ops.ROI_WORKSPACE = False -- ADVICE r4: the old test
+    compared the ordered path with itself): the same bits and levels, with duplicate boxes (equal keys but for the index),
+    zero-size boxes, boxes outside the image, NaN boxes and images beyond the four the key has bits for.  P = 7 never
+    takes the ordered path (P * P < 128): it must still honour the workspace argument."""
     from dynamask_amd import synth
-    feats = [_dev(f) for f in synth.make_fpn(2, 320, 448, 32, seed=40)[:4]]
-    rois = synth.make_rois(2, (n + 1) // 2, 320, 448, seed=41)[:n].contiguous()
+    B = 6
+    feats = [_dev(f) for f in synth.make_fpn(B, 160, 224, 32, seed=40)[:4]]
+    per = max(1, (n + B - 1) // B)
+    rois = synth.make_rois(B, per, 160, 224, seed=41)[:n].clone()
+    g = _g(42)
+    if n >= 16:
+        dup = torch.randint(0, n, (n // 8,), generator=g)
+        rois[dup] = rois[(dup + 3) % n]                                   # duplicates (in other rows)
+        rois[5, 3:] = rois[5, 1:3]                                        # zero size
+        rois[6, 1:] = torch.tensor([-500., -400., -300., -350.])          # outside the image
+        rois[7, 1:] = torch.tensor([float('nan'), 10., 50., 60.])         # NaN corner
+        rois[8, 1:] = float('nan')
+    rois = rois.contiguous()
     scales = (0.25, 0.125, 0.0625, 0.03125)
-    ref, lv_ref = ops.roi_align(feats, _dev(rois), P, scales, return_levels=True)
     was = (ops.ROI_WORKSPACE, ops.ROI_WORKSPACE_MIN)
-    os.environ[knob] = '1'
-    os.environ['DM_ROI_SORT_MIN'] = '1'
     try:
-        ops.lib().dm_reload_env_knobs()
+        ops.ROI_WORKSPACE = False
+        ref, lv_ref = ops.roi_align(feats, _dev(rois), P, scales, return_levels=True)
         ops.ROI_WORKSPACE, ops.ROI_WORKSPACE_MIN = True, 1
+        import os
+        os.environ['DM_ROI_SORT_MIN'] = '1'
+        ops.lib().dm_reload_env_knobs()
         out, lv = ops.roi_align(feats, _dev(rois), P, scales, return_levels=True)
         out2, _ = ops.roi_align(feats, _dev(rois), P, scales, return_levels=True)
     finally:
-        del os.environ[knob]
-        del os.environ['DM_ROI_SORT_MIN']
+        os.environ.pop('DM_ROI_SORT_MIN', None)
         ops.lib().dm_reload_env_knobs()
         ops.ROI_WORKSPACE, ops.ROI_WORKSPACE_MIN = was
     assert torch.equal(lv, lv_ref)
-    assert torch.equal(out, out2)
-    if knob == 'DM_ROI_SORT':
-        assert torch.equal(out, ref)
-    else:
-        _close(out, ref, atol=2e-6, rtol=2e-6)
+    nan_ref = torch.isnan(ref)
+    assert torch.equal(torch.isnan(out), nan_ref)
+    assert torch.equal(out.masked_fill(nan_ref, 0.), ref.masked_fill(nan_ref, 0.))
+    assert torch.equal(out2.masked_fill(nan_ref, 0.), out.masked_fill(nan_ref, 0.))
+    if n >= 16:
+        good = torch.ones(n, dtype=torch.bool)
+        good[[7, 8]] = False
+        assert torch.isfinite(out[good.to(out.device)]).all()
 
 
 def test_split_k_entry_points_with_a_workspace_smaller_than_they_ask_for(ops):

@@ -35,7 +35,11 @@ TP_STEPS=6 rocprofv3 --kernel-trace --output-format csv -d $out/prof_tl -- pytho
 python3 tools/timeline.py "$(ls $out/prof_tl/*/*kernel_trace.csv | head -1)" chain > $out/${tag}_train_timeline.txt 2>&1
 rm -rf $out/prof_tl
 python3 tools/step_shapes.py > $out/${tag}_step_shapes_solo.txt 2>&1
-python3 tools/roi_exp.py all > $out/${tag}_roi_exp.txt 2>&1
+# the 100-detection inference call (bucketed HIP-graph replay): launches, union busy time, kernel families per replay
+rm -rf $out/prof_inf
+rocprofv3 --kernel-trace --output-format csv -d $out/prof_inf -- python3 tools/infer100_probe.py > /dev/null 2>&1
+python3 tools/infer_timeline.py "$(ls $out/prof_inf/*/*kernel_trace.csv | head -1)" 6 > $out/${tag}_infer100_timeline.txt 2>&1
+rm -rf $out/prof_inf
 echo "traces done"
 python3 tools/kbench.py > $out/${tag}_kbench.txt 2>&1
 python3 tools/tail_probe.py > $out/${tag}_tail_probe.txt 2>&1
@@ -48,12 +52,8 @@ cat $out/${tag}_traffic_pmc.txt
 python3 tools/make_pmc_json.py $out/traffic_fetch $out/traffic_write $out/traffic_mfma $out/${tag}_roofline_kernel_stats.csv 6 $out/${tag}_pmc_traffic.json > /dev/null
 echo "pmc json done"
 hipcc --offload-arch=gfx950 -O3 -w tools/micro/mfma_mix.hip -o /tmp/mfma_mix 2> /dev/null && /tmp/mfma_mix > $out/${tag}_mfma_mix.txt
-python3 tools/conv1_exp.py > $out/${tag}_conv1_exp.txt 2>&1
-python3 tools/coord_exp.py > $out/${tag}_coord_exp.txt 2>&1
 python3 tools/dcn_offsets_exp.py > $out/${tag}_dcn_offsets_exp.txt 2>&1
 python3 tools/small_n.py > $out/${tag}_small_n.txt 2>&1
 python3 tools/col2im_exp.py > $out/${tag}_col2im_exp.txt 2>&1
-python3 tools/dcn_fused_probe.py > $out/${tag}_dcn_fused_probe.txt 2>&1
 python3 tools/op_probe.py wgradcat wgrad > $out/${tag}_wgrad_probe.txt 2>&1
-bash tools/dcn_stamps.sh > $out/${tag}_dcn_fused_stamps.txt 2>&1
 echo "all done"

@@ -24,7 +24,7 @@ res=$out/${tag}_roialign_ceiling.txt
   for v in 1 2 3 4 5 6 7; do ${bin}_$v $rois | tail -1; done
   echo
   echo "## 1b. round 2's configuration (launch order, 32 channels per workgroup), and launch order with 16 channels"
-  DM_ROI_ORDER=0 DM_ROI_CT=32 ${bin}_0 $rois | tail -1
+  ${bin}_0 $rois | tail -1
   DM_ROI_ORDER=0 DM_ROI_CT=16 ${bin}_0 $rois | tail -1
   echo
   echo "## 1c. 7x7 (bbox extraction) full kernel"
