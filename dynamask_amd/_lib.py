@@ -4,7 +4,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DYNAMASK_HIP_LIB') or os.path.join(_HERE, 'libdynamask_hip.so')      # override: kernel experiments
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -41,7 +41,7 @@ SIGNATURES = {
     'dm_gumbel_select_fwd': ([_vp, _vp, _c_int, _c_int, _c_float, _vp, _vp, _vp, _vp], _c_int),
     'dm_gumbel_select_bwd': ([_vp, _vp, _c_int, _c_int, _c_float, _vp, _vp], _c_int),
     'dm_class_balance_fwd_bwd': ([_vp, _c_int, _c_int, _vp, _vp, _vp], _c_int),
-    'dm_bn_stats': ([_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_float, _vp, _vp], _c_int),
+    'dm_bn_stats': ([_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_float, _vp, _vp, _vp], _c_int),
     'dm_bn_scratch_floats': ([_c_int], ctypes.c_longlong),
     'dm_bn_relu_maxpool_fwd': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_float, _vp, _vp], _c_int),
     'dm_bn_relu_maxpool_argmax': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_float, _vp, _vp], _c_int),

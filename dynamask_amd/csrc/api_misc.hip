@@ -11,7 +11,7 @@ extern "C" const char* dm_error_string(int code) {
   }
 }
 
-extern "C" int dm_abi_version(void) { return 22; }
+extern "C" int dm_abi_version(void) { return 23; }
 
 // ---------------------------------------------------------------------------
 // Optimiser step on the flat mask-head parameter buffer: SGD with momentum and

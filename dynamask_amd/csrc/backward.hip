@@ -1678,9 +1678,12 @@ __global__ __launch_bounds__(NTH) void dcn_col2im_lds_kernel(const float* __rest
         if (it0 + u * (int)blockDim.x >= 9 * HWq) continue;
         // The four pixels of an item lie side by side: where two neighbours sample one row and adjacent
         // columns (w_low differs by one -- every interior pixel while the offsets vary by less than a pixel), the
-        // right-hand cells of the left pixel ARE the left-hand cells of the right one.  Their fixed-point products are
-        // added in registers (integer adds: the same sums as two atomics) and go out as one atomic: 10 instead of 16
-        // per channel for a fully linked item.  The kernel is bound by the LDS atomics (ds_add_u64, ~18 cycles per
+        // right-hand cells of the left pixel ARE the left-hand cells of the right one.  The two fp32 products are added in
+        // registers (ONE more fp32 rounding: tl += ct) and the sum is cut to the 2^-36 grid and sent as one atomic: 10
+        // instead of 16 per channel for a fully linked item.  So a merged cell is another association of the same
+        // products than two atomics would give (last bits differ from the scatter() path of planes with HW % 4 != 0) --
+        // still a function of the data alone, the same bits every run and whatever the arrival order (an
+        // earlier comment claimed integer adds).  The kernel is bound by the LDS atomics (ds_add_u64, ~18 cycles per
         // wave instruction), not by anything this adds.
         const int tap = tapv[u], ki = tap / 3, kj = tap - ki * 3;
         const int y = pv[u] / W, x0 = pv[u] - y * W;

@@ -30,7 +30,8 @@ __device__ __forceinline__ float block_sum_bcast(float v, float* smem) {
 __global__ __launch_bounds__(1024) void bn_stats_kernel(const float* __restrict__ x, int NB, int C, int HW,
                                                         float* __restrict__ mean, float* __restrict__ var,
                                                         float* __restrict__ running_mean,
-                                                        float* __restrict__ running_var, float momentum) {
+                                                        float* __restrict__ running_var, float momentum,
+                                                        const float* __restrict__ mean_shift) {
   __shared__ float red[16];
   const int c = blockIdx.x;
   const long long total = (long long)NB * HW;
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(1024) void bn_stats_kernel(const float* __restrict_
     var[c] = v;
     if (running_mean && running_var) {
       const float unbiased = total > 1 ? v * (float)total / (float)(total - 1) : v;
-      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (mean_shift ? m + mean_shift[c] : m);
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
     }
   }
@@ -103,7 +104,8 @@ __global__ __launch_bounds__(256) void bn_stats_split_kernel(const float* __rest
 
 __global__ void bn_stats_finalize_kernel(const float* __restrict__ part_sum, const float* __restrict__ part_sq, int C,
                                          long long total, float* __restrict__ mean, float* __restrict__ var,
-                                         float* __restrict__ running_mean, float* __restrict__ running_var, float momentum) {
+                                         float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+                                         const float* __restrict__ mean_shift) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const float m = bn_partials_ordered(part_sum, c) / (float)total;
@@ -112,7 +114,7 @@ __global__ void bn_stats_finalize_kernel(const float* __restrict__ part_sum, con
   var[c] = v;
   if (running_mean && running_var) {
     const float unbiased = total > 1 ? v * (float)total / (float)(total - 1) : v;
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (mean_shift ? m + mean_shift[c] : m);
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
   }
 }
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_rows_kernel(const float* 
 extern "C" long long dm_bn_scratch_floats(int C) { return C > 0 ? (long long)C * kBnSplits * 2 : -1; }
 
 extern "C" int dm_bn_stats(const float* x, int NB, int C, int HW, float* mean, float* var, float* running_mean,
-                           float* running_var, float momentum, float* scratch, dm_stream_t stream) {
+                           float* running_var, float momentum, const float* mean_shift, float* scratch, dm_stream_t stream) {
   if (!x || !mean || !var || NB <= 0 || C <= 0 || HW <= 0) return DM_ERR_INVALID_ARG;
   if (scratch && NB >= kBnSplits) {
     hipStream_t st = (hipStream_t)stream;
@@ -213,11 +215,11 @@ extern "C" int dm_bn_stats(const float* x, int NB, int C, int HW, float* mean, f
     rc = dm_check_launch();
     if (rc != DM_OK) return rc;
     DM_LAUNCH(bn_stats_finalize_kernel, dim3(dm_ceil_div(C, 128)), dim3(128), 0, st, ps, pq, C, (long long)NB * HW, mean, var,
-              running_mean, running_var, momentum);
+              running_mean, running_var, momentum, mean_shift);
     return dm_check_launch();
   }
   DM_LAUNCH(bn_stats_kernel, dim3(C), dim3(1024), 0, (hipStream_t)stream, x, NB, C, HW, mean, var,
-                     running_mean, running_var, momentum);
+                     running_mean, running_var, momentum, mean_shift);
   return dm_check_launch();
 }
 

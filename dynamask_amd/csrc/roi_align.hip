@@ -1083,6 +1083,210 @@ __global__ __launch_bounds__(256, WPC) void roi_align_band_kernel(RoiArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Adjoint of the RoIAlign in GATHER form (round 5), for output grids up to 64 x 64.
+// Why: the training step extracted [256, 256, 56, 56] = 822 MB of P2 for MaskPre (K2) and read it twice more (conv1 and
+// its weight gradient).  conv1 is 1x1 and RoIAlign linear, so conv1 runs on the P2 map instead (12x fewer pixels) and 128
+// channels are extracted; the price is that conv1's weight gradient then needs the ADJOINT of the 56 x 56 extraction,
+// G = A^T g_y1 on the map.  The scatter kernel below (roi_align_kernel<true>) issues one float atomic per sample tap:
+// 103 M outputs x ~12 taps = 1.2 G atomics = 3.8 ms at the memory-side atomic rate -- which is why round 2 kept the
+// commutation for inference only.
+// Here a workgroup owns (RoI, channel quad): the RoI's gradient planes sit in LDS as [pixel] float4, and a thread owns a
+// CELL of the RoI's footprint on the map.  The RoIAlign is separable, out = Ay . M . Ax^T with banded Ay, Ax (a sample
+// touches the two pixels around it), so cell (Y, X) sums wy * wx * g[py][px] over the samples whose low or high tap is Y
+// (resp. X): along an axis the sample coordinate grows with the sample index, so those are two runs of consecutive
+// samples, found by a lower-bound search once per footprint row / column.  The sum is formed in registers in a fixed
+// order and leaves with ONE float atomic per cell and channel (RoIs overlap on the map): 167 M for the training step's
+// 256 RoIs x 128 channels instead of 1.2 G.
+// Samples per axis beyond kAdjMaxSamples (P * g: g > 6 at P = 56) and sampling grids of non-positive size take the
+// per-tap atomics of the generic path inside this kernel.
+constexpr int kAdjMaxSamples = 384;
+
+__global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(RoiArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float4 lds4[];
+  const int P = a.P, PP = P * P;
+  const int chunks = a.C >> 2;
+  const int k = blockIdx.x / chunks;
+  const int c0 = (blockIdx.x - k * chunks) << 2;
+  const int tid = threadIdx.x;
+  const float* r = a.rois + (size_t)k * 5;
+  const int b = (int)r[0];
+  const float x1 = r[1], y1 = r[2], x2 = r[3], y2 = r[4];
+  const int lvl = (a.L > 1) ? roi_level(x1, y1, x2, y2, a.finest, a.L) : 0;
+  if (b < 0 || b >= a.B) return;
+  int Hl = a.H[0], Wl = a.W[0];
+  float sc = a.scale[0];
+  float* glvl = a.gfeat[0];
+#pragma unroll
+  for (int l = 1; l < DM_MAX_LEVELS; ++l)
+    if (lvl == l) {
+      Hl = a.H[l];
+      Wl = a.W[l];
+      sc = a.scale[l];
+      glvl = a.gfeat[l];
+    }
+  const float sw = x1 * sc - 0.5f, sh = y1 * sc - 0.5f;
+  const float ew = x2 * sc - 0.5f, eh = y2 * sc - 0.5f;
+  const float rw = ew - sw, rh = eh - sh;
+  const float bh = rh / (float)P, bw = rw / (float)P;
+  const int gh = a.sr > 0 ? a.sr : (int)ceilf(rh / (float)P);
+  const int gw = a.sr > 0 ? a.sr : (int)ceilf(rw / (float)P);
+  if (gh <= 0 || gw <= 0) return;                       // (the forward wrote zeros: no gradient)
+  const float inv_count = 1.0f / (float)(gh * gw);
+  const size_t plane = (size_t)Hl * Wl;
+  float* const gimg = glvl + ((size_t)b * a.C + c0) * plane;
+  const float* const go = a.gout + ((size_t)k * a.C + c0) * PP;
+  const int ny = P * gh, nx = P * gw;
+
+  // the RoI's four gradient planes -> LDS [pixel] float4
+  float4* const gq = lds4;
+  for (int i = tid; i < PP; i += 256) gq[i] = make_float4(go[i], go[PP + i], go[2 * PP + i], go[3 * PP + i]);
+
+  // generic path: one atomic per tap (huge sampling grids; a fixed sampling_ratio on a box of non-positive size or with
+  // samples more than a pixel apart)
+  auto generic = [&]() {
+    for (int pos = tid; pos < PP; pos += 256) {
+      const int ph = pos / P, pw = pos - ph * P;
+      const float4 g4 = gq[pos];
+      for (int iy = 0; iy < gh; ++iy) {
+        int yl, yh;
+        float wyl, wyh;
+        axis_sample(sh, bh, gh, ph, iy, Hl, yl, yh, wyl, wyh);
+        for (int ix = 0; ix < gw; ++ix) {
+          int xl, xh;
+          float wxl, wxh;
+          axis_sample(sw, bw, gw, pw, ix, Wl, xl, xh, wxl, wxh);
+          const float w[4] = {wyl * wxl * inv_count, wyl * wxh * inv_count, wyh * wxl * inv_count, wyh * wxh * inv_count};
+          const int off[4] = {yl * Wl + xl, yl * Wl + xh, yh * Wl + xl, yh * Wl + xh};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            if (w[t] == 0.f) continue;
+            atomicAdd(gimg + off[t], w[t] * g4.x);
+            atomicAdd(gimg + plane + off[t], w[t] * g4.y);
+            atomicAdd(gimg + 2 * plane + off[t], w[t] * g4.z);
+            atomicAdd(gimg + 3 * plane + off[t], w[t] * g4.w);
+          }
+        }
+      }
+    }
+  };
+  if (ny > kAdjMaxSamples || nx > kAdjMaxSamples || !(bh > 0.f) || !(bw > 0.f)) {
+    __syncthreads();
+    generic();
+    return;
+  }
+
+  // per-axis sample tables: low tap (monotone in the sample index; a void sample keeps the order and has zero weights),
+  // high tap, the two weights (the y weights carry 1 / (gh * gw))
+  int* const lo_y = reinterpret_cast<int*>(gq + PP);
+  int* const hi_y = lo_y + kAdjMaxSamples;
+  float* const wl_y = reinterpret_cast<float*>(hi_y + kAdjMaxSamples);
+  float* const wh_y = wl_y + kAdjMaxSamples;
+  int* const lo_x = reinterpret_cast<int*>(wh_y + kAdjMaxSamples);
+  int* const hi_x = lo_x + kAdjMaxSamples;
+  float* const wl_x = reinterpret_cast<float*>(hi_x + kAdjMaxSamples);
+  float* const wh_x = wl_x + kAdjMaxSamples;
+  // entry lists by cell: (output row / column, weight), the entries of a cell contiguous; first entry of a cell in off_*
+  int* const ep_y = reinterpret_cast<int*>(wh_x + kAdjMaxSamples);
+  float* const ew_y = reinterpret_cast<float*>(ep_y + 2 * kAdjMaxSamples);
+  int* const ep_x = reinterpret_cast<int*>(ew_y + 2 * kAdjMaxSamples);
+  float* const ew_x = reinterpret_cast<float*>(ep_x + 2 * kAdjMaxSamples);
+  int* const off_y = reinterpret_cast<int*>(ew_x + 2 * kAdjMaxSamples);      // [Hf + 1]
+  int* const off_x = off_y + (kAdjMaxSamples + 2);                            // [Wf + 1]  (a footprint has at most n + 1 rows)
+  for (int s_ = tid; s_ < ny + nx; s_ += 256) {
+    const bool xa = s_ >= ny;
+    const int s = xa ? s_ - ny : s_;
+    const int g = xa ? gw : gh, size = xa ? Wl : Hl;
+    const int p = s / g, i = s - p * g;
+    int lo, hi;
+    float wl, wh;
+    axis_sample(xa ? sw : sh, xa ? bw : bh, g, p, i, size, lo, hi, wl, wh);
+    if (wl == 0.f && wh == 0.f) {
+      // void sample (axis_sample reports taps 0, 0): keep its place in the order -- before the map or after it
+      const float c = (xa ? sw : sh) + (float)p * (xa ? bw : bh) + ((float)i + 0.5f) * (xa ? bw : bh) / (float)g;
+      lo = hi = c < 0.f ? 0 : size - 1;
+    }
+    if (xa) {
+      lo_x[s] = lo; hi_x[s] = hi; wl_x[s] = wl; wh_x[s] = wh;
+    } else {
+      lo_y[s] = lo; hi_y[s] = hi; wl_y[s] = wl * inv_count; wh_y[s] = wh * inv_count;
+    }
+  }
+  __syncthreads();
+  const int Y0 = lo_y[0], Hf = hi_y[ny - 1] - Y0 + 1;
+  const int X0 = lo_x[0], Wf = hi_x[nx - 1] - X0 + 1;
+  if (Hf > kAdjMaxSamples + 1 || Wf > kAdjMaxSamples + 1) {      // (samples more than a pixel apart: a fixed sampling_ratio)
+    generic();
+    return;
+  }
+  // first entry of each footprint row / column: the samples whose low tap lies below it + those whose high tap does
+  auto lower = [](const int* t, int n, int v) {      // first index with t[i] >= v
+    int l = 0, h = n;
+    while (l < h) {
+      const int m = (l + h) >> 1;
+      if (t[m] < v) l = m + 1; else h = m;
+    }
+    return l;
+  };
+  for (int c_ = tid; c_ < Hf + 1 + Wf + 1; c_ += 256) {
+    const bool xa = c_ >= Hf + 1;
+    const int c = xa ? c_ - (Hf + 1) : c_;
+    const int v = (xa ? X0 : Y0) + c;
+    const int* lo = xa ? lo_x : lo_y;
+    const int* hi = xa ? hi_x : hi_y;
+    const int n = xa ? nx : ny;
+    const int a0 = lower(lo, n, v), a1 = lower(lo, n, v + 1), h0 = lower(hi, n, v), h1 = lower(hi, n, v + 1);
+    (xa ? off_x : off_y)[c] = a0 + h0;
+    const int last = xa ? Wf : Hf;
+    if (c < last) {
+      int* ep = xa ? ep_x : ep_y;
+      float* ew = xa ? ew_x : ew_y;
+      const float* wl = xa ? wl_x : wl_y;
+      const float* wh = xa ? wh_x : wh_y;
+      const int g = xa ? gw : gh;
+      int e = a0 + h0;
+      for (int s = h0; s < h1; ++s, ++e) { ep[e] = s / g; ew[e] = wh[s]; }      // high taps first: the lower sample indices
+      for (int s = a0; s < a1; ++s, ++e) { ep[e] = s / g; ew[e] = wl[s]; }
+    }
+  }
+  __syncthreads();
+  const int cells = Hf * Wf;
+  const unsigned m_wf = Wf > 1 ? 0xFFFFFFFFu / (unsigned)Wf + 1u : 0u;
+  for (int cell = tid; cell < cells; cell += 256) {
+    const int yy = Wf > 1 ? (int)__umulhi((unsigned)cell, m_wf) : cell;
+    const int xx = cell - yy * Wf;
+    const int ey0 = off_y[yy], ey1 = off_y[yy + 1], ex0 = off_x[xx], ex1 = off_x[xx + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ey = ey0; ey < ey1; ++ey) {
+      const float wy = ew_y[ey];
+      const float4* row = gq + ep_y[ey] * P;
+      float4 racc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int ex = ex0; ex < ex1; ++ex) {
+        const float wx = ew_x[ex];
+        const float4 v = row[ep_x[ex]];
+        racc.x += wx * v.x;
+        racc.y += wx * v.y;
+        racc.z += wx * v.z;
+        racc.w += wx * v.w;
+      }
+      acc.x += wy * racc.x;
+      acc.y += wy * racc.y;
+      acc.z += wy * racc.z;
+      acc.w += wy * racc.w;
+    }
+    float* const o = gimg + (size_t)(Y0 + yy) * Wl + (X0 + xx);
+    atomicAdd(o, acc.x);
+    atomicAdd(o + plane, acc.y);
+    atomicAdd(o + 2 * plane, acc.z);
+    atomicAdd(o + 3 * plane, acc.w);
+  }
+}
+
+// LDS bytes of roi_align_bwd_gather_kernel: the gradient quads + the tables above
+static inline size_t roi_adj_lds_bytes(int P) {
+  return (size_t)P * P * 16 + (size_t)kAdjMaxSamples * 4 * (8 + 8) + (size_t)(kAdjMaxSamples + 2) * 4 * 2;
+}
+
 // The two knobs of the forward launchers, read from the environment ONCE (first launch) and clamped;
 // dm_reload_env_knobs() re-reads them (tools that sweep settings in one process).  Neither changes a result.
 // (Rounds 3-4 had eleven: chunk size, workgroup orders, nontemporal stores, the units / plan / persistent kernels.  What
@@ -1256,6 +1460,14 @@ extern "C" int dm_roi_align_bwd(const float* grad_out, float* const* grad_feats,
   }
   if (N == 0) return DM_OK;
   a.gout = grad_out;
+  if (P > 16 && P <= 64 && C % 4 == 0 && (long long)N * (C / 4) <= 0x7fffffffLL) {
+    // larger output grids (the 56 x 56 extraction in front of MaskPre): gather form, one atomic per footprint cell
+    static bool raised[DM_MAX_DEVICES] = {false};
+    const size_t lds = roi_adj_lds_bytes(P);
+    if (dm_ensure_lds_limit(reinterpret_cast<const void*>(&roi_align_bwd_gather_kernel), (int)lds, raised) != DM_OK) return DM_ERR_LAUNCH;
+    DM_LAUNCH(roi_align_bwd_gather_kernel, dim3((unsigned)(N * (C / 4))), dim3(256), lds, (hipStream_t)stream, a);
+    return dm_check_launch();
+  }
   const int chunks = dm_ceil_div(C, a.CT);
   DM_LAUNCH((roi_align_kernel<true, 0>), dim3(N * chunks), dim3(256), 0, (hipStream_t)stream, a);
   return dm_check_launch();

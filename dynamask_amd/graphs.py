@@ -28,6 +28,7 @@ class GraphedMaskLogits:
         self._graphs = {}          # key -> (graph, rois_static, labels_static, out_static)
         self.captures = 0
         self.replays = 0
+        self._params = None
 
     def bucket_for(self, n):
         for b in self.buckets:
@@ -39,7 +40,10 @@ class GraphedMaskLogits:
         """(address, version) of every parameter the captured launches read, directly or through a kernel-layout pack:
         an in-place update (optimizer step, load_state_dict, copy_) bumps ``_version`` without touching
         ops.WEIGHT_EPOCH, and a replay would combine stale packed weights with the new class-logit weights."""
-        return tuple((p.data_ptr(), p._version) for p in self.head.mask_head.parameters())
+        ps = self._params
+        if ps is None:          # (the module tree is walked once: the head's parameter OBJECTS do not change, their storage may)
+            ps = self._params = list(self.head.mask_head.parameters())
+        return tuple([p.data_ptr() for p in ps]), sum(p._version for p in ps)
 
     def _key(self, bucket, x):
         return (bucket, tuple(int(t.data_ptr()) for t in x), tuple(tuple(t.shape) for t in x), ops.WEIGHT_EPOCH[0],

@@ -766,14 +766,17 @@ def _bn_scratch(device, C):
     return buf
 
 
-def bn_stats(x, running_mean=None, running_var=None, momentum=0.1):
+def bn_stats(x, running_mean=None, running_var=None, momentum=0.1, mean_shift=None):
+    """``mean_shift`` [C]: the running mean moves towards mean + mean_shift (x lacks a per-channel bias, see the header)."""
     _chk(x, 'x')
+    if mean_shift is not None:
+        _chk(mean_shift, 'mean_shift')
     NB, C, H, W = x.shape
     mean = torch.empty((C,), device=x.device, dtype=torch.float32)
     var = torch.empty((C,), device=x.device, dtype=torch.float32)
     scratch = _bn_scratch(x.device, C)
     check(lib().dm_bn_stats(_p(x), NB, C, H * W, _p(mean), _p(var), _p(running_mean), _p(running_var), momentum,
-                            _p(scratch), _stream()), 'dm_bn_stats')
+                            _p(mean_shift), _p(scratch), _stream()), 'dm_bn_stats')
     return mean, var
 
 

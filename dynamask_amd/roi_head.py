@@ -11,6 +11,8 @@ branch losses, mask targets on the device; dynamask_roi_head.py:21-46) and
 import torch
 import torch.nn as nn
 
+import os
+
 from . import ops
 from .mask_heads import _Conv
 from .registry import HEADS, build_head, build_roi_extractor
@@ -27,6 +29,10 @@ def bbox2roi(bbox_list):
             rois = bboxes.new_zeros((0, 5))
         rois_list.append(rois)
     return torch.cat(rois_list, 0)
+
+
+# training: MaskPre's conv1 on the P2 map + a 128-channel extraction (train_path.MaskPreMapFn); 0 = the reference's order
+_MASKPRE_ON_MAP = os.environ.get('DM_MASKPRE_MAP', '1') != '0'
 
 
 class _BN(nn.Module):
@@ -242,6 +248,22 @@ class DynaMaskRoIHead(nn.Module):
             y, hot, idx = ops.gumbel_select(logits, noise.contiguous(), 0.5)
         return (hot, idx, logits, y) if return_index else hot
 
+    def get_mask_label_from_map(self, feat_map, rois, noise=None):
+        """``get_mask_label(semantic_roi_extractor([feat_map], rois), noise, return_index=True)`` of the training step
+        (dynamask_roi_head.py:59-60) without the [N, 256, 56, 56] tensor: MaskPre's 1x1 conv1 runs on the map and 128
+        channels are extracted (train_path.MaskPreMapFn).  The deterministic mode and DM_MASKPRE_MAP=0 take the
+        reference's order of operations."""
+        from . import train_path
+        lay = self.semantic_roi_extractor.roi_layers[0]
+        if ops.DETERMINISTIC[0] or not _MASKPRE_ON_MAP or self.semantic_roi_extractor.num_inputs != 1:
+            return self.get_mask_label(self.semantic_roi_extractor([feat_map], rois), noise, return_index=True)
+        logits = train_path.MaskPreMapFn.apply(self.mask_predictor, feat_map, rois, lay.output_size[0], lay.spatial_scale,
+                                               lay.sampling_ratio, *list(self.mask_predictor.parameters()))
+        if noise is None:
+            noise = self.sample_uniform(logits.shape, logits.device)
+        hot, idx = train_path.GumbelSelectFn.apply(logits, noise, 0.5)
+        return hot, idx, logits, None
+
     # ------------------------------------------------------------------ training entry points
     def forward_train(self, x, img_metas, proposal_list, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None,
                       noise=None):
@@ -329,6 +351,13 @@ class DynaMaskRoIHead(nn.Module):
         stage_mask_targets = self.mask_head.get_targets(pos_bboxes, pos_assigned_gt_inds, gt_masks)
         return self._mask_forward_train_tensors(x, pos_rois, torch.cat(pos_labels), stage_mask_targets, noise=noise)
 
+    def _selector(self, x, pos_rois, noise):
+        """dynamask_roi_head.py:59-60: the 56 x 56 extraction of P2 (detached) -> MaskPre -> ST-Gumbel selection."""
+        if torch.is_grad_enabled() and self.mask_predictor.training:
+            return self.get_mask_label_from_map(x[0].detach(), pos_rois, noise)
+        ins_semantic_feats = self.semantic_roi_extractor([x[0].detach(), ], pos_rois)
+        return self.get_mask_label(ins_semantic_feats, noise, return_index=True)
+
     def _mask_forward_train_tensors(self, x, pos_rois, pos_labels, stage_mask_targets, noise=None):
         """dynamask_roi_head.py:57-73 from ``pos_rois`` on."""
         # The resolution selector (56x56 extraction of P2 -> MaskPre -> ST-Gumbel) shares nothing with the mask head
@@ -348,8 +377,7 @@ class DynaMaskRoIHead(nn.Module):
             def selector():
                 side.wait_event(ready)
                 with torch.cuda.stream(side):
-                    ins_semantic_feats = self.semantic_roi_extractor([x[0].detach(), ], pos_rois)
-                    sel['out'] = self.get_mask_label(ins_semantic_feats, noise, return_index=True)
+                    sel['out'] = self._selector(x, pos_rois, noise)
             try:
                 mask_results = self._mask_forward(x, pos_rois, pos_labels, _between=selector)
             finally:
@@ -360,8 +388,7 @@ class DynaMaskRoIHead(nn.Module):
                 t.record_stream(main)
         else:
             mask_results = self._mask_forward(x, pos_rois, pos_labels)
-            ins_semantic_feats = self.semantic_roi_extractor([x[0].detach(), ], pos_rois)
-            mask_labels, idx, logits, y = self.get_mask_label(ins_semantic_feats, noise, return_index=True)
+            mask_labels, idx, logits, y = self._selector(x, pos_rois, noise)
         loss_mask = self.mask_head.loss_func(mask_results['stage_instance_preds'], mask_results['stage_detail_preds'],
                                              stage_mask_targets, mask_labels)
         mask_results.update(loss_mask=loss_mask, mask_labels=mask_labels, mask_index=idx, mask_logits=logits)

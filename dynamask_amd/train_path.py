@@ -577,10 +577,52 @@ def roi_extract_train(extractor, feats, rois):
     return RoIExtractFn.apply(rois, lay.output_size[0], scales, lay.sampling_ratio, float(extractor.finest_scale), *feats)
 
 
+def _maskpre_tail_forward(mp, p1):
+    """MaskPre behind its first pooling (base_roi_head.py:17-26): conv2 -> BN -> ReLU -> pool -> fc1 -> ReLU -> fc2."""
+    y2 = mp.conv2.run(p1)
+    m2, v2 = ops.bn_stats(y2, mp.bn2.running_mean, mp.bn2.running_var, mp.bn2.momentum)
+    p2 = ops.bn_relu_maxpool(y2, m2, v2, mp.bn2.weight.detach(), mp.bn2.bias.detach(), mp.bn2.eps)
+    mp.bn1.num_batches_tracked += 1
+    mp.bn2.num_batches_tracked += 1
+    h = mp.fc1.run(p2.reshape(p2.size(0), 3136), relu=True)
+    return y2, m2, v2, p2, h, mp.fc2.run(h)
+
+
+def _maskpre_tail_backward(mp, g, y1, m1, v1, p1, y2, m2, v2, p2, h, pg):
+    """-> d loss / d y1 (the first BatchNorm's input); parameter gradients of everything behind conv1 into ``pg`` or,
+    where the parameters have them, straight into the flat views."""
+    n = y1.shape[0]
+
+    def fc_bwd(fc, gy, xin):
+        gy4 = gy.contiguous().view(n, fc.out_features, 1, 1)
+        x4 = xin.contiguous().view(n, fc.in_features, 1, 1)
+        params_grad(fc.weight, fc.bias, gy4, x4, 1, pg, (fc.out_features, fc.in_features, 1, 1))
+        wq = fc._pk.get('flip', fc.weight, lambda t: ops.pack_conv_weight(
+            t.view(fc.out_features, fc.in_features, 1, 1), transpose_flip=True))
+        return ops.conv2d(gy4, wq, None, fc.in_features, 1).view(n, fc.in_features)
+
+    g_h = fc_bwd(mp.fc2, g, h)
+    ops.relu_backward_(g_h, h)
+    g_p2 = fc_bwd(mp.fc1, g_h, p2.reshape(n, 3136)).view_as(p2).contiguous()
+    g_y2, gg2, gb2 = ops.bn_relu_maxpool_backward(y2, m2, v2, mp.bn2.weight.detach(), mp.bn2.bias.detach(), g_p2, mp.bn2.eps)
+    pg[mp.bn2.weight], pg[mp.bn2.bias] = gg2, gb2
+    conv = mp.conv2
+    params_grad(conv.weight, conv.bias, g_y2, p1, conv.kernel_size, pg, tuple(conv.weight.shape))
+    wq = conv._pk.get(('flip', 0, conv.in_channels), conv.weight,
+                      lambda t: ops.pack_conv_weight(t, transpose_flip=True), job=(True, None, None, None))
+    g_p1 = ops.conv2d(g_y2, wq, None, conv.in_channels, conv.kernel_size)
+    g_y1, gg1, gb1 = ops.bn_relu_maxpool_backward(y1, m1, v1, mp.bn1.weight.detach(), mp.bn1.bias.detach(), g_p1, mp.bn1.eps)
+    pg[mp.bn1.weight], pg[mp.bn1.bias] = gg1, gb1
+    return g_y1
+
+
 class MaskPreFn(torch.autograd.Function):
     """MaskPre (base_roi_head.py:10-27) in train mode: forward + backward.
     Inputs: (mask_pre_module, x, *mask_pre.parameters()); x is the detached 56x56
-    RoI feature (dynamask_roi_head.py:59), so no data gradient leaves the block."""
+    RoI feature (dynamask_roi_head.py:59), so no data gradient leaves the block.
+    (The default training path since round 5 is MaskPreMapFn below; this form -- conv1 on the extracted [N, 256, 56, 56]
+    tensor, as the reference computes it -- is what the deterministic mode and direct callers of
+    ``get_mask_label(ins_semantic_feats)`` use.)"""
 
     @staticmethod
     def forward(ctx, mp, x, *params):
@@ -588,14 +630,7 @@ class MaskPreFn(torch.autograd.Function):
         y1 = mp.conv1.run(x)
         m1, v1 = ops.bn_stats(y1, mp.bn1.running_mean, mp.bn1.running_var, mp.bn1.momentum)
         p1 = ops.bn_relu_maxpool(y1, m1, v1, mp.bn1.weight.detach(), mp.bn1.bias.detach(), mp.bn1.eps)
-        y2 = mp.conv2.run(p1)
-        m2, v2 = ops.bn_stats(y2, mp.bn2.running_mean, mp.bn2.running_var, mp.bn2.momentum)
-        p2 = ops.bn_relu_maxpool(y2, m2, v2, mp.bn2.weight.detach(), mp.bn2.bias.detach(), mp.bn2.eps)
-        mp.bn1.num_batches_tracked += 1
-        mp.bn2.num_batches_tracked += 1
-        flat = p2.reshape(p2.size(0), 3136)
-        h = mp.fc1.run(flat, relu=True)
-        logits = mp.fc2.run(h)
+        y2, m2, v2, p2, h, logits = _maskpre_tail_forward(mp, p1)
         ctx.mp = mp
         ctx.sv = (x, y1, m1, v1, p1, y2, m2, v2, p2, h)
         return logits
@@ -605,41 +640,68 @@ class MaskPreFn(torch.autograd.Function):
         mp = ctx.mp
         hazard.engine_handoff(g)
         x, y1, m1, v1, p1, y2, m2, v2, p2, h = ctx.sv
-        n = x.shape[0]
         pg = {}
-
-        def params_bwd(weight, bias, gy4, x4, ks, wshape):
-            params_grad(weight, bias, gy4, x4, ks, pg, wshape)
-
-        def fc_bwd(fc, gy, xin, need_data=True):
-            gy4 = gy.contiguous().view(n, fc.out_features, 1, 1)
-            x4 = xin.contiguous().view(n, fc.in_features, 1, 1)
-            params_bwd(fc.weight, fc.bias, gy4, x4, 1, (fc.out_features, fc.in_features, 1, 1))
-            if not need_data:
-                return None
-            wq = fc._pk.get('flip', fc.weight, lambda t: ops.pack_conv_weight(
-                t.view(fc.out_features, fc.in_features, 1, 1), transpose_flip=True))
-            return ops.conv2d(gy4, wq, None, fc.in_features, 1).view(n, fc.in_features)
-
-        def conv_bwd(conv, gy, xin, need_data=True):
-            params_bwd(conv.weight, conv.bias, gy, xin, conv.kernel_size, tuple(conv.weight.shape))
-            if not need_data:
-                return None
-            wq = conv._pk.get(('flip', 0, conv.in_channels), conv.weight,
-                              lambda t: ops.pack_conv_weight(t, transpose_flip=True), job=(True, None, None, None))
-            return ops.conv2d(gy, wq, None, conv.in_channels, conv.kernel_size)
-
-        g_h = fc_bwd(mp.fc2, g, h)
-        ops.relu_backward_(g_h, h)
-        g_p2 = fc_bwd(mp.fc1, g_h, p2.reshape(n, 3136)).view_as(p2).contiguous()
-        g_y2, gg2, gb2 = ops.bn_relu_maxpool_backward(y2, m2, v2, mp.bn2.weight.detach(), mp.bn2.bias.detach(), g_p2, mp.bn2.eps)
-        pg[mp.bn2.weight], pg[mp.bn2.bias] = gg2, gb2
-        g_p1 = conv_bwd(mp.conv2, g_y2, p1)
-        g_y1, gg1, gb1 = ops.bn_relu_maxpool_backward(y1, m1, v1, mp.bn1.weight.detach(), mp.bn1.bias.detach(), g_p1, mp.bn1.eps)
-        pg[mp.bn1.weight], pg[mp.bn1.bias] = gg1, gb1
-        conv_bwd(mp.conv1, g_y1, x, need_data=False)
+        g_y1 = _maskpre_tail_backward(mp, g, y1, m1, v1, p1, y2, m2, v2, p2, h, pg)
+        params_grad(mp.conv1.weight, mp.conv1.bias, g_y1, x, mp.conv1.kernel_size, pg, tuple(mp.conv1.weight.shape))
         _join_caller_after_backward(x.device)
         return (None, None, *[pg.get(p) for p in mp.parameters()])
+
+
+class MaskPreMapFn(torch.autograd.Function):
+    """MaskPre in train mode with its first convolution applied to the P2 MAP (round 5; SURVEY 2.3 K2: "best fused with
+    K9 so the 3.2 MB / RoI tensor never hits HBM").
+
+    ``conv1`` is 1x1 and the RoIAlign a linear interpolation: conv1(RoIAlign56(x)) = RoIAlign56(W1 x) + b1
+    (base_roi_head.py:13, dynamask_roi_head.py:59; samples outside the map are 0 on both sides).  So W1 is applied once to
+    [B, 256, 200, 336] (8.8 GFLOP instead of 52.6 on 256 x 3136 extracted pixels) and 128 channels are extracted, not 256:
+    the [N, 256, 56, 56] tensor (822 MB at the training shape, written once and read twice) no longer exists.  Train-mode
+    BatchNorm cancels b1, which therefore only enters the running mean (``mean_shift`` of dm_bn_stats).  Backward: conv1's
+    weight gradient is taken on the map -- G = adjoint of the extraction applied to d loss / d y1 (dm_roi_align_bwd's
+    gather form: one atomic per footprint cell), dW1 = G . x^T -- its bias gradient is the channel sums of d loss / d y1
+    (a rounding residue, as in the reference: BatchNorm's backward sums to zero).  x[0] is detached in the reference, so no
+    data gradient leaves the block.  Sums differ from MaskPreFn's by association only; the deterministic mode
+    (ops.DETERMINISTIC) keeps MaskPreFn (the adjoint's float atomics land in arrival order).
+    Inputs: (mask_pre, p2_map, rois, output_size, spatial_scale, sampling_ratio, *mask_pre.parameters())."""
+
+    @staticmethod
+    def forward(ctx, mp, feat_map, rois, output_size, spatial_scale, sampling_ratio, *params):
+        feat_map = feat_map.contiguous()
+        rois = rois.contiguous()
+        c1 = mp.conv1
+        y_map = ops.conv2d([feat_map], c1.packed([feat_map.shape[1]]), None, c1.out_channels, 1)      # W1 x, no bias
+        y1 = ops.roi_align([y_map], rois, output_size, [spatial_scale], sampling_ratio)               # = conv1(RoIAlign(x)) - b1
+        map_shape = tuple(y_map.shape)
+        del y_map
+        m1, v1 = ops.bn_stats(y1, mp.bn1.running_mean, mp.bn1.running_var, mp.bn1.momentum, mean_shift=c1.bias.detach())
+        p1 = ops.bn_relu_maxpool(y1, m1, v1, mp.bn1.weight.detach(), mp.bn1.bias.detach(), mp.bn1.eps)
+        y2, m2, v2, p2, h, logits = _maskpre_tail_forward(mp, p1)
+        ctx.mp = mp
+        ctx.sv = (feat_map, rois, y1, m1, v1, p1, y2, m2, v2, p2, h)
+        ctx.cfg = (output_size, spatial_scale, sampling_ratio, map_shape)
+        return logits
+
+    @staticmethod
+    def backward(ctx, g):
+        mp = ctx.mp
+        hazard.engine_handoff(g)
+        feat_map, rois, y1, m1, v1, p1, y2, m2, v2, p2, h = ctx.sv
+        output_size, spatial_scale, sampling_ratio, map_shape = ctx.cfg
+        pg = {}
+        g_y1 = _maskpre_tail_backward(mp, g, y1, m1, v1, p1, y2, m2, v2, p2, h, pg)
+        c1 = mp.conv1
+        tb = _direct(c1.bias)
+        if tb is not None:
+            ops.channel_sum(g_y1, out=tb)
+        else:
+            pg[c1.bias] = ops.channel_sum(g_y1)
+        (g_map,) = ops.roi_align_backward(g_y1, [map_shape], rois, output_size, [spatial_scale], sampling_ratio)
+        del g_y1
+        tw = _direct(c1.weight)
+        gw = ops.conv2d_wgrad(g_map, feat_map, 1, dw=tw)
+        if tw is None:
+            pg[c1.weight] = gw.view_as(c1.weight)
+        _join_caller_after_backward(feat_map.device)
+        return (None, None, None, None, None, None, *[pg.get(p) for p in mp.parameters()])
 
 
 class GumbelSelectFn(torch.autograd.Function):

@@ -53,7 +53,7 @@ extern "C" {
 typedef void* dm_stream_t; /* hipStream_t */
 
 const char* dm_error_string(int code);
-/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient, dm_conv_pack_weight_batch, dm_mask_loss_stage; 15: dm_class_logits_up2x_fwd; 16: dm_conv2d_wgrad_slab / dm_conv2d_wgrad_scratch_floats; 17: dm_class_logits_bwd_slab / dm_class_logits_bwd_scratch_floats; 18: dm_reload_env_knobs, dm_roi_align_fwd_ws / dm_roi_align_workspace_bytes, dm_conv_pack_weight_split / dm_conv_packed_floats_split and flag bits 4, 5 of dm_conv2d_fwd; 19: dm_dcn_bwd_data_fused and its pack; 20: dm_conv2d_fwd_ws / dm_conv2d_splitk_floats; 21: dm_deform_conv_fwd_ws / dm_deform_conv_splitk_floats; 22: the bf16-split layouts (dm_conv_pack_weight_split, dm_conv_packed_floats_split, flag bits 4 / 5 of dm_conv2d_fwd) and the one-kernel DCN data gradient (dm_dcn_bwd_*) REMOVED -- measured, never the parity path, see docs/HISTORY.md). */
+/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient, dm_conv_pack_weight_batch, dm_mask_loss_stage; 15: dm_class_logits_up2x_fwd; 16: dm_conv2d_wgrad_slab / dm_conv2d_wgrad_scratch_floats; 17: dm_class_logits_bwd_slab / dm_class_logits_bwd_scratch_floats; 18: dm_reload_env_knobs, dm_roi_align_fwd_ws / dm_roi_align_workspace_bytes, dm_conv_pack_weight_split / dm_conv_packed_floats_split and flag bits 4, 5 of dm_conv2d_fwd; 19: dm_dcn_bwd_data_fused and its pack; 20: dm_conv2d_fwd_ws / dm_conv2d_splitk_floats; 21: dm_deform_conv_fwd_ws / dm_deform_conv_splitk_floats; 22: the bf16-split layouts (dm_conv_pack_weight_split, dm_conv_packed_floats_split, flag bits 4 / 5 of dm_conv2d_fwd) and the one-kernel DCN data gradient (dm_dcn_bwd_*) REMOVED -- measured, never the parity path, see docs/HISTORY.md; 23: dm_bn_stats takes mean_shift, dm_roi_align_bwd takes the gather form for 16 < P <= 64). */
 int dm_abi_version(void);
 /* Re-read the DM_ROI_* experiment knobs from the environment (they are otherwise read once, at the first launch, and
  * clamped to validated ranges).  For measurement tools that sweep settings inside one process; no knob changes a result. */
@@ -327,8 +327,11 @@ int dm_mask_loss_stage(const float* inst_pred, const float* det_pred, const floa
  * of MaskPre run through dm_conv2d_fwd.
  * x [NB, C, H, W]; mean/var/gamma/beta [C]; out [NB, C, (H-1)/2+1, (W-1)/2+1]
  * ------------------------------------------------------------------------- */
+/* mean_shift (ABI 23; [C] or NULL): the running mean is updated with mean + mean_shift.  Used when x is the activation
+ * WITHOUT a per-channel bias that train-mode BatchNorm cancels anyway: MaskPre's conv1 applied to the P2 map before the
+ * 56 x 56 extraction (conv1 is 1x1, RoIAlign linear: conv1(RoIAlign(x)) = RoIAlign(W1 x) + b1), base_roi_head.py:13-16. */
 int dm_bn_stats(const float* x, int NB, int C, int HW, float* mean, float* var, float* running_mean,
-                float* running_var, float momentum, float* scratch, dm_stream_t stream);
+                float* running_var, float momentum, const float* mean_shift, float* scratch, dm_stream_t stream);
 /* scratch for dm_bn_stats / dm_bn_relu_maxpool_bwd (may be null: one workgroup per channel) */
 long long dm_bn_scratch_floats(int C);
 int dm_bn_relu_maxpool_fwd(const float* x, int NB, int C, int H, int W, const float* mean, const float* var,

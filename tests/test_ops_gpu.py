@@ -82,6 +82,37 @@ def test_roi_align_single_level_56_and_sampling_ratio(ops):
     assert ops.roi_align([_dev(feats[0])], _dev(rois[:0]), 14, [1 / 4]).shape == (0, 16, 14, 14)
 
 
+@pytest.mark.parametrize('P,levels,sr', [(56, 1, 0), (28, 4, 0), (56, 1, 2), (24, 1, 0)])
+def test_roi_align_adjoint_in_gather_form_matches_autograd_of_the_oracle(ops, P, levels, sr):
+    """roi_align_bwd_gather_kernel (16 < P <= 64; round 5: what lets MaskPre's conv1 run on the P2 map in training, its
+    weight gradient taken through the adjoint of the 56 x 56 extraction): one workgroup per (RoI, channel quad), a thread
+    per footprint cell, one float atomic per cell.  Against autograd of the oracle's RoIAlign
+    (single_level_roi_extractor.py:53-81 / mmcv RoIAlign backward): RoIs from 8 to 640 pixels (sampling grids 1 .. 3 at
+    P = 56 on stride 4), boxes over the border (void samples, clamped taps), zero-size and flipped boxes (no gradient), a
+    fixed sampling ratio with samples more than a pixel apart (the kernel's per-tap path), overlapping RoIs."""
+    from dynamask_amd import synth
+    from tolerances import assert_grad_close
+    C = 8
+    feats = [f.requires_grad_(True) for f in synth.make_fpn(2, 160, 224, C, seed=31)[:levels]]
+    rois = synth.make_rois(2, 14, 160, 224, seed=32, max_size=640.0)
+    extra = torch.tensor([[0., -30., -20., 60., 50.], [0., 150., 100., 400., 300.], [1., 50., 50., 50., 50.],
+                          [1., 90., 80., 40., 30.], [1., 0., 0., 223., 159.], [0., 10., 10., 18., 18.]])
+    rois = torch.cat([rois, extra], 0)
+    rois = rois[torch.argsort(rois[:, 0], stable=True)].contiguous()
+    strides = (4, 8, 16, 32)[:levels]
+    if levels == 1:
+        ref = ref_ops.roi_align(feats[0], rois, P, 1 / 4, sampling_ratio=sr)
+    else:
+        ref = ref_ops.single_roi_extractor(feats, rois, P, strides)
+    go = torch.randn(ref.shape, generator=_g(33))
+    ref.backward(go)
+    grads = ops.roi_align_backward(_dev(go), [tuple(f.shape) for f in feats], _dev(rois), P, [1.0 / s_ for s_ in strides],
+                                   sampling_ratio=sr)
+    for lvl, (gr, f) in enumerate(zip(grads, feats)):
+        ref_g = f.grad if f.grad is not None else torch.zeros_like(f)
+        assert_grad_close(gr, ref_g, f'level {lvl}', rel=1e-4, zero=not bool(ref_g.abs().max() > 0))
+
+
 def test_roi_align_backward(ops):
     from dynamask_amd import synth
     feats = [f.requires_grad_(True) for f in synth.make_fpn(2, 160, 224, 8, seed=11)[:4]]

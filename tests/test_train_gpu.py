@@ -403,9 +403,12 @@ def test_deterministic_mode_gives_bit_identical_training_runs(monkeypatch):
             assert torch.equal(a[s][0], x[s][0]), f'{what}: loss of step {s}'
             assert torch.equal(a[s][1], x[s][1]), f'{what}: gradients of step {s}'
         assert torch.equal(pa, px), f'{what}: parameters'
+    # the default mode: float atomics, and (round 5) MaskPre's conv1 on the P2 map with its weight gradient through the
+    # adjoint of the 56 x 56 extraction -- another association of the same products (the deterministic mode keeps the
+    # reference's order): 1e-4 of the gradient's scale, was 2e-5 for the atomics' arrival order alone
     scale = float(a[0][1].abs().max())
-    assert float((a[0][1] - d[0][1]).abs().max()) <= 2e-5 * scale
-    torch.testing.assert_close(pa, pd, atol=2e-6, rtol=1e-4)
+    assert float((a[0][1] - d[0][1]).abs().max()) <= 1e-4 * scale
+    torch.testing.assert_close(pa, pd, atol=1e-5, rtol=1e-4)
 
 
 def test_assigner_ignore_regions_match_reference_golden(golden_dir):
