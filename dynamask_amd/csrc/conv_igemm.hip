@@ -655,6 +655,21 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __
   }
 }
 
+// How many K splits pay for a launch that leaves most of the chip idle (1: none).  A launch of one round walks its chunks
+// one after the other at ~2.1 us (3x3) / ~1.5 us (1x1) per chunk whatever the RoI count (tools/small_n.py: conv14 64-71 us
+// for 32 chunks, fuse14 50 us for 33); S splits save (1 - 1/S) of that and cost a second launch (~5 us) that reads S and
+// writes one copy of the output at ~4 TB/s; at least 8 us of net gain.
+static int conv_split_choice(int chunks, bool k3, int Smax, long long out_floats) {
+  const double chain_us = chunks * (k3 ? 2.1 : 1.5), out_mb = (double)out_floats * 4e-6;
+  double best = 8.0;
+  int S = 1;
+  for (int c = 2; c <= Smax; ++c) {
+    const double g = chain_us * (1.0 - 1.0 / c) - (5.0 + (c + 1) * out_mb * 0.25);
+    if (g > best) { best = g; S = c; }
+  }
+  return S;
+}
+
 template <int KS, int WGM, int WGN, int WM, int WN, int CK, int MAXPOS, int TAIL = 0>
 int launch_conv_mp(ConvArgs& a, hipStream_t st) {
   constexpr int TM = WGM * WM * 32;
@@ -679,15 +694,7 @@ int launch_conv_mp(ConvArgs& a, hipStream_t st) {
     // (1 - 1/S) of that and cost a second launch (~5 us) that reads S and writes one copy of the output at ~4 TB/s.
     // (Without this test the 1x1 convolutions of the 28 x 28 / 56 x 56 stages split too: 17.7 reduce launches of 15.7 us
     // each per 100-detection call, more than the splits saved.)
-    int S = 1;
-    {
-      const double chain_us = chunks * (KS == 3 ? 2.1 : 1.5), out_mb = (double)per * 4e-6;
-      double best = 8.0;                               // at least 8 us of net gain
-      for (int c = 2; c <= Smax; ++c) {
-        const double g = chain_us * (1.0 - 1.0 / c) - (5.0 + (c + 1) * out_mb * 0.25);
-        if (g > best) { best = g; S = c; }
-      }
-    }
+    const int S = conv_split_choice(chunks, KS == 3, Smax, per);
     if (S >= 2) {
       a.kchunks = dm_ceil_div(chunks, S);
       a.ksplit = dm_ceil_div(chunks, a.kchunks);
@@ -898,9 +905,14 @@ static int conv2d_launch(const float* const* srcs, const int* src_channels, cons
         // (100 RoIs of 14 x 14: 306 tiles x 2 splits on 768 slots; the 128 x 32 tiles without a split: 0.233 ms)
         if (a.ws && wgs < slots) {
           const long long per = (long long)NB * Cout * H * W;
-          const int S = (int)min((long long)min(8, slots / wgs), per > 0 ? a.ws_floats / per : 0LL);
-          if (S >= 2) {
-            a.want_split = S;
+          // (the split is DECIDED here, with launch_conv_mp's own cost model, before the tile build is chosen --
+          // a launch the model then declined to split used to run the 128 x 128 tiles unsplit instead of the 128 x 32 ones)
+          int chunks = 0;
+          for (int s_ = 0; s_ < num_srcs; ++s_) chunks += dm_ceil_div(src_channels[s_], 8);
+          int Smax = (int)min((long long)min(8, slots / wgs), per > 0 ? a.ws_floats / per : 0LL);
+          Smax = min(Smax, chunks / 4);
+          if (conv_split_choice(chunks, true, Smax, per) >= 2) {
+            a.want_split = Smax;
             return launch_conv<3, 2, 2, 2, 2, 8>(a, st);
           }
         }

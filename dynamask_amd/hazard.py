@@ -300,6 +300,7 @@ def touch(name, reads=(), writes=(), stream=None):
     table of dm_conv_pack_weight_batch).  ``stream``: a torch stream (default: the current one)."""
     if not ENABLED[0] or _capturing():
         return
+    install()
     s = _stream_id() if stream is None else int(stream.cuda_stream)
     TRACKER.launch(s, name, [_entry(t, f'r{i}') for i, t in enumerate(reads) if t is not None and t.is_cuda],
                    [_entry(t, f'w{i}') for i, t in enumerate(writes) if t is not None and t.is_cuda])
@@ -426,3 +427,10 @@ def reset():
     TRACKER.reset()
     _PENDING.clear()
     _PENDING_ARRAYS.clear()
+
+
+if ENABLED[0]:          # DM_HAZARD set in the environment: see every wait from the first one on
+    try:
+        install()
+    except Exception:      # noqa: BLE001  (torch without CUDA bindings: nothing to patch)
+        pass

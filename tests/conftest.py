@@ -31,3 +31,18 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope='session')
 def golden_dir():
     return os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_runtest_teardown(item, nextitem):
+    """DM_HAZARD=1 python -m pytest -m gpu: every test runs under the stream-hazard tracker (dynamask_amd/hazard.py); a
+    report raised by a test's launches fails THAT test (the planted-hazard test of test_hazard_gpu.py resets the tracker
+    itself)."""
+    import os
+    if os.environ.get('DM_HAZARD', '0') in ('', '0'):
+        return
+    from dynamask_amd import hazard
+    reports = hazard.reports()
+    hazard.reset()
+    if reports:
+        import pytest
+        pytest.fail('stream hazards reported during this test:\n' + '\n'.join(reports), pytrace=False)
