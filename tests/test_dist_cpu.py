@@ -179,12 +179,14 @@ TOP_LEVEL_TRAIN_KEYS = ('train_ms_per_step', 'train_img_per_s', 'train_imgs_per_
 
 def test_two_rank_rehearsal_line_carries_the_training_step_at_top_level():
     """the driver's SCALE record keeps only the top-level keys of the line, so the training-step
-    figures (the unit of the north star's scaling curve) must be there at every N.  profiles/r04_bench_rehearsal_gpus2.json
-    is the line `DM_BENCH_REHEARSAL=1 python bench.py --gpus 2` printed on the one-GPU box this round
+    figures (the unit of the north star's scaling curve) must be there at every N.  profiles/rNN_bench_rehearsal_gpus2.json
+    (the latest round's) is the line `DM_BENCH_REHEARSAL=1 python bench.py --gpus 2` printed on the one-GPU box
     (tools/collect_profiles.sh); bench.py's source must name the same keys."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(root, 'profiles', 'r04_bench_rehearsal_gpus2.json')) as f:
+    import glob
+    latest = sorted(glob.glob(os.path.join(root, 'profiles', 'r[0-9][0-9]_bench_rehearsal_gpus2.json')))[-1]
+    with open(latest) as f:
         line = [l for l in f.read().splitlines() if l.startswith('{')]
     assert len(line) == 1
     out = json.loads(line[0])
