@@ -872,22 +872,28 @@ __global__ __launch_bounds__(256) void dcn_splitk_reduce_kernel(const float* __r
 // walks its chunks of 8 channels one after the other at ~3.5 us each whatever the RoI count (tools/small_n.py: dcn14 105-115 us
 // for 32 chunks at 8-16 RoIs); S splits save (1 - 1/S) of that and cost a second launch that reads S and writes one copy of
 // the output.  Sets a.ksplit / kchan / ws_stride; a.ksplit stays 1 when it does not pay.
-static void dcn_choose_split(DcnArgs& a, long long wgs, long long slots, long long ws_floats) {
+static void dcn_choose_split(DcnArgs& a, long long wgs, long long slots, long long ws_floats, bool lds_tiles = false) {
   a.ksplit = 1;
-  // (only calls of a handful of RoIs: from ~32 on the workgroups are bound by what they share -- every one streams its
-  // cout tile's weights from L2 -- and more of them gain nothing: the full head at 32 / 64 / 100 RoIs measured 1-2 % slower
-  // with the split, 13 % / 3 % faster at 8 / 16)
-  if (!a.ws || a.q_begin != 0 || wgs <= 0 || a.NB > 24) return;
+  if (!a.ws || a.q_begin != 0 || wgs <= 0) return;
   const int chunks = a.C / 8;
   const long long per = (long long)a.NB * a.Cout * a.HW;
-  long long Smax = min(min(8LL, slots / wgs), (long long)chunks / 2);
-  if (per > 0) Smax = min(Smax, ws_floats / per);
-  const double chain_us = chunks * 3.5, out_mb = (double)per * 4e-6;
-  double best = 8.0;
   int S = 1;
-  for (int c = 2; c <= Smax; ++c) {
-    const double g = chain_us * (1.0 - 1.0 / c) - (5.0 + (c + 1) * out_mb * 0.25);
-    if (g > best) { best = g; S = c; }
+  if (a.NB <= 24) {
+    // a handful of RoIs: the cost model (13 % / 3 % on the full head at 8 / 16 RoIs)
+    long long Smax = min(min(8LL, slots / wgs), (long long)chunks / 2);
+    if (per > 0) Smax = min(Smax, ws_floats / per);
+    const double chain_us = chunks * 3.5, out_mb = (double)per * 4e-6;
+    double best = 8.0;
+    for (int c = 2; c <= Smax; ++c) {
+      const double g = chain_us * (1.0 - 1.0 / c) - (5.0 + (c + 1) * out_mb * 0.25);
+      if (g > best) { best = g; S = c; }
+    }
+  } else if (lds_tiles && wgs < slots && chunks >= 12 && per > 0 && ws_floats / per >= 3) {
+    // 25 .. 128 RoIs of 14 x 14 on the 128 x 128 LDS kernel (round 5, tools/small_n.py with forced splits): the launch is
+    // less than one round of workgroups, each walking 32 chunks alone on its CU -- three splits: 32 / 50 / 64 / 100 RoIs
+    // 0.179 / 0.198 / 0.200 / 0.332 -> 0.157 / 0.138 / 0.197 / 0.248 ms (two: 0.177 / 0.181 / 0.183 / 0.279).  The band
+    // kernels of the 28 x 28 / 56 x 56 stages gain <= 8 % or lose (56 x 56: 0.283 -> 0.346 at 100 RoIs): not split.
+    S = 3;
   }
   if (S >= 2) {
     const int per_split = dm_ceil_div(chunks, S);
@@ -953,7 +959,7 @@ extern "C" int dm_deform_conv_fwd(const float* x, const float* offset, int NB, i
 extern "C" long long dm_deform_conv_splitk_floats(int NB, int C, int H, int W, int Cout) {
   if (NB <= 0 || C < 32 || H <= 0 || W <= 0 || Cout <= 0) return 0;
   const long long wgs = (long long)dm_ceil_div(Cout, 128) * dm_ceil_div((long long)NB * H * W, 128);
-  if (wgs * 2 > 2LL * dm_num_cus()) return 0;
+  if (wgs * 2 > 2LL * dm_num_cus() && !(H * W <= 256 && wgs < 2LL * dm_num_cus())) return 0;      // (14 x 14: up to one round)
   return 8LL * NB * Cout * H * W;
 }
 
@@ -1038,7 +1044,7 @@ static int deform_conv_fwd_impl(const float* x, const float* offset, int NB, int
       a.Q = Q;
       return launch_dcn<2, 2, 1, 1>(a, st);
     }
-    dcn_choose_split(a, (long long)a.MT * NTiles, slots, a.ws_floats);
+    dcn_choose_split(a, (long long)a.MT * NTiles, slots, a.ws_floats, true);
     DM_LAUNCH(deform_conv_lds_kernel, dim3(a.MT * NTiles, a.ksplit), dim3(256), lds_bytes, st, a);
     return dcn_finish_split(a, a.relu, a.out, st);
   }
