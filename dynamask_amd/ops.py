@@ -88,7 +88,7 @@ def _float_array(vals):
 # 14x14 / 7x7 extractions of 192 RoIs or more go through dm_roi_align_fwd_ws with a scratch buffer (DM_ROI_WORKSPACE=0: never):
 # the library orders the RoIs by level and position on the device first (DM_ROI_SORT, default on: 57 -> 50.7 us for 512 RoIs,
 # the same bits)
-ROI_WORKSPACE = os.environ.get('DM_ROI_WORKSPACE', '1') == '1'
+ROI_WORKSPACE = True          # (tests compare with the unordered kernel by clearing it)
 ROI_WORKSPACE_MIN = int(os.environ.get('DM_ROI_SORT_MIN', '192'))
 
 
@@ -838,8 +838,8 @@ def channel_sum(g, out=None):
     return out
 
 
-CLB_SLAB = [os.environ.get('DM_CLB_SLAB', '1') != '0']      # class-logit parameter gradients without contended atomics (A/B: DM_CLB_SLAB=0)
-WGRAD_SLAB = [os.environ.get('DM_WGRAD_SLAB', '1') not in ('', '0')]      # weight gradients by slab reduce (no atomics); 0: float atomics
+CLB_SLAB = [True]      # class-logit parameter gradients without contended atomics (False: per-RoI float atomics)
+WGRAD_SLAB = [True]    # weight gradients by slab reduce (no atomics); False: float atomics
 _WGRAD_SCRATCH = [0]
 
 

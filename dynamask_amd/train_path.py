@@ -20,9 +20,9 @@ from . import hazard, ops
 
 # maps of at least this many pixels keep the DCN column matrix from the forward for the weight gradient (56 x 56 and, since the
 # leaf work was dealt over three side streams, 28 x 28: 20.09 -> 20.00 ms per step over three runs each; all three: 20.2)
-_KEEP_COL_MIN_PIXELS = int(os.environ.get('DM_TRAIN_KEEP_COL_MIN_PIXELS', '784'))
+_KEEP_COL_MIN_PIXELS = 784
 # the training forward splits the RoIs in two halves on two streams from this many RoIs on
-_FWD_SPLIT_MIN_ROIS = int(os.environ.get('DM_TRAIN_FWD_SPLIT_MIN_ROIS', '128'))
+_FWD_SPLIT_MIN_ROIS = 128
 _SIDE_STREAMS = {'leaf': 0, 'selector': 1, 'bbox': 1, 'coord': 2}      # slots of the shared pool (streams.py)
 
 
@@ -75,7 +75,8 @@ class _SideWork:
         pool: the DCN weight gradient and the 1x1 output convolution's, issued before the coordinate gradient, go to the
         selector / bbox stream, which is idle in the middle of the backward, and so does the offset convolution's
         (20.8 -> 20.45 -> 20.15 -> 20.05 ms per step; the fuse convolution's weight gradients there as well: 20.6, on the
-        coordinate-gradient stream: no change; the semantic branch on the selector stream: 20.6).  ``DM_LEAF_ALT=0`` puts everything back on the leaf stream."""
+        coordinate-gradient stream: no change; the semantic branch on the selector stream: 20.6; everything on the one leaf
+        stream: 20.9; re-measured in round 5 with MaskPre on the map, profiles/r05_train_experiments.txt: the same ranking)."""
         self.side = side_stream(dev)
         self.enabled = self.side is not None
         self.keep = []
@@ -84,7 +85,7 @@ class _SideWork:
         if self.enabled:
             self.main = torch.cuda.current_stream(dev)
             self.enabled = self.side != self.main
-            if self.enabled and alt is not None and os.environ.get('DM_LEAF_ALT', '1') != '0':
+            if self.enabled and alt is not None:
                 self.alt = side_stream(dev, alt)
                 if self.alt is None or self.alt == self.main or self.alt == self.side:
                     self.alt = None

@@ -6,7 +6,8 @@
             chain's stages, so that the relative timing of the four streams changes from pass to pass: a result that
             depends on timing shows up as a differing tensor.
 --hazard  : the first two passes run under the stream-hazard tracker (dynamask_amd/hazard.py) and its reports are printed.
-Environment: DM_MFMA_SPLIT=3|6 selects the bf16-split modes (while they exist), DM_LEAF_ALT=0 etc. as in train_path.py.
+(Round 5 used it with the bf16-split modes that have since been removed: their timing showed the dropped product of
+profiles/r05_race_hunt.txt in 39 of 39 passes.)
 """
 import argparse
 import os
@@ -114,8 +115,8 @@ for rep in range(1, args.reps):
                 print(f'   pass {rep}: {names.get(id(p))} {tuple(p.shape)}: {nz.shape[0]} elements differ; rows {sorted(set(nz[:, 0].tolist()))[:20]} '
                       f'cols {sorted(set(nz[:, 1].tolist()))[:40]}; labels count of those rows {[int((labels == r).sum()) for r in sorted(set(nz[:, 0].tolist()))[:20]]}')
         off += k
-print(f'mode: split={ops.MFMA_SPLIT if hasattr(ops, "MFMA_SPLIT") else 0} deterministic={ops.DETERMINISTIC[0]} '
-      f'side_streams={os.environ.get("DM_TRAIN_SIDE_STREAM", "1")} leaf_alt={os.environ.get("DM_LEAF_ALT", "1")} perturb={args.perturb}')
+print(f'mode: deterministic={ops.DETERMINISTIC[0]} '
+      f'side_streams={os.environ.get("DM_TRAIN_SIDE_STREAM", "1")} perturb={args.perturb}')
 print(f'{n_diff} of {args.reps - 1} repeated passes differ from the first; {len(distinct)} distinct results, sequence {"".join(chr(65 + min(k, 25)) for k in seq)}')
 for n, (c, d) in sorted(differ.items()):
     print(f'  {n}: differs in {c} passes, max |diff| {d:.3e}')
