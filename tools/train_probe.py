@@ -72,3 +72,30 @@ if os.environ.get('TP_WINDOWS'):
         a1 = stats()
         print(f'window {w}: {(t1 - t0) / 4 * 1e3:6.2f} ms/step (host issue {(th - t0) / 4 * 1e3:6.2f})  device allocs +{a1[0] - a0[0]} frees +{a1[1] - a0[1]}  '
               f'reserved {a1[2]:.2f} GiB peak active {a1[3]:.2f} GiB  gc {g0}', flush=True)
+
+# A/B of a Python-level switch inside one process: TP_AB=ops.WGRAD_CAT alternates windows of 8 steps with the flag
+# (a one-element list in dynamask_amd.<module>) True and False, and prints the median of each side
+if os.environ.get('TP_AB'):
+    import importlib, statistics
+    modname, attr = os.environ['TP_AB'].rsplit('.', 1)
+    flag = getattr(importlib.import_module('dynamask_amd.' + modname), attr)
+    def window(k=8):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            grp.zero_grad()
+            res = head._mask_forward_train(feats, rois, labels, targets, noise=noise)
+            res['loss_mask']['loss_masks'].backward()
+            grp.all_reduce_async()
+            grp.sgd_step(lr=0.02, momentum=0.9, weight_decay=1e-4)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / k * 1e3
+    sides = {True: [], False: []}
+    for r in range(int(os.environ.get('TP_AB_ROUNDS', 6))):
+        for v in (True, False):
+            flag[0] = v
+            window(2)
+            sides[v].append(window())
+    for v in (True, False):
+        print(f'{os.environ["TP_AB"]}={v}: median {statistics.median(sides[v]):.3f} ms/step  ({" ".join(f"{x:.2f}" for x in sides[v])})', flush=True)
+    flag[0] = True
