@@ -324,43 +324,70 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 }
 
 // dw[co][coloff + j] += sum over the slabs (and db[co] += sum over the splits' bias rows), in a fixed order: a workgroup
-// owns 256 / P consecutive outputs, partition p of P adds the slabs p, p + P, p + 2P ... in that order (independent loads,
-// unrolled), and the partitions' sums are added in order p = 0 .. P-1.  (One thread per output walking up to 2048 slabs
-// one after the other took 0.4 ms for a 64 x 64 tile.)
+// owns 256 / P consecutive QUADS of outputs (four neighbouring columns of a row: one 16-byte load per slab; ld and the
+// slab stride are multiples of 4 floats), partition p of P adds the slabs p, p + P, p + 2P ... in that order (independent
+// loads, unrolled), and the partitions' sums are added in order p = 0 .. P-1.  (One thread per output walking up to 2048
+// slabs one after the other took 0.4 ms for a 64 x 64 tile; one thread per output and dword loads -- rounds 4 / 5 --
+// 49 us on average for the 33 MB of slabs a launch leaves, 0.7 TB/s out of the Infinity Cache.)
 template <int P>
 __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __restrict__ slab, int slabs, long long stride, int ld,
                                                                 int Cout, int Jtot, float* __restrict__ dw, int ldw, int coloff,
                                                                 const float* __restrict__ slab_db, int splits, int rows,
                                                                 float* __restrict__ db) {
   constexpr int OUT = 256 / P;
-  __shared__ float part[P][OUT];
+  __shared__ float4 part[P][OUT];                        // 4 KB: also the bias workgroups' [8][32] floats
   const int o = threadIdx.x % OUT, pidx = threadIdx.x / OUT;
-  const long long total = (long long)Cout * Jtot;
+  const int Q4 = (Jtot + 3) >> 2;                       // quads per row
+  const long long total = (long long)Cout * Q4;
   const long long nblk = (total + OUT - 1) / OUT;
   if ((long long)blockIdx.x < nblk) {
     const long long idx = (long long)blockIdx.x * OUT + o;
-    float sacc = 0.f;
+    float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
     int co = 0, j = 0;
     if (idx < total) {
-      co = (int)(idx / Jtot); j = (int)(idx - (long long)co * Jtot);
+      co = (int)(idx / Q4); j = 4 * (int)(idx - (long long)co * Q4);
       const float* p = slab + (size_t)co * ld + j;
 #pragma unroll 8
-      for (int k = pidx; k < slabs; k += P) sacc += p[(size_t)k * stride];
+      for (int k = pidx; k < slabs; k += P) {
+        const float4 v = *reinterpret_cast<const float4*>(p + (size_t)k * stride);
+        sacc.x += v.x; sacc.y += v.y; sacc.z += v.z; sacc.w += v.w;
+      }
     }
     if (P > 1) {
       part[pidx][o] = sacc;
       __syncthreads();
       if (pidx == 0) {
 #pragma unroll
-        for (int q = 1; q < P; ++q) sacc += part[q][o];
+        for (int q = 1; q < P; ++q) {
+          const float4 v = part[q][o];
+          sacc.x += v.x; sacc.y += v.y; sacc.z += v.z; sacc.w += v.w;
+        }
       }
     }
-    if (pidx == 0 && idx < total) dw[(size_t)co * ldw + coloff + j] += sacc;
+    if (pidx == 0 && idx < total) {
+      float* d = dw + (size_t)co * ldw + coloff + j;
+      d[0] += sacc.x;
+      if (j + 1 < Jtot) d[1] += sacc.y;
+      if (j + 2 < Jtot) d[2] += sacc.z;
+      if (j + 3 < Jtot) d[3] += sacc.w;
+    }
   } else if (db) {
-    // the last workgroup: bias rows
-    for (int c = threadIdx.x; c < Cout; c += blockDim.x) {
-      float sacc = slab_db[c];
-      for (int k = 1; k < splits; ++k) sacc += slab_db[(size_t)k * rows + c];
+    // the workgroups behind the outputs: bias rows, 32 channels each, the splits dealt over 8 partitions (k = q, q + 8 ...)
+    // whose sums are added in order q = 0 .. 7.  (Round 4 / early round 5: ONE workgroup, a thread per channel walking
+    // the splits one dependent load after the other -- 105-120 us for 170 splits, the whole cost of the reduce launches
+    // that carried a bias: 0.75 ms of the training step's 20.7 ms of kernel time.)
+    float* pb = reinterpret_cast<float*>(part);                 // [8][32]
+    const int c = ((int)(blockIdx.x - nblk)) * 32 + (threadIdx.x & 31), q = threadIdx.x >> 5;
+    float sacc = 0.f;
+    if (c < Cout) {
+#pragma unroll 8
+      for (int k = q; k < splits; k += 8) sacc += slab_db[(size_t)k * rows + c];
+    }
+    pb[q * 32 + (threadIdx.x & 31)] = sacc;
+    __syncthreads();
+    if (q == 0 && c < Cout) {
+#pragma unroll
+      for (int r = 1; r < 8; ++r) sacc += pb[r * 32 + threadIdx.x];
       db[c] += sacc;
     }
   }
@@ -565,9 +592,9 @@ static int wgrad_target_wgs() {
 }
 
 static void launch_slab_reduce(const WgradArgs& a, int slabs, int splits, int Jtot, hipStream_t st) {
-  const long long total = (long long)a.Cout * Jtot;
-  const int P = slabs <= 8 ? 1 : (slabs <= 64 ? 4 : 16);
-  const long long nblk = (total + 256 / P - 1) / (256 / P) + (a.db ? 1 : 0);       // + one workgroup for the bias rows
+  const long long total = (long long)a.Cout * ((Jtot + 3) / 4);                      // quads of outputs
+  const int P = slabs <= 8 ? 1 : (slabs <= 64 ? 4 : (slabs <= 256 ? 16 : 64));      // 680 slabs of a 64 x 64 tile: 64 partitions
+  const long long nblk = (total + 256 / P - 1) / (256 / P) + (a.db ? (a.Cout + 31) / 32 : 0);       // + the bias rows' workgroups
   const float* sdb = a.db ? a.slab_db : nullptr;
   if (P == 1)
     DM_LAUNCH((wgrad_slab_reduce_kernel<1>), dim3((unsigned)nblk), dim3(256), 0, st, a.slab, slabs, a.slab_stride, a.slab_ld, a.Cout, Jtot,
@@ -575,8 +602,11 @@ static void launch_slab_reduce(const WgradArgs& a, int slabs, int splits, int Jt
   else if (P == 4)
     DM_LAUNCH((wgrad_slab_reduce_kernel<4>), dim3((unsigned)nblk), dim3(256), 0, st, a.slab, slabs, a.slab_stride, a.slab_ld, a.Cout, Jtot,
               a.dw, a.ldw, a.coloff, sdb, splits, a.slab_rows, a.db);
-  else
+  else if (P == 16)
     DM_LAUNCH((wgrad_slab_reduce_kernel<16>), dim3((unsigned)nblk), dim3(256), 0, st, a.slab, slabs, a.slab_stride, a.slab_ld, a.Cout, Jtot,
+              a.dw, a.ldw, a.coloff, sdb, splits, a.slab_rows, a.db);
+  else
+    DM_LAUNCH((wgrad_slab_reduce_kernel<64>), dim3((unsigned)nblk), dim3(256), 0, st, a.slab, slabs, a.slab_stride, a.slab_ld, a.Cout, Jtot,
               a.dw, a.ldw, a.coloff, sdb, splits, a.slab_rows, a.db);
 }
 
