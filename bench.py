@@ -127,11 +127,13 @@ def time_kernel_single_in_graph(fn, iters=15):
         return None
 
 
-def time_kernel_cold(fn, iters=9, evict_mib=512):
+def time_kernel_cold(fn, iters=9, evict_mib=512, dirty=True):
     """Duration (ms) of ONE `fn` launch from COLD caches: before every timed launch a read-modify-write sweep over
     `evict_mib` MiB of another buffer pushes the feature maps and the previous output out of the 256 MiB Infinity Cache and
     the L2s; the events bracket only the launch (a one-launch HIP graph, enqueued while the sweep is still running, so no
-    host latency sits between the events).  Median of `iters`."""
+    host latency sits between the events).  Median of `iters`.  ``dirty=False``: the sweep only READS its buffer (a sum), so
+    the lines the timed launch displaces are clean -- with the read-modify-write sweep every line the launch allocates in
+    the Infinity Cache first sends a modified line of the sweep back to HBM, traffic that is the evictor's, not the launch's."""
     try:
         fn()
         torch.cuda.synchronize()
@@ -141,7 +143,10 @@ def time_kernel_cold(fn, iters=9, evict_mib=512):
         sweep = torch.zeros(evict_mib * (1 << 20) // 4, device='cuda', dtype=torch.float32)
         ts = []
         for i in range(iters + 2):
-            sweep.add_(1.0)
+            if dirty:
+                sweep.add_(1.0)
+            else:
+                sink = sweep.sum()      # noqa: F841
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             g.replay()
@@ -589,6 +594,7 @@ def main():
         ms_r = time_kernel_graphed(lambda: ext(feats[:4], rois))
         ms_r1 = time_kernel_single_in_graph(lambda: ext(feats[:4], rois))
         ms_rc = time_kernel_cold(lambda: ext(feats[:4], rois))
+        ms_rcc = time_kernel_cold(lambda: ext(feats[:4], rois), dirty=False)
         _, lv = ops.roi_align(feats[:4], rois, 14, [1 / 4, 1 / 8, 1 / 16, 1 / 32], return_levels=True)
         nbytes = roialign_algorithmic_bytes(rois_c, lv.cpu().long(), [tuple(f.shape[2:]) for f in feats_c[:4]])
         # `frac` is the HBM figure: the call from COLD caches (194 MB of maps + output fit the 256 MiB Infinity
@@ -598,12 +604,15 @@ def main():
         ach_w = nbytes / (ms_r * 1e-3) / 1e9
         result['roofline_roialign'] = {'kernel': 'roi_order_kernel + roi_align_tile_kernel (one dm_roi_align_fwd_ws call: RoIs ranked by level and position on the device, then LDS-staged channel-quad tiles, merged stencils; P2..P5 -> [512,256,14,14]); '
                                                  'ms_per_launch / achieved / frac = ONE call from cold caches (a 512 MiB read-modify-write sweep of another buffer before every '
-                                                 'timed call, events around a one-call HIP graph, median of 9); ms_per_launch_warm / frac_warm = 20 calls replayed back to back '
+                                                 'timed call, events around a one-call HIP graph, median of 9); ms_per_launch_cold_clean / frac_cold_clean = the same with a sweep that only '
+                                                 'READS its 512 MiB (the lines the call displaces are clean: no write-back of the evictor\'s data inside the timed region); ms_per_launch_warm / frac_warm = 20 calls replayed back to back '
                                                  'as one HIP graph / 20 (maps + output stay in the Infinity Cache), median of 7 replays; ms_per_launch_single = replay of a '
                                                  'graph of two calls minus a graph of one (medians of 15): one warm call with one predecessor',
                                        'bound': 'hbm', 'achieved': ach_r, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                        'frac': ach_r / PEAK_HBM_GBS, 'traffic': None, 'ms_per_launch': ms_hbm,
                                        'cache_state': 'cold' if ms_rc else 'warm (cold timing unavailable)',
+                                       'ms_per_launch_cold_clean': ms_rcc,
+                                       'frac_cold_clean': (nbytes / (ms_rcc * 1e-3) / 1e9 / PEAK_HBM_GBS) if ms_rcc else None,
                                        'ms_per_launch_warm': ms_r, 'achieved_warm': ach_w, 'frac_warm': ach_w / PEAK_HBM_GBS,
                                        'ms_per_launch_single': ms_r1,
                                        'frac_single': (nbytes / (ms_r1 * 1e-3) / 1e9 / PEAK_HBM_GBS) if ms_r1 else None,
