@@ -861,6 +861,25 @@ __global__ __launch_bounds__(256, 2) void deform_conv_band_kernel(DcnArgs a, int
 // out = relu?(sum over the splits, in index order) of a split-K launch (ws: [splits][NB * Cout * HW])
 __global__ __launch_bounds__(256) void dcn_splitk_reduce_kernel(const float* __restrict__ ws, int splits, long long stride,
                                                                long long total, int relu, float* __restrict__ out) {
+  // (total, stride: multiples of 4 floats, ws / out 16-byte aligned -- checked by dcn_finish_split, which otherwise passes v4 = 0
+  // through the sign of ``splits``)
+  const bool v4 = splits > 0;
+  splits = v4 ? splits : -splits;
+  if (v4) {
+    const float4* ws4 = reinterpret_cast<const float4*>(ws);
+    float4* out4 = reinterpret_cast<float4*>(out);
+    const long long total4 = total >> 2, stride4 = stride >> 2;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (long long)gridDim.x * blockDim.x) {
+      float4 v = ws4[e];
+      for (int s_ = 1; s_ < splits; ++s_) {
+        const float4 w = ws4[(size_t)s_ * stride4 + e];
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+      }
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      out4[e] = v;
+    }
+    return;
+  }
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     float v = ws[e];
     for (int s_ = 1; s_ < splits; ++s_) v += ws[(size_t)s_ * stride + e];
@@ -908,8 +927,9 @@ static int dcn_finish_split(const DcnArgs& a, int relu, float* out, hipStream_t 
   int rc = dm_check_launch();
   if (rc != DM_OK) return rc;
   const long long total = a.ws_stride;
-  DM_LAUNCH(dcn_splitk_reduce_kernel, dim3((unsigned)min((long long)4096, (total + 255) / 256)), dim3(256), 0, st, a.ws, a.ksplit,
-            a.ws_stride, total, relu, out);
+  const bool v4 = (total & 3) == 0 && ((((uintptr_t)a.ws) | ((uintptr_t)out)) & 15) == 0;
+  DM_LAUNCH(dcn_splitk_reduce_kernel, dim3((unsigned)min((long long)4096, ((v4 ? total / 4 : total) + 255) / 256)), dim3(256), 0, st, a.ws,
+            v4 ? a.ksplit : -a.ksplit, a.ws_stride, total, relu, out);
   return dm_check_launch();
 }
 
