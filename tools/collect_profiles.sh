@@ -56,4 +56,6 @@ python3 tools/dcn_offsets_exp.py > $out/${tag}_dcn_offsets_exp.txt 2>&1
 python3 tools/small_n.py > $out/${tag}_small_n.txt 2>&1
 python3 tools/col2im_exp.py > $out/${tag}_col2im_exp.txt 2>&1
 python3 tools/op_probe.py wgradcat wgrad > $out/${tag}_wgrad_probe.txt 2>&1
+ROI_REPS=3 python3 tools/roi_cold.py > $out/${tag}_roi_cold.txt 2>&1
+python3 tools/infer_streams_exp.py > $out/${tag}_infer_streams_exp.txt 2>&1
 echo "all done"
