@@ -628,10 +628,15 @@ __device__ __forceinline__ void roi_tile_fwd(const RoiArgs& a, const float* __re
           }
           if (DM_ABL(a, 4) && acc.x != 12345.678f) continue;      // (keeps the value live without the store)
           char* const oq = ob + (size_t)(4 * q) * PB;
-          *reinterpret_cast<float*>(oq + ot) = acc.x;
-          *reinterpret_cast<float*>(oq + PB + ot) = acc.y;
-          *reinterpret_cast<float*>(oq + 2 * PB + ot) = acc.z;
-          *reinterpret_cast<float*>(oq + 3 * PB + ot) = acc.w;
+          // (round 5) streaming stores: the output is not re-read by this kernel, and without the hint every line it writes
+          // takes a place in the Infinity Cache from which a modified line has to be written back first when the caches are
+          // cold and full of another kernel's data -- 86 -> 81 us from cold caches, cache-warm and the headline step unchanged
+          // (round 4 had tried them cache-warm only: no difference there).  The same hint on the LOADS costs 30 us: the maps
+          // are shared by neighbouring workgroups through the caches.
+          __builtin_nontemporal_store(acc.x, reinterpret_cast<float*>(oq + ot));
+          __builtin_nontemporal_store(acc.y, reinterpret_cast<float*>(oq + PB + ot));
+          __builtin_nontemporal_store(acc.z, reinterpret_cast<float*>(oq + 2 * PB + ot));
+          __builtin_nontemporal_store(acc.w, reinterpret_cast<float*>(oq + 3 * PB + ot));
         }
       }
     }
