@@ -641,7 +641,7 @@ static int launch_wgrad3_narrow(const WgradArgs& g, hipStream_t st) {
   a.units_per_split = dm_ceil_div(a.units, nsplit);
   const int splits = dm_ceil_div(a.units, a.units_per_split);
   WgradArgs red = g;
-  if (g.scratch && !g.fx) {
+  if (g.scratch && !g.fx && (((uintptr_t)g.scratch) & 15) == 0) {      // (the reduce reads the slabs by 16-byte loads)
     const int ld = a.groups * 32 * 9;
     const long long stride = (long long)g.Cout * ld, need = (long long)splits * stride + (long long)splits * MR;
     if (need <= g.scratch_floats) {
@@ -685,7 +685,7 @@ void launch_wgrad(WgradArgs a, hipStream_t st) {
   a.nsplit = dm_ceil_div(chunks, a.chunks_per_split);
   const dim3 grid((unsigned)(a.MT * a.JT * a.nsplit));
   const int WGK = (TM == 128 && TN == 128) ? 1 : (TM == 128) ? 2 : (TN == 256) ? 1 : (TN == 128) ? 2 : 4;
-  if (a.scratch && !a.fx) {
+  if (a.scratch && !a.fx && (((uintptr_t)a.scratch) & 15) == 0) {      // (the reduce reads the slabs by 16-byte loads)
     const int rows = a.MT * TM, ld = a.JT * TN;
     const long long stride = (long long)rows * ld, need = (long long)a.nsplit * WGK * stride + (long long)a.nsplit * rows;
     if (need <= a.scratch_floats) {

@@ -473,8 +473,8 @@ int dm_conv2d_wgrad(const float* dy, long long dy_batch_stride, int Cout, const 
 /* The same sums without atomics: every split of the pixel axis writes its partial tile to a slab of `scratch`, a second
  * kernel adds the slabs in index order into dw (and the splits' bias rows into db) -- bit-identical from run to run, as the
  * reference's weight gradient is (a deterministic addmm_, mmdet/ops/dcn/src/deform_conv_cuda.cpp:460-465).  scratch: at
- * least dm_conv2d_wgrad_scratch_floats() floats for ANY shape (a launch that would need more falls back to the atomics of
- * dm_conv2d_wgrad); contents undefined afterwards; not shared between streams.  dw / db are accumulated into, as above. */
+ * least dm_conv2d_wgrad_scratch_floats() floats for ANY shape, 16-byte aligned (a launch that would need more, or a scratch
+ * that is not aligned, falls back to the atomics of dm_conv2d_wgrad); contents undefined afterwards; not shared between streams.  dw / db are accumulated into, as above. */
 long long dm_conv2d_wgrad_scratch_floats(void);
 int dm_conv2d_wgrad_slab(const float* dy, long long dy_batch_stride, int Cout, const float* x, long long x_batch_stride,
                          int Cs, int NB, int H, int W, int ksize, float* dw, int ldw, int col_offset, float* db,
