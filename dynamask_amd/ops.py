@@ -714,7 +714,7 @@ def mask_loss(inst_pred, det_pred, inst_tgt, det_tgt, weight, need_grad=True):
     per_roi = torch.zeros((N,), device=inst_pred.device, dtype=torch.float32)
     gi = torch.empty_like(inst_pred) if need_grad else None
     gd = torch.empty_like(det_pred) if need_grad else None
-    scratch = torch.empty((max(16 * N, 1),), device=inst_pred.device, dtype=torch.float32)
+    scratch = torch.empty((max(int(lib().dm_mask_loss_scratch_floats(N)), 1),), device=inst_pred.device, dtype=torch.float32)
     check(lib().dm_mask_loss_fwd_bwd(_p(inst_pred), _p(det_pred), _p(inst_tgt), _p(det_tgt), _p(weight), N, HW,
                                      _p(sums), _p(per_roi), _p(gi), _p(gd), _p(scratch), _stream()), 'dm_mask_loss_fwd_bwd')
     return sums, per_roi, gi, gd
@@ -731,7 +731,7 @@ def mask_loss_stage(inst_pred, det_pred, inst_tgt, det_tgt, mask_labels, stage, 
     HW = inst_pred.numel() // max(N, 1)
     gi = torch.empty_like(inst_pred) if want_inst_grad else None
     gd = torch.empty_like(det_pred)
-    scratch = torch.empty((max(16 * N, 1),), device=inst_pred.device, dtype=torch.float32)
+    scratch = torch.empty((max(int(lib().dm_mask_loss_scratch_floats(N)), 1),), device=inst_pred.device, dtype=torch.float32)
     check(lib().dm_mask_loss_stage(_p(inst_pred), _p(det_pred), _p(inst_tgt), _p(det_tgt), _p(mask_labels), K, int(stage), N,
                                    HW, float(detail_weight), _p(loss_terms), _p(grad_ml), _p(gi), _p(gd), _p(scratch),
                                    _stream()), 'dm_mask_loss_stage')
