@@ -4,7 +4,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DYNAMASK_HIP_LIB') or os.path.join(_HERE, 'libdynamask_hip.so')      # override: kernel experiments
-ABI_VERSION = 23
+ABI_VERSION = 24
+REQUIRED_BUILD_FLAG = '-packed-fp32-ops'        # dynamask_amd/build.py NO_PACKED_FP32; dm_build_info() must carry it
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -14,6 +15,7 @@ _vp = ctypes.c_void_p
 SIGNATURES = {
     'dm_error_string': ([_c_int], ctypes.c_char_p),
     'dm_abi_version': ([], _c_int),
+    'dm_build_info': ([], ctypes.c_char_p),
     'dm_reload_env_knobs': ([], _c_int),
     'dm_roi_align_fwd': ([_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _c_float, _vp, _vp, _vp], _c_int),
     'dm_roi_align_workspace_bytes': ([_c_int, _c_int], ctypes.c_longlong),
@@ -118,6 +120,15 @@ class DynaMaskLibraryError(RuntimeError):
     pass
 
 
+def check_build_info(info):
+    """Refuse a library that does not say it was compiled without packed fp32 (include/dynamask_hip.h dm_build_info)."""
+    if REQUIRED_BUILD_FLAG not in info and os.environ.get('DM_ALLOW_PACKED_FP32') != '1':
+        raise DynaMaskLibraryError(
+            f'{LIB_PATH} was not built with {REQUIRED_BUILD_FLAG!r} (dm_build_info: {info!r}): packed fp32 '
+            'instructions dropped a product under multi-queue load (profiles/r05_race_hunt.txt).  Rebuild with '
+            '`python -m dynamask_amd.build`, or set DM_ALLOW_PACKED_FP32=1 for an A/B measurement')
+
+
 def lib():
     """Load the library once.  Fails loudly: there is no fallback path."""
     global _LIB
@@ -138,6 +149,7 @@ def lib():
             fn.restype = restype
         if L.dm_abi_version() != ABI_VERSION:
             raise DynaMaskLibraryError('libdynamask_hip.so ABI version mismatch: rebuild')
+        check_build_info(L.dm_build_info().decode())
         _LIB = L
     from . import hazard
     if hazard.ENABLED[0]:

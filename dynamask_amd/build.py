@@ -46,7 +46,10 @@ def build_library(force=False, verbose=True, extra_flags=(), lib=LIB, objdir=Non
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s) + '.o')
         if force or not _newer(o, [s] + deps[-3:]):
-            cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', *FLAGS, *extra_flags, '-I' + os.path.join(ROOT, 'include'),
+            # the flag set travels into the library (dm_build_info): _lib.py refuses one that lacks -packed-fp32-ops
+            said = ' '.join([*FLAGS, *extra_flags]) or 'none'
+            cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', *FLAGS, *extra_flags, f'-DDM_BUILD_FLAGS="{said}"',
+                   '-I' + os.path.join(ROOT, 'include'),
                    '-I' + CSRC, '-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd), flush=True)

@@ -11,7 +11,19 @@ extern "C" const char* dm_error_string(int code) {
   }
 }
 
-extern "C" int dm_abi_version(void) { return 23; }
+extern "C" int dm_abi_version(void) { return 24; }
+
+// How this library was compiled: the compiler and the product-wide flag set dynamask_amd/build.py passed (it hands them
+// over as -DDM_BUILD_FLAGS="..."; a recipe that does not say what it used yields "flags=unknown").  The host binding
+// refuses a library whose string lacks "-packed-fp32-ops" (build.py FLAGS: a compiler-generated v_pk_fma_f32 dropped a
+// product beside other queues, profiles/r05_race_hunt.txt), so that a build recipe which silently drops the flag is
+// caught at load time and not by a gradient that is occasionally off by one product.
+#ifndef DM_BUILD_FLAGS
+#define DM_BUILD_FLAGS "unknown"
+#endif
+extern "C" const char* dm_build_info(void) {
+  return "libdynamask_hip abi=24 arch=gfx950 compiler=" __clang_version__ " flags=" DM_BUILD_FLAGS;
+}
 
 // ---------------------------------------------------------------------------
 // Optimiser step on the flat mask-head parameter buffer: SGD with momentum and

@@ -39,11 +39,30 @@ class GraphedMaskLogits:
     def _weights_key(self):
         """(address, version) of every parameter the captured launches read, directly or through a kernel-layout pack:
         an in-place update (optimizer step, load_state_dict, copy_) bumps ``_version`` without touching
-        ops.WEIGHT_EPOCH, and a replay would combine stale packed weights with the new class-logit weights."""
-        ps = self._params
-        if ps is None:          # (the module tree is walked once: the head's parameter OBJECTS do not change, their storage may)
-            ps = self._params = list(self.head.mask_head.parameters())
-        return tuple([p.data_ptr() for p in ps]), sum(p._version for p in ps)
+        ops.WEIGHT_EPOCH, and a replay would combine stale packed weights with the new class-logit weights.
+        The module tree is walked once into slots -- (owner module, parameter name) and (parent, child name, child) --
+        and every call re-reads the CURRENT object of each slot (a dict lookup each, ~15 us for the head against ~110 us
+        for ``parameters()``): a Parameter that was replaced (``load_state_dict(..., assign=True)``, ``m.weight =
+        nn.Parameter(...)``, prune / parametrize re-registration) changes the key through its address, a replaced,
+        added or removed submodule or parameter slot rebuilds the slot lists."""
+        head = self.head.mask_head
+        for _ in range(2):
+            if self._params is None:
+                mods = list(head.modules())
+                self._params = ([(m, n) for m in mods for n, p in m._parameters.items() if p is not None],
+                                [(m, n, c) for m in mods for n, c in m._modules.items()],
+                                [(m, len(m._parameters), len(m._modules)) for m in mods])
+            slots, edges, counts = self._params
+            try:
+                ok = (all(m._modules[n] is c for m, n, c in edges)
+                      and all(len(m._parameters) == a and len(m._modules) == b for m, a, b in counts))
+                ps = [m._parameters[n] for m, n in slots] if ok else None
+            except KeyError:
+                ps = None
+            if ps is not None and not any(p is None for p in ps):
+                return tuple([p.data_ptr() for p in ps]), sum(p._version for p in ps)
+            self._params = None
+        raise RuntimeError('the mask head changed while its graph key was built')
 
     def _key(self, bucket, x):
         return (bucket, tuple(int(t.data_ptr()) for t in x), tuple(tuple(t.shape) for t in x), ops.WEIGHT_EPOCH[0],

@@ -53,8 +53,13 @@ extern "C" {
 typedef void* dm_stream_t; /* hipStream_t */
 
 const char* dm_error_string(int code);
-/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient, dm_conv_pack_weight_batch, dm_mask_loss_stage; 15: dm_class_logits_up2x_fwd; 16: dm_conv2d_wgrad_slab / dm_conv2d_wgrad_scratch_floats; 17: dm_class_logits_bwd_slab / dm_class_logits_bwd_scratch_floats; 18: dm_reload_env_knobs, dm_roi_align_fwd_ws / dm_roi_align_workspace_bytes, dm_conv_pack_weight_split / dm_conv_packed_floats_split and flag bits 4, 5 of dm_conv2d_fwd; 19: dm_dcn_bwd_data_fused and its pack; 20: dm_conv2d_fwd_ws / dm_conv2d_splitk_floats; 21: dm_deform_conv_fwd_ws / dm_deform_conv_splitk_floats; 22: the bf16-split layouts (dm_conv_pack_weight_split, dm_conv_packed_floats_split, flag bits 4 / 5 of dm_conv2d_fwd) and the one-kernel DCN data gradient (dm_dcn_bwd_*) REMOVED -- measured, never the parity path, see docs/HISTORY.md; 23: dm_bn_stats takes mean_shift, dm_roi_align_bwd takes the gather form for 16 < P <= 64). */
+/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient, dm_conv_pack_weight_batch, dm_mask_loss_stage; 15: dm_class_logits_up2x_fwd; 16: dm_conv2d_wgrad_slab / dm_conv2d_wgrad_scratch_floats; 17: dm_class_logits_bwd_slab / dm_class_logits_bwd_scratch_floats; 18: dm_reload_env_knobs, dm_roi_align_fwd_ws / dm_roi_align_workspace_bytes, dm_conv_pack_weight_split / dm_conv_packed_floats_split and flag bits 4, 5 of dm_conv2d_fwd; 19: dm_dcn_bwd_data_fused and its pack; 20: dm_conv2d_fwd_ws / dm_conv2d_splitk_floats; 21: dm_deform_conv_fwd_ws / dm_deform_conv_splitk_floats; 22: the bf16-split layouts (dm_conv_pack_weight_split, dm_conv_packed_floats_split, flag bits 4 / 5 of dm_conv2d_fwd) and the one-kernel DCN data gradient (dm_dcn_bwd_*) REMOVED -- measured, never the parity path, see docs/HISTORY.md; 23: dm_bn_stats takes mean_shift, dm_roi_align_bwd takes the gather form for 16 < P <= 64; 24: dm_build_info). */
 int dm_abi_version(void);
+/* "libdynamask_hip abi=N arch=gfx950 compiler=<clang version> flags=<the product-wide flags of dynamask_amd/build.py>"
+ * (static storage).  The library must be compiled WITHOUT packed fp32 instructions (flag "-packed-fp32-ops", see
+ * build.py); the host binding checks this string at load time and refuses a library that does not say so.  A build
+ * recipe other than build.py passes its flag set as -DDM_BUILD_FLAGS="..."; without it the string says flags=unknown. */
+const char* dm_build_info(void);
 /* Re-read the DM_ROI_* experiment knobs from the environment (they are otherwise read once, at the first launch, and
  * clamped to validated ranges).  For measurement tools that sweep settings inside one process; no knob changes a result. */
 int dm_reload_env_knobs(void);

@@ -34,6 +34,34 @@ def test_library_exports_every_declared_symbol():
     assert L.dm_error_string(-1).decode().startswith('invalid')
 
 
+def test_library_says_how_it_was_built_and_the_loader_checks_it(tmp_path, monkeypatch):
+    """dm_build_info() carries the product-wide flags of build.py; _lib.lib() refuses a library that does not say it was
+    built without packed fp32 (a recipe that drops the flag must not load silently)."""
+    import subprocess
+    from dynamask_amd import _lib, build
+    L = _lib.lib()
+    info = L.dm_build_info().decode()
+    assert f'abi={_lib.ABI_VERSION}' in info and 'gfx950' in info and 'clang' in info.lower()
+    for f in build.FLAGS:
+        assert f in info, (f, info)
+    assert _lib.REQUIRED_BUILD_FLAG in info
+    # a library compiled by "some other recipe": the one translation unit that holds dm_build_info, no flag handed over
+    src = os.path.join(ROOT, 'dynamask_amd', 'csrc', 'api_misc.hip')
+    other = tmp_path / 'libother.so'
+    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O1', '-fPIC', '-std=c++17', '-shared',
+                           '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.dirname(src), src, '-o', str(other)])
+    import ctypes
+    O = ctypes.CDLL(str(other))
+    O.dm_build_info.restype = ctypes.c_char_p
+    assert O.dm_build_info().decode().endswith('flags=unknown')
+    with pytest.raises(_lib.DynaMaskLibraryError, match='packed fp32'):
+        _lib.check_build_info(O.dm_build_info().decode())
+    monkeypatch.setenv('DM_ALLOW_PACKED_FP32', '1')
+    _lib.check_build_info(O.dm_build_info().decode())          # the A/B escape hatch
+    monkeypatch.delenv('DM_ALLOW_PACKED_FP32')
+    _lib.check_build_info(info)
+
+
 def test_argument_validation_without_gpu():
     from dynamask_amd import _lib
     L = _lib.lib()
@@ -135,3 +163,32 @@ def test_library_contains_no_packed_fp32_instructions(tmp_path):
         bad += sum(out.count(op) for op in ('v_pk_fma_f32', 'v_pk_mul_f32', 'v_pk_add_f32'))
     assert total > 1000, 'the disassembly does not look like the operator library'
     assert bad == 0, f'{bad} packed fp32 instructions in the library: build with dynamask_amd.build.FLAGS'
+
+
+def test_graph_weight_key_sees_replaced_parameters_and_modules():
+    """graphs.GraphedMaskLogits._weights_key: the cached walk must notice a Parameter OBJECT that was
+    replaced, not only in-place updates -- otherwise a HIP graph keeps replaying the old weights."""
+    import torch.nn as nn
+    from dynamask_amd import graphs, registry
+    head = registry.build_head(_cfg())
+    g = graphs.GraphedMaskLogits(head)
+    k0 = g._weights_key()
+    assert g._weights_key() == k0
+    mh = head.mask_head
+    with torch.no_grad():
+        mh.stages[0].instance_logits.weight.add_(1.0)                          # in place: version
+    k1 = g._weights_key()
+    assert k1 != k0
+    mh.stages[1].fuse_transform_out.weight = nn.Parameter(mh.stages[1].fuse_transform_out.weight.detach().clone())
+    k2 = g._weights_key()
+    assert k2 != k1                                                             # replaced object: address
+    sd = {k: v.clone() for k, v in mh.state_dict().items()}
+    mh.load_state_dict(sd, assign=True)
+    k3 = g._weights_key()
+    assert k3 != k2
+    from dynamask_amd import mask_heads
+    mh.instance_convs[1] = mask_heads.ConvModule(256, 256, 3, padding=1)       # replaced submodule
+    k4 = g._weights_key()
+    assert k4 != k3 and len(k4[0]) == len(k0[0])
+    mh.stages[2].fuse_conv[0].bias = None                                       # a slot that disappears
+    assert len(g._weights_key()[0]) == len(k0[0]) - 1
