@@ -167,6 +167,31 @@ class SFMStage(nn.Module):
         return ip, dp, tail
 
 
+def _paste_geometry(det_bboxes, ori_shape, scale_factor, rescale):
+    """The canvas size and the boxes in canvas pixels, as both heads' ``get_seg_masks`` derive them
+    (dynamask_head.py:293-305 = fcn_mask_head.py:176-186)."""
+    import numpy as np
+    bboxes = det_bboxes[:, :4]
+    if rescale:
+        img_h, img_w = ori_shape[:2]
+    else:
+        img_h = int(np.round(ori_shape[0] * scale_factor).astype(np.int32))
+        img_w = int(np.round(ori_shape[1] * scale_factor).astype(np.int32))
+        scale_factor = 1.0
+    if not isinstance(scale_factor, (float, torch.Tensor)):
+        scale_factor = bboxes.new_tensor(scale_factor)
+    return (bboxes / scale_factor).contiguous(), int(img_h), int(img_w)
+
+
+def _bitmaps_to_host(im_mask):
+    """device -> host as the reference does (``im_mask[i].cpu().numpy()``), but ONE copy of all masks into a fresh pinned
+    buffer (PCIe rate instead of the pageable-memory rate); returns the [N, h, w] bool array."""
+    host = torch.empty(im_mask.shape, dtype=im_mask.dtype, pin_memory=True)
+    host.copy_(im_mask, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    return host.numpy()
+
+
 @HEADS.register_module()
 class DynaMaskHead(nn.Module):
     """dynamask_head.py:128-244."""
@@ -411,29 +436,14 @@ class DynaMaskHead(nn.Module):
     def get_seg_masks(self, mask_pred, det_bboxes, det_labels, rcnn_test_cfg, ori_shape, scale_factor, rescale):
         """dynamask_head.py:279-342: sigmoid -> paste into the image -> threshold ->
         list of (h, w) bool numpy arrays (one paste kernel for all detections)."""
-        import numpy as np
-        bboxes = det_bboxes[:, :4]
-        if rescale:
-            img_h, img_w = ori_shape[:2]
-        else:
-            img_h = int(np.round(ori_shape[0] * scale_factor).astype(np.int32))
-            img_w = int(np.round(ori_shape[1] * scale_factor).astype(np.int32))
-            scale_factor = 1.0
-        if not isinstance(scale_factor, (float, torch.Tensor)):
-            scale_factor = bboxes.new_tensor(scale_factor)
-        bboxes = (bboxes / scale_factor).contiguous()
+        bboxes, img_h, img_w = _paste_geometry(det_bboxes, ori_shape, scale_factor, rescale)
         threshold = rcnn_test_cfg.mask_thr_binary
         if threshold < 0:
             raise NotImplementedError('visualisation mode (mask_thr_binary < 0) is not on the path')
         if mask_pred.shape[1] > 1:
             mask_pred = mask_pred[range(len(mask_pred)), det_labels][:, None]
         im_mask = ops.paste_masks(mask_pred.contiguous(), bboxes, img_h, img_w, threshold, apply_sigmoid=True)
-        # device -> host as the reference does (im_mask[i].cpu().numpy()), but ONE copy of all
-        # masks into a fresh pinned buffer (PCIe rate instead of the pageable-memory rate)
-        host = torch.empty(im_mask.shape, dtype=im_mask.dtype, pin_memory=True)
-        host.copy_(im_mask, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
-        im = host.numpy()
+        im = _bitmaps_to_host(im_mask)
         return [im[i] for i in range(len(im))]
 
 
@@ -443,17 +453,7 @@ class DynaMaskHead(nn.Module):
         encoding run on the device, only run boundaries are copied to the host.  Returns one
         COCO RLE dict per detection -- what ``mask_util.encode(np.array(m[:, :, None],
         order='F'))[0]`` yields for the bitmap ``get_seg_masks`` would have returned."""
-        import numpy as np
-        bboxes = det_bboxes[:, :4]
-        if rescale:
-            img_h, img_w = ori_shape[:2]
-        else:
-            img_h = int(np.round(ori_shape[0] * scale_factor).astype(np.int32))
-            img_w = int(np.round(ori_shape[1] * scale_factor).astype(np.int32))
-            scale_factor = 1.0
-        if not isinstance(scale_factor, (float, torch.Tensor)):
-            scale_factor = bboxes.new_tensor(scale_factor)
-        bboxes = (bboxes / scale_factor).contiguous()
+        bboxes, img_h, img_w = _paste_geometry(det_bboxes, ori_shape, scale_factor, rescale)
         threshold = rcnn_test_cfg.mask_thr_binary
         if threshold < 0:
             raise NotImplementedError('visualisation mode (mask_thr_binary < 0) is not on the path')
@@ -610,3 +610,83 @@ class FCNMaskHead(nn.Module):
         if self.upsample is not None:
             x = self.upsample(x, relu=(self.upsample_method == 'deconv'))
         return self.conv_logits.run(x)
+
+    # ------------------------------------------------ callers either side of the path
+    def get_targets(self, sampling_results, gt_masks, rcnn_train_cfg):
+        """fcn_mask_head.py:128-135 + core/mask/mask_target.py:7-62: per image, clip the positive proposals to the GT
+        canvas, crop-and-resize the assigned GT bitmap to ``rcnn_train_cfg.mask_size`` (RoIAlign, scale 1, adaptive
+        grid, aligned) and threshold at 0.5 -> float [N, S, S].  On the device: ``gt_masks`` are [G, H, W] tensors, or
+        BitmapMasks- / PolygonMasks-like holders (``.masks``), as ``DynaMaskHead.get_targets`` takes them."""
+        ms = rcnn_train_cfg.mask_size if hasattr(rcnn_train_cfg, 'mask_size') else rcnn_train_cfg['mask_size']
+        size = ms if isinstance(ms, int) else ms[0]
+        if not isinstance(ms, int) and ms[0] != ms[1]:
+            raise NotImplementedError('square mask targets only (mask_size is an int in every config of the reference)')
+        out = []
+        for res, masks in zip(sampling_results, gt_masks):
+            boxes, inds = res.pos_bboxes, res.pos_assigned_gt_inds
+            if boxes.shape[0] == 0:
+                out.append(boxes.new_zeros((0, size, size)))
+                continue
+            if hasattr(masks, 'masks') and isinstance(masks.masks, (list, tuple)):
+                packed = ops.pack_polygons(masks.masks, boxes.device)
+                b = boxes[:, :4].contiguous().float().clone()
+                b[:, 0::2].clamp_(0, float(masks.width))
+                b[:, 1::2].clamp_(0, float(masks.height))
+                out.append(ops.polygon_mask_targets(packed, b, inds.long().contiguous(), size).float())
+                continue
+            if hasattr(masks, 'masks'):
+                masks = torch.from_numpy(masks.masks).to(boxes.device)
+            m = masks.to(torch.float32).contiguous()[:, None]
+            maxh, maxw = m.shape[-2:]
+            rois = ops.mask_target_rois(boxes[:, :4].contiguous().float(), inds.long().contiguous(), maxw, maxh)
+            out.append(ops.threshold_ge(ops.roi_align([m], rois, size, [1.0], 0), 0.5).squeeze(1).float())
+        return torch.cat(out) if out else out
+
+    def loss(self, mask_pred, mask_targets, labels):
+        """fcn_mask_head.py:137-149 cannot run in the fork: ``mask_cross_entropy`` lost its ``label`` argument
+        (cross_entropy_loss.py:90-120), so ``CrossEntropyLoss(use_mask=True)`` raises there too."""
+        raise NotImplementedError('FCNMaskHead.loss is broken in the reference fork itself (SURVEY App. C Q5)')
+
+    def _selected(self, mask_pred, det_bboxes, det_labels):
+        if isinstance(mask_pred, torch.Tensor):
+            apply_sigmoid = True            # single-scale testing hands over logits (fcn_mask_head.py:168-169)
+        else:                               # multi-scale testing: probabilities, already averaged, as an ndarray (:170-171)
+            mask_pred, apply_sigmoid = det_bboxes.new_tensor(mask_pred), False
+        if not self.class_agnostic:
+            n = len(mask_pred)
+            mask_pred = mask_pred[torch.arange(n, device=mask_pred.device), det_labels.to(mask_pred.device)][:, None]
+        return mask_pred.contiguous(), apply_sigmoid
+
+    def get_seg_masks(self, mask_pred, det_bboxes, det_labels, rcnn_test_cfg, ori_shape, scale_factor, rescale):
+        """fcn_mask_head.py:151-237: (sigmoid ->) class select -> paste into the image -> threshold -> ``cls_segms``:
+        one list per class holding the (h, w) bool arrays of that class's detections, in detection order.  The
+        [n, classes, S, S] logits are gathered first (the sigmoid commutes with the selection), then one paste kernel
+        runs for all detections and ONE device -> host copy carries the bitmaps."""
+        bboxes, img_h, img_w = _paste_geometry(det_bboxes, ori_shape, scale_factor, rescale)
+        threshold = rcnn_test_cfg.mask_thr_binary
+        if threshold < 0:
+            raise NotImplementedError('visualisation mode (mask_thr_binary < 0) is not on the path')
+        cls_segms = [[] for _ in range(self.num_classes)]
+        if len(mask_pred) == 0:
+            return cls_segms
+        sel, apply_sigmoid = self._selected(mask_pred, det_bboxes, det_labels)
+        im = _bitmaps_to_host(ops.paste_masks(sel, bboxes, img_h, img_w, threshold, apply_sigmoid=apply_sigmoid))
+        for i, lab in enumerate(det_labels.tolist()):
+            cls_segms[lab].append(im[i])
+        return cls_segms
+
+    def get_seg_rles(self, mask_pred, det_bboxes, det_labels, rcnn_test_cfg, ori_shape, scale_factor, rescale):
+        """``get_seg_masks`` followed by ``encode_mask_results`` (core/mask/utils.py:36-63) without the bitmaps: paste,
+        threshold and run-length encoding on the device; returns ``cls_segms`` of COCO RLE dicts."""
+        bboxes, img_h, img_w = _paste_geometry(det_bboxes, ori_shape, scale_factor, rescale)
+        threshold = rcnn_test_cfg.mask_thr_binary
+        if threshold < 0:
+            raise NotImplementedError('visualisation mode (mask_thr_binary < 0) is not on the path')
+        cls_segms = [[] for _ in range(self.num_classes)]
+        if len(mask_pred) == 0:
+            return cls_segms
+        sel, apply_sigmoid = self._selected(mask_pred, det_bboxes, det_labels)
+        rles = ops.paste_rle(sel, bboxes, img_h, img_w, threshold, apply_sigmoid=apply_sigmoid)
+        for lab, r in zip(det_labels.tolist(), rles):
+            cls_segms[lab].append(r)
+        return cls_segms

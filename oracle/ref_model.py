@@ -356,6 +356,44 @@ def get_seg_masks(mask_logits, det_bboxes, ori_shape, scale_factor, rescale, thr
     return im_mask
 
 
+def fcn_get_seg_masks(mask_pred, det_bboxes, det_labels, ori_shape, scale_factor, rescale, num_classes=80,
+                      class_agnostic=False, thr=0.5, device_type='cuda'):
+    """FCNMaskHead.get_seg_masks -- mask_heads/fcn_mask_head.py:151-237: sigmoid of a tensor (an ndarray is taken as
+    probabilities, :168-171), the detection's class row (:211-212), paste, threshold, then grouped per class in
+    detection order (:233-235) -> list over classes of lists of bool [h, w] tensors."""
+    import numpy as np
+    probs = mask_pred.sigmoid() if isinstance(mask_pred, torch.Tensor) else torch.as_tensor(mask_pred, dtype=torch.float32)
+    if not class_agnostic:
+        probs = probs[range(len(probs)), det_labels][:, None]
+    bboxes = det_bboxes[:, :4]
+    if rescale:
+        img_h, img_w = ori_shape[:2]
+    else:
+        img_h = int(np.round(ori_shape[0] * scale_factor).astype(np.int32))
+        img_w = int(np.round(ori_shape[1] * scale_factor).astype(np.int32))
+        scale_factor = 1.0
+    bboxes = bboxes / scale_factor
+    N = len(probs)
+    im_mask = torch.zeros(N, img_h, img_w, dtype=torch.bool)
+    if device_type == 'cpu':
+        for i in range(N):
+            chunk, (ys, xs) = paste_masks(probs[i:i + 1], bboxes[i:i + 1], img_h, img_w, skip_empty=True)
+            im_mask[i:i + 1, ys, xs] = chunk >= thr
+    elif N:
+        chunk, _ = paste_masks(probs, bboxes, img_h, img_w, skip_empty=False)
+        im_mask[:] = chunk >= thr
+    cls_segms = [[] for _ in range(num_classes)]
+    for i in range(N):
+        cls_segms[int(det_labels[i])].append(im_mask[i])
+    return cls_segms
+
+
+def fcn_get_targets(pos_bboxes_list, pos_assigned_gt_inds_list, gt_masks_list, mask_size=28):
+    """FCNMaskHead.get_targets -- mask_heads/fcn_mask_head.py:128-135 -> core/mask/mask_target.py:7-62: clip to the GT
+    canvas, crop_and_resize at ``mask_size``, concatenated over the images."""
+    return get_targets(pos_bboxes_list, pos_assigned_gt_inds_list, gt_masks_list, stage_sup_size=(mask_size,))[0]
+
+
 # --------------------------------------------------------------------------- bbox branch (8f rank 4)
 def bbox_head_forward(sd, x, pre='bbox_head.'):
     """Shared2FCBBoxHead.forward -- roi_heads/bbox_heads/convfc_bbox_head.py:138-186 with

@@ -127,6 +127,22 @@ def paste_inputs():
     return dict(logits=logits, det_bboxes=det, ori_shape=(200, 300, 3))
 
 
+def fcn_paste_inputs():
+    """FCNMaskHead.get_seg_masks: [7, 80, 28, 28] class logits, detections whose labels repeat (the per-class lists
+    keep detection order), boxes that stick out of the canvas and one of zero width."""
+    g = _g(115)
+    n = 7
+    labels = torch.tensor([17, 3, 17, 79, 0, 3, 17])
+    t = synth.make_targets(n, sizes=(28, 112), seed=116)[0]                               # [7,28,28] blobs
+    logits = torch.randn(n, 80, 28, 28, generator=g)
+    logits[torch.arange(n), labels] = (t * 2 - 1) * 2.5 + torch.randn(t.shape, generator=g)
+    boxes = torch.tensor([[12.3, 18.9, 95.2, 133.7], [0.0, 0.0, 299.0, 199.0], [148.5, 33.0, 287.0, 64.5],
+                          [-25.0, 96.0, 64.0, 236.0], [200.2, 120.4, 330.9, 180.0], [40.0, 5.5, 77.7, 50.1],
+                          [120.0, 80.0, 120.0, 160.0]])                                    # last: zero width
+    det = torch.cat([boxes, torch.full((n, 1), 0.8)], 1)
+    return dict(logits=logits, det_bboxes=det, det_labels=labels, ori_shape=(200, 300, 3))
+
+
 def target_inputs():
     """Two images: GT bitmaps [G,H,W] (uint8), positive boxes, assigned GT indices."""
     g = _g(114)

@@ -131,6 +131,28 @@ def test_paste_and_targets_match_reference(golden_dir):
         assert np.array_equal(tg[i].numpy().astype(np.uint8), g9[f't{i}'])
 
 
+def test_fcn_callers_oracle_matches_reference_golden(golden_dir):
+    """g14: the reference's own FCNMaskHead.get_seg_masks / get_targets (fcn_mask_head.py:128-237, mask_target.py)."""
+    g = _load(golden_dir, 'g14_fcn_callers.npz')
+    pi = gi.fcn_paste_inputs()
+    for ag in (False, True):
+        logits = pi['logits'] if not ag else pi['logits'][torch.arange(7), pi['det_labels']][:, None]
+        for rescale, sf in ((False, 1.0), (True, 1.0), (True, 1.25)):
+            segs = ref_model.fcn_get_seg_masks(logits, pi['det_bboxes'], pi['det_labels'], pi['ori_shape'], sf, rescale,
+                                               class_agnostic=ag, device_type='cpu')
+            key = f'ag{int(ag)}_rescale{int(rescale)}_sf{sf}'
+            assert np.array_equal(np.array([len(c) for c in segs], np.int32), g['counts_' + key])
+            flat = np.stack([m.numpy() for c in segs for m in c]).astype(np.uint8)
+            assert np.array_equal(flat, g['seg_' + key])
+        segs = ref_model.fcn_get_seg_masks(logits.sigmoid().numpy(), pi['det_bboxes'], pi['det_labels'], pi['ori_shape'], 1.0, True,
+                                           class_agnostic=ag, device_type='cpu')
+        assert np.array_equal(np.stack([m.numpy() for c in segs for m in c]).astype(np.uint8), g[f'seg_ag{int(ag)}_ndarray'])
+    ti = gi.target_inputs()
+    for size in (28, 14):
+        tg = ref_model.fcn_get_targets([t['boxes'] for t in ti], [t['inds'] for t in ti], [t['masks'] for t in ti], mask_size=size)
+        assert np.array_equal(tg.numpy().astype(np.uint8), g[f'targets{size}'])
+
+
 def test_bbox_branch_oracle_matches_reference_golden(golden_dir):
     """g10: Shared2FCBBoxHead.forward / BBoxHead.get_bboxes / delta2bbox / multiclass_nms of the
     reference (the NMS inside is a stand-in: mmcv is third-party, see make_golden_bbox.py)."""

@@ -340,6 +340,62 @@ def test_mask_targets_and_paste_match_reference_golden(golden_dir):
         assert ne4.mean() < 2e-4, ne4.mean()
 
 
+def test_fcn_mask_head_callers_match_reference_golden(golden_dir):
+    """FCNMaskHead.get_seg_masks / get_seg_rles / get_targets (fcn_mask_head.py:128-237) on the device against g14 =
+    the reference's own methods: per-class grouping and order exact, bitmaps exact up to pixels whose interpolated
+    value sits within an ulp of the threshold; the zero-width box follows the reference's whole-canvas GPU path
+    (the golden ran on CPU, one tight region per mask) and is checked against the oracle's restatement of that path."""
+    import types
+    from dynamask_amd import registry
+    from dynamask_amd.registry import ConfigDict
+    g = np.load(os.path.join(golden_dir, 'g14_fcn_callers.npz'))
+    pi = gi.fcn_paste_inputs()
+    order = [i for c in range(80) for i in range(7) if int(pi['det_labels'][i]) == c]       # detection index of every flattened row
+    for ag in (False, True):
+        head = registry.build_head(dict(type='FCNMaskHead', **dict(gi.FCN_HEAD_CFG, class_agnostic=ag))).cuda()
+        logits = pi['logits'] if not ag else pi['logits'][torch.arange(7), pi['det_labels']][:, None]
+        for rescale, sf in ((False, 1.0), (True, 1.0), (True, 1.25)):
+            key = f'ag{int(ag)}_rescale{int(rescale)}_sf{sf}'
+            segs = head.get_seg_masks(_dev(logits), _dev(pi['det_bboxes']), pi['det_labels'].cuda(), ConfigDict(mask_thr_binary=0.5),
+                                      pi['ori_shape'], sf, rescale)
+            assert len(segs) == 80 and [len(c) for c in segs] == g['counts_' + key].tolist()
+            flat = np.stack([m for c in segs for m in c])
+            assert flat.dtype == np.bool_
+            ref = g['seg_' + key]
+            regular = [k for k, i in enumerate(order) if i != 6]
+            ne = flat[regular].astype(np.uint8) != ref[regular]
+            full = ref_model.fcn_get_seg_masks(logits, pi['det_bboxes'], pi['det_labels'], pi['ori_shape'], sf, rescale,
+                                               class_agnostic=ag, device_type='cuda')
+            ne6 = flat[order.index(6)] != [m for c in full for m in c][order.index(6)].numpy()
+            print(f'fcn paste {key}: {int(ne.sum())} of {ne.size} pixels differ from the reference golden, {int(ne6.sum())} (zero-width box) from the oracle')
+            assert ne.mean() < 2e-5 and ne6.mean() < 2e-4
+            # the RLE form of the same call decodes to the same bitmaps
+            rles = head.get_seg_rles(_dev(logits), _dev(pi['det_bboxes']), pi['det_labels'].cuda(), ConfigDict(mask_thr_binary=0.5),
+                                     pi['ori_shape'], sf, rescale)
+            assert [len(c) for c in rles] == [len(c) for c in segs]
+            for r, m in zip([r for c in rles for r in c], flat):
+                assert r == ref_ops.rle_encode(m.astype(np.uint8))
+        # ndarray of probabilities (multi-scale testing): no sigmoid
+        segs = head.get_seg_masks(logits.sigmoid().numpy(), _dev(pi['det_bboxes']), pi['det_labels'].cuda(), ConfigDict(mask_thr_binary=0.5),
+                                  pi['ori_shape'], 1.0, True)
+        flat = np.stack([m for c in segs for m in c])
+        ne = flat[regular].astype(np.uint8) != g[f'seg_ag{int(ag)}_ndarray'][regular]
+        assert ne.mean() < 2e-5
+        assert head.get_seg_masks(_dev(logits[:0]), _dev(pi['det_bboxes'][:0]), pi['det_labels'][:0].cuda(), ConfigDict(mask_thr_binary=0.5),
+                                  pi['ori_shape'], 1.0, True) == [[] for _ in range(80)]
+    head = registry.build_head(dict(type='FCNMaskHead', **gi.FCN_HEAD_CFG)).cuda()
+    ti = gi.target_inputs()
+    res = [types.SimpleNamespace(pos_bboxes=_dev(t['boxes']), pos_assigned_gt_inds=_dev(t['inds'])) for t in ti]
+    for size in (28, 14):
+        tg = head.get_targets(res, [t['masks'].cuda() for t in ti], ConfigDict(mask_size=size))
+        assert tg.dtype == torch.float32 and tuple(tg.shape) == g[f'targets{size}'].shape
+        ne = tg.cpu().numpy().astype(np.uint8) != g[f'targets{size}']
+        print(f'fcn mask targets {size}: {int(ne.sum())} of {ne.size} differ')
+        assert ne.mean() < 2e-4
+    with pytest.raises(NotImplementedError):
+        head.loss(None, None, None)
+
+
 def test_simple_test_mask_end_to_end():
     hi = gi.head_inputs()
     m = _roi_head()
