@@ -363,6 +363,92 @@ def train_step_bench(head, dev, rank, world, steps=4, warmup=4, rehearsal=False)
     return step_ms, float(res['loss_mask']['loss_masks'].detach()), grp.numel, B, comm_ms, collective, forced_ms, exposed_ms
 
 
+def count_host_syncs(fn):
+    """Number of synchronising calls `fn` makes on the host (torch's sync debug mode warns on every .item() / .tolist()
+    / .cpu() / blocking copy / explicit synchronize of the CURRENT device that waits for the GPU); None if unavailable."""
+    import warnings
+    try:
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode('warn')
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            fn()
+        return sum(1 for x in w if 'synchroniz' in str(x.message).lower())
+    except Exception as e:      # noqa: BLE001
+        print(f'[bench] sync counting unavailable: {e}', file=sys.stderr)
+        return None
+    finally:
+        torch.cuda.set_sync_debug_mode('default')
+
+
+def entry_points_bench(sd, dev, iters=7):
+    """The entry points the reference's detector actually calls, at the reference's shapes, each as a whole (rows f1, f2, f4
+    of SURVEY 8f beside the path): ``DynaMaskRoIHead.forward_train`` (two_stage.py:161-164 -> dynamask_roi_head.py:21-46:
+    assigner + sampler per image, bbox branch, device mask targets, mask path, losses) + backward; the mask targets alone
+    (dynamask_head.py:246-271); paste + threshold + RLE of 100 detections (dynamask_head.py:279-342 + core/mask/utils.py:36-63)."""
+    from dynamask_amd import bbox_heads, registry, synth  # noqa: F401
+    from dynamask_amd.registry import ConfigDict
+    B = 2
+    rh = registry.build_head(dict(
+        type='DynaMaskRoIHead',
+        bbox_roi_extractor=dict(type='SingleRoIExtractor', **synth.BBOX_ROI_EXTRACTOR_CFG),
+        bbox_head=dict(type='Shared2FCBBoxHead', **synth.BBOX_HEAD_CFG),
+        mask_roi_extractor=dict(type='SingleRoIExtractor', **synth.MASK_ROI_EXTRACTOR_CFG),
+        mask_head=dict(type='DynaMaskHead', **synth.MASK_HEAD_CFG),
+        train_cfg=registry._to_cfgdict(synth.RCNN_TRAIN_CFG), test_cfg=ConfigDict(**synth.RCNN_TEST_CFG)))
+    rh.load_state_dict({**sd, **synth.init_bbox_head_state(seed=8)}, strict=True)
+    rh = rh.to(dev).train()
+    feats = [f.to(dev) for f in synth.make_fpn(B, IMG_H, IMG_W, 256, seed=40)]
+    tb = synth.make_train_batch(B, IMG_H, IMG_W, seed=41)
+    props = [p.to(dev) for p in tb['proposals']]
+    gtb = [t.to(dev) for t in tb['gt_bboxes']]
+    gtl = [t.to(dev) for t in tb['gt_labels']]
+    gtm = [t.to(dev) for t in tb['gt_masks']]
+    kept = {}
+
+    def ft():
+        for p_ in rh.parameters():
+            p_.grad = None
+        losses = rh.forward_train(feats, tb['img_metas'], props, gtb, gtl, None, gtm)
+        sum(v for k, v in losses.items() if 'loss' in k).backward()
+        kept['losses'] = losses
+    for _ in range(3):
+        ft()
+    out = {'forward_train_ms': time_kernel_median(ft, iters=iters, warmup=1),
+           'forward_train_host_syncs': count_host_syncs(ft)}
+    # the mask targets alone, for the positives the sampler of the last call kept (<= 128 per image, four sizes)
+    with torch.no_grad():
+        srs = []
+        for i in range(B):
+            ar = rh.bbox_assigner.assign(props[i], gtb[i], None, gtl[i])
+            srs.append(rh.bbox_sampler.sample(ar, props[i], gtb[i], gtl[i]))
+        pb, pi = [r.pos_bboxes for r in srs], [r.pos_assigned_gt_inds for r in srs]
+        gt_call = lambda: rh.mask_head.get_targets(pb, pi, gtm)      # noqa: E731
+        out['get_targets_ms'] = time_kernel_median(gt_call, iters=iters, warmup=2)
+        out['get_targets_host_syncs'] = count_host_syncs(gt_call)
+        n_pos = sum(int(b_.shape[0]) for b_ in pb)
+        # paste + threshold + RLE of 100 detections at 112 x 112 into the 800 x 1333 canvas; the RLE strings on the host
+        rois = synth.make_rois(1, 100, IMG_H, IMG_W, seed=42).to(dev)
+        det = torch.cat([rois[:, 1:], torch.ones(100, 1, device=dev)], 1)
+        logits = ((synth.make_targets(100, sizes=(112,), seed=43)[0] * 2 - 1) * 3).unsqueeze(1).to(dev)
+        lab = torch.zeros(100, dtype=torch.long, device=dev)
+        cfg = ConfigDict(mask_thr_binary=0.5)
+        rle_call = lambda: rh.mask_head.get_seg_rles(logits, det, lab, cfg, (IMG_H, IMG_W, 3), 1.0, True)      # noqa: E731
+        bit_call = lambda: rh.mask_head.get_seg_masks(logits, det, lab, cfg, (IMG_H, IMG_W, 3), 1.0, True)     # noqa: E731
+        out['paste_rle_ms'] = time_kernel_median(rle_call, iters=iters, warmup=2)
+        out['paste_rle_host_syncs'] = count_host_syncs(rle_call)
+        out['paste_bitmaps_ms'] = time_kernel_median(bit_call, iters=iters, warmup=2)
+    out['what'] = (f'forward_train: {B} images x 1000 proposals (15 / 7 GT boxes with 800x1333 bitmaps), MaxIoUAssigner + RandomSampler(512, 0.25) '
+                   f'-> {n_pos} positives, RoIAlign7 + Shared2FC + CE / L1 losses, device mask targets at 14/28/56/112, RoIAlign14 + '
+                   'RoIAlign56 + MaskPre + ST-Gumbel + DynaMaskHead + DynaCrossEntropyLoss, then backward of the summed losses (no '
+                   'optimiser step); get_targets: the same positives, four sizes; paste_rle: 100 detections, 112x112 logits -> sigmoid '
+                   '-> paste into 800x1333 -> >= 0.5 -> COCO RLE dicts on the host (paste_bitmaps: bool arrays on the host instead); '
+                   'median of individually event-timed calls incl. their host work; *_host_syncs = blocking host<-device waits per call')
+    out['losses'] = {k: float(v) for k, v in kept['losses'].items()}
+    del rh, feats
+    return out
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -487,6 +573,12 @@ def main():
     train_ms, train_loss, n_flat, train_b, comm_ms, collective, forced_ms, exposed_ms = train_step_bench(
         head, dev, rank, world, steps=t_steps, warmup=t_warm, rehearsal=rehearsal)
 
+    entry = None
+    if rank == 0 and os.environ.get('DM_BENCH_NO_ENTRY', '0') != '1':
+        # the reference's real entry points as a whole (rank 0): before the headline's graph capture, like the training leg
+        entry = entry_points_bench(sd, dev)
+        torch.cuda.empty_cache()
+
     def step():
         with torch.no_grad():
             return head._mask_forward(feats, rois, labels, last_stage=1)
@@ -560,6 +652,10 @@ def main():
         'allreduce_alone_ms': comm_ms, 'allreduce_exposed_ms': exposed_ms, 'collective': collective,
         'infer_ms_per_roi_batch': ms_per_step, 'infer_img_per_s': value,
     })
+    if entry is not None:
+        for k in ('forward_train_ms', 'get_targets_ms', 'paste_rle_ms'):
+            result[k] = entry[k]
+        result['entry_points'] = entry
     if args.leg == 'train':
         result.update({
             'metric': 'img/s (DynaMask mask-path training step: 2 img/GPU x 128 positive RoIs, fwd + loss + bwd + '
@@ -589,6 +685,18 @@ def main():
                               'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                               'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': None, 'ms_per_launch': ms,
                               'flops_per_launch': flops}
+        # ---- the second-largest kernel of the step: DCN 3x3 256->256 (deform_groups 2) on [512,256,14,14] ----
+        dcn = head.mask_head.stages[0].fuse_conv[1]
+        off = torch.randn(ROIS_PER_IMG, 36, 14, 14, device=dev) * 0.5
+        wd = dcn._pk.get('w', dcn.weight, ops.pack_conv_weight, job=(False, None, None, None))
+        dcn_call = lambda: ops.deform_conv(x, off, wd, 256, 2, relu=True)      # noqa: E731
+        ms_d = sorted(time_kernel(dcn_call, iters=10, warmup=2) for _ in range(5))[2]
+        ach_d = flops / (ms_d * 1e-3) / 1e12
+        result['roofline_dcn'] = {'kernel': 'deform_conv_lds_kernel (+ its last-round launch): DCNv1 3x3 256->256, deform_groups 2, +ReLU, 512 RoIs '
+                                            '@14x14, offsets N(0, 0.5) px; the bilinear gather is the MFMA B-operand producer (no column matrix); '
+                                            'flops = the dense contraction only (2 N 196 256 256 9), the gather arithmetic is not counted',
+                                  'bound': 'mfma', 'achieved': ach_d, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                  'frac': ach_d / PEAK_FP32_MFMA_TFLOPS, 'traffic': None, 'ms_per_launch': ms_d, 'flops_per_launch': flops}
         # ---- RoIAlign 14x14 multi-level (the north star's HBM-roofline kernel) ----
         ext = head.mask_roi_extractor
         ms_r = time_kernel_graphed(lambda: ext(feats[:4], rois))
@@ -622,10 +730,12 @@ def main():
             try:
                 t = json.load(open(pmc))
                 result['roofline']['traffic'] = t.get('conv3x3_bytes_per_launch')
+                result['roofline_dcn']['traffic'] = t.get('dcn3x3_bytes_per_launch')
                 result['roofline_roialign']['traffic'] = t.get('roialign_bytes_per_launch')
                 src = ('profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of '
                        'tools/collect_profiles.sh (' + str(t.get('collected', 'date n/a')) + '), not measured in this run')
                 result['roofline']['traffic_source'] = src
+                result['roofline_dcn']['traffic_source'] = src
                 result['roofline_roialign']['traffic_source'] = src
             except Exception:
                 pass
@@ -637,20 +747,32 @@ def main():
         if stats:
             try:
                 import csv
-                parts = {}
+                parts, mm = {}, {'conv_igemm_kernel<3': {}, 'deform_conv': {}}
                 for row in csv.DictReader(open(stats)):
                     for kname in ('roi_align_tile_kernel', 'roi_order_kernel'):
                         if kname in row['Name']:
                             parts[kname] = float(row['AverageNs']) / 1e3
+                    for kname in mm:
+                        if kname in row['Name']:
+                            mm[kname][row['Name'].split('(anonymous namespace)::')[1].split('(')[0]] = float(row['AverageNs']) / 1e3
+                rsrc = ('profiles/' + os.path.basename(stats) + ' (rocprofv3 --kernel-trace --stats over tools/pmc_probe.py), '
+                        'not measured in this run')
                 if 'roi_align_tile_kernel' in parts:
                     us = sum(parts.values())               # the call = the ordering kernel (if it ran) + the extraction
                     result['roofline_roialign']['us_per_launch_rocprof_committed'] = us
                     result['roofline_roialign']['us_per_kernel_rocprof_committed'] = parts
                     result['roofline_roialign']['frac_rocprof_committed'] = nbytes / (us * 1e-6) / 1e9 / PEAK_HBM_GBS
-                    result['roofline_roialign']['rocprof_source'] = ('profiles/' + os.path.basename(stats) + ' (rocprofv3 --kernel-trace '
-                                                                    '--stats over tools/pmc_probe.py), not measured in this run')
-            except Exception:
-                pass
+                    result['roofline_roialign']['rocprof_source'] = rsrc
+                # the same bookkeeping for the two MFMA kernels: a call = its main launch + its last-round launch, summed
+                for key, kname in (('roofline', 'conv_igemm_kernel<3'), ('roofline_dcn', 'deform_conv')):
+                    if mm[kname]:
+                        us = sum(mm[kname].values())
+                        result[key]['ms_per_launch_rocprof_committed'] = us / 1e3
+                        result[key]['us_per_kernel_rocprof_committed'] = mm[kname]
+                        result[key]['frac_rocprof_committed'] = flops / (us * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS
+                        result[key]['rocprof_source'] = rsrc
+            except Exception as e:      # noqa: BLE001
+                print(f'[bench] committed rocprof figures unavailable: {e}', file=sys.stderr)
         extra = {}
         # ---- the reference's real inference shape (dynamask_roi_head.py:117-158, tools/benchmark.py:63-89): <= 100
         # detections per image, every exit to 112x112 + boundary merge, through the product's bucketed HIP-graph
@@ -710,7 +832,34 @@ def main():
         f5 = [f.to(dev) for f in synth.make_fpn(1, 1024, 2048, 256, seed=20)]
         r5 = synth.make_rois(1, ROIS_PER_IMG, 1024, 2048, seed=21).to(dev)
         extra['fcn_carafe_cfg5_2048x1024_ms'] = fcn_ms('carafe', f5, r5)
-        del f5, r5
+        # configs[4] as an inference call of the reference (standard_roi_head.simple_test_mask -> FCNMaskHead.forward ->
+        # get_seg_masks, fcn_mask_head.py:151-237, -> encode_mask_results): 100 detections on the 2048x1024 image,
+        # RoIAlign14 + 4 conv3x3 + CARAFE x2 + 80-class logits + class select + sigmoid + paste + threshold + RLE on the host
+        from dynamask_amd.registry import ConfigDict as _CD
+        cfg5 = dict(type='FCNMaskHead', **gi.FCN_HEAD_CFG)
+        cfg5.pop('loss_mask')
+        cfg5['upsample_cfg'] = dict(type='carafe', scale_factor=2, up_kernel=5, up_group=1, encoder_kernel=3, encoder_dilation=1,
+                                    compressed_channels=64)
+        fcn5 = registry.build_head(cfg5)
+        fcn5.load_state_dict({k[len('mask_head.'):]: v for k, v in synth.init_fcn_head_state(seed=7, upsample='carafe', test_mode=True).items()},
+                             strict=True)
+        fcn5 = fcn5.to(dev).eval()
+        det5 = torch.cat([r5[:100, 1:], torch.ones(100, 1, device=dev)], 1)
+        lab5 = labels[:100].contiguous()
+
+        def fcn5_infer(rle=True):
+            with torch.no_grad():
+                mp = fcn5(head.mask_roi_extractor(f5[:4], r5[:100].contiguous()))
+                fn_ = fcn5.get_seg_rles if rle else fcn5.get_seg_masks
+                return fn_(mp, det5, lab5, _CD(mask_thr_binary=0.5), (1024, 2048, 3), 1.0, True)
+        result['fcn_carafe_cfg5_infer100_rle_ms'] = time_kernel_median(fcn5_infer, iters=7, warmup=2)
+        extra['fcn_carafe_cfg5_infer100'] = {
+            'rle_ms': result['fcn_carafe_cfg5_infer100_rle_ms'],
+            'bitmaps_ms': time_kernel_median(lambda: fcn5_infer(False), iters=7, warmup=2),
+            'what': 'BASELINE configs[4] workload as ONE inference call on one GPU: 2048x1024 FPN maps, 100 detections, RoIAlign14 -> '
+                    'FCNMaskHead (4 conv3x3, CARAFE x2, 80-class 1x1) -> FCNMaskHead.get_seg_rles (class select, sigmoid, paste into '
+                    '1024x2048, >= 0.5, COCO RLE dicts on the host) / get_seg_masks (bool arrays on the host); event-timed incl. host work'}
+        del f5, r5, fcn5
         # ---- measured device-to-device copy rate (second denominator for the HBM-bound kernels) ----
         a_ = torch.empty(1 << 28, device=dev, dtype=torch.float32)
         b_ = torch.empty_like(a_)

@@ -94,6 +94,42 @@ def make_targets(n, sizes=(14, 28, 56, 112), seed=3):
     return out
 
 
+def make_train_batch(batch=2, img_h=800, img_w=1333, n_props=1000, n_gt=(15, 7), seed=30):
+    """What ``forward_train`` receives per image at the reference's training shape (configs/dynamask/coco/
+    r50-dynamask-1x.py:109-134: 1000 RPN proposals with a score column, sampler 512 x 0.25): ``n_gt[i]`` ground-truth
+    boxes with labels and [G, H, W] uint8 bitmaps (an ellipse inside each box), 60 % of the proposals jittered copies of
+    the GT boxes (so that the sampler finds its 128 positives), the rest scattered."""
+    g = _gen(seed)
+    out = dict(proposals=[], gt_bboxes=[], gt_labels=[], gt_masks=[],
+               img_metas=[dict(img_shape=(img_h, img_w, 3), pad_shape=(img_h, img_w, 3)) for _ in range(batch)])
+    yy, xx = torch.meshgrid(torch.arange(img_h, dtype=torch.float32) + 0.5, torch.arange(img_w, dtype=torch.float32) + 0.5,
+                            indexing='ij')
+    for b in range(batch):
+        G = n_gt[b % len(n_gt)]
+        c = torch.rand(G, 2, generator=g) * torch.tensor([img_w - 300.0, img_h - 300.0]) + 150
+        wh = torch.rand(G, 2, generator=g) * 300 + 40
+        gtb = torch.cat([c - wh / 2, c + wh / 2], 1)
+        gtb[:, 0::2] = gtb[:, 0::2].clamp(0, img_w - 1)
+        gtb[:, 1::2] = gtb[:, 1::2].clamp(0, img_h - 1)
+        cx, cy = (gtb[:, 0] + gtb[:, 2]) / 2, (gtb[:, 1] + gtb[:, 3]) / 2
+        ax, ay = (gtb[:, 2] - gtb[:, 0]) / 2, (gtb[:, 3] - gtb[:, 1]) / 2
+        m = ((((xx[None] - cx[:, None, None]) / ax[:, None, None]) ** 2
+              + ((yy[None] - cy[:, None, None]) / ay[:, None, None]) ** 2) <= 1.0).to(torch.uint8)
+        n_near = int(0.6 * n_props)
+        near = gtb[torch.randint(0, G, (n_near,), generator=g)] + torch.randn(n_near, 4, generator=g) * 12
+        far = make_rois(1, n_props - n_near, img_h, img_w, seed=seed + 100 + b)[:, 1:]
+        props = torch.cat([near, far])
+        props[:, 0::2] = props[:, 0::2].clamp(0, img_w - 1)
+        props[:, 1::2] = props[:, 1::2].clamp(0, img_h - 1)
+        props[:, 2] = torch.maximum(props[:, 2], props[:, 0] + 1)
+        props[:, 3] = torch.maximum(props[:, 3], props[:, 1] + 1)
+        out['proposals'].append(torch.cat([props, torch.rand(n_props, 1, generator=g)], 1))
+        out['gt_bboxes'].append(gtb)
+        out['gt_labels'].append(torch.randint(0, 80, (G,), generator=g))
+        out['gt_masks'].append(m)
+    return out
+
+
 # ------------------------------------------------------------ weight initialisers
 def _kaiming_fan_out(shape, g):
     fan_out = shape[0] * shape[2] * shape[3]
@@ -254,4 +290,10 @@ BBOX_HEAD_CFG = dict(in_channels=256, fc_out_channels=1024, roi_feat_size=7, num
                      loss_bbox=dict(type='L1Loss', loss_weight=2.0))
 BBOX_ROI_EXTRACTOR_CFG = dict(roi_layer=dict(type='RoIAlign', output_size=7, sampling_ratio=0), out_channels=256,
                               featmap_strides=[4, 8, 16, 32])
+# configs/dynamask/coco/r50-dynamask-1x.py:118-134
+RCNN_TRAIN_CFG = dict(
+    assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5, match_low_quality=True,
+                  ignore_iof_thr=-1),
+    sampler=dict(type='RandomSampler', num=512, pos_fraction=0.25, neg_pos_ub=-1, add_gt_as_proposals=True),
+    flops=[0.23, 0.62, 1.01, 1.4], Lambda=0.3, mask_size=28, pos_weight=-1, debug=False)
 RCNN_TEST_CFG = dict(score_thr=0.05, nms=dict(type='nms', iou_threshold=0.5), max_per_img=100, mask_thr_binary=0.5)
