@@ -4,7 +4,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DYNAMASK_HIP_LIB') or os.path.join(_HERE, 'libdynamask_hip.so')      # override: kernel experiments
-ABI_VERSION = 24
+ABI_VERSION = 25
 REQUIRED_BUILD_FLAG = '-packed-fp32-ops'        # dynamask_amd/build.py NO_PACKED_FP32; dm_build_info() must carry it
 
 _c_int = ctypes.c_int
@@ -37,6 +37,8 @@ SIGNATURES = {
     'dm_deform_conv_splitk_floats': ([_c_int, _c_int, _c_int, _c_int, _c_int], ctypes.c_longlong),
     'dm_upsample2x_bilinear_fwd': ([_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp], _c_int),
     'dm_boundary_merge': ([_vp, _vp, _c_int, _c_int, _vp], _c_int),
+    'dm_boundary_merge_chain': ([_vp, _vp, _vp, _vp, _c_int, _c_int, _vp], _c_int),
+    'dm_stage_head_fwd': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_float, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp], _c_int),
     'dm_deconv_pack_weight': ([_vp, _c_int, _c_int, _vp, _vp], _c_int),
     'dm_deconv2x2_fwd': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _vp, _vp], _c_int),
     'dm_carafe_fwd': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp], _c_int),

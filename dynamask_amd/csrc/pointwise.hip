@@ -30,6 +30,15 @@ __device__ __forceinline__ float block_sum(float v, float* smem) {
   return r;
 }
 
+// A product that stays a product: hipcc contracts a * b - c into one fma wherever it sees both (-ffp-contract=fast, and
+// __fmul_rn is a plain multiplication to it), per kernel as its scheduler likes -- a source coordinate rs * o whose
+// fraction is then taken by a subtraction came out an ulp apart in two kernels that must agree.  The pragma clears the
+// 'contract' flag of this one multiplication; it survives inlining.
+__device__ __forceinline__ float dm_mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+
 // One bilinear x2 value, spelled as an explicit fma chain: the three kernels that interpolate (generic, half-pixel fast
 // path, logits of the upsampled stage) must round alike -- left to the compiler, the same source expression contracted
 // differently next to different code and the fused exit differed from upsample + logits in the last bit.
@@ -43,15 +52,14 @@ __device__ __forceinline__ float dm_up2x_interp(float hy, float ly, float hx, fl
 // grid_sample(bilinear, zeros, align_corners=False) at RoI-relative pixel
 // centres.  Thread = one sample point; its 4 taps/weights are computed once and
 // reused over the channel chunk of the workgroup.
-__global__ __launch_bounds__(256) void point_sample_kernel(const float* __restrict__ feat, int B, int C, int H, int W,
-                                                           const float* __restrict__ rois, int N, int S, float scale,
-                                                           float* __restrict__ out, int CT, int pos_blocks) {
+__device__ __forceinline__ void point_sample_body(int bid, const float* __restrict__ feat, int B, int C, int H, int W,
+                                                  const float* __restrict__ rois, int N, int S, float scale,
+                                                  float* __restrict__ out, int CT) {
   // Thread = one sample point of the flat (RoI, position) list (S*S = 196 would leave a quarter of a 256-thread
   // workgroup idle per RoI); the two taps of a row come as ONE 8-byte load from the pair base column
   // cb = clamp(x0, 0, W-2), with the weights moved to the pair's slots (a tap outside the map keeps weight 0, so the
   // expression below is the reference's four-term sum): half the gather instructions of a load per tap.
   const int chunks = (C + CT - 1) / CT;
-  int bid = blockIdx.x;
   const int chunk = bid % chunks;
   const int pb = bid / chunks;
   const int SS = S * S;
@@ -124,22 +132,27 @@ __global__ __launch_bounds__(256) void point_sample_kernel(const float* __restri
   }
 }
 
+__global__ __launch_bounds__(256) void point_sample_kernel(const float* __restrict__ feat, int B, int C, int H, int W,
+                                                           const float* __restrict__ rois, int N, int S, float scale,
+                                                           float* __restrict__ out, int CT, int pos_blocks) {
+  point_sample_body(blockIdx.x, feat, B, C, H, W, rois, N, S, scale, out, CT);
+}
+
 // ------------------------------------------------------------------ K7
 // A workgroup = 64 pixels of one RoI x four interleaved channel subsets (one per wave); the two weight rows W[label] are
 // workgroup-uniform (scalar loads).  The waves' partial sums meet in LDS and are added in wave order.  (Round 2 gave a
 // thread a pixel and ALL channels: one 256-thread workgroup per 14 x 14 RoI, 8 waves per CU with four loads in flight
 // each -- 1.2 TB/s on a kernel that only streams x.)
-__global__ __launch_bounds__(256) void class_logits_kernel(const float* __restrict__ x, int N, int C, int HW,
-                                                           const float* __restrict__ wi, const float* __restrict__ bi,
-                                                           const float* __restrict__ wd, const float* __restrict__ bd,
-                                                           int num_classes, const int64_t* __restrict__ labels,
-                                                           float* __restrict__ inst, float* __restrict__ det,
-                                                           float* __restrict__ sig, int sig_ct, int sig_off,
-                                                           int pix_blocks) {
-  __shared__ float red[3][64][2];
-  const int n = blockIdx.x / pix_blocks;
+__device__ __forceinline__ void class_logits_body(int bid, float (&red)[3][64][2], const float* __restrict__ x, int N, int C, int HW,
+                                                  const float* __restrict__ wi, const float* __restrict__ bi,
+                                                  const float* __restrict__ wd, const float* __restrict__ bd,
+                                                  int num_classes, const int64_t* __restrict__ labels,
+                                                  float* __restrict__ inst, float* __restrict__ det,
+                                                  float* __restrict__ sig, int sig_ct, int sig_off,
+                                                  int pix_blocks) {
+  const int n = bid / pix_blocks;
   const int lane = threadIdx.x & 63, part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (scalar: the weights of the channel loop are scalar loads)
-  const int p = (blockIdx.x - n * pix_blocks) * 64 + lane;
+  const int p = (bid - n * pix_blocks) * 64 + lane;
   const bool ok = p < HW;
   int lab = (int)labels[n];
   lab = min(max(lab, 0), num_classes - 1);
@@ -172,6 +185,37 @@ __global__ __launch_bounds__(256) void class_logits_kernel(const float* __restri
     sig[((size_t)n * sig_ct + sig_off) * HW + p] = sigmoidf_(ai);
     sig[((size_t)n * sig_ct + sig_off + 1) * HW + p] = sigmoidf_(ad);
   }
+}
+
+__global__ __launch_bounds__(256) void class_logits_kernel(const float* __restrict__ x, int N, int C, int HW,
+                                                           const float* __restrict__ wi, const float* __restrict__ bi,
+                                                           const float* __restrict__ wd, const float* __restrict__ bd,
+                                                           int num_classes, const int64_t* __restrict__ labels,
+                                                           float* __restrict__ inst, float* __restrict__ det,
+                                                           float* __restrict__ sig, int sig_ct, int sig_off,
+                                                           int pix_blocks) {
+  __shared__ float red[3][64][2];
+  class_logits_body(blockIdx.x, red, x, N, C, HW, wi, bi, wd, bd, num_classes, labels, inst, det, sig, sig_ct, sig_off, pix_blocks);
+}
+
+// The head of an SFM stage in ONE launch (round 6): the point sample of the stage's semantic map (K4) and the two
+// class-gathered logits of its instance features (K7) share no data -- both only feed the fusion convolution behind them
+// (dynamask_head.py:104-116).  Workgroups [0, ps_blocks) run the body of point_sample_kernel, the rest that of
+// class_logits_kernel: the same code, so the same bits, one launch less per stage in a chain of 5-10 us launches.
+struct StageHeadArgs {
+  const float* feat; int B, Cs, H, W; const float* rois; int N, S; float scale; float* ps_out; int CT;
+  const float* x; int C, HW; const float *wi, *bi, *wd, *bd; int num_classes; const int64_t* labels;
+  float *inst, *det, *sig; int sig_ct, sig_off, pix_blocks;
+  int ps_blocks;
+};
+__global__ __launch_bounds__(256) void stage_head_kernel(StageHeadArgs a) {
+  __shared__ float red[3][64][2];
+  if ((int)blockIdx.x < a.ps_blocks) {
+    point_sample_body(blockIdx.x, a.feat, a.B, a.Cs, a.H, a.W, a.rois, a.N, a.S, a.scale, a.ps_out, a.CT);
+    return;
+  }
+  class_logits_body(blockIdx.x - a.ps_blocks, red, a.x, a.N, a.C, a.HW, a.wi, a.bi, a.wd, a.bd, a.num_classes, a.labels, a.inst,
+                    a.det, a.sig, a.sig_ct, a.sig_off, a.pix_blocks);
 }
 
 // K7 at twice the resolution of its input: logits of relu(upsample2x(x)) without the upsampled tensor (the last stage
@@ -303,7 +347,7 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict
     const long long t = idx / OWq;
     const int oy = (int)(t % OH);
     const long long nc = t / OH;
-    const float sy = ac ? rh * (float)oy : fmaxf(rh * ((float)oy + 0.5f) - 0.5f, 0.f);
+    const float sy = ac ? dm_mul_rn(rh, (float)oy) : fmaxf(rh * ((float)oy + 0.5f) - 0.5f, 0.f);      // (ac: a rounded product, see boundary_merge_kernel)
     const int y0 = (int)sy;
     const int y1 = y0 + ((y0 < H - 1) ? 1 : 0);
     const float ly = sy - (float)y0, hy = 1.f - ly;
@@ -313,7 +357,7 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int ox = xq * 4 + e;
-      const float sx = ac ? rw * (float)ox : fmaxf(rw * ((float)ox + 0.5f) - 0.5f, 0.f);
+      const float sx = ac ? dm_mul_rn(rw, (float)ox) : fmaxf(rw * ((float)ox + 0.5f) - 0.5f, 0.f);
       int x0 = (int)sx;
       x0 = min(x0, W - 1);
       const int x1 = x0 + ((x0 < W - 1) ? 1 : 0);
@@ -450,13 +494,109 @@ __global__ __launch_bounds__(256) void boundary_merge_kernel(const float* __rest
   float* f = fine + (size_t)r * OS * OS;
   for (int i = threadIdx.x; i < OS * OS; i += blockDim.x) {
     const int oy = i / OS, ox = i - oy * OS;
-    const float sy = rs * (float)oy, sx = rs * (float)ox;
+    const float sy = dm_mul_rn(rs, (float)oy), sx = dm_mul_rn(rs, (float)ox);      // (rounded products: no fma contraction with the subtraction below, as F.interpolate computes them, and the same bits in every kernel that merges)
     const int y0 = (int)sy, x0 = (int)sx;
     const int y1 = y0 + ((y0 < S - 1) ? 1 : 0), x1 = x0 + ((x0 < S - 1) ? 1 : 0);
     const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
-    const float nbv = hy * (hx * nb[y0 * S + x0] + lx * nb[y0 * S + x1]) + ly * (hx * nb[y1 * S + x0] + lx * nb[y1 * S + x1]);
+    // (the explicit fma chain of dm_up2x_interp: boundary_merge_chain_kernel below must produce the same bits)
+    const float nbv = dm_up2x_interp(hy, ly, hx, lx, nb[y0 * S + x0], nb[y0 * S + x1], nb[y1 * S + x0], nb[y1 * S + x1]);
     if (nbv >= 0.5f) {
-      f[i] = hy * (hx * cl[y0 * S + x0] + lx * cl[y0 * S + x1]) + ly * (hx * cl[y1 * S + x0] + lx * cl[y1 * S + x1]);
+      f[i] = dm_up2x_interp(hy, ly, hx, lx, cl[y0 * S + x0], cl[y0 * S + x1], cl[y1 * S + x0], cl[y1 * S + x1]);
+    }
+  }
+}
+
+// K15 for the whole inference tail in ONE launch (round 6): the two dependent merges S -> 2S -> 4S of
+// dynamask_roi_head.py:138-149 and, optionally, the final align_corners x2 upsample of the last stage's logits
+// (dynamask_head.py:240-243) that produces the 4S x 4S "fine" logits in the first place.  The launch sequence it replaces
+// -- upsample2x (instance), upsample2x (detail, unused by inference), boundary_merge(S), boundary_merge(2S) -- ran one
+// workgroup per RoI: 34 us for the 112 x 112 merge whether 16 or 100 RoIs, behind the join of the RoI streams.
+// Here a workgroup owns a band of MC_ROWS output rows of one RoI and recomputes what the band depends on: the
+// coarsest logits whole (S x S: 784 floats), the merged 2S x 2S rows its outputs interpolate between plus one halo row
+// either side (the 3 x 3 boundary stencil), nothing else.  The merged 2S x 2S logits are NOT written back: the
+// reference overwrites them in place, but they are temporaries there (only the 4S x 4S result is used).
+// Every value is computed by the expressions of boundary_merge_kernel / upsample2x_kernel, operand for operand: the
+// result has the bits of the four launches it replaces.
+constexpr int MC_ROWS = 16;
+__device__ __forceinline__ bool mc_boundary(const float* __restrict__ cl, int rows_lo, int rows_hi, int row_off, int S, int y, int x) {
+  // generate_block_target(boundary_width=1) on the mask sigmoid(cl) >= 0.5 (see boundary_merge_kernel); rows of the image
+  // are [rows_lo, rows_hi), the LDS copy starts at image row row_off
+  const bool m = sigmoidf_(cl[(y - row_off) * S + x]) >= 0.5f;
+  int sum_in = 0;
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int yy = y + dy, xx = x + dx;
+      if (yy >= rows_lo && yy < rows_hi && xx >= 0 && xx < S) sum_in += (sigmoidf_(cl[(yy - row_off) * S + xx]) >= 0.5f) ? 1 : 0;
+    }
+  return (m && sum_in < 9) || (!m && sum_in > 0);
+}
+
+__global__ __launch_bounds__(256) void boundary_merge_chain_kernel(const float* __restrict__ p1, const float* __restrict__ p2,
+                                                                   const float* __restrict__ fin2, float* __restrict__ out4,
+                                                                   int n, int S, int bands) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int S2 = 2 * S, S4 = 4 * S;
+  const int r = blockIdx.x / bands, band = blockIdx.x - r * bands;
+  const int oy0 = band * MC_ROWS, oy1 = min(oy0 + MC_ROWS, S4);
+  const float rs1 = S2 > 1 ? (float)(S - 1) / (float)(S2 - 1) : 0.f;
+  const float rs2 = S4 > 1 ? (float)(S2 - 1) / (float)(S4 - 1) : 0.f;
+  // rows of the 2S grid the band's outputs interpolate between, and one halo row either side for their 3 x 3 stencils
+  const int ya = (int)dm_mul_rn(rs2, (float)oy0);
+  const int yl = (int)dm_mul_rn(rs2, (float)(oy1 - 1));
+  const int yb = yl + ((yl < S2 - 1) ? 1 : 0);
+  const int ra = max(ya - 1, 0), rb = min(yb + 1, S2 - 1);
+  const int mrows = rb - ra + 1, nrows = yb - ya + 1;
+  float* cl1 = lds;                       // [S * S]      coarsest logits
+  float* nb1 = cl1 + S * S;               // [S * S]      1 = not a boundary pixel
+  float* m2 = nb1 + S * S;                // [mrows * 2S] merged 2S logits, image rows ra .. rb
+  float* nb2 = m2 + (MC_ROWS / 2 + 5) * S2;  // [nrows * 2S] rows ya .. yb
+  const float* c1 = p1 + (size_t)r * S * S;
+  for (int i = threadIdx.x; i < S * S; i += blockDim.x) cl1[i] = c1[i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < S * S; i += blockDim.x) {
+    const int y = i / S, x = i - y * S;
+    nb1[i] = mc_boundary(cl1, 0, S, 0, S, y, x) ? 0.f : 1.f;
+  }
+  __syncthreads();
+  const float* f2 = p2 + (size_t)r * S2 * S2;
+  for (int i = threadIdx.x; i < mrows * S2; i += blockDim.x) {
+    const int yy = i / S2, ox = i - yy * S2, oy = ra + yy;
+    const float sy = dm_mul_rn(rs1, (float)oy), sx = dm_mul_rn(rs1, (float)ox);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + ((y0 < S - 1) ? 1 : 0), x1 = x0 + ((x0 < S - 1) ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    const float nbv = dm_up2x_interp(hy, ly, hx, lx, nb1[y0 * S + x0], nb1[y0 * S + x1], nb1[y1 * S + x0], nb1[y1 * S + x1]);
+    float v = f2[oy * S2 + ox];
+    if (nbv >= 0.5f) v = dm_up2x_interp(hy, ly, hx, lx, cl1[y0 * S + x0], cl1[y0 * S + x1], cl1[y1 * S + x0], cl1[y1 * S + x1]);
+    m2[i] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nrows * S2; i += blockDim.x) {
+    const int yy = i / S2, x = i - yy * S2;
+    nb2[i] = mc_boundary(m2, 0, S2, ra, S2, ya + yy, x) ? 0.f : 1.f;
+  }
+  __syncthreads();
+  float* o = out4 + (size_t)r * S4 * S4;
+  const float* f4 = fin2 ? fin2 + (size_t)r * S2 * S2 : nullptr;
+  for (int i = threadIdx.x; i < (oy1 - oy0) * S4; i += blockDim.x) {
+    const int yy = i / S4, ox = i - yy * S4, oy = oy0 + yy;
+    const float sy = dm_mul_rn(rs2, (float)oy), sx = dm_mul_rn(rs2, (float)ox);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + ((y0 < S2 - 1) ? 1 : 0), x1 = x0 + ((x0 < S2 - 1) ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    const float* nr0 = nb2 + (y0 - ya) * S2;
+    const float* nr1 = nb2 + (y1 - ya) * S2;
+    const float nbv = dm_up2x_interp(hy, ly, hx, lx, nr0[x0], nr0[x1], nr1[x0], nr1[x1]);
+    if (nbv >= 0.5f) {
+      const float* mr0 = m2 + (y0 - ra) * S2;
+      const float* mr1 = m2 + (y1 - ra) * S2;
+      o[oy * S4 + ox] = dm_up2x_interp(hy, ly, hx, lx, mr0[x0], mr0[x1], mr1[x0], mr1[x1]);
+    } else if (f4) {
+      // the fine logits do not exist yet: upsample2x_kernel's align_corners value of the last stage's 2S x 2S logits
+      // (same source coordinates: its ratio (H - 1) / (OH - 1) is rs2, and min(x0, W - 1) never binds for ox < 4S)
+      o[oy * S4 + ox] = dm_up2x_interp(hy, ly, hx, lx, f4[y0 * S2 + x0], f4[y0 * S2 + x1], f4[y1 * S2 + x0], f4[y1 * S2 + x1]);
     }
   }
 }
@@ -759,6 +899,28 @@ extern "C" int dm_class_logits_fwd(const float* x, int N, int C, int HW, const f
   return dm_check_launch();
 }
 
+// (ABI 25) dm_point_sample_fwd + dm_class_logits_fwd of one SFM stage as one launch (see stage_head_kernel).
+extern "C" int dm_stage_head_fwd(const float* sem, int B, int Cs, int H, int W, const float* rois, int N, int S, float spatial_scale,
+                                 float* sampled, const float* x, int C, const float* w_inst, const float* b_inst, const float* w_det,
+                                 const float* b_det, int num_classes, const int64_t* labels, float* inst, float* det, float* sig_out,
+                                 int sig_ch_total, int sig_ch_offset, dm_stream_t stream) {
+  if (!sem || !rois || !sampled || B <= 0 || Cs <= 0 || H <= 0 || W <= 0 || N < 0 || S <= 0) return DM_ERR_INVALID_ARG;
+  if (!x || !w_inst || !b_inst || !w_det || !b_det || !labels || !inst || !det || C <= 0 || num_classes <= 0) return DM_ERR_INVALID_ARG;
+  if (sig_out && (sig_ch_offset < 0 || sig_ch_offset + 2 > sig_ch_total)) return DM_ERR_INVALID_ARG;
+  if (N == 0) return DM_OK;
+  StageHeadArgs a;
+  a.feat = sem; a.B = B; a.Cs = Cs; a.H = H; a.W = W; a.rois = rois; a.N = N; a.S = S; a.scale = spatial_scale; a.ps_out = sampled;
+  a.CT = 16;
+  a.x = x; a.C = C; a.HW = S * S; a.wi = w_inst; a.bi = b_inst; a.wd = w_det; a.bd = b_det; a.num_classes = num_classes;
+  a.labels = labels; a.inst = inst; a.det = det; a.sig = sig_out; a.sig_ct = sig_ch_total; a.sig_off = sig_ch_offset;
+  a.pix_blocks = dm_ceil_div(S * S, 64);
+  const long long ps = (((long long)N * S * S + 255) / 256) * dm_ceil_div(Cs, a.CT), cl = (long long)N * a.pix_blocks;
+  if (ps + cl > 0x7fffffffLL) return DM_ERR_UNSUPPORTED;
+  a.ps_blocks = (int)ps;
+  DM_LAUNCH(stage_head_kernel, dim3((unsigned)(ps + cl)), dim3(256), 0, (hipStream_t)stream, a);
+  return dm_check_launch();
+}
+
 extern "C" int dm_class_logits_up2x_fwd(const float* x, int N, int C, int H, int W, const float* w_inst, const float* b_inst,
                                         const float* w_det, const float* b_det, int num_classes, const int64_t* labels,
                                         float* inst, float* det, dm_stream_t stream) {
@@ -796,6 +958,21 @@ extern "C" int dm_boundary_merge(const float* coarse, float* fine, int n, int S,
   if (n == 0) return DM_OK;
   DM_LAUNCH(boundary_merge_kernel, dim3(n), dim3(256), 2 * S * S * sizeof(float), (hipStream_t)stream, coarse,
                      fine, n, S);
+  return dm_check_launch();
+}
+
+// (ABI 25) The inference tail in one launch: out_4s = merge(merge(p_s -> p_2s) -> fine), fine = the align_corners x2
+// upsample of final_2s when that is given (then out_4s is write-only), else out_4s itself (merged in place).
+extern "C" int dm_boundary_merge_chain(const float* p_s, const float* p_2s, const float* final_2s, float* out_4s, int n, int S,
+                                       dm_stream_t stream) {
+  if (!p_s || !p_2s || !out_4s || n < 0 || S <= 1) return DM_ERR_INVALID_ARG;
+  const size_t lds_bytes = sizeof(float) * ((size_t)2 * S * S + (size_t)(MC_ROWS / 2 + 5) * 2 * S * 2);
+  if (lds_bytes > 64 * 1024) return DM_ERR_UNSUPPORTED;
+  if (n == 0) return DM_OK;
+  const int bands = dm_ceil_div(4 * S, MC_ROWS);
+  if ((long long)n * bands > 0x7fffffffLL) return DM_ERR_UNSUPPORTED;
+  DM_LAUNCH(boundary_merge_chain_kernel, dim3((unsigned)(n * bands)), dim3(256), lds_bytes, (hipStream_t)stream, p_s, p_2s, final_2s,
+            out_4s, n, S, bands);
   return dm_check_launch();
 }
 

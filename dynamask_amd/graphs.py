@@ -75,8 +75,7 @@ class GraphedMaskLogits:
         head = self.head
 
         def run():
-            res = head._mask_forward(x, rois, labels)
-            return head.merge_stage_preds(res['stage_instance_preds'])
+            return head._merged_logits(x, rois, labels)
         with torch.no_grad():
             # once eagerly on a side stream: packs the weights and sizes the allocator before the capture
             s = torch.cuda.Stream(device=dev)

@@ -146,25 +146,64 @@ class SFMStage(nn.Module):
         return self.semantic_transform_in.run(semantic_feat, relu=True)
 
     def forward(self, instance_feats, semantic_feat, rois, roi_labels, upsample=True, sem=None, pred_out=None):
+        return run_steps(self.steps(instance_feats, semantic_feat, rois, roi_labels, upsample, sem, pred_out))
+
+    def steps(self, instance_feats, semantic_feat, rois, roi_labels, upsample=True, sem=None, pred_out=None, sem_ready=None):
+        """``forward`` as a generator that yields after every launch (``run_steps`` exhausts it): a caller that runs
+        several RoI chunks on several streams issues their launches in turn (roi_head._mask_forward_infer), so that
+        no stream waits for the host -- or for the graph's node order -- to get through another stream's whole chain.
+        ``sem_ready``: an event recorded behind the launch that produces ``sem`` on another stream."""
         n, c, s = instance_feats.shape[0], self.instance_in_channel, self.out_size
         co = self.instance_out_channel
         # instance-wise semantic feats: relu(conv1x1) on the whole FPN map, then point sample
         if sem is None:
             sem = self.semantic_map(semantic_feat)
-        ins_sem = ops.point_sample(sem, rois, s, self.spatial_scale)
+            yield
+        elif sem_ready is not None:
+            torch.cuda.current_stream(instance_feats.device).wait_event(sem_ready)
         # [fused_feats(co-2) | sigmoid(ip) | sigmoid(dp)] is assembled in place
         tail = torch.empty((n, co, s, s), device=instance_feats.device, dtype=torch.float32)
         nc = self.num_classes
-        ip, dp = ops.class_logits(instance_feats, self.instance_logits.weight.detach().view(nc, c),
-                                  self.instance_logits.bias.detach(), self.detail_logits.weight.detach().view(nc, c),
-                                  self.detail_logits.bias.detach(), roi_labels, sig_out=tail, sig_ch_offset=co - 2,
-                                  out=pred_out)
+        logit_args = (instance_feats, self.instance_logits.weight.detach().view(nc, c), self.instance_logits.bias.detach(),
+                      self.detail_logits.weight.detach().view(nc, c), self.detail_logits.bias.detach(), roi_labels)
+        if FUSED_STAGE_HEAD[0] and n > 0:
+            # the point sample and the two class-gathered logits share no data: one launch (ops.stage_head, same bits)
+            ins_sem, ip, dp = ops.stage_head(sem, rois, s, self.spatial_scale, *logit_args, sig_out=tail, sig_ch_offset=co - 2,
+                                             out=pred_out)
+            yield
+        else:
+            ins_sem = ops.point_sample(sem, rois, s, self.spatial_scale)
+            yield
+            ip, dp = ops.class_logits(*logit_args, sig_out=tail, sig_ch_offset=co - 2, out=pred_out)
+            yield
         fused = self.fuse_conv[0].run([instance_feats, ins_sem, tail[:, co - 2:]], relu=True)
-        fused = self.fuse_conv[1](fused, relu=True)
+        yield
+        dcn = self.fuse_conv[1]
+        offset = dcn.conv_offset.run(fused)
+        yield
+        wp = dcn._pk.get('w', dcn.weight, ops.pack_conv_weight, job=(False, None, None, None))
+        fused = ops.deform_conv(fused, offset, wp, dcn.out_channels, dcn.deform_groups, relu=True)
+        yield
         self.fuse_transform_out.run(fused, relu=True, out=tail, out_ch_offset=0)
+        yield
         if upsample:
             tail = ops.upsample2x(tail, align_corners=False, relu=True)
+            yield
         return ip, dp, tail
+
+
+# inference launches fused in round 6 (A/B switches for tools/infer_bench.py and the equality tests; same bits either way)
+import os as _os
+FUSED_STAGE_HEAD = [_os.environ.get('DM_FUSED_STAGE_HEAD', '1') != '0']      # point sample + class logits: one launch per stage
+
+
+def run_steps(gen):
+    """Exhaust a ``steps`` generator and hand back what it returns."""
+    try:
+        while True:
+            next(gen)
+    except StopIteration as e:
+        return e.value
 
 
 def _paste_geometry(det_bboxes, ori_shape, scale_factor, rescale):
@@ -265,13 +304,14 @@ class DynaMaskHead(nn.Module):
                 dcn._pk.get('w', dcn.weight, ops.pack_conv_weight, job=(False, None, None, None))
             stage.fuse_transform_out.packed([dcn.out_channels])
 
-    def pred_sizes(self, last_stage=None):
+    def pred_sizes(self, last_stage=None, defer_final_up=False):
         """Spatial size of every (instance, detail) logit pair ``forward`` returns, in order."""
         n = len(self.stages) if last_stage is None else min(last_stage, len(self.stages))
         sizes = [self.stages[i].out_size for i in range(n)]
         if last_stage is not None and last_stage < len(self.stages):
             return sizes + [self.stages[last_stage].out_size]
-        return sizes + [2 * self.stages[-1].out_size]
+        last = 2 * self.stages[-1].out_size
+        return sizes + [last // 2 if (defer_final_up and not self.pre_upsample_last_stage) else last]
 
     def forward(self, instance_feats, semantic_feats, rois, roi_labels, last_stage=None, sems=None, pred_out=None):
         """Returns (stage_instance_preds, stage_detail_preds) as the reference.
@@ -281,9 +321,22 @@ class DynaMaskHead(nn.Module):
         ``sems`` (extension): precomputed ``semantic_maps`` (multi-stream inference).
         ``pred_out`` (extension): one ``(instance, detail)`` pair of [N, 1, S, S] tensors per returned logit pair
         (``pred_sizes``) to write into -- the row slices of a chunked, multi-stream caller's buffers."""
+        return run_steps(self.steps(instance_feats, semantic_feats, rois, roi_labels, last_stage, sems, pred_out))
+
+    def steps(self, instance_feats, semantic_feats, rois, roi_labels, last_stage=None, sems=None, pred_out=None, sem_ready=None,
+              extract=None, defer_final_up=False):
+        """``forward`` as a generator that yields after every launch (see ``SFMStage.steps``).  ``sem_ready``: per stage,
+        the event behind the launch that produces ``sems[idx]`` on another stream (None: same stream).  ``extract``: a
+        callable producing ``instance_feats`` -- the RoI extraction as the chain's first step.  ``defer_final_up``: hand
+        back the last stage's logits at ITS resolution (2S) -- the caller folds their align_corners x2 upsample into the
+        boundary merge (ops.boundary_merge_chain)."""
+        if extract is not None:
+            instance_feats = extract()
+            yield
         po = (lambda i: None) if pred_out is None else (lambda i: pred_out[i])
         for conv in self.instance_convs:
             instance_feats = conv(instance_feats)
+            yield
         stage_instance_preds, stage_detail_preds = [], []
         roi_labels = roi_labels.long().contiguous()
         fused_exit = False
@@ -303,24 +356,29 @@ class DynaMaskHead(nn.Module):
             # the stage's own resolution instead (ops.class_logits_up2x), the upsampled tensor never exists
             fused_exit = (last_stage is not None and idx + 1 == last_stage and idx + 1 < len(self.stages) and upsample_flag
                           and not torch.is_grad_enabled() and ops.class_logits_up2x_supported(instance_feats))
-            ip, dp, instance_feats = stage(instance_feats, semantic_feats[-idx - 3], rois, roi_labels,
-                                           upsample_flag and not fused_exit,
-                                           sem=None if sems is None else sems[idx], pred_out=po(idx))
+            ip, dp, instance_feats = yield from stage.steps(
+                instance_feats, semantic_feats[-idx - 3], rois, roi_labels, upsample_flag and not fused_exit,
+                sem=None if sems is None else sems[idx], pred_out=po(idx),
+                sem_ready=None if sem_ready is None else sem_ready[idx])
             stage_instance_preds.append(ip)
             stage_detail_preds.append(dp)
-        if self.stage_num_classes[-1] == 1:
-            roi_labels = roi_labels.clamp(max=0)
+        # (dynamask_head.py:236-237 clamps the labels to 0 for the class-agnostic last stage: the kernel clamps every
+        # label into [0, num_classes - 1] itself, which for one class is that clamp -- no torch launch for it)
         nc = self.stage_num_classes[-1]
         c = self.final_instance_logits.in_channels
+        direct = self.pre_upsample_last_stage or defer_final_up
         ip, dp = ops.class_logits(instance_feats, self.final_instance_logits.weight.detach().view(nc, c),
                                   self.final_instance_logits.bias.detach(),
                                   self.final_detail_logits.weight.detach().view(nc, c),
                                   self.final_detail_logits.bias.detach(), roi_labels,
-                                  out=po(len(self.stages)) if self.pre_upsample_last_stage else None)
-        if not self.pre_upsample_last_stage:
+                                  out=po(len(self.stages)) if direct else None)
+        yield
+        if not direct:
             fin = po(len(self.stages))
             ip = ops.upsample2x(ip, align_corners=True, out=None if fin is None else fin[0])
+            yield
             dp = ops.upsample2x(dp, align_corners=True, out=None if fin is None else fin[1])
+            yield
         stage_instance_preds.append(ip)
         stage_detail_preds.append(dp)
         return stage_instance_preds, stage_detail_preds

@@ -676,6 +676,65 @@ def boundary_merge_(coarse, fine):
     return fine
 
 
+def boundary_merge_chain(p_s, p_2s, fine_or_final, out=None):
+    """The inference tail in one launch (dm_boundary_merge_chain): ``merge(merge(p_s -> p_2s) -> fine)``.
+    ``fine_or_final``: the [n, 1, 4S, 4S] fine logits (merged in place and returned), or the last stage's [n, 1, 2S, 2S]
+    logits -- then the fine logits are their align_corners x2 upsample, computed inside the kernel, and the result goes
+    to ``out`` (allocated if None).  ``p_2s`` is not modified."""
+    _chk(p_s, 'p_s')
+    _chk(p_2s, 'p_2s')
+    _chk(fine_or_final, 'fine_or_final')
+    n, S = p_s.shape[0], p_s.shape[-1]
+    assert p_s.shape[-2] == S and tuple(p_2s.shape[-2:]) == (2 * S, 2 * S) and p_2s.shape[0] == n == fine_or_final.shape[0]
+    if n == 0:
+        return fine_or_final if fine_or_final.shape[-1] == 4 * S else p_s.new_zeros((0, 1, 4 * S, 4 * S))
+    if fine_or_final.shape[-1] == 4 * S:
+        assert out is None or out is fine_or_final
+        check(lib().dm_boundary_merge_chain(_p(p_s), _p(p_2s), None, _p(fine_or_final), n, S, _stream()), 'dm_boundary_merge_chain')
+        return fine_or_final
+    assert tuple(fine_or_final.shape[-2:]) == (2 * S, 2 * S)
+    if out is None:
+        out = torch.empty((n, 1, 4 * S, 4 * S), device=p_s.device, dtype=torch.float32)
+    else:
+        _chk(out, 'out')
+        assert out.shape[0] == n and tuple(out.shape[-2:]) == (4 * S, 4 * S)
+    check(lib().dm_boundary_merge_chain(_p(p_s), _p(p_2s), _p(fine_or_final), _p(out), n, S, _stream()), 'dm_boundary_merge_chain')
+    return out
+
+
+def stage_head(sem, rois, output_size, spatial_scale, x, w_inst, b_inst, w_det, b_det, labels, sig_out=None, sig_ch_offset=0, out=None):
+    """``point_sample(sem, rois, output_size, spatial_scale)`` and ``class_logits(x, ..., sig_out, sig_ch_offset, out)`` of
+    one SFM stage as ONE launch (dm_stage_head_fwd) -> (sampled, inst, det)."""
+    _chk(sem, 'sem')
+    _chk(rois, 'rois')
+    _chk(x, 'x')
+    for t, n_ in ((w_inst, 'w_inst'), (b_inst, 'b_inst'), (w_det, 'w_det'), (b_det, 'b_det')):
+        _chk(t, n_)
+    _chk(labels, 'labels', torch.int64)
+    B, Cs, H, W = sem.shape
+    N, C, S, S2 = x.shape
+    assert S == S2 == output_size and rois.shape[0] == N
+    nc = w_inst.shape[0]
+    sampled = torch.empty((N, Cs, S, S), device=x.device, dtype=torch.float32)
+    if out is None:
+        inst = torch.empty((N, 1, S, S), device=x.device, dtype=torch.float32)
+        det = torch.empty((N, 1, S, S), device=x.device, dtype=torch.float32)
+    else:
+        inst, det = out
+        for t, nm in ((inst, 'out[0]'), (det, 'out[1]')):
+            _chk(t, nm)
+            assert tuple(t.shape) == (N, 1, S, S)
+    sig_ct = 0
+    if sig_out is not None:
+        _chk(sig_out, 'sig_out')
+        assert sig_out.shape[0] == N and sig_out.shape[2:] == x.shape[2:]
+        sig_ct = sig_out.shape[1]
+    check(lib().dm_stage_head_fwd(_p(sem), B, Cs, H, W, _p(rois), N, S, spatial_scale, _p(sampled), _p(x), C, _p(w_inst), _p(b_inst),
+                                  _p(w_det), _p(b_det), nc, _p(labels), _p(inst), _p(det), _p(sig_out), sig_ct, sig_ch_offset,
+                                  _stream()), 'dm_stage_head_fwd')
+    return sampled, inst, det
+
+
 def gumbel_select(logits, U, temperature=0.5):
     _chk(logits, 'logits')
     _chk(U, 'U')

@@ -31,6 +31,8 @@ def bbox2roi(bbox_list):
     return torch.cat(rois_list, 0)
 
 
+# inference: the final x2 upsample + both boundary merges as one launch per RoI chunk (0: the four launches, same bits)
+FUSED_MERGE_TAIL = [os.environ.get('DM_FUSED_MERGE_TAIL', '1') != '0']
 # training: MaskPre's conv1 on the P2 map + a 128-channel extraction (train_path.MaskPreMapFn); 0 = the reference's order
 _MASKPRE_ON_MAP = os.environ.get('DM_MASKPRE_MAP', '1') != '0'
 
@@ -149,6 +151,7 @@ class DynaMaskRoIHead(nn.Module):
         # inference: RoI chunks on separate HIP streams (see _mask_forward)
         self.num_streams = 2
         self.stream_split_min = 64           # (100 detections to 112x112: 2.34 ms on one stream, 2.27 split over two; 32: no further gain)
+        self.overlap_semantic_maps = os.environ.get('DM_SEM_OVERLAP', '1') != '0'      # the FPN-wide 1x1 convs beside the RoI chains
 
     def init_assigner_sampler(self):
         """standard_roi_head.py:13-20."""
@@ -184,20 +187,50 @@ class DynaMaskRoIHead(nn.Module):
         with ops.splitk_scope():           # inference: launches of few workgroups may split their K loop
             return self._mask_forward_infer(x, rois, roi_labels, last_stage)
 
-    def _mask_forward_infer(self, x, rois, roi_labels, last_stage=None):
+    def _mask_forward_infer(self, x, rois, roi_labels, last_stage=None, merge=False):
+        """Inference: the RoIs are independent, so they are split into chunks on separate HIP streams (the tail of every
+        kernel -- its last, partially filled round of workgroups over the 256 CUs -- overlaps the other chunk's work),
+        and the FPN-wide semantic maps (``relu(semantic_transform_in(P_l))``, which no RoI enters) run on a stream of
+        their own BESIDE the chains instead of in front of them: a chain waits for map k only in front of stage k's
+        point sample.  The chains' launches are issued in turn (``DynaMaskHead.steps``): issued one chain after the
+        other -- eagerly, or as the node order of a captured graph -- the second chain started ~35 launches late."""
+        from .mask_heads import run_steps
         n = rois.shape[0]
+        if merge:
+            return self._mask_forward_merged(x, rois, roi_labels)
         n_streams = self.num_streams if n >= self.stream_split_min else 1
+        head, ext = self.mask_head, self.mask_roi_extractor
+        dev = rois.device
+        cur = torch.cuda.current_stream(dev)
+        if not self.overlap_semantic_maps:
+            if n_streams <= 1:
+                ins_feats = ext(x[:ext.num_inputs], rois)
+                ips, dps = head(ins_feats, x, rois, roi_labels, last_stage=last_stage)
+                return dict(stage_instance_preds=ips, stage_detail_preds=dps)
+        head.prepack()                 # packs are cached by whoever asks first: before the fork, on this stream
+        n_sem = len(head.stages) if last_stage is None else min(last_stage, len(head.stages))
+        # the semantic maps: outputs allocated here (the caller's stream owns the memory), produced on the pool's last stream
+        sems, sem_ready = [], []
+        sem_stream = self._side_streams(n_streams + 1, dev)[-1] if self.overlap_semantic_maps else cur
+        if sem_stream is not cur:
+            sem_stream.wait_stream(cur)
+        for i in range(n_sem):
+            st_ = head.stages[i]
+            f = x[-i - 3]
+            out = torch.empty((f.shape[0], st_.semantic_transform_in.out_channels, f.shape[2], f.shape[3]), device=dev,
+                              dtype=torch.float32)
+            with torch.cuda.stream(sem_stream), ops.overlapped_streams():
+                st_.semantic_transform_in.run(f, relu=True, out=out)
+                sem_ready.append(sem_stream.record_event() if sem_stream is not cur else None)
+            sems.append(out)
         if n_streams <= 1:
-            ins_feats = self.mask_roi_extractor(x[:self.mask_roi_extractor.num_inputs], rois)
-            ips, dps = self.mask_head(ins_feats, x, rois, roi_labels, last_stage=last_stage)
+            gen = head.steps(None, x, rois, roi_labels, last_stage=last_stage, sems=sems, sem_ready=sem_ready,
+                             extract=lambda: ext(x[:ext.num_inputs], rois))
+            ips, dps = run_steps(gen)
+            if sem_stream is not cur:
+                cur.wait_stream(sem_stream)
             return dict(stage_instance_preds=ips, stage_detail_preds=dps)
-        # RoIs are independent: split them over HIP streams so that the tail of every kernel
-        # (its last, partially filled round of workgroups over the 256 CUs) overlaps the other
-        # chunk's work.  The FPN-wide semantic maps are computed once and shared.
-        cur = torch.cuda.current_stream()
-        streams = self._side_streams(n_streams, rois.device)
-        sems = self.mask_head.semantic_maps(x, last_stage)
-        self.mask_head.prepack()                 # packs are cached by whoever asks first: before the fork, on this stream
+        streams = self._side_streams(n_streams, dev)
         split = getattr(self, 'stream_split', None)      # optional cumulative fractions, e.g. (0.4, 1.0)
         if split is not None and len(split) == n_streams:
             bounds = [0] + [round(f * n) for f in split]
@@ -205,21 +238,88 @@ class DynaMaskRoIHead(nn.Module):
             bounds = [round(i * n / n_streams) for i in range(n_streams + 1)]
         # every chunk writes its rows of the logit tensors in place (allocated here, on the caller's stream, before
         # the fork): no concatenation after the join
-        sizes = self.mask_head.pred_sizes(last_stage)
-        ips = [torch.empty((n, 1, s_, s_), device=rois.device, dtype=torch.float32) for s_ in sizes]
-        dps = [torch.empty((n, 1, s_, s_), device=rois.device, dtype=torch.float32) for s_ in sizes]
+        sizes = head.pred_sizes(last_stage)
+        ips = [torch.empty((n, 1, s_, s_), device=dev, dtype=torch.float32) for s_ in sizes]
+        dps = [torch.empty((n, 1, s_, s_), device=dev, dtype=torch.float32) for s_ in sizes]
+        chains = []
         for st, lo, hi in zip(streams, bounds[:-1], bounds[1:]):
             if hi <= lo:
                 continue
             st.wait_stream(cur)
-            with torch.cuda.stream(st), ops.overlapped_streams():
-                r, l = rois[lo:hi], roi_labels[lo:hi]
-                ins = self.mask_roi_extractor(x[:self.mask_roi_extractor.num_inputs], r)
-                self.mask_head(ins, x, r, l, last_stage=last_stage, sems=sems,
-                               pred_out=[(a[lo:hi], b[lo:hi]) for a, b in zip(ips, dps)])
+            r, l = rois[lo:hi], roi_labels[lo:hi]
+            gen = head.steps(None, x, r, l, last_stage=last_stage, sems=sems, sem_ready=sem_ready,
+                             pred_out=[(a[lo:hi], b[lo:hi]) for a, b in zip(ips, dps)],
+                             extract=(lambda r=r: ext(x[:ext.num_inputs], r)))
+            chains.append((st, gen))
+        while chains:                   # one launch of every chain in turn
+            for st, gen in list(chains):
+                with torch.cuda.stream(st), ops.overlapped_streams():
+                    try:
+                        next(gen)
+                    except StopIteration:
+                        chains.remove((st, gen))
         for st in streams:
             cur.wait_stream(st)
+        if sem_stream is not cur:
+            cur.wait_stream(sem_stream)
         return dict(stage_instance_preds=ips, stage_detail_preds=dps)
+
+    def _mask_forward_merged(self, x, rois, roi_labels):
+        """``merge_stage_preds(_mask_forward(...)['stage_instance_preds'])`` for inference with the tail of every RoI
+        chunk folded into its chain: the last stage's logits stay at 56 x 56 and ONE launch per chunk does the final
+        align_corners x2 upsample and both boundary merges (ops.boundary_merge_chain; same bits as the four launches it
+        replaces).  Each chunk merges its own rows on its own stream, in front of the join, not behind it."""
+        from .mask_heads import run_steps
+        n = rois.shape[0]
+        head, ext = self.mask_head, self.mask_roi_extractor
+        dev = rois.device
+        cur = torch.cuda.current_stream(dev)
+        assert len(head.stages) == 3 and not head.pre_upsample_last_stage
+        n_streams = self.num_streams if n >= self.stream_split_min else 1
+        head.prepack()
+        sems, sem_ready = [], []
+        sem_stream = self._side_streams(n_streams + 1, dev)[-1] if self.overlap_semantic_maps else cur
+        if sem_stream is not cur:
+            sem_stream.wait_stream(cur)
+        for i in range(len(head.stages)):
+            st_ = head.stages[i]
+            f = x[-i - 3]
+            out = torch.empty((f.shape[0], st_.semantic_transform_in.out_channels, f.shape[2], f.shape[3]), device=dev,
+                              dtype=torch.float32)
+            with torch.cuda.stream(sem_stream), ops.overlapped_streams():
+                st_.semantic_transform_in.run(f, relu=True, out=out)
+                sem_ready.append(sem_stream.record_event() if sem_stream is not cur else None)
+            sems.append(out)
+        s_out = head.stage_sup_size[-1]
+        merged = torch.empty((n, 1, s_out, s_out), device=dev, dtype=torch.float32)
+
+        def chain(r, l, lo, hi):
+            ips, _ = yield from head.steps(None, x, r, l, sems=sems, sem_ready=sem_ready, defer_final_up=True,
+                                           extract=lambda: ext(x[:ext.num_inputs], r))
+            ops.boundary_merge_chain(ips[1], ips[2], ips[3], out=merged[lo:hi])
+            yield
+        if n_streams <= 1:
+            run_steps(chain(rois, roi_labels, 0, n))
+        else:
+            streams = self._side_streams(n_streams, dev)
+            bounds = [round(i * n / n_streams) for i in range(n_streams + 1)]
+            chains = []
+            for st, lo, hi in zip(streams, bounds[:-1], bounds[1:]):
+                if hi > lo:
+                    st.wait_stream(cur)
+                    chains.append((st, chain(rois[lo:hi], roi_labels[lo:hi], lo, hi)))
+            while chains:
+                for st, gen in list(chains):
+                    with torch.cuda.stream(st), ops.overlapped_streams():
+                        try:
+                            next(gen)
+                        except StopIteration:
+                            chains.remove((st, gen))
+            for st in streams:
+                cur.wait_stream(st)
+        if sem_stream is not cur:
+            cur.wait_stream(sem_stream)
+        return merged
 
     def _side_streams(self, k, device):
         """k streams for k RoI chunks, from the package's shared pool (streams.py: hardware queues are few)."""
@@ -420,9 +520,21 @@ class DynaMaskRoIHead(nn.Module):
             merged = graphs(x, mask_rois, det_labels)      # bucketed HIP-graph replay (graphs.py); None: too many RoIs
             if merged is not None:
                 return merged
+        return self._merged_logits(x, mask_rois, det_labels)
+
+    def _merged_logits(self, x, mask_rois, det_labels):
+        """The launch sequence of ``simple_test_mask_logits`` (what graphs.GraphedMaskLogits captures)."""
         # the reference chunks by 100 RoIs "to avoid memory overflow" (:132); 288 GB of HBM do not need it
+        if FUSED_MERGE_TAIL[0] and not torch.is_grad_enabled() and self._merged_tail_supported():
+            with ops.splitk_scope():
+                return self._mask_forward_infer(x, mask_rois, det_labels, merge=True)
         res = self._mask_forward(x, mask_rois, det_labels)
         return self.merge_stage_preds(res['stage_instance_preds'])
+
+    def _merged_tail_supported(self):
+        h = self.mask_head
+        return (len(h.stages) == 3 and not h.pre_upsample_last_stage
+                and list(h.stage_sup_size) == [h.stage_sup_size[0] * k for k in (1, 2, 4, 8)])
 
     def enable_inference_graphs(self, on=True, buckets=None):
         """Replay ``simple_test_mask_logits`` as a HIP graph per bucket of detection counts (16 / 32 / 64 / 100 by

@@ -53,7 +53,7 @@ extern "C" {
 typedef void* dm_stream_t; /* hipStream_t */
 
 const char* dm_error_string(int code);
-/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient, dm_conv_pack_weight_batch, dm_mask_loss_stage; 15: dm_class_logits_up2x_fwd; 16: dm_conv2d_wgrad_slab / dm_conv2d_wgrad_scratch_floats; 17: dm_class_logits_bwd_slab / dm_class_logits_bwd_scratch_floats; 18: dm_reload_env_knobs, dm_roi_align_fwd_ws / dm_roi_align_workspace_bytes, dm_conv_pack_weight_split / dm_conv_packed_floats_split and flag bits 4, 5 of dm_conv2d_fwd; 19: dm_dcn_bwd_data_fused and its pack; 20: dm_conv2d_fwd_ws / dm_conv2d_splitk_floats; 21: dm_deform_conv_fwd_ws / dm_deform_conv_splitk_floats; 22: the bf16-split layouts (dm_conv_pack_weight_split, dm_conv_packed_floats_split, flag bits 4 / 5 of dm_conv2d_fwd) and the one-kernel DCN data gradient (dm_dcn_bwd_*) REMOVED -- measured, never the parity path, see docs/HISTORY.md; 23: dm_bn_stats takes mean_shift, dm_roi_align_bwd takes the gather form for 16 < P <= 64; 24: dm_build_info). */
+/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient, dm_conv_pack_weight_batch, dm_mask_loss_stage; 15: dm_class_logits_up2x_fwd; 16: dm_conv2d_wgrad_slab / dm_conv2d_wgrad_scratch_floats; 17: dm_class_logits_bwd_slab / dm_class_logits_bwd_scratch_floats; 18: dm_reload_env_knobs, dm_roi_align_fwd_ws / dm_roi_align_workspace_bytes, dm_conv_pack_weight_split / dm_conv_packed_floats_split and flag bits 4, 5 of dm_conv2d_fwd; 19: dm_dcn_bwd_data_fused and its pack; 20: dm_conv2d_fwd_ws / dm_conv2d_splitk_floats; 21: dm_deform_conv_fwd_ws / dm_deform_conv_splitk_floats; 22: the bf16-split layouts (dm_conv_pack_weight_split, dm_conv_packed_floats_split, flag bits 4 / 5 of dm_conv2d_fwd) and the one-kernel DCN data gradient (dm_dcn_bwd_*) REMOVED -- measured, never the parity path, see docs/HISTORY.md; 23: dm_bn_stats takes mean_shift, dm_roi_align_bwd takes the gather form for 16 < P <= 64; 24: dm_build_info; 25: dm_boundary_merge_chain, dm_stage_head_fwd). */
 int dm_abi_version(void);
 /* "libdynamask_hip abi=N arch=gfx950 compiler=<clang version> flags=<the product-wide flags of dynamask_amd/build.py>"
  * (static storage).  The library must be compiled WITHOUT packed fp32 instructions (flag "-packed-fp32-ops", see
@@ -201,6 +201,14 @@ int dm_class_logits_fwd(const float* x, int N, int C, int HW, const float* w_ins
                         float* inst, float* det, float* sig_out, int sig_ch_total, int sig_ch_offset,
                         dm_stream_t stream);
 
+/* (ABI 25) One SFM stage's head in one launch: dm_point_sample_fwd(sem, rois -> sampled [N,Cs,S,S]) and
+ * dm_class_logits_fwd(x [N,C,S,S] -> inst, det (+ sigmoid slices of sig_out)) -- mmdet/models/roi_heads/mask_heads/
+ * dynamask_head.py:104-116; the two share no data, the kernel runs the two bodies in disjoint workgroup ranges (same bits). */
+int dm_stage_head_fwd(const float* sem, int B, int Cs, int H, int W, const float* rois, int N, int S, float spatial_scale,
+                      float* sampled, const float* x, int C, const float* w_inst, const float* b_inst, const float* w_det,
+                      const float* b_det, int num_classes, const int64_t* labels, float* inst, float* det, float* sig_out,
+                      int sig_ch_total, int sig_ch_offset, dm_stream_t stream);
+
 /* K7 on relu(upsample2x(x)) (bilinear, align_corners=False) without the upsampled tensor: the logits an exit needs when
  * the stage before it would only have been upsampled for them -- dynamask_head.py:120-122 (F.interpolate + relu) followed
  * by :110-113 of the next stage / :236-237.  x [N, C, H, W] (W even, H, W >= 2: else DM_ERR_UNSUPPORTED and the caller
@@ -252,6 +260,14 @@ int dm_upsample2x_bilinear_fwd(const float* in, int NC, int H, int W, int align_
  * the x2 align_corners=True upsampled non-boundary mask is >= 0.5).
  * ------------------------------------------------------------------------- */
 int dm_boundary_merge(const float* coarse, float* fine, int n, int S, dm_stream_t stream);
+/* (ABI 25) The whole inference tail of dynamask_roi_head.py:138-149 in ONE launch: the two dependent merges
+ * S -> 2S -> 4S and, when final_2s is given, the align_corners x2 upsample (dynamask_head.py:240-243,
+ * F.interpolate(..., scale_factor=2, align_corners=True)) that produces the 4S x 4S logits the second merge overwrites:
+ *   p_s [n,S,S], p_2s [n,2S,2S] (read only: the merged 2S logits are temporaries and are not written back),
+ *   final_2s [n,2S,2S] or NULL (then out_4s holds the fine logits on entry and is merged in place),  out_4s [n,4S,4S].
+ * Bits: those of dm_upsample2x_bilinear_fwd + dm_boundary_merge(S) + dm_boundary_merge(2S). */
+int dm_boundary_merge_chain(const float* p_s, const float* p_2s, const float* final_2s, float* out_4s, int n, int S,
+                            dm_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * K16  deconv 2x2 stride 2 (+bias, +ReLU): nn.ConvTranspose2d(C, Cout, 2, 2)

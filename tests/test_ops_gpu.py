@@ -308,6 +308,67 @@ def test_boundary_merge_matches_reference_golden(ops, golden_dir):
     _close(preds[-1], g['merged'], atol=1e-5, rtol=1e-5)
 
 
+def test_boundary_merge_chain_has_the_bits_of_the_launches_it_replaces(ops, golden_dir):
+    """dm_boundary_merge_chain (round 6): both merges of dynamask_roi_head.py:138-149 in one launch, with and without the
+    final align_corners x2 upsample folded in -- against g5 (the reference's own merge) and bit for bit against
+    dm_upsample2x_bilinear_fwd + dm_boundary_merge x 2, also at sizes where the bands are ragged."""
+    g = np.load(os.path.join(golden_dir, 'g5_merge.npz'))
+    ips = [_dev(t.clone()) for t in gi.merge_inputs()['ips']]
+    p28, p56, p112 = ips[1], ips[2], ips[3]
+    keep56 = p56.clone()
+    out = ops.boundary_merge_chain(p28, p56, p112.clone())
+    _close(out, g['merged'], atol=1e-5, rtol=1e-5)
+    assert torch.equal(p56, keep56)                                             # the 2S logits are not written back
+    seq56, seq112 = p56.clone(), p112.clone()
+    ops.boundary_merge_(p28, seq56)
+    ops.boundary_merge_(seq56, seq112)
+    assert torch.equal(out, seq112)
+    gen = torch.Generator().manual_seed(91)
+    for S, n in ((28, 7), (14, 3), (7, 2), (5, 4)):
+        a = _dev(torch.randn(n, 1, S, S, generator=gen) * 2)
+        b = _dev(torch.randn(n, 1, 2 * S, 2 * S, generator=gen) * 2)
+        fin = _dev(torch.randn(n, 1, 2 * S, 2 * S, generator=gen) * 2)
+        a[0, 0, :2, :2] = 0.0                                                  # exact ties of the sigmoid threshold
+        got = ops.boundary_merge_chain(a, b, fin)
+        assert tuple(got.shape) == (n, 1, 4 * S, 4 * S)
+        fine = ops.upsample2x(fin, align_corners=True)
+        b2 = b.clone()
+        ops.boundary_merge_(a, b2)
+        ops.boundary_merge_(b2, fine)
+        assert torch.equal(got, fine), S
+        # ... and against the oracle's merge of the same three tensors
+        ref = ref_model.boundary_merge([None, a.cpu(), b.cpu(), F.interpolate(fin.cpu(), scale_factor=2, mode='bilinear',
+                                                                              align_corners=True)])
+        bad = (got.cpu() - ref).abs() > 1e-4 + 1e-4 * ref.abs()
+        assert bad.float().mean() < 2e-3, (S, float(bad.float().mean()))      # (threshold ties of |logit| ~ 1e-7 may flip a 3x3 block)
+    assert ops.boundary_merge_chain(a[:0], b[:0], fin[:0]).shape[0] == 0
+
+
+def test_stage_head_launch_equals_point_sample_and_class_logits(ops):
+    """dm_stage_head_fwd (round 6) = dm_point_sample_fwd + dm_class_logits_fwd in one launch: same bits, at the three
+    stage shapes, with RoIs of two images, an out-of-range batch index and a label outside [0, classes)."""
+    gen = torch.Generator().manual_seed(92)
+    for C, S, Cs, H, W in ((256, 14, 256, 50, 84), (128, 28, 128, 100, 168), (64, 56, 64, 40, 60)):
+        n = 9
+        sem = _dev(torch.randn(2, Cs, H, W, generator=gen))
+        x = _dev(torch.randn(n, C, S, S, generator=gen))
+        rois = torch.cat([torch.randint(0, 2, (n, 1), generator=gen).float(), torch.rand(n, 2, generator=gen) * 100,
+                          torch.rand(n, 2, generator=gen) * 200 + 100], 1)
+        rois[3, 0] = 5.0                                                           # no such image: zero rows
+        rois = _dev(rois)
+        labels = torch.randint(0, 80, (n,), generator=gen)
+        labels[1] = 93
+        labels = labels.cuda()
+        wi, bi, wd, bd = (_dev(torch.randn(80, C, generator=gen)), _dev(torch.randn(80, generator=gen)),
+                          _dev(torch.randn(80, C, generator=gen)), _dev(torch.randn(80, generator=gen)))
+        sig_a = torch.zeros(n, C // 2, S, S, device='cuda')
+        sig_b = torch.zeros_like(sig_a)
+        ps = ops.point_sample(sem, rois, S, 0.25)
+        ip, dp = ops.class_logits(x, wi, bi, wd, bd, labels, sig_out=sig_a, sig_ch_offset=C // 2 - 2)
+        ps2, ip2, dp2 = ops.stage_head(sem, rois, S, 0.25, x, wi, bi, wd, bd, labels, sig_out=sig_b, sig_ch_offset=C // 2 - 2)
+        assert torch.equal(ps, ps2) and torch.equal(ip, ip2) and torch.equal(dp, dp2) and torch.equal(sig_a, sig_b)
+
+
 def test_gumbel_selector_matches_reference_golden(ops, golden_dir):
     g = np.load(os.path.join(golden_dir, 'g3_gumbel.npz'))
     logits = gi.gumbel_logits()

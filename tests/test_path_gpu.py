@@ -112,6 +112,34 @@ def test_simple_test_mask_logits_vs_oracle():
     assert float(tied.float().mean()) < 1e-2
 
 
+def test_fused_inference_launches_give_the_bits_of_the_unfused_sequence():
+    """Round 6: simple_test_mask_logits with the stage heads and the merge tail fused (the default) against the launch
+    sequence of round 5 (DM_FUSED_STAGE_HEAD / DM_FUSED_MERGE_TAIL switches), one stream and two, eager and as the
+    bucketed HIP graph: bit for bit."""
+    from dynamask_amd import mask_heads, roi_head
+    hi = gi.head_inputs()
+    m = _roi_head()
+    feats = [_dev(f) for f in hi['feats']]
+    boxes, labels = _dev(hi['rois'][:, 1:].contiguous()), _dev(hi['labels'])
+    sel = hi['rois'][:, 0] == 0
+    boxes, labels = boxes[_dev(sel)].contiguous(), labels[_dev(sel)].contiguous()
+    outs = {}
+    with torch.no_grad():
+        for split_min in (64, 2):                 # one chain / two chains on two streams
+            m.stream_split_min = split_min
+            for fused in (False, True):
+                mask_heads.FUSED_STAGE_HEAD[0] = fused
+                roi_head.FUSED_MERGE_TAIL[0] = fused
+                outs[(split_min, fused)] = m.simple_test_mask_logits(feats, boxes, labels).clone()
+            m.enable_inference_graphs(True)
+            outs[(split_min, 'graph')] = m.simple_test_mask_logits(feats, boxes, labels).clone()
+            m.enable_inference_graphs(False)
+    ref = outs[(64, False)]
+    assert tuple(ref.shape) == (boxes.shape[0], 1, 112, 112)
+    for k, v in outs.items():
+        assert torch.equal(v, ref), k
+
+
 def test_fcn_mask_head_matches_reference_golden(golden_dir):
     from dynamask_amd import registry, mask_heads  # noqa: F401
     g = np.load(os.path.join(golden_dir, 'g6_fcn.npz'))

@@ -27,3 +27,17 @@ for s, e, n, q in g:
 print('per replay:')
 for k, (c, us) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:16]:
     print(f'  {us / reps:8.1f} us  x{c / reps:4.1f}  {k}')
+if len(sys.argv) > 3 and sys.argv[3] == 'order':
+    # the LAST replay launch by launch: start (us from the replay's first launch), duration, queue, workgroups, kernel
+    last = g[-int(round(len(g) / reps)):]
+    by = {(int(r['Start_Timestamp']), r['Kernel_Name']): r for r in rows}
+    z = last[0][0]
+    qs = sorted(set(e[3] for e in last))
+    print(f'last replay, launch by launch ({len(last)} launches, span {(max(e[1] for e in last) - z) / 1e3:.1f} us):')
+    for s, e, n, q in last:
+        r = by[(s, n)]
+        wgs = 1
+        for ax in 'XYZ':
+            wgs *= max(int(r.get(f'Grid_Size_{ax}', 1) or 1) // max(int(r.get(f'Workgroup_Size_{ax}', 1) or 1), 1), 1)
+        k = re.sub(r'\(anonymous namespace\)::', '', n); k = re.sub(r'^void ', '', k).split('(')[0][:46]
+        print(f'  {(s - z) / 1e3:8.1f} +{(e - s) / 1e3:7.1f} us  q{qs.index(q)}  {wgs:6d} wg  lds {r.get("LDS_Block_Size", "?"):>6}  {k}')
