@@ -4,7 +4,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DYNAMASK_HIP_LIB') or os.path.join(_HERE, 'libdynamask_hip.so')      # override: kernel experiments
-ABI_VERSION = 25
+ABI_VERSION = 26
 REQUIRED_BUILD_FLAG = '-packed-fp32-ops'        # dynamask_amd/build.py NO_PACKED_FP32; dm_build_info() must carry it
 
 _c_int = ctypes.c_int
@@ -29,6 +29,7 @@ SIGNATURES = {
     'dm_conv2d_fwd_ws': ([_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp, ctypes.c_longlong, _vp], _c_int),
     'dm_conv2d_splitk_floats': ([_c_int, _c_int, _c_int, _c_int, _c_int], ctypes.c_longlong),
     'dm_conv2d_fwd_masked': ([_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _vp], _c_int),
+    'dm_conv1x1_group_fwd': ([_c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _vp, _vp, _c_int, _vp, _vp], _c_int),
     'dm_point_sample_fwd': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_float, _vp, _vp], _c_int),
     'dm_class_logits_fwd': ([_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp], _c_int),
     'dm_class_logits_up2x_fwd': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp], _c_int),

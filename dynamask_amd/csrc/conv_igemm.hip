@@ -70,8 +70,10 @@ struct ConvArgs {
 // chunks spill 35-55 dwords at 168 and lose a third of their rate; with 16-channel chunks (half the
 // prefetch registers) they fit without scratch, and three per CU beats the longer chunk: the DCN
 // column-gradient GEMMs 1.56 -> 1.20, 0.94 -> 0.78, 0.75 -> 0.67 ms, fusion 130->64 @56^2 0.56 -> 0.45 ms.
+// The kernel body takes its place in the grid as arguments (bx of gx workgroups, split by): conv_igemm_kernel passes
+// blockIdx / gridDim, conv_igemm_group_kernel (several independent convolutions in one launch) a range of its grid.
 template <int KS, int WGM, int WGN, int WM, int WN, int CK, int MAXPOS, int TAIL = 0>
-__global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && WM == 2 && WN == 2 && MAXPOS == 1) || (KS == 1 && CK == 16) ? 3 : 1) void conv_igemm_kernel(ConvArgs a) {
+__device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bx, const int gx, const int by) {
   static_assert(TAIL == 0 || (TAIL == 4 && WGM == 1), "tail rows need a single cout tile");
   constexpr int TM = WGM * WM * 32;
   constexpr int TMA = TM + TAIL;              // rows of the LDS A image
@@ -102,8 +104,8 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
   // 8 apart in launch order: same XCD, back to back.  The ragged tail keeps the plain order.
   int m_tile, n_tile;
   {
-    const int b = blockIdx.x, grp = 8 * a.MT;
-    const int full = (gridDim.x / grp) * grp;
+    const int b = bx, grp = 8 * a.MT;
+    const int full = (gx / grp) * grp;
     if (b < full) {
       const int g = b / grp, r = b - g * grp;
       m_tile = r / 8;
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
   const float* e_mask = a.mask;
   int e_relu = a.relu, e_oct = a.out_ch_total, e_oco = a.out_ch_offset;
   if (a.ksplit > 1) {
-    const int sp = blockIdx.y;
+    const int sp = by;
     e_out = a.ws + (size_t)sp * a.ws_stride;
     e_bias = nullptr; e_mask = nullptr; e_relu = 0;
     e_oct = a.Cout; e_oco = 0;
@@ -555,6 +557,27 @@ __global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && 
       }
     }
   }
+}
+
+template <int KS, int WGM, int WGN, int WM, int WN, int CK, int MAXPOS, int TAIL = 0>
+__global__ __launch_bounds__(WGM* WGN * 64, (KS == 3 && WGM == 2 && WGN == 2 && WM == 2 && WN == 2 && MAXPOS == 1) || (KS == 1 && CK == 16) ? 3 : 1) void conv_igemm_kernel(ConvArgs a) {
+  conv_igemm_body<KS, WGM, WGN, WM, WN, CK, MAXPOS, TAIL>(a, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y);
+}
+
+// Up to three INDEPENDENT convolutions in one launch (round 6: the three FPN-wide semantic_transform_in 1x1 convolutions of
+// the SFM stages, dynamask_head.py:104 -- P4 256->256, P3 256->128, P2 256->64: 66 / 132 / 525 workgroups that each walk
+// a K = 256 loop, one launch after the other in front of everything else): workgroups [end[i-1], end[i]) run problem i
+// with the body above, i.e. the same code on the same operands as a launch of its own.
+struct ConvGroup {
+  ConvArgs a[3];
+  int end[3];
+};
+template <int KS, int WGM, int WGN, int WM, int WN, int CK, int MAXPOS>
+__global__ __launch_bounds__(WGM* WGN * 64, (KS == 1 && CK == 16) ? 3 : 1) void conv_igemm_group_kernel(ConvGroup g) {
+  const int b = (int)blockIdx.x;
+  if (b < g.end[0]) conv_igemm_body<KS, WGM, WGN, WM, WN, CK, MAXPOS, 0>(g.a[0], b, g.end[0], 0);
+  else if (b < g.end[1]) conv_igemm_body<KS, WGM, WGN, WM, WN, CK, MAXPOS, 0>(g.a[1], b - g.end[0], g.end[1] - g.end[0], 0);
+  else conv_igemm_body<KS, WGM, WGN, WM, WN, CK, MAXPOS, 0>(g.a[2], b - g.end[1], g.end[2] - g.end[1], 0);
 }
 
 // Packed weight layout [tap][KQ][CoutP][4]: KQ quads = sum over sources of
@@ -1014,4 +1037,42 @@ extern "C" int dm_deconv2x2_fwd(const float* x, int NB, int C, int H, int W, con
   a.wq = w_packed; a.bias = bias; a.Cout = 4 * Cout; a.CoutP = dm_conv_packed_cout(4 * Cout);
   a.relu = relu; a.out = out; a.out_ch_total = 0; a.out_ch_offset = 0; a.shuffle = Cout; a.q_begin = 0;
   return launch_conv<1, 2, 2, 2, 2, 16>(a, (hipStream_t)stream);
+}
+
+// (ABI 26) `count` (1..3) independent single-source 1x1 convolutions (+ bias, + ReLU) in ONE launch: x[i] [NB, Cin[i], H[i], W[i]]
+// -> out[i] [NB, Cout[i], H[i], W[i]], weights packed by dm_conv_pack_weight (ksize 1, one source).  Every problem runs the
+// 64-cout x 128-pixel build of the kernel, in its own range of the grid: the results are those of dm_conv2d_fwd launches
+// that take that build (32 < Cout <= 64) and differ from the 128-cout build's (Cout > 64) in nothing -- both walk K in
+// chunks of 16 channels in the same order.
+extern "C" int dm_conv1x1_group_fwd(int count, const float* const* x, const int* Cin, const int* H, const int* W, int NB,
+                                    const float* const* w_packed, const float* const* bias, const int* Cout, int relu,
+                                    float* const* out, dm_stream_t stream) {
+  if (count < 1 || count > 3 || !x || !Cin || !H || !W || !w_packed || !bias || !Cout || !out || NB < 0) return DM_ERR_INVALID_ARG;
+  if (relu & ~1) return DM_ERR_INVALID_ARG;
+  if (NB == 0) return DM_OK;
+  ConvGroup g;
+  int total = 0;
+  constexpr int TM = 64, TN = 128;
+  for (int i = 0; i < 3; ++i) {
+    const int j = i < count ? i : count - 1;          // unused slots repeat the last problem (never selected: end[] stops)
+    if (!x[j] || !w_packed[j] || !out[j] || Cin[j] <= 0 || H[j] <= 0 || W[j] <= 0 || Cout[j] <= 0) return DM_ERR_INVALID_ARG;
+    if ((long long)NB * H[j] * W[j] > 0x7fffffffLL) return DM_ERR_INVALID_ARG;
+    ConvArgs& a = g.a[i];
+    for (int s = 0; s < DM_MAX_SOURCES; ++s) { a.src[s] = nullptr; a.src_c[s] = 0; a.src_bs[s] = 0; }
+    a.src[0] = x[j]; a.src_c[0] = Cin[j]; a.src_bs[0] = (long long)Cin[j] * H[j] * W[j]; a.num_srcs = 1;
+    a.KQ = packed_quads(1, a.src_c);
+    a.NB = NB; a.H = H[j]; a.W = W[j]; a.HW = H[j] * W[j]; a.Q = NB * H[j] * W[j];
+    a.wq = w_packed[j]; a.bias = bias[j]; a.Cout = Cout[j]; a.CoutP = dm_conv_packed_cout(Cout[j]);
+    a.relu = relu & 1; a.out = out[j]; a.out_ch_total = Cout[j]; a.out_ch_offset = 0;
+    a.shuffle = 0; a.q_begin = 0; a.mask = nullptr; a.ws = nullptr; a.ksplit = 1;
+    a.off32 = ((long long)NB * a.src_bs[0] * 4 < (1LL << 32)) ? 1 : 0;
+    a.MT = dm_ceil_div(a.CoutP, TM);
+    a.Wp = 0; a.plane = TN;
+    if (i < count) total += a.MT * dm_ceil_div(a.Q, TN);
+    g.end[i] = total;
+  }
+  constexpr int CK = 16, NWC = CK / 4;
+  const size_t lds_bytes = 16 * ((size_t)NWC * TM + (size_t)NWC * TN);
+  DM_LAUNCH((conv_igemm_group_kernel<1, 2, 2, 1, 2, 16, 1>), dim3((unsigned)total), dim3(256), lds_bytes, (hipStream_t)stream, g);
+  return dm_check_launch();
 }

@@ -195,6 +195,7 @@ class SFMStage(nn.Module):
 # inference launches fused in round 6 (A/B switches for tools/infer_bench.py and the equality tests; same bits either way)
 import os as _os
 FUSED_STAGE_HEAD = [_os.environ.get('DM_FUSED_STAGE_HEAD', '1') != '0']      # point sample + class logits: one launch per stage
+GROUPED_SEMANTIC_MAPS = [_os.environ.get('DM_GROUPED_SEM', '1') != '0']       # the stages' FPN-wide 1x1 convolutions: one launch
 
 
 def run_steps(gen):
@@ -284,9 +285,17 @@ class DynaMaskHead(nn.Module):
             nn.init.constant_(m.bias, 0)
 
     def semantic_maps(self, semantic_feats, last_stage=None):
-        """Per-stage relu(semantic_transform_in(.)) maps (shared by all RoIs)."""
+        """Per-stage relu(semantic_transform_in(.)) maps (shared by all RoIs).  Without autograd, two or three of them
+        are ONE launch (ops.conv1x1_group: no RoI enters them, and as three launches of 66 / 132 / 525 workgroups they
+        headed the inference chain with ~100 us in which most of the chip idles); same bits either way."""
         n = len(self.stages) if last_stage is None else min(last_stage, len(self.stages))
-        return [self.stages[i].semantic_map(semantic_feats[-i - 3]) for i in range(n)]
+        feats = [semantic_feats[-i - 3] for i in range(n)]
+        convs = [self.stages[i].semantic_transform_in for i in range(n)]
+        if (GROUPED_SEMANTIC_MAPS[0] and 2 <= n <= 3 and not torch.is_grad_enabled() and all(f.is_contiguous() for f in feats)
+                and all(c.bias is not None for c in convs)):
+            return ops.conv1x1_group(feats, [c.packed([c.in_channels]) for c in convs], [c.bias.detach() for c in convs],
+                                     [c.out_channels for c in convs], relu=True)
+        return [self.stages[i].semantic_map(feats[i]) for i in range(n)]
 
     def prepack(self, fused_dcn=None):
         """Refresh the kernel-layout weights of everything ``forward`` launches (except the semantic 1x1 convs, which

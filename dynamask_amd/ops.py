@@ -534,6 +534,32 @@ def conv2d(srcs, w_packed, bias, cout, ksize, relu=False, out=None, out_ch_offse
     return out
 
 
+def conv1x1_group(xs, w_packeds, biases, couts, relu=False, outs=None):
+    """Up to three independent single-source 1x1 convolutions (+ bias, + ReLU) as ONE launch (dm_conv1x1_group_fwd): the
+    FPN-wide semantic convolutions of the SFM stages.  Same bits as ``conv2d`` per problem."""
+    k = len(xs)
+    assert 1 <= k <= 3 and len(w_packeds) == k and len(biases) == k and len(couts) == k
+    NB = xs[0].shape[0]
+    for x, w in zip(xs, w_packeds):
+        _chk(x, 'x')
+        _chk(w, 'w_packed')
+        assert x.shape[0] == NB
+    for x, w, c in zip(xs, w_packeds, couts):
+        assert w.numel() == packed_floats(c, 1, [x.shape[1]]), 'weights packed for other sources'
+    if outs is None:
+        outs = [torch.empty((NB, c, x.shape[2], x.shape[3]), device=x.device, dtype=torch.float32) for x, c in zip(xs, couts)]
+    for o, x, c in zip(outs, xs, couts):
+        _chk(o, 'out')
+        assert tuple(o.shape) == (NB, c, x.shape[2], x.shape[3])
+    bias_arr = (ctypes.c_void_p * k)(*[0 if b is None else _chk(b, 'bias').data_ptr() for b in biases])
+    if hazard.ENABLED[0]:
+        hazard.note_ptr_array(bias_arr, [b for b in biases if b is not None])
+    check(lib().dm_conv1x1_group_fwd(k, _ptr_array(xs), _int_array([x.shape[1] for x in xs]), _int_array([x.shape[2] for x in xs]),
+                                     _int_array([x.shape[3] for x in xs]), NB, _ptr_array(w_packeds), bias_arr, _int_array(couts),
+                                     1 if relu else 0, _ptr_array(outs), _stream()), 'dm_conv1x1_group_fwd')
+    return outs
+
+
 def deform_conv(x, offset, w_packed, cout, deform_groups, relu=False, out=None):
     _chk(x, 'x')
     _chk(offset, 'offset')

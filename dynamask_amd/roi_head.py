@@ -151,7 +151,10 @@ class DynaMaskRoIHead(nn.Module):
         # inference: RoI chunks on separate HIP streams (see _mask_forward)
         self.num_streams = 2
         self.stream_split_min = 64           # (100 detections to 112x112: 2.34 ms on one stream, 2.27 split over two; 32: no further gain)
-        self.overlap_semantic_maps = os.environ.get('DM_SEM_OVERLAP', '1') != '0'      # the FPN-wide 1x1 convs beside the RoI chains
+        # the FPN-wide semantic 1x1 convolutions on a stream of their own BESIDE the RoI chains instead of in front of them:
+        # measured (profiles/r06_infer_experiments.txt) neutral at 100 detections, +2 % at 16 and on the 512-RoI headline -- a
+        # fork inside a HIP graph costs more than the ~100 us it hides; off, and the maps are one grouped launch instead
+        self.overlap_semantic_maps = os.environ.get('DM_SEM_OVERLAP', '0') == '1'
 
     def init_assigner_sampler(self):
         """standard_roi_head.py:13-20."""
@@ -202,11 +205,6 @@ class DynaMaskRoIHead(nn.Module):
         head, ext = self.mask_head, self.mask_roi_extractor
         dev = rois.device
         cur = torch.cuda.current_stream(dev)
-        if not self.overlap_semantic_maps:
-            if n_streams <= 1:
-                ins_feats = ext(x[:ext.num_inputs], rois)
-                ips, dps = head(ins_feats, x, rois, roi_labels, last_stage=last_stage)
-                return dict(stage_instance_preds=ips, stage_detail_preds=dps)
         head.prepack()                 # packs are cached by whoever asks first: before the fork, on this stream
         n_sem = len(head.stages) if last_stage is None else min(last_stage, len(head.stages))
         # the semantic maps: outputs allocated here (the caller's stream owns the memory), produced on the pool's last stream
@@ -214,7 +212,9 @@ class DynaMaskRoIHead(nn.Module):
         sem_stream = self._side_streams(n_streams + 1, dev)[-1] if self.overlap_semantic_maps else cur
         if sem_stream is not cur:
             sem_stream.wait_stream(cur)
-        for i in range(n_sem):
+        else:
+            sems, sem_ready = head.semantic_maps(x, last_stage), [None] * n_sem          # one grouped launch, in front of the chains
+        for i in range(n_sem if sem_stream is not cur else 0):
             st_ = head.stages[i]
             f = x[-i - 3]
             out = torch.empty((f.shape[0], st_.semantic_transform_in.out_channels, f.shape[2], f.shape[3]), device=dev,
@@ -281,7 +281,9 @@ class DynaMaskRoIHead(nn.Module):
         sem_stream = self._side_streams(n_streams + 1, dev)[-1] if self.overlap_semantic_maps else cur
         if sem_stream is not cur:
             sem_stream.wait_stream(cur)
-        for i in range(len(head.stages)):
+        if sem_stream is cur:
+            sems, sem_ready = head.semantic_maps(x), [None] * len(head.stages)            # one grouped launch, in front of the chains
+        for i in range(len(head.stages) if sem_stream is not cur else 0):
             st_ = head.stages[i]
             f = x[-i - 3]
             out = torch.empty((f.shape[0], st_.semantic_transform_in.out_channels, f.shape[2], f.shape[3]), device=dev,

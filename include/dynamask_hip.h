@@ -53,7 +53,7 @@ extern "C" {
 typedef void* dm_stream_t; /* hipStream_t */
 
 const char* dm_error_string(int code);
-/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient, dm_conv_pack_weight_batch, dm_mask_loss_stage; 15: dm_class_logits_up2x_fwd; 16: dm_conv2d_wgrad_slab / dm_conv2d_wgrad_scratch_floats; 17: dm_class_logits_bwd_slab / dm_class_logits_bwd_scratch_floats; 18: dm_reload_env_knobs, dm_roi_align_fwd_ws / dm_roi_align_workspace_bytes, dm_conv_pack_weight_split / dm_conv_packed_floats_split and flag bits 4, 5 of dm_conv2d_fwd; 19: dm_dcn_bwd_data_fused and its pack; 20: dm_conv2d_fwd_ws / dm_conv2d_splitk_floats; 21: dm_deform_conv_fwd_ws / dm_deform_conv_splitk_floats; 22: the bf16-split layouts (dm_conv_pack_weight_split, dm_conv_packed_floats_split, flag bits 4 / 5 of dm_conv2d_fwd) and the one-kernel DCN data gradient (dm_dcn_bwd_*) REMOVED -- measured, never the parity path, see docs/HISTORY.md; 23: dm_bn_stats takes mean_shift, dm_roi_align_bwd takes the gather form for 16 < P <= 64; 24: dm_build_info; 25: dm_boundary_merge_chain, dm_stage_head_fwd). */
+/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient, dm_conv_pack_weight_batch, dm_mask_loss_stage; 15: dm_class_logits_up2x_fwd; 16: dm_conv2d_wgrad_slab / dm_conv2d_wgrad_scratch_floats; 17: dm_class_logits_bwd_slab / dm_class_logits_bwd_scratch_floats; 18: dm_reload_env_knobs, dm_roi_align_fwd_ws / dm_roi_align_workspace_bytes, dm_conv_pack_weight_split / dm_conv_packed_floats_split and flag bits 4, 5 of dm_conv2d_fwd; 19: dm_dcn_bwd_data_fused and its pack; 20: dm_conv2d_fwd_ws / dm_conv2d_splitk_floats; 21: dm_deform_conv_fwd_ws / dm_deform_conv_splitk_floats; 22: the bf16-split layouts (dm_conv_pack_weight_split, dm_conv_packed_floats_split, flag bits 4 / 5 of dm_conv2d_fwd) and the one-kernel DCN data gradient (dm_dcn_bwd_*) REMOVED -- measured, never the parity path, see docs/HISTORY.md; 23: dm_bn_stats takes mean_shift, dm_roi_align_bwd takes the gather form for 16 < P <= 64; 24: dm_build_info; 25: dm_boundary_merge_chain, dm_stage_head_fwd; 26: dm_conv1x1_group_fwd). */
 int dm_abi_version(void);
 /* "libdynamask_hip abi=N arch=gfx950 compiler=<clang version> flags=<the product-wide flags of dynamask_amd/build.py>"
  * (static storage).  The library must be compiled WITHOUT packed fp32 instructions (flag "-packed-fp32-ops", see
@@ -168,6 +168,15 @@ int dm_conv2d_fwd_ws(const float* const* srcs, const int* src_channels, const lo
                      int num_srcs, int NB, int H, int W, const float* w_packed, const float* bias, int Cout, int ksize,
                      int relu, float* out, int out_ch_total, int out_ch_offset, float* workspace,
                      long long workspace_floats, dm_stream_t stream);
+
+/* (ABI 26) Up to three independent single-source 1x1 convolutions (+ bias, + ReLU) as ONE launch -- the FPN-wide
+ * semantic_transform_in convolutions of the three SFM stages (mmdet/models/roi_heads/mask_heads/dynamask_head.py:104,
+ * relu(conv1x1(P4 / P3 / P2))), which no RoI enters and which otherwise head the inference chain as three launches.
+ * x, Cin, H, W, w_packed, bias, Cout, out: HOST arrays of `count` entries (device pointers inside); w_packed[i] as
+ * dm_conv_pack_weight(ksize 1, one source) lays it out; bias[i] may be NULL.  Same bits as dm_conv2d_fwd per problem. */
+int dm_conv1x1_group_fwd(int count, const float* const* x, const int* Cin, const int* H, const int* W, int NB,
+                         const float* const* w_packed, const float* const* bias, const int* Cout, int relu, float* const* out,
+                         dm_stream_t stream);
 
 /* dm_conv2d_fwd whose epilogue also applies a ReLU adjoint: outputs where `mask` (same layout, channel count and
  * channel offset as `out`) is not > 0 are stored as 0.  Used for data gradients: the mask is the activation the

@@ -344,6 +344,26 @@ def test_boundary_merge_chain_has_the_bits_of_the_launches_it_replaces(ops, gold
     assert ops.boundary_merge_chain(a[:0], b[:0], fin[:0]).shape[0] == 0
 
 
+def test_grouped_1x1_convs_equal_their_own_launches(ops):
+    """dm_conv1x1_group_fwd (round 6): the three FPN-wide semantic convolutions in one launch -- bit for bit what three
+    dm_conv2d_fwd launches produce (256 -> 256 / 128 / 64 on maps of three sizes, two images), and the 2- and 1-problem forms."""
+    gen = torch.Generator().manual_seed(93)
+    xs = [_dev(torch.randn(2, 256, h, w, generator=gen)) for h, w in ((13, 21), (25, 42), (50, 84))]
+    couts = [256, 128, 64]
+    ws = [_dev(torch.randn(c, 256, 1, 1, generator=gen) / 16) for c in couts]
+    bs = [_dev(torch.randn(c, generator=gen)) for c in couts]
+    wq = [ops.pack_conv_weight(w) for w in ws]
+    ref = [ops.conv2d(x, q, b, c, 1, relu=True) for x, q, b, c in zip(xs, wq, bs, couts)]
+    for k in (3, 2, 1):
+        got = ops.conv1x1_group(xs[:k], wq[:k], bs[:k], couts[:k], relu=True)
+        for g_, r_ in zip(got, ref):
+            assert torch.equal(g_, r_), k
+    for x, w, b, r_ in zip(xs, ws, bs, ref):
+        _close(r_, F.relu(F.conv2d(x.cpu(), w.cpu(), b.cpu())), atol=1e-4, rtol=1e-4)
+    got = ops.conv1x1_group(xs[1:], wq[1:], [None, bs[2]], couts[1:], relu=False)           # a problem without bias
+    assert torch.equal(got[0], ops.conv2d(xs[1], wq[1], None, 128, 1)) and torch.equal(got[1], ops.conv2d(xs[2], wq[2], bs[2], 64, 1))
+
+
 def test_stage_head_launch_equals_point_sample_and_class_logits(ops):
     """dm_stage_head_fwd (round 6) = dm_point_sample_fwd + dm_class_logits_fwd in one launch: same bits, at the three
     stage shapes, with RoIs of two images, an out-of-range batch index and a label outside [0, classes)."""
