@@ -4,7 +4,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DYNAMASK_HIP_LIB') or os.path.join(_HERE, 'libdynamask_hip.so')      # override: kernel experiments
-ABI_VERSION = 26
+ABI_VERSION = 27
 REQUIRED_BUILD_FLAG = '-packed-fp32-ops'        # dynamask_amd/build.py NO_PACKED_FP32; dm_build_info() must carry it
 
 _c_int = ctypes.c_int
@@ -35,6 +35,8 @@ SIGNATURES = {
     'dm_class_logits_up2x_fwd': ([_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp], _c_int),
     'dm_deform_conv_fwd': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _vp, _vp], _c_int),
     'dm_deform_conv_fwd_ws': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _vp, _vp, ctypes.c_longlong, _vp], _c_int),
+    'dm_deform_conv_tout_supported': ([_c_int, _c_int, _c_int, _c_int, _c_int, _c_int], _c_int),
+    'dm_deform_conv_tout_fwd': ([_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _vp, _c_int, _vp, _c_int, _vp, _vp], _c_int),
     'dm_deform_conv_splitk_floats': ([_c_int, _c_int, _c_int, _c_int, _c_int], ctypes.c_longlong),
     'dm_upsample2x_bilinear_fwd': ([_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp], _c_int),
     'dm_boundary_merge': ([_vp, _vp, _c_int, _c_int, _vp], _c_int),

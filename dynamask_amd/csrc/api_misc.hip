@@ -11,7 +11,7 @@ extern "C" const char* dm_error_string(int code) {
   }
 }
 
-extern "C" int dm_abi_version(void) { return 26; }
+extern "C" int dm_abi_version(void) { return 27; }
 
 // How this library was compiled: the compiler and the product-wide flag set dynamask_amd/build.py passed (it hands them
 // over as -DDM_BUILD_FLAGS="..."; a recipe that does not say what it used yields "flags=unknown").  The host binding
@@ -22,7 +22,7 @@ extern "C" int dm_abi_version(void) { return 26; }
 #define DM_BUILD_FLAGS "unknown"
 #endif
 extern "C" const char* dm_build_info(void) {
-  return "libdynamask_hip abi=26 arch=gfx950 compiler=" __clang_version__ " flags=" DM_BUILD_FLAGS;
+  return "libdynamask_hip abi=27 arch=gfx950 compiler=" __clang_version__ " flags=" DM_BUILD_FLAGS;
 }
 
 // ---------------------------------------------------------------------------

@@ -34,6 +34,13 @@ struct DcnArgs {
   float* ws = nullptr;
   long long ws_stride = 0, ws_floats = 0;
   int ksplit = 1, kchan = 0;
+  // the 1x1 convolution behind the DCN, chained in the epilogue of the band kernel (round 6, dm_deform_conv_tout_fwd):
+  // out2[m] = relu(b2[m] + sum_k w2[m][k] * relu(dcn[k])), w2t = [Cout][M2P] (transposed, rows of 32-padded couts);
+  // store_out = 0: the DCN output itself is not written
+  const float* w2t = nullptr;
+  const float* b2 = nullptr;
+  float* out2 = nullptr;
+  int M2 = 0, out2_ct = 0, store_out = 1;
 };
 
 // One bilinear sample from its two row pairs.  Spelled as an explicit fma chain so that every kernel
@@ -837,6 +844,52 @@ __global__ __launch_bounds__(256, 2) void deform_conv_band_kernel(DcnArgs a, int
       }
     }
   }
+  // The 1x1 convolution + ReLU that follows the DCN in an SFM stage (fuse_transform_out, dynamask_head.py:117-121), chained
+  // here while the DCN's 32 pixels x all couts are still in this wave's accumulators: the MFMA D layout IS a B operand --
+  // register r of tile i holds dcn[k = i*32 + (r&3) + 8*(r>>2) + 4*hi][pixel = lane & 31], i.e. for the k pair (kb, kb + 4)
+  // lanes 0-31 / 32-63 carry exactly B[k][n] of a 32x32x2 step -- so the second GEMM needs no LDS round trip for its
+  // input, only its weights (staged transposed: lane = cout).  Walking i, r upward adds the products in the order
+  // (0,4),(1,5),(2,6),(3,7),(8,12),... -- the order the 1x1 kernel of conv_igemm.hip uses (quad pairs of a 16-channel
+  // chunk): the result has the bits of the two launches it replaces.  The DCN output is then never written (inference).
+  if (WGM == 1 && a.w2t) {
+    constexpr int MT2 = (WM + 1) / 2;          // cout tiles of the 1x1 (host: ceil(M2 / 32) <= MT2)
+    constexpr int M2P = MT2 * 32;
+    __syncthreads();                           // every wave is done with the last chunk's operands in LDS
+    {
+      const dm_f32x4* src = reinterpret_cast<const dm_f32x4*>(a.w2t);
+      dm_f32x4* dst = reinterpret_cast<dm_f32x4*>(lds);
+      for (int idx = tid; idx < a.Cout * (M2P / 4); idx += NT) dst[idx] = src[idx];
+    }
+    __syncthreads();
+    const float* w2t = lds;
+    dm_f32x16 acc2[MT2];
+#pragma unroll
+    for (int t = 0; t < MT2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kb = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const float b = fmaxf(acc[i][r], 0.f);
+#pragma unroll
+        for (int t = 0; t < MT2; ++t)
+          acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2t[kb * M2P + t * 32 + l31], b, acc2[t], 0, 0, 0);
+      }
+    const int p = p0 + wave_n * 32 + l31;
+    if (p < HW) {
+      float* po2 = a.out2 + (size_t)n * a.out2_ct * HW + p;
+#pragma unroll
+      for (int t = 0; t < MT2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (co < a.M2) po2[(size_t)co * HW] = fmaxf(acc2[t][r] + a.b2[co], 0.f);
+        }
+    }
+    if (!a.store_out) return;
+  }
   // epilogue: lane = pixel column, registers walk the couts
   {
     const int p = p0 + wave_n * 32 + l31;
@@ -939,6 +992,12 @@ int launch_dcn_band(DcnArgs& a, hipStream_t st) {
   if (8 * BR * a.W / 4 > XR * 256 || a.H < BR) return DM_ERR_UNSUPPORTED;      // the staging registers must cover the band planes
   const int tiles = dm_ceil_div(a.HW, (4 / WGM) * 32);
   const size_t lds_bytes = 16 * (size_t)(9 * 2 * WM * WGM * 32) + 4 * (size_t)8 * BR * a.W;
+  if (a.w2t) {
+    // the chained 1x1: this wave layout only (a wave holds every cout of its pixels), its weights must fit the kernel's LDS
+    if (WGM != 1 || dm_ceil_div(a.M2, 32) > (WM + 1) / 2 || (size_t)a.Cout * ((WM + 1) / 2) * 32 * 4 > lds_bytes || a.Cout != WM * 32)
+      return DM_ERR_UNSUPPORTED;
+    a.ws = nullptr;                            // (no split-K: the second GEMM needs the complete channel sums)
+  }
   dcn_choose_split(a, (long long)a.NB * tiles, 2LL * dm_num_cus(), a.ws_floats);
   DM_LAUNCH((deform_conv_band_kernel<WM, WGM, XR>), dim3((unsigned)(a.NB * tiles), (unsigned)a.ksplit), dim3(256), lds_bytes, st, a, tiles, BR);
   return dcn_finish_split(a, a.relu, a.out, st);
@@ -963,9 +1022,15 @@ int launch_dcn(DcnArgs& a, hipStream_t st) {
 
 }  // namespace
 
+struct DcnTout {      // the chained 1x1 (nullptr members: plain DCN)
+  const float* w2t = nullptr;
+  const float* b2 = nullptr;
+  float* out2 = nullptr;
+  int M2 = 0, out2_ct = 0;
+};
 static int deform_conv_fwd_impl(const float* x, const float* offset, int NB, int C, int H, int W,
                                 const float* w_packed, int Cout, int deform_groups, int relu, float* out, float* ws,
-                                long long ws_floats, dm_stream_t stream);
+                                long long ws_floats, dm_stream_t stream, const DcnTout* tout = nullptr);
 
 extern "C" int dm_deform_conv_fwd(const float* x, const float* offset, int NB, int C, int H, int W,
                                   const float* w_packed, int Cout, int deform_groups, int relu, float* out,
@@ -989,9 +1054,46 @@ extern "C" int dm_deform_conv_fwd_ws(const float* x, const float* offset, int NB
   return deform_conv_fwd_impl(x, offset, NB, C, H, W, w_packed, Cout, deform_groups, relu, out, workspace, workspace_floats, stream);
 }
 
+// Does this shape take the band kernel in the wave layout that can chain the 1x1 (a wave = 32 pixels x all couts)?
+static bool dcn_tout_shape_ok(int NB, int C, int H, int W, int Cout, int M2) {
+  if (NB <= 0 || C <= 0 || H <= 0 || W <= 0 || Cout != C || M2 <= 0) return false;
+  const int HW = H * W, CoutP = dm_conv_packed_cout(Cout);
+  const int max_rows = (W - 1 + 128 + W - 1) / W;
+  if (!(H >= 16 && (W & 3) == 0 && 8 * 16 * W / 4 <= 7 * 256 && (16 - max_rows) / 2 >= DCN_NEAR_ROWS && HW > 256 && HW < 65536 &&
+        (CoutP == 64 || CoutP == 128) && Cout > 32 && Cout == CoutP))
+    return false;
+  const bool narrow = 8 * 16 * W / 4 <= 4 * 256;
+  const bool few = (long long)NB * dm_ceil_div(HW, 128) * 4 < (long long)dm_num_cus() * 3;
+  if (few) return false;                                   // (one cout tile per wave there: 2-4 x the workgroups, worth more)
+  if (CoutP == 128 && !narrow) return false;               // <2, 2, 7>: two waves share a pixel column
+  return dm_ceil_div(M2, 32) <= (CoutP / 32 + 1) / 2;
+}
+
+extern "C" int dm_deform_conv_tout_supported(int NB, int C, int H, int W, int Cout, int M2) {
+  return dcn_tout_shape_ok(NB, C, H, W, Cout, M2) ? 1 : 0;
+}
+
+// (ABI 27) DCN 3x3 + ReLU + the 1x1 convolution + bias + ReLU behind it (SFMStage.fuse_conv[1] -> fuse_transform_out,
+// mmdet/models/roi_heads/mask_heads/dynamask_head.py:117-121) in ONE launch: out2[:, :M2] of a tensor with out2_ch_total
+// channels; w2t = the 1x1 weight transposed to [Cout][32-padded M2] (zeros in the padding); out_dcn: NULL (inference: the
+// DCN output is never written) or [NB, Cout, H, W] to keep relu(DCN) as well.  DM_ERR_UNSUPPORTED when
+// dm_deform_conv_tout_supported() says 0 -- the caller then launches the two operators.  Same bits as those two launches.
+extern "C" int dm_deform_conv_tout_fwd(const float* x, const float* offset, int NB, int C, int H, int W, const float* w_packed,
+                                       int Cout, int deform_groups, const float* w2t, const float* b2, int M2, float* out2,
+                                       int out2_ch_total, float* out_dcn, dm_stream_t stream) {
+  if (!w2t || !b2 || !out2 || M2 <= 0 || M2 > out2_ch_total) return DM_ERR_INVALID_ARG;
+  if (NB == 0) return DM_OK;
+  if (!dcn_tout_shape_ok(NB, C, H, W, Cout, M2)) return DM_ERR_UNSUPPORTED;
+  DcnTout t;
+  t.w2t = w2t; t.b2 = b2; t.out2 = out2; t.M2 = M2; t.out2_ct = out2_ch_total;
+  // (out == NULL is the "do not store" request; the implementation needs a non-null pointer to get past its checks)
+  return deform_conv_fwd_impl(x, offset, NB, C, H, W, w_packed, Cout, deform_groups, 1, out_dcn ? out_dcn : out2, nullptr, 0, stream,
+                              &t) ;
+}
+
 static int deform_conv_fwd_impl(const float* x, const float* offset, int NB, int C, int H, int W,
                                 const float* w_packed, int Cout, int deform_groups, int relu, float* out, float* ws,
-                                long long ws_floats, dm_stream_t stream) {
+                                long long ws_floats, dm_stream_t stream, const DcnTout* tout) {
   if (!x || !offset || !w_packed || !out) return DM_ERR_INVALID_ARG;
   if (NB < 0 || C <= 0 || H <= 0 || W <= 0 || Cout <= 0 || deform_groups <= 0 || C % deform_groups != 0)
     return DM_ERR_INVALID_ARG;
@@ -1005,6 +1107,10 @@ static int deform_conv_fwd_impl(const float* x, const float* offset, int NB, int
   a.relu = relu & 1; a.out = out;
   a.ws = (ws && ws_floats > 0) ? ws : nullptr;
   a.ws_floats = a.ws ? ws_floats : 0;
+  if (tout) {
+    a.w2t = tout->w2t; a.b2 = tout->b2; a.out2 = tout->out2; a.M2 = tout->M2; a.out2_ct = tout->out2_ct;
+    a.store_out = (out != tout->out2) ? 1 : 0;
+  }
   hipStream_t st = (hipStream_t)stream;
   // 8-wave workgroups: 4 threads share a pixel column, so a thread owns <= 3 taps
   // (a 256-cout tile would gather each sample once but needs > 256 VGPRs: it spills)
@@ -1033,6 +1139,7 @@ static int deform_conv_fwd_impl(const float* x, const float* offset, int NB, int
       return narrow ? launch_dcn_band<4, 1, 4>(a, st) : launch_dcn_band<2, 2, 7>(a, st);
     }
   }
+  if (tout) return DM_ERR_UNSUPPORTED;                      // (dcn_tout_shape_ok mirrors the conditions above)
   if (Cout > 64 && (long long)dm_ceil_div(a.CoutP, 128) * dm_ceil_div(a.Q, 128) * 20 <= (long long)dm_num_cus() * 9)
     return launch_dcn<2, 2, 1, 1>(a, st);
   if (Cout > 64 && a.HW >= 128 && a.HW <= 256 && (a.HW & 3) == 0 && (C / deform_groups) % 8 == 0) {

@@ -182,10 +182,20 @@ class SFMStage(nn.Module):
         offset = dcn.conv_offset.run(fused)
         yield
         wp = dcn._pk.get('w', dcn.weight, ops.pack_conv_weight, job=(False, None, None, None))
-        fused = ops.deform_conv(fused, offset, wp, dcn.out_channels, dcn.deform_groups, relu=True)
-        yield
-        self.fuse_transform_out.run(fused, relu=True, out=tail, out_ch_offset=0)
-        yield
+        tout = self.fuse_transform_out
+        if (FUSED_DCN_TOUT[0] and not torch.is_grad_enabled() and tout.bias is not None
+                and ops.deform_conv_tout_supported(fused, dcn.out_channels, tout.out_channels)):
+            # 28 x 28 / 56 x 56 at more than a handful of RoIs: the 1x1 runs on the DCN's accumulators, the DCN output
+            # ([N, 64, 56, 56]: 80 MB at 100 RoIs, written once and read once) never exists
+            w2t = tout._pk.get('tout', tout.weight, ops.pack_tout_weight)
+            ops.deform_conv_tout(fused, offset, wp, dcn.out_channels, dcn.deform_groups, w2t, tout.bias.detach(),
+                                 tout.out_channels, tail)
+            yield
+        else:
+            fused = ops.deform_conv(fused, offset, wp, dcn.out_channels, dcn.deform_groups, relu=True)
+            yield
+            tout.run(fused, relu=True, out=tail, out_ch_offset=0)
+            yield
         if upsample:
             tail = ops.upsample2x(tail, align_corners=False, relu=True)
             yield
@@ -195,6 +205,7 @@ class SFMStage(nn.Module):
 # inference launches fused in round 6 (A/B switches for tools/infer_bench.py and the equality tests; same bits either way)
 import os as _os
 FUSED_STAGE_HEAD = [_os.environ.get('DM_FUSED_STAGE_HEAD', '1') != '0']      # point sample + class logits: one launch per stage
+FUSED_DCN_TOUT = [_os.environ.get('DM_FUSED_DCN_TOUT', '1') != '0']            # DCN + fuse_transform_out: one launch (28^2 / 56^2)
 GROUPED_SEMANTIC_MAPS = [_os.environ.get('DM_GROUPED_SEM', '1') != '0']       # the stages' FPN-wide 1x1 convolutions: one launch
 
 
@@ -312,6 +323,8 @@ class DynaMaskHead(nn.Module):
             if fused_dcn is None or fused_dcn[i]:
                 dcn._pk.get('w', dcn.weight, ops.pack_conv_weight, job=(False, None, None, None))
             stage.fuse_transform_out.packed([dcn.out_channels])
+            if FUSED_DCN_TOUT[0] and not torch.is_grad_enabled() and stage.fuse_transform_out.weight.is_cuda:
+                stage.fuse_transform_out._pk.get('tout', stage.fuse_transform_out.weight, ops.pack_tout_weight)
 
     def pred_sizes(self, last_stage=None, defer_final_up=False):
         """Spatial size of every (instance, detail) logit pair ``forward`` returns, in order."""

@@ -585,6 +585,43 @@ def deform_conv(x, offset, w_packed, cout, deform_groups, relu=False, out=None):
     return out
 
 
+def deform_conv_tout_supported(x, cout, m2):
+    """Can ``deform_conv_tout`` take this shape (else: ``deform_conv`` + ``conv2d``)?"""
+    NB, C, H, W = x.shape
+    return bool(lib().dm_deform_conv_tout_supported(NB, C, H, W, cout, m2))
+
+
+def pack_tout_weight(w):
+    """The 1x1 weight [M2, C, 1, 1] behind a DCN, as ``deform_conv_tout`` reads it: transposed [C][M2 padded to 32], zeros
+    in the padding."""
+    m2, c = w.shape[0], w.shape[1]
+    m2p = (m2 + 31) // 32 * 32
+    out = torch.zeros((c, m2p), device=w.device, dtype=torch.float32)
+    out[:, :m2] = w.detach().reshape(m2, c).t()
+    return out
+
+
+def deform_conv_tout(x, offset, w_packed, cout, deform_groups, w2t, b2, m2, out2, keep_dcn=False):
+    """relu(DCN 3x3) -> 1x1 conv + bias + ReLU into channels [0, m2) of ``out2`` in ONE launch (dm_deform_conv_tout_fwd:
+    the second GEMM runs on the DCN's accumulators in registers; same bits as ``deform_conv(relu=True)`` followed by
+    ``conv2d(relu=True, out=out2)``).  ``keep_dcn``: also return relu(DCN) (else it is never written)."""
+    _chk(x, 'x')
+    _chk(offset, 'offset')
+    _chk(w_packed, 'w_packed')
+    _chk(w2t, 'w2t')
+    _chk(b2, 'b2')
+    _chk(out2, 'out2')
+    NB, C, H, W = x.shape
+    assert offset.shape == (NB, deform_groups * 18, H, W)
+    assert w_packed.numel() == packed_floats(cout, 3, [C])
+    assert tuple(w2t.shape) == (cout, (m2 + 31) // 32 * 32) and b2.numel() == m2
+    assert out2.shape[0] == NB and tuple(out2.shape[2:]) == (H, W) and out2.shape[1] >= m2
+    dcn = torch.empty((NB, cout, H, W), device=x.device, dtype=torch.float32) if keep_dcn else None
+    check(lib().dm_deform_conv_tout_fwd(_p(x), _p(offset), NB, C, H, W, _p(w_packed), cout, deform_groups, _p(w2t), _p(b2), m2,
+                                        _p(out2), out2.shape[1], _p(dcn), _stream()), 'dm_deform_conv_tout_fwd')
+    return dcn
+
+
 def pack_deconv_weight(w):
     _chk(w, 'weight')
     cin, cout, kh, kw = w.shape

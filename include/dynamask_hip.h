@@ -53,7 +53,7 @@ extern "C" {
 typedef void* dm_stream_t; /* hipStream_t */
 
 const char* dm_error_string(int code);
-/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient, dm_conv_pack_weight_batch, dm_mask_loss_stage; 15: dm_class_logits_up2x_fwd; 16: dm_conv2d_wgrad_slab / dm_conv2d_wgrad_scratch_floats; 17: dm_class_logits_bwd_slab / dm_class_logits_bwd_scratch_floats; 18: dm_reload_env_knobs, dm_roi_align_fwd_ws / dm_roi_align_workspace_bytes, dm_conv_pack_weight_split / dm_conv_packed_floats_split and flag bits 4, 5 of dm_conv2d_fwd; 19: dm_dcn_bwd_data_fused and its pack; 20: dm_conv2d_fwd_ws / dm_conv2d_splitk_floats; 21: dm_deform_conv_fwd_ws / dm_deform_conv_splitk_floats; 22: the bf16-split layouts (dm_conv_pack_weight_split, dm_conv_packed_floats_split, flag bits 4 / 5 of dm_conv2d_fwd) and the one-kernel DCN data gradient (dm_dcn_bwd_*) REMOVED -- measured, never the parity path, see docs/HISTORY.md; 23: dm_bn_stats takes mean_shift, dm_roi_align_bwd takes the gather form for 16 < P <= 64; 24: dm_build_info; 25: dm_boundary_merge_chain, dm_stage_head_fwd; 26: dm_conv1x1_group_fwd). */
+/* ABI version: bumped whenever a signature or the meaning of an argument changes (8: flag bit 3 of dm_conv2d_fwd; 9: RoI assignment / bbox training entry points; 10: dm_detail_target takes the fuse weights from device memory; 11: FCNMaskHead upsample backward; 12: dm_fc_fwd takes a scratch slab, deterministic split-K; 13: dm_deform_coord_grad / dm_deform_col2im, dm_conv2d_fwd_masked, dm_scale, dm_polygon_mask_targets, dm_ignore_columns, dm_upsample2x_bilinear_bwd overwrites; 14: dm_random_sample, dm_bn_relu_maxpool_argmax, the *_fx deterministic accumulators + dm_fx_to_float, dm_mask_loss_fwd_bwd takes a scratch, dm_conv2d_wgrad takes the bias gradient, dm_conv_pack_weight_batch, dm_mask_loss_stage; 15: dm_class_logits_up2x_fwd; 16: dm_conv2d_wgrad_slab / dm_conv2d_wgrad_scratch_floats; 17: dm_class_logits_bwd_slab / dm_class_logits_bwd_scratch_floats; 18: dm_reload_env_knobs, dm_roi_align_fwd_ws / dm_roi_align_workspace_bytes, dm_conv_pack_weight_split / dm_conv_packed_floats_split and flag bits 4, 5 of dm_conv2d_fwd; 19: dm_dcn_bwd_data_fused and its pack; 20: dm_conv2d_fwd_ws / dm_conv2d_splitk_floats; 21: dm_deform_conv_fwd_ws / dm_deform_conv_splitk_floats; 22: the bf16-split layouts (dm_conv_pack_weight_split, dm_conv_packed_floats_split, flag bits 4 / 5 of dm_conv2d_fwd) and the one-kernel DCN data gradient (dm_dcn_bwd_*) REMOVED -- measured, never the parity path, see docs/HISTORY.md; 23: dm_bn_stats takes mean_shift, dm_roi_align_bwd takes the gather form for 16 < P <= 64; 24: dm_build_info; 25: dm_boundary_merge_chain, dm_stage_head_fwd; 26: dm_conv1x1_group_fwd; 27: dm_deform_conv_tout_fwd / dm_deform_conv_tout_supported). */
 int dm_abi_version(void);
 /* "libdynamask_hip abi=N arch=gfx950 compiler=<clang version> flags=<the product-wide flags of dynamask_amd/build.py>"
  * (static storage).  The library must be compiled WITHOUT packed fp32 instructions (flag "-packed-fp32-ops", see
@@ -240,6 +240,18 @@ int dm_class_logits_up2x_fwd(const float* x, int N, int C, int H, int W, const f
 int dm_deform_conv_fwd(const float* x, const float* offset, int NB, int C, int H, int W,
                        const float* w_packed, int Cout, int deform_groups, int relu, float* out,
                        dm_stream_t stream);
+/* (ABI 27) K8 + the 1x1 behind it in one launch: relu(DCN 3x3) -> 1x1 conv + bias + ReLU, i.e. SFMStage.fuse_conv[1]
+ * followed by fuse_transform_out (mmdet/models/roi_heads/mask_heads/dynamask_head.py:117-121), for the 28 x 28 / 56 x 56
+ * stages at more than a handful of RoIs (dm_deform_conv_tout_supported: 1 = this shape takes the kernel build in which a
+ * wave holds every output channel of its pixels; the 1x1 then runs on the accumulators in registers).
+ *   w2t  [Cout][M2P]  the 1x1 weight [M2, Cout] transposed, M2P = M2 rounded up to 32, zeros in the padding
+ *   out2 [NB, out2_ch_total, H, W]: channels [0, M2) are written;   out_dcn: NULL (the DCN output is not stored) or
+ *   [NB, Cout, H, W].  Returns DM_ERR_UNSUPPORTED for other shapes.  Bits: those of dm_deform_conv_fwd + dm_conv2d_fwd. */
+int dm_deform_conv_tout_supported(int NB, int C, int H, int W, int Cout, int M2);
+int dm_deform_conv_tout_fwd(const float* x, const float* offset, int NB, int C, int H, int W, const float* w_packed, int Cout,
+                            int deform_groups, const float* w2t, const float* b2, int M2, float* out2, int out2_ch_total,
+                            float* out_dcn, dm_stream_t stream);
+
 /* (ABI 21) dm_deform_conv_fwd with a caller-owned workspace: a launch that leaves most of the chip idle (the <= 100-RoI
  * inference calls) splits its channel loop over up to eight workgroups per tile; a second kernel adds the splits in index
  * order (+ ReLU).  Same bits every run; they differ from dm_deform_conv_fwd's by the association of the channel sums.

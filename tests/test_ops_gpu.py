@@ -344,6 +344,40 @@ def test_boundary_merge_chain_has_the_bits_of_the_launches_it_replaces(ops, gold
     assert ops.boundary_merge_chain(a[:0], b[:0], fin[:0]).shape[0] == 0
 
 
+def test_dcn_with_chained_1x1_has_the_bits_of_the_two_launches(ops):
+    """dm_deform_conv_tout_fwd (round 6): DCN 3x3 + ReLU + fuse_transform_out (1x1 + bias + ReLU) in one launch, the second
+    GEMM on the accumulators in registers -- bit for bit the two launches, at the 28 x 28 / 128-channel and 56 x 56 /
+    64-channel stage shapes with offsets that leave the LDS band, into a channel slice of a wider tensor, with and
+    without keeping the DCN output; shapes the kernel does not take are refused."""
+    gen = torch.Generator().manual_seed(94)
+    for C, S, n in ((128, 28, 40), (64, 56, 12), (64, 56, 9)):
+        m2 = C // 2 - 2
+        x = _dev(torch.randn(n, C, S, S, generator=gen))
+        off = torch.randn(n, 36, S, S, generator=gen) * 1.5
+        off[0, :, :4, :4] = 9.0                                                     # far samples: the slow pass of the band kernel
+        off = _dev(off)
+        w = _dev(torch.randn(C, C, 3, 3, generator=gen) / (9 * C) ** 0.5)
+        w2 = _dev(torch.randn(m2, C, 1, 1, generator=gen) / C ** 0.5)
+        b2 = _dev(torch.randn(m2, generator=gen))
+        wp, w2p, w2t = ops.pack_conv_weight(w), ops.pack_conv_weight(w2), ops.pack_tout_weight(w2)
+        assert ops.deform_conv_tout_supported(x, C, m2)
+        d_ref = ops.deform_conv(x, off, wp, C, 2, relu=True)
+        t_ref = torch.full((n, C // 2, S, S), 7.0, device='cuda')
+        ops.conv2d(d_ref, w2p, b2, m2, 1, relu=True, out=t_ref, out_ch_offset=0)
+        for keep in (False, True):
+            t = torch.full((n, C // 2, S, S), 7.0, device='cuda')
+            d = ops.deform_conv_tout(x, off, wp, C, 2, w2t, b2, m2, t, keep_dcn=keep)
+            assert torch.equal(t, t_ref), (C, S, keep)                               # incl. the two channels behind m2: untouched
+            assert (d is None) if not keep else torch.equal(d, d_ref)
+    xs = _dev(torch.randn(4, 64, 56, 56, generator=gen))                            # a handful of RoIs: another wave layout
+    assert not ops.deform_conv_tout_supported(xs, 64, 30)
+    assert not ops.deform_conv_tout_supported(_dev(torch.randn(40, 256, 14, 14, generator=gen)), 256, 126)
+    with pytest.raises(RuntimeError, match='not supported'):
+        ops.deform_conv_tout(xs, _dev(torch.zeros(4, 36, 56, 56)), ops.pack_conv_weight(_dev(torch.randn(64, 64, 3, 3, generator=gen))), 64, 2,
+                             ops.pack_tout_weight(_dev(torch.randn(30, 64, 1, 1, generator=gen))), _dev(torch.zeros(30)), 30,
+                             torch.zeros(4, 32, 56, 56, device='cuda'))
+
+
 def test_grouped_1x1_convs_equal_their_own_launches(ops):
     """dm_conv1x1_group_fwd (round 6): the three FPN-wide semantic convolutions in one launch -- bit for bit what three
     dm_conv2d_fwd launches produce (256 -> 256 / 128 / 64 on maps of three sizes, two images), and the 2- and 1-problem forms."""

@@ -134,13 +134,14 @@ def test_fused_inference_launches_give_the_bits_of_the_unfused_sequence():
             for fused in (False, True):
                 mask_heads.FUSED_STAGE_HEAD[0] = fused
                 mask_heads.GROUPED_SEMANTIC_MAPS[0] = fused
+                mask_heads.FUSED_DCN_TOUT[0] = fused
                 roi_head.FUSED_MERGE_TAIL[0] = fused
                 outs[(split_min, fused)] = m.simple_test_mask_logits(feats, boxes, labels).clone()
             m.enable_inference_graphs(True)
             outs[(split_min, 'graph')] = m.simple_test_mask_logits(feats, boxes, labels).clone()
             m.enable_inference_graphs(False)
         _ops.CONV_SPLITK[0] = split_was
-        mask_heads.FUSED_STAGE_HEAD[0] = mask_heads.GROUPED_SEMANTIC_MAPS[0] = roi_head.FUSED_MERGE_TAIL[0] = True
+        mask_heads.FUSED_STAGE_HEAD[0] = mask_heads.GROUPED_SEMANTIC_MAPS[0] = mask_heads.FUSED_DCN_TOUT[0] = roi_head.FUSED_MERGE_TAIL[0] = True
         m.stream_split_min = 64
         with_split = m.simple_test_mask_logits(feats, boxes, labels).clone()
     ref = outs[(64, False)]
