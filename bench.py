@@ -373,7 +373,7 @@ def count_host_syncs(fn):
         with warnings.catch_warnings(record=True) as w:
             warnings.simplefilter('always')
             fn()
-        return sum(1 for x in w if 'synchroniz' in str(x.message).lower())
+        return sum(1 for x in w if 'synchronizing' in str(x.message).lower())      # (not the mode's own "prototype feature" notice)
     except Exception as e:      # noqa: BLE001
         print(f'[bench] sync counting unavailable: {e}', file=sys.stderr)
         return None

@@ -136,6 +136,13 @@ class SamplingResult:
         return torch.cat([self.pos_bboxes, self.neg_bboxes])
 
 
+class _PendingSample:
+    """Buffers of a ``random_sample`` launch whose counts have not been read yet (RandomSampler.sample_deferred)."""
+
+    def __init__(self, buffers, num_gts):
+        self.buffers, self.num_gts = buffers, num_gts
+
+
 @BBOX_SAMPLERS.register_module()
 class RandomSampler:
     """``RandomSampler(num, pos_fraction, neg_pos_ub=-1, add_gt_as_proposals=True)`` of the reference's config
@@ -173,7 +180,7 @@ class RandomSampler:
             keys.append(k.to(dev))
         return keys
 
-    def sample(self, assign_result, bboxes, gt_bboxes, gt_labels=None, **kwargs):
+    def sample(self, assign_result, bboxes, gt_bboxes, gt_labels=None, _defer=False, **kwargs):
         boxes = bboxes.reshape(-1, bboxes.shape[-1])[:, :4]
         n_prepended = 0
         if self.add_gt_as_proposals and len(gt_bboxes) > 0:
@@ -199,5 +206,27 @@ class RandomSampler:
         labels = None if assign_result.labels is None else assign_result.labels.contiguous()
         buffers = ops.random_sample(gt_inds, boxes, n_prepended, gt_bboxes.float().reshape(-1, 4).contiguous(), labels,
                                     pos_keys, neg_keys, self.cpu_rng, self.num, quota_pos, float(self.neg_pos_ub))
+        if _defer:
+            return _PendingSample(buffers, gt_bboxes.shape[0])
         n_pos, n_neg = buffers['counts'][:2].tolist()          # the one host sync: the heads' tensors are sized by it
         return SamplingResult(buffers, n_pos, n_neg, gt_bboxes.shape[0])
+
+    def sample_deferred(self, assign_result, bboxes, gt_bboxes, gt_labels=None, **kwargs):
+        """``sample`` without its host sync: the kernels are enqueued, the result is ``finish_samples``' to size.  A caller
+        with several images (``DynaMaskRoIHead.forward_train``) defers them all and waits ONCE for all the counts."""
+        return self.sample(assign_result, bboxes, gt_bboxes, gt_labels, _defer=True, **kwargs)
+
+    @staticmethod
+    def finish_samples(pending):
+        """SamplingResults of ``sample_deferred`` calls: one device -> host read for the (positives, negatives) of all."""
+        live = [p for p in pending if isinstance(p, _PendingSample)]
+        counts = torch.stack([p.buffers['counts'][:2] for p in live]).tolist() if live else []
+        it = iter(counts)
+        out = []
+        for p in pending:
+            if isinstance(p, _PendingSample):
+                n_pos, n_neg = next(it)
+                out.append(SamplingResult(p.buffers, n_pos, n_neg, p.num_gts))
+            else:
+                out.append(p)                                   # (an image without proposals: already a SamplingResult)
+        return out

@@ -143,6 +143,10 @@ class Shared2FCBBoxHead(nn.Module):
             label_weights = torch.cat(label_weights, 0)
             bbox_targets = torch.cat(bbox_targets, 0)
             bbox_weights = torch.cat(bbox_weights, 0)
+            # every sampled row carries a weight > 0 (_get_target_single: pos_weight, made 1 when <= 0, for positives; 1 for
+            # negatives): the count the classification loss normalises by is the row count, known on the host -- ``loss``
+            # below takes it from here instead of reading it back from the device (a host sync per step)
+            label_weights._dm_num_weighted = int(label_weights.shape[0])
         return labels, label_weights, bbox_targets, bbox_weights
 
     def loss(self, cls_score, bbox_pred, rois, labels, label_weights, bbox_targets, bbox_weights, reduction_override=None):
@@ -150,7 +154,8 @@ class Shared2FCBBoxHead(nn.Module):
         from .losses import accuracy
         losses = dict()
         if cls_score is not None:
-            avg_factor = max(torch.sum(label_weights > 0).float().item(), 1.)
+            known = getattr(label_weights, '_dm_num_weighted', None)      # set by get_targets: all of its rows are weighted
+            avg_factor = max(float(known) if known is not None else torch.sum(label_weights > 0).float().item(), 1.)
             if cls_score.numel() > 0:
                 losses['loss_cls'] = self.loss_cls(cls_score, labels, label_weights, avg_factor=avg_factor,
                                                    reduction_override=reduction_override)

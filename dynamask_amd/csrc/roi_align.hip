@@ -1137,11 +1137,17 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(RoiArgs a) {
   const int gh = a.sr > 0 ? a.sr : (int)ceilf(rh / (float)P);
   const int gw = a.sr > 0 ? a.sr : (int)ceilf(rw / (float)P);
   if (gh <= 0 || gw <= 0) return;                       // (the forward wrote zeros: no gradient)
+  // a box that is not finite, or so large that its sampling grid exceeds 4096 samples per bin and axis (229 000 feature
+  // pixels at P = 56: no clipped proposal comes near): (int)ceilf(inf) is not defined, P * g overflows an int and slips
+  // past the table test below, and the per-tap path would loop over g * g samples per bin without end -- no gradient
+  // for it.  Written so that a NaN fails the test.
+  if (!(fabsf(rh) <= 4096.f * (float)P) || !(fabsf(rw) <= 4096.f * (float)P)) return;
   const float inv_count = 1.0f / (float)(gh * gw);
   const size_t plane = (size_t)Hl * Wl;
   float* const gimg = glvl + ((size_t)b * a.C + c0) * plane;
   const float* const go = a.gout + ((size_t)k * a.C + c0) * PP;
-  const int ny = P * gh, nx = P * gw;
+  const long long ny64 = (long long)P * gh, nx64 = (long long)P * gw;
+  const int ny = (int)min(ny64, (long long)kAdjMaxSamples + 1), nx = (int)min(nx64, (long long)kAdjMaxSamples + 1);
 
   // the RoI's four gradient planes -> LDS [pixel] float4
   float4* const gq = lds4;
@@ -1175,7 +1181,13 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(RoiArgs a) {
       }
     }
   };
-  if (ny > kAdjMaxSamples || nx > kAdjMaxSamples || !(bh > 0.f) || !(bw > 0.f)) {
+  // The tables below rely on the sample coordinate growing with the sample index.  With the adaptive grid (sr == 0) a
+  // bin holds g = ceil(bin) samples, so consecutive samples are bin / g in (0.5, 1] pixels apart: monotone in fp32.  A
+  // FIXED sampling_ratio on a tiny box puts them bin / g apart, and below an ulp of the coordinate (~3e-5 px on P2) the
+  // last sample of bin p can round above the first of bin p + 1 across a pixel boundary -- taps would be dropped or
+  // counted twice.  Such boxes take the per-tap path.
+  const bool dense_fixed = a.sr > 0 && (!(bh > 1e-3f * (float)gh) || !(bw > 1e-3f * (float)gw));
+  if (ny > kAdjMaxSamples || nx > kAdjMaxSamples || !(bh > 0.f) || !(bw > 0.f) || dense_fixed) {
     __syncthreads();
     generic();
     return;

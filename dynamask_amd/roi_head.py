@@ -329,8 +329,25 @@ class DynaMaskRoIHead(nn.Module):
         return [streams.side(device, i) for i in range(k)]      # more chunks than pool streams: they share (still ordered)
 
     def sample_uniform(self, shape, device):
-        """The reference draws on the CPU generator and copies (dynamask_roi_head.py:90-91, Q9)."""
-        return torch.rand(shape).to(device)
+        """The reference draws on the CPU generator and copies (dynamask_roi_head.py:90-91, Q9).  Same draw here; the copy
+        goes through a pinned staging buffer and does not block the host (a pageable-memory copy waits for the stream).
+        The buffer is reused: the event of its previous copy is waited for before the next draw overwrites it."""
+        device = torch.device(device)
+        if device.type != 'cuda':
+            return torch.rand(shape).to(device)
+        n = 1
+        for d in shape:
+            n *= int(d)
+        st = getattr(self, '_noise_stage', None)
+        if st is None or st[0].numel() < n:
+            st = self._noise_stage = [torch.empty(max(n, 1024), dtype=torch.float32).pin_memory(), None]
+        if st[1] is not None:
+            st[1].synchronize()
+        host = st[0][:n].view(shape)
+        torch.rand(shape, out=host)
+        dev_t = host.to(device, non_blocking=True)
+        st[1] = torch.cuda.current_stream(device).record_event()
+        return dev_t
 
     def get_mask_label(self, ins_semantic_feats, noise=None, return_index=False):
         """dynamask_roi_head.py:84-87,97-114: logits -> ST-Gumbel-softmax (hard)."""
@@ -377,10 +394,16 @@ class DynaMaskRoIHead(nn.Module):
         if gt_bboxes_ignore is None:
             gt_bboxes_ignore = [None for _ in range(num_imgs)]
         sampling_results = []
+        # assignment and sampling of every image are enqueued first; the host then waits ONCE for all the (positive,
+        # negative) counts that size the heads' tensors, not once per image (RandomSampler.sample_deferred)
+        deferred = hasattr(self.bbox_sampler, 'sample_deferred')
+        do_sample = self.bbox_sampler.sample_deferred if deferred else self.bbox_sampler.sample
         for i in range(num_imgs):
             assign_result = self.bbox_assigner.assign(proposal_list[i], gt_bboxes[i], gt_bboxes_ignore[i], gt_labels[i])
-            sampling_results.append(self.bbox_sampler.sample(assign_result, proposal_list[i], gt_bboxes[i], gt_labels[i],
-                                                             feats=[lvl_feat[i][None] for lvl_feat in x]))
+            sampling_results.append(do_sample(assign_result, proposal_list[i], gt_bboxes[i], gt_labels[i],
+                                              feats=[lvl_feat[i][None] for lvl_feat in x]))
+        if deferred:
+            sampling_results = self.bbox_sampler.finish_samples(sampling_results)
         # the bbox branch and the mask branch meet only in the sum of the losses: the bbox branch is issued on its own
         # stream (its backward follows it there) and joined before the losses are handed back
         losses = {}
@@ -496,7 +519,11 @@ class DynaMaskRoIHead(nn.Module):
         mask_results.update(loss_mask=loss_mask, mask_labels=mask_labels, mask_index=idx, mask_logits=logits)
         if self.train_cfg is not None and getattr(self.train_cfg, 'get', None) and self.train_cfg.get('flops') is not None:
             # dynamask_roi_head.py:68-71: computed and attached, never added to the losses (Quirk Q3)
-            fl = mask_labels.new_tensor(self.train_cfg.flops)
+            key = (mask_labels.device, tuple(float(v) for v in self.train_cfg.flops))
+            fl = getattr(self, '_flops_dev', (None, None))
+            if fl[0] != key:      # (uploaded once: ``new_tensor`` of a Python list is a blocking host -> device copy per step)
+                fl = self._flops_dev = (key, mask_labels.new_tensor(self.train_cfg.flops))
+            fl = fl[1]
             budget = (mask_labels.detach() * fl).sum() / len(mask_labels) - 1.0
             mask_results['loss_flops'] = {'loss_flops': self.train_cfg.Lambda * torch.clamp(
                 budget / (self.train_cfg.flops[-1] - self.train_cfg.flops[0]), min=0)}

@@ -113,6 +113,35 @@ def test_roi_align_adjoint_in_gather_form_matches_autograd_of_the_oracle(ops, P,
         assert_grad_close(gr, ref_g, f'level {lvl}', rel=1e-4, zero=not bool(ref_g.abs().max() > 0))
 
 
+def test_roi_align_adjoint_dense_fixed_grid_and_non_finite_boxes(ops):
+    """ADVICE r5 on roi_align_bwd_gather_kernel: (a) a FIXED sampling ratio on boxes a fraction of a pixel wide puts the
+    samples closer than an ulp of their coordinate -- no monotone order to build the tables on: per-tap path, against
+    autograd of the oracle; (b) boxes with Inf / NaN coordinates or of absurd size contribute no gradient and the launch
+    terminates (the per-tap path would loop over an unbounded sampling grid)."""
+    from dynamask_amd import synth
+    from tolerances import assert_grad_close
+    P, C = 56, 8
+    feat = synth.make_fpn(1, 160, 224, C, seed=35)[0].requires_grad_(True)
+    rois = torch.tensor([[0., 100.0, 60.0, 100.004, 60.004],         # 0.001 feature pixels wide: bin / g ~ 1e-5
+                         [0., 40.0, 33.9999, 40.02, 34.0001],        # straddles a pixel boundary
+                         [0., 10.0, 10.0, 90.0, 70.0]])              # an ordinary box beside them
+    ref = ref_ops.roi_align(feat, rois, P, 1 / 4, sampling_ratio=2)
+    go = torch.randn(ref.shape, generator=_g(36))
+    ref.backward(go)
+    gr = ops.roi_align_backward(_dev(go), [tuple(feat.shape)], _dev(rois), P, [0.25], sampling_ratio=2)[0]
+    assert_grad_close(gr, feat.grad, 'dense fixed grid', rel=1e-4)
+    inf, nan = float('inf'), float('nan')
+    bad = torch.tensor([[0., 10., 10., inf, 50.], [0., -inf, 10., 50., 50.], [0., nan, 10., 50., 50.], [0., 0., 0., 3e9, 40.],
+                        [0., 10.0, 10.0, 90.0, 70.0]])
+    go2 = torch.randn(5, C, P, P, generator=_g(37))
+    for sr in (0, 2):
+        g_bad = ops.roi_align_backward(_dev(go2), [tuple(feat.shape)], _dev(bad), P, [0.25], sampling_ratio=sr)[0]
+        g_ok = ops.roi_align_backward(_dev(go2[4:]), [tuple(feat.shape)], _dev(bad[4:]), P, [0.25], sampling_ratio=sr)[0]
+        torch.cuda.synchronize()
+        assert torch.isfinite(g_bad).all()
+        assert_grad_close(g_bad, g_ok.cpu(), f'only the finite box contributes (sr={sr})', rel=1e-5)
+
+
 def test_roi_align_backward(ops):
     from dynamask_amd import synth
     feats = [f.requires_grad_(True) for f in synth.make_fpn(2, 160, 224, 8, seed=11)[:4]]
