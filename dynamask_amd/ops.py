@@ -601,7 +601,7 @@ def pack_tout_weight(w):
     return out
 
 
-def deform_conv_tout(x, offset, w_packed, cout, deform_groups, w2t, b2, m2, out2, keep_dcn=False):
+def deform_conv_tout(x, offset, w_packed, cout, deform_groups, w2t, b2, m2, out2, keep_dcn=False, dcn_out=None):
     """relu(DCN 3x3) -> 1x1 conv + bias + ReLU into channels [0, m2) of ``out2`` in ONE launch (dm_deform_conv_tout_fwd:
     the second GEMM runs on the DCN's accumulators in registers; same bits as ``deform_conv(relu=True)`` followed by
     ``conv2d(relu=True, out=out2)``).  ``keep_dcn``: also return relu(DCN) (else it is never written)."""
@@ -616,7 +616,12 @@ def deform_conv_tout(x, offset, w_packed, cout, deform_groups, w2t, b2, m2, out2
     assert w_packed.numel() == packed_floats(cout, 3, [C])
     assert tuple(w2t.shape) == (cout, (m2 + 31) // 32 * 32) and b2.numel() == m2
     assert out2.shape[0] == NB and tuple(out2.shape[2:]) == (H, W) and out2.shape[1] >= m2
-    dcn = torch.empty((NB, cout, H, W), device=x.device, dtype=torch.float32) if keep_dcn else None
+    dcn = None
+    if dcn_out is not None:                 # (a caller's buffer for relu(DCN): implies keep_dcn)
+        dcn = _chk(dcn_out, 'dcn_out')
+        assert tuple(dcn.shape) == (NB, cout, H, W)
+    elif keep_dcn:
+        dcn = torch.empty((NB, cout, H, W), device=x.device, dtype=torch.float32)
     check(lib().dm_deform_conv_tout_fwd(_p(x), _p(offset), NB, C, H, W, _p(w_packed), cout, deform_groups, _p(w2t), _p(b2), m2,
                                         _p(out2), out2.shape[1], _p(dcn), _stream()), 'dm_deform_conv_tout_fwd')
     return dcn
