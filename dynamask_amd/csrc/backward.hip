@@ -2277,7 +2277,7 @@ extern "C" int dm_deform_col2im(const float* colgrad, const float* offset, int N
               W, deform_groups, grad_x);
   } else if (cpg % 2 == 0 && 2 * plane_b <= 64 * 1024) {
     // (56 x 56: two 25 KB planes, three workgroups per CU -- with 8 waves each 1.09 -> 1.02 ms at 256 RoIs x 64 channels; four
-    // planes in 100 KB: 1.85 ms with 4 waves, 1.17 with 8; one plane: 1.29 -- tools/col2im_exp.py)
+    // planes in 100 KB: 1.85 ms with 4 waves, 1.17 with 8; one plane: 1.29 -- a round-4 probe, docs/HISTORY.md)
     DM_LAUNCH((dcn_col2im_lds_kernel<2, 512>), dim3((unsigned)(NB * (C / 2))), dim3(512), 2 * plane_b, st, colgrad, offset, NB, C, H,
               W, deform_groups, grad_x);
   } else if (plane_b <= 64 * 1024) {

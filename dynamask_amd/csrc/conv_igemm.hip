@@ -951,7 +951,7 @@ static int conv2d_launch(const float* const* srcs, const int* src_channels, cons
       // keeps a second stream busy (flag bit 3) has that stream's workgroups fill the last round;
       // the extra dependent launch then only delays its own stream (measured: 250 vs 241 img/s).
       // Worth it while the last round is at most ~0.6 full (measured at 0.01 .. 0.99); DM_CONV_TAIL=0
-      // turns it off for tools/tail_probe.py.
+      // turns it off (A/B measurements).
       static const int tail_mode = getenv("DM_CONV_TAIL") ? atoi(getenv("DM_CONV_TAIL")) : 1;
       const int MT = dm_ceil_div(a.CoutP, 128), NTiles = dm_ceil_div(a.Q, 128);
       // workgroups per CU: 3 when the staged plane needs one position per thread (the 168-VGPR build

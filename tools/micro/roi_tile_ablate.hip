@@ -1,11 +1,12 @@
 // Ceiling measurement of the 14x14 multi-level RoIAlign kernel (reproducible evidence).
-// Compiles the LIBRARY's roi_align.hip with -DDM_ROI_ABLATE=<variant>, ONE BINARY PER VARIANT (tools/roi_ceiling.sh builds
-// eight): the ablation bits are compile-time constants (DM_ABL in roi_align.hip), variant 0 is the product kernel
+// Compiles the LIBRARY's roi_align.hip with -DDM_ROI_ABLATE=<variant>, ONE BINARY PER VARIANT (eight; the round-4 driver
+// script went with the prune of round 6, profiles/r04_roialign_ceiling.txt is what it wrote): the ablation bits are compile-time constants (DM_ABL in roi_align.hip), variant 0 is the product kernel
 // instruction for instruction.  Bit 1 = no global loads (the staging commits register garbage), bit 2 = one LDS tap per
 // output instead of the merged stencil, bit 4 = no output stores.  Workload = bench.py's: FPN maps of a
 // 1333x800 image (P2..P5, 256 channels, random), the 512 RoIs of synth.make_rois(seed=1) (rois_512_1333x800.txt).
 //
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Idynamask_amd/csrc -DDM_ROI_ABLATE=3 tools/micro/roi_tile_ablate.hip -o gpurun_out/roi_tile_ablate_3
+//   (pass the product's flags -- dynamask_amd/build.py FLAGS: no packed fp32 -- or variant 0 is not the product's codegen)
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Xclang -target-feature -Xclang -packed-fp32-ops -Iinclude -Idynamask_amd/csrc -DDM_ROI_ABLATE=3 tools/micro/roi_tile_ablate.hip -o gpurun_out/roi_tile_ablate_3
 //   gpurun_out/roi_tile_ablate_3 tools/micro/rois_512_1333x800.txt          # that variant, 14x14
 //   ROI_P=7 ...                                                              # the 7x7 bbox extraction
 #ifndef DM_ROI_ABLATE
