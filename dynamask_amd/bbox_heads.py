@@ -14,7 +14,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import hazard, ops
 from .registry import HEADS, Registry, build_from_cfg
 
 BBOX_CODERS = Registry('bbox_coder')
@@ -212,6 +212,7 @@ class BBoxHeadFn(torch.autograd.Function):
         return cls_score, bbox_pred
 
     @staticmethod
+    @hazard.backward_node
     def backward(ctx, g_cls, g_reg):
         head, acts = ctx.head, ctx.acts
         from . import hazard

@@ -130,6 +130,7 @@ class Tracker:
         self.spans = {}            # storage key -> (lo, hi)
         self.guard = {}            # storage key -> {stream}: record_stream() was called (the allocator orders reuse)
         self.reports = []
+        self.returned = {}         # storage key -> (stream, clock snapshot) of the custom backward that returned it
         self.launches = 0
         self.names = {}            # stream id -> label for reports
 
@@ -229,8 +230,28 @@ class Tracker:
         streams = list(self.clock)
         return [r for r in recs if not all(st == r.stream or self.ordered(st, r) for st in streams)]
 
+    def returned_from(self, s, key):
+        """A custom backward on stream ``s`` hands a gradient (storage ``key``) back to the autograd engine."""
+        self.returned[key] = (s, dict(self._clk(s)))
+
     def handoff(self, s, key, pat):
-        """The autograd engine hands a tensor to a node on stream ``s``: it makes ``s`` wait for the producer."""
+        """The autograd engine hands a tensor to a node on stream ``s``: it makes ``s`` wait for the PRODUCER NODE's
+        stream as of that node's return (torch/csrc/autograd/input_buffer.cpp) -- not for every stream that ever wrote
+        the tensor.  Where the producing backward told us its return (``returned_from``), only that snapshot is merged,
+        and a write on another stream that the producer had not joined by then is what the tracker exists to find: a
+        gradient finished on a side stream behind the engine's back.  Gradients of torch's own nodes (no
+        return record) keep the lenient rule: wait for whoever wrote them."""
+        ret = self.returned.pop(key, None)
+        if ret is not None:
+            rs, snap = ret
+            for r in self.records.get(key, ()):
+                if r.write and r.pat.overlaps(pat) and r.stream != rs and snap.get(r.stream, 0) < r.tick \
+                        and self.host.get(r.stream, 0) < r.tick:
+                    self._report('unjoined gradient', f'autograd hand-off of {r.pat}', s, r,
+                                 f'the backward that produced it returned on stream {self._label(rs)} without waiting for '
+                                 f'that write: the engine orders the consumer behind stream {self._label(rs)} only')
+            self._merge(self._clk(s), snap)
+            return
         for r in self.records.get(key, ()):
             if r.write and r.stream != s and r.pat.overlaps(pat):
                 self._merge(self._clk(s), r.clock)
@@ -315,6 +336,31 @@ def engine_handoff(*tensors):
     for t in tensors:
         if t is not None and getattr(t, 'is_cuda', False):
             TRACKER.handoff(s, t.untyped_storage().data_ptr(), tensor_pattern(t))
+
+
+def engine_return(outs):
+    """At the exit of a custom backward: the gradients it hands back, and the stream (with everything that stream is
+    ordered behind) the engine will make their consumers wait for."""
+    if not ENABLED[0] or _capturing():
+        return
+    s = _stream_id()
+    for t in (outs if isinstance(outs, (tuple, list)) else (outs,)):
+        if t is not None and getattr(t, 'is_cuda', False):
+            TRACKER.returned_from(s, t.untyped_storage().data_ptr())
+
+
+def backward_node(fn):
+    """Decorator for the ``backward`` staticmethods of the package's autograd Functions: reports the return to the
+    tracker (a plain call when the tracker is off)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(ctx, *grads):
+        out = fn(ctx, *grads)
+        if ENABLED[0]:
+            engine_return(out)
+        return out
+    return wrapped
 
 
 class _LibProxy:

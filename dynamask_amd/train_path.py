@@ -135,6 +135,7 @@ class RoIExtractFn(torch.autograd.Function):
         return ops.roi_align(feats, rois, output_size, scales, sampling_ratio, finest_scale)
 
     @staticmethod
+    @hazard.backward_node
     def backward(ctx, g):
         (rois,) = ctx.saved_tensors
         hazard.engine_handoff(g)
@@ -395,6 +396,7 @@ class MaskHeadFn(torch.autograd.Function):
         return ips, dps, saved, feats, rois, labels
 
     @staticmethod
+    @hazard.backward_node
     def backward(ctx, *grads):
         head, sv, feats, rois, labels = ctx.head, ctx.saved, ctx.feats, ctx.rois, ctx.labels
         hazard.engine_handoff(*grads)
@@ -637,6 +639,7 @@ class MaskPreFn(torch.autograd.Function):
         return logits
 
     @staticmethod
+    @hazard.backward_node
     def backward(ctx, g):
         mp = ctx.mp
         hazard.engine_handoff(g)
@@ -682,6 +685,7 @@ class MaskPreMapFn(torch.autograd.Function):
         return logits
 
     @staticmethod
+    @hazard.backward_node
     def backward(ctx, g):
         mp = ctx.mp
         hazard.engine_handoff(g)
@@ -717,6 +721,7 @@ class GumbelSelectFn(torch.autograd.Function):
         return hot, idx
 
     @staticmethod
+    @hazard.backward_node
     def backward(ctx, g_hot, _g_idx):
         (y,) = ctx.saved_tensors
         hazard.engine_handoff(g_hot)
@@ -749,6 +754,7 @@ class FCNMaskHeadFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @hazard.backward_node
     def backward(ctx, g):
         head, acts, u, aux = ctx.head, ctx.acts, ctx.u, ctx.aux
         hazard.engine_handoff(g)

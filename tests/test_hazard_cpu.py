@@ -127,3 +127,38 @@ def test_records_do_not_grow_without_bound():
         else:
             t.wait(MAIN, t.record(SIDE))
     assert len(t.records[0x1000]) < 64
+
+
+def test_handoff_waits_for_the_producer_node_only_and_reports_unjoined_side_stream_gradients():
+    """the autograd engine orders a consumer behind the PRODUCER NODE's stream as of its return, not behind
+    every stream that wrote the gradient.  A backward that finishes a gradient on a side stream and returns without
+    joining it is reported; one that joins first is not, and its consumer ends up ordered behind the side stream too."""
+    from dynamask_amd.hazard import Pattern, Tracker
+    pat = Pattern(0, 1024)
+    ent = lambda key: (key, key, key + 1024, pat, 'g')          # noqa: E731
+    # -- producer node on stream 1 writes the gradient on side stream 2 and returns WITHOUT a join
+    t = Tracker()
+    t.launch(1, 'producer_main')
+    t.wait(2, t.record(1))
+    t.launch(2, 'producer_side', writes=[ent(4096)])
+    t.returned_from(1, 4096)
+    t.handoff(3, 4096, pat)
+    assert len(t.reports) == 1 and 'unjoined gradient' in t.reports[0] and 'producer_side' in t.reports[0]
+    t.launch(3, 'consumer', reads=[ent(4096)])                   # ... and the read itself is a hazard as well
+    assert any('read-after-write' in r for r in t.reports)
+    # -- the same with the join in front of the return: clean, and the consumer is ordered behind the side stream
+    t = Tracker()
+    t.launch(1, 'producer_main')
+    t.wait(2, t.record(1))
+    t.launch(2, 'producer_side', writes=[ent(4096)])
+    t.wait(1, t.record(2))
+    t.returned_from(1, 4096)
+    t.handoff(3, 4096, pat)
+    t.launch(3, 'consumer', reads=[ent(4096)])
+    assert t.reports == []
+    # -- a gradient of one of torch's own nodes (no return record): the lenient rule of before
+    t = Tracker()
+    t.launch(2, 'torch_node', writes=[ent(8192)])
+    t.handoff(3, 8192, pat)
+    t.launch(3, 'consumer', reads=[ent(8192)])
+    assert t.reports == []
