@@ -247,6 +247,25 @@ def test_mask_pre_on_the_map_matches_the_reference_order_in_training():
             continue
         assert_grad_close(gb[k], ga[k], k)
     assert len(flipped) <= 2, f'channels of conv1 / bn1 beyond the gate: {sorted(flipped)}'
+    # ... and a channel beyond the gate must actually HOLD a tie (a per-channel bug of that size would pass
+    # otherwise): relu(bn1(conv1(x))) of that channel recomputed from the extracted tensor, and among its 3 x 3 / stride-2
+    # pooling windows at least one whose two largest candidates are closer than the ~1e-6 the two orders differ by
+    if flipped:
+        import torch.nn.functional as F
+        m = _roi_head(train=True)
+        mp = m.mask_predictor
+        with torch.no_grad():
+            mp.conv1.bias.add_(torch.linspace(-0.5, 0.5, 128, device='cuda'))
+            x = ops.roi_align([_dev(feat)], _dev(rois), 56, [0.25])
+            for c in sorted(flipped):
+                y = F.conv2d(x, mp.conv1.weight[c:c + 1], mp.conv1.bias[c:c + 1])            # [N, 1, 56, 56]
+                z = F.relu((y - y.mean()) / torch.sqrt(y.var(unbiased=False) + mp.bn1.eps) * mp.bn1.weight[c] + mp.bn1.bias[c])
+                win = F.unfold(F.pad(z, (1, 1, 1, 1), value=float('-inf')), kernel_size=3, stride=2)   # [N, 9, 784]
+                top2 = win.topk(2, dim=1).values
+                live = top2[:, 0] > 0                                                          # (a window of zeros routes no gradient)
+                gap = (top2[:, 0] - top2[:, 1])[live]
+                print(f'channel {c}: smallest top-2 gap of a live pooling window {float(gap.min()):.3g}')
+                assert float(gap.min()) < 2e-5 * max(float(z.max()), 1.0), f'channel {c} differs beyond the gate without a pooling tie'
 
 
 def test_dyna_loss_and_grads_match_reference_golden(golden_dir):
