@@ -191,126 +191,59 @@ class DynaMaskRoIHead(nn.Module):
             return self._mask_forward_infer(x, rois, roi_labels, last_stage)
 
     def _mask_forward_infer(self, x, rois, roi_labels, last_stage=None, merge=False):
-        """Inference: the RoIs are independent, so they are split into chunks on separate HIP streams (the tail of every
-        kernel -- its last, partially filled round of workgroups over the 256 CUs -- overlaps the other chunk's work),
-        and the FPN-wide semantic maps (``relu(semantic_transform_in(P_l))``, which no RoI enters) run on a stream of
-        their own BESIDE the chains instead of in front of them: a chain waits for map k only in front of stage k's
-        point sample.  The chains' launches are issued in turn (``DynaMaskHead.steps``): issued one chain after the
-        other -- eagerly, or as the node order of a captured graph -- the second chain started ~35 launches late."""
+        """Inference.  The FPN-wide semantic maps (``relu(semantic_transform_in(P_l))``, which no RoI enters) are one
+        grouped launch in front of everything else (``overlap_semantic_maps``: on a stream of their own beside the
+        chains instead -- measured, not the default); the RoIs are independent, so from ``stream_split_min`` RoIs on they
+        are split into chunks on separate HIP streams (the tail of every kernel -- its last, partially filled round of
+        workgroups over the 256 CUs -- overlaps the other chunk's work) whose launches are issued in turn
+        (``DynaMaskHead.steps``), every chunk writing its rows of the result tensors in place.
+
+        ``merge`` (``simple_test_mask_logits``): hand back the merged 112 x 112 logits of dynamask_roi_head.py:138-149
+        instead of the per-stage dict -- the last stage's logits then stay at 56 x 56 and ONE launch per chunk does the
+        final align_corners x2 upsample and both boundary merges (ops.boundary_merge_chain; same bits as the four launches
+        it replaces), on the chunk's own stream, in front of the join instead of behind it."""
         from .mask_heads import run_steps
         n = rois.shape[0]
-        if merge:
-            return self._mask_forward_merged(x, rois, roi_labels)
-        n_streams = self.num_streams if n >= self.stream_split_min else 1
         head, ext = self.mask_head, self.mask_roi_extractor
         dev = rois.device
         cur = torch.cuda.current_stream(dev)
+        n_streams = self.num_streams if n >= self.stream_split_min else 1
         head.prepack()                 # packs are cached by whoever asks first: before the fork, on this stream
-        n_sem = len(head.stages) if last_stage is None else min(last_stage, len(head.stages))
-        # the semantic maps: outputs allocated here (the caller's stream owns the memory), produced on the pool's last stream
-        sems, sem_ready = [], []
-        sem_stream = self._side_streams(n_streams + 1, dev)[-1] if self.overlap_semantic_maps else cur
-        if sem_stream is not cur:
-            sem_stream.wait_stream(cur)
+        sems, sem_ready, sem_stream = self._semantic_maps_for_chains(x, last_stage, n_streams, cur)
+        if merge:
+            assert last_stage is None and self._merged_tail_supported()
+            s_out = head.stage_sup_size[-1]
+            merged = torch.empty((n, 1, s_out, s_out), device=dev, dtype=torch.float32)
+            ips = dps = None
         else:
-            sems, sem_ready = head.semantic_maps(x, last_stage), [None] * n_sem          # one grouped launch, in front of the chains
-        for i in range(n_sem if sem_stream is not cur else 0):
-            st_ = head.stages[i]
-            f = x[-i - 3]
-            out = torch.empty((f.shape[0], st_.semantic_transform_in.out_channels, f.shape[2], f.shape[3]), device=dev,
-                              dtype=torch.float32)
-            with torch.cuda.stream(sem_stream), ops.overlapped_streams():
-                st_.semantic_transform_in.run(f, relu=True, out=out)
-                sem_ready.append(sem_stream.record_event() if sem_stream is not cur else None)
-            sems.append(out)
-        if n_streams <= 1:
-            gen = head.steps(None, x, rois, roi_labels, last_stage=last_stage, sems=sems, sem_ready=sem_ready,
-                             extract=lambda: ext(x[:ext.num_inputs], rois))
-            ips, dps = run_steps(gen)
-            if sem_stream is not cur:
-                cur.wait_stream(sem_stream)
-            return dict(stage_instance_preds=ips, stage_detail_preds=dps)
-        streams = self._side_streams(n_streams, dev)
-        split = getattr(self, 'stream_split', None)      # optional cumulative fractions, e.g. (0.4, 1.0)
-        if split is not None and len(split) == n_streams:
-            bounds = [0] + [round(f * n) for f in split]
-        else:
-            bounds = [round(i * n / n_streams) for i in range(n_streams + 1)]
-        # every chunk writes its rows of the logit tensors in place (allocated here, on the caller's stream, before
-        # the fork): no concatenation after the join
-        sizes = head.pred_sizes(last_stage)
-        ips = [torch.empty((n, 1, s_, s_), device=dev, dtype=torch.float32) for s_ in sizes]
-        dps = [torch.empty((n, 1, s_, s_), device=dev, dtype=torch.float32) for s_ in sizes]
-        chains = []
-        for st, lo, hi in zip(streams, bounds[:-1], bounds[1:]):
-            if hi <= lo:
-                continue
-            st.wait_stream(cur)
+            # allocated here, on the caller's stream, before the fork: no concatenation after the join
+            sizes = head.pred_sizes(last_stage)
+            ips = [torch.empty((n, 1, s_, s_), device=dev, dtype=torch.float32) for s_ in sizes]
+            dps = [torch.empty((n, 1, s_, s_), device=dev, dtype=torch.float32) for s_ in sizes]
+
+        def chain(lo, hi):
             r, l = rois[lo:hi], roi_labels[lo:hi]
-            gen = head.steps(None, x, r, l, last_stage=last_stage, sems=sems, sem_ready=sem_ready,
-                             pred_out=[(a[lo:hi], b[lo:hi]) for a, b in zip(ips, dps)],
-                             extract=(lambda r=r: ext(x[:ext.num_inputs], r)))
-            chains.append((st, gen))
-        while chains:                   # one launch of every chain in turn
-            for st, gen in list(chains):
-                with torch.cuda.stream(st), ops.overlapped_streams():
-                    try:
-                        next(gen)
-                    except StopIteration:
-                        chains.remove((st, gen))
-        for st in streams:
-            cur.wait_stream(st)
-        if sem_stream is not cur:
-            cur.wait_stream(sem_stream)
-        return dict(stage_instance_preds=ips, stage_detail_preds=dps)
-
-    def _mask_forward_merged(self, x, rois, roi_labels):
-        """``merge_stage_preds(_mask_forward(...)['stage_instance_preds'])`` for inference with the tail of every RoI
-        chunk folded into its chain: the last stage's logits stay at 56 x 56 and ONE launch per chunk does the final
-        align_corners x2 upsample and both boundary merges (ops.boundary_merge_chain; same bits as the four launches it
-        replaces).  Each chunk merges its own rows on its own stream, in front of the join, not behind it."""
-        from .mask_heads import run_steps
-        n = rois.shape[0]
-        head, ext = self.mask_head, self.mask_roi_extractor
-        dev = rois.device
-        cur = torch.cuda.current_stream(dev)
-        assert len(head.stages) == 3 and not head.pre_upsample_last_stage
-        n_streams = self.num_streams if n >= self.stream_split_min else 1
-        head.prepack()
-        sems, sem_ready = [], []
-        sem_stream = self._side_streams(n_streams + 1, dev)[-1] if self.overlap_semantic_maps else cur
-        if sem_stream is not cur:
-            sem_stream.wait_stream(cur)
-        if sem_stream is cur:
-            sems, sem_ready = head.semantic_maps(x), [None] * len(head.stages)            # one grouped launch, in front of the chains
-        for i in range(len(head.stages) if sem_stream is not cur else 0):
-            st_ = head.stages[i]
-            f = x[-i - 3]
-            out = torch.empty((f.shape[0], st_.semantic_transform_in.out_channels, f.shape[2], f.shape[3]), device=dev,
-                              dtype=torch.float32)
-            with torch.cuda.stream(sem_stream), ops.overlapped_streams():
-                st_.semantic_transform_in.run(f, relu=True, out=out)
-                sem_ready.append(sem_stream.record_event() if sem_stream is not cur else None)
-            sems.append(out)
-        s_out = head.stage_sup_size[-1]
-        merged = torch.empty((n, 1, s_out, s_out), device=dev, dtype=torch.float32)
-
-        def chain(r, l, lo, hi):
-            ips, _ = yield from head.steps(None, x, r, l, sems=sems, sem_ready=sem_ready, defer_final_up=True,
-                                           extract=lambda: ext(x[:ext.num_inputs], r))
-            ops.boundary_merge_chain(ips[1], ips[2], ips[3], out=merged[lo:hi])
-            yield
+            out = None if merge else [(a[lo:hi], b[lo:hi]) for a, b in zip(ips, dps)]
+            got, _ = yield from head.steps(None, x, r, l, last_stage=last_stage, sems=sems, sem_ready=sem_ready, pred_out=out,
+                                           defer_final_up=merge, extract=lambda: ext(x[:ext.num_inputs], r))
+            if merge:
+                ops.boundary_merge_chain(got[1], got[2], got[3], out=merged[lo:hi])
+                yield
         if n_streams <= 1:
-            run_steps(chain(rois, roi_labels, 0, n))
+            run_steps(chain(0, n))
         else:
+            split = getattr(self, 'stream_split', None)      # optional cumulative fractions, e.g. (0.4, 1.0)
+            if split is not None and len(split) == n_streams:
+                bounds = [0] + [round(f * n) for f in split]
+            else:
+                bounds = [round(i * n / n_streams) for i in range(n_streams + 1)]
             streams = self._side_streams(n_streams, dev)
-            bounds = [round(i * n / n_streams) for i in range(n_streams + 1)]
             chains = []
             for st, lo, hi in zip(streams, bounds[:-1], bounds[1:]):
                 if hi > lo:
                     st.wait_stream(cur)
-                    chains.append((st, chain(rois[lo:hi], roi_labels[lo:hi], lo, hi)))
-            while chains:
+                    chains.append((st, chain(lo, hi)))
+            while chains:                   # one launch of every chain in turn
                 for st, gen in list(chains):
                     with torch.cuda.stream(st), ops.overlapped_streams():
                         try:
@@ -321,7 +254,29 @@ class DynaMaskRoIHead(nn.Module):
                 cur.wait_stream(st)
         if sem_stream is not cur:
             cur.wait_stream(sem_stream)
-        return merged
+        return merged if merge else dict(stage_instance_preds=ips, stage_detail_preds=dps)
+
+    def _semantic_maps_for_chains(self, x, last_stage, n_streams, cur):
+        """(maps, events, stream): the stages' semantic maps for the RoI chains of ``_mask_forward_infer`` -- one grouped
+        launch on the caller's stream (events None), or, with ``overlap_semantic_maps``, one launch each on the pool's
+        next stream with an event behind each that a chain waits for in front of that stage's point sample."""
+        head = self.mask_head
+        n_sem = len(head.stages) if last_stage is None else min(last_stage, len(head.stages))
+        if not self.overlap_semantic_maps:
+            return head.semantic_maps(x, last_stage), [None] * n_sem, cur
+        dev = x[0].device
+        sem_stream = self._side_streams(n_streams + 1, dev)[-1]
+        sem_stream.wait_stream(cur)
+        sems, sem_ready = [], []
+        for i in range(n_sem):
+            conv, f = head.stages[i].semantic_transform_in, x[-i - 3]
+            # (allocated on the caller's stream, which owns the memory; produced on the side stream)
+            out = torch.empty((f.shape[0], conv.out_channels, f.shape[2], f.shape[3]), device=dev, dtype=torch.float32)
+            with torch.cuda.stream(sem_stream), ops.overlapped_streams():
+                conv.run(f, relu=True, out=out)
+                sem_ready.append(sem_stream.record_event())
+            sems.append(out)
+        return sems, sem_ready, sem_stream
 
     def _side_streams(self, k, device):
         """k streams for k RoI chunks, from the package's shared pool (streams.py: hardware queues are few)."""

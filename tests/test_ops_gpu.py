@@ -398,6 +398,10 @@ def test_dcn_with_chained_1x1_has_the_bits_of_the_two_launches(ops):
             d = ops.deform_conv_tout(x, off, wp, C, 2, w2t, b2, m2, t, keep_dcn=keep)
             assert torch.equal(t, t_ref), (C, S, keep)                               # incl. the two channels behind m2: untouched
             assert (d is None) if not keep else torch.equal(d, d_ref)
+        buf = torch.empty_like(d_ref)                                                # relu(DCN) into a caller's buffer
+        t = torch.full((n, C // 2, S, S), 7.0, device='cuda')
+        assert ops.deform_conv_tout(x, off, wp, C, 2, w2t, b2, m2, t, dcn_out=buf) is buf
+        assert torch.equal(buf, d_ref) and torch.equal(t, t_ref)
     xs = _dev(torch.randn(4, 64, 56, 56, generator=gen))                            # a handful of RoIs: another wave layout
     assert not ops.deform_conv_tout_supported(xs, 64, 30)
     assert not ops.deform_conv_tout_supported(_dev(torch.randn(40, 256, 14, 14, generator=gen)), 256, 126)
