@@ -32,3 +32,23 @@ for (H, W) in ((800, 1333), (608, 1024), (333, 500), (1024, 2048)):
                 ok &= sum(len(b) for b in bb) == sum(len(s) for s in sg)
         torch.cuda.synchronize()
         print(f'{H}x{W} N={N}: {"ok" if ok else "FAIL"}', flush=True)
+
+# ---- the fused inference launches of round 6 at odd detection counts (both sides of the two-stream threshold, padded
+# graph buckets): bits of the unfused launch sequence (split-K off: one order of sums), and the graph equals eager
+from dynamask_amd import ops
+feats = [f.to(dev) for f in synth.make_fpn(1, 800, 1333, 256, seed=3)]
+ops.CONV_SPLITK[0] = False
+for N in (1, 2, 7, 16, 17, 63, 64, 65, 99, 100, 101, 200):
+    rois = synth.make_rois(1, N, 800, 1333, seed=100 + N).to(dev)
+    boxes, labels = rois[:, 1:].contiguous(), synth.make_labels(N, seed=N + 5).to(dev)
+    outs = []
+    with torch.no_grad():
+        for fused in (False, True):
+            mask_heads.FUSED_STAGE_HEAD[0] = mask_heads.GROUPED_SEMANTIC_MAPS[0] = mask_heads.FUSED_DCN_TOUT[0] = fused
+            roi_head.FUSED_MERGE_TAIL[0] = fused
+            outs.append(m.simple_test_mask_logits(feats, boxes, labels).clone())
+        m.enable_inference_graphs(True)
+        outs.append(m.simple_test_mask_logits(feats, boxes, labels).clone())
+        m.enable_inference_graphs(False)
+    ok = torch.isfinite(outs[0]).all().item() and torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    print(f'fused inference N={N}: {"ok" if ok else "FAIL"} (unfused == fused: {torch.equal(outs[0], outs[1])}, graph == eager: {torch.equal(outs[1], outs[2])})', flush=True)
