@@ -1140,7 +1140,13 @@ static int deform_conv_fwd_impl(const float* x, const float* offset, int NB, int
     }
   }
   if (tout) return DM_ERR_UNSUPPORTED;                      // (dcn_tout_shape_ok mirrors the conditions above)
-  if (Cout > 64 && (long long)dm_ceil_div(a.CoutP, 128) * dm_ceil_div(a.Q, 128) * 20 <= (long long)dm_num_cus() * 9)
+  // A handful of RoIs: 64 x 64 tiles (four times the workgroups of the 128 x 128 LDS kernel) -- unless the caller brought a
+  // workspace and the map takes the LDS kernel: then that kernel with its K loop split (dcn_choose_split: up to 8 ways at
+  // <= 24 RoIs, 3 above) is the faster way to fill the chip (round 6: the 16- / 32-detection inference calls 0.652 / 0.949 ->
+  // 0.626 / 0.918 ms; the 14 x 14 DCN was their largest launch, 90 us at 16 RoIs).
+  const bool lds_split = a.ws && Cout > 64 && a.HW >= 128 && a.HW <= 256 && (a.HW & 3) == 0;
+  if (!lds_split && Cout > 64 &&
+      (long long)dm_ceil_div(a.CoutP, 128) * dm_ceil_div(a.Q, 128) * 20 <= (long long)dm_num_cus() * 9)
     return launch_dcn<2, 2, 1, 1>(a, st);
   if (Cout > 64 && a.HW >= 128 && a.HW <= 256 && (a.HW & 3) == 0 && (C / deform_groups) % 8 == 0) {
     // small maps (14x14): planes in LDS, 128 x 128 tile
