@@ -793,7 +793,7 @@ def main():
             result['inference_100dets_ms'] = inf['graph_100dets_ms']
             result['inference_16dets_ms'] = inf['graph_16dets_ms']
             inf['what'] = ('simple_test_mask_logits: RoIAlign14 + DynaMaskHead to 112x112 + boundary merge for the first N RoIs '
-                           'of the image; graph = DynaMaskRoIHead.enable_inference_graphs() (buckets 16/32/64/100)')
+                           'of the image; graph = DynaMaskRoIHead.enable_inference_graphs() (buckets 16/24/32/48/64/80/100)')
             extra['inference'] = inf
         # ---- other exits, for context (not the headline) ----
         with torch.no_grad():

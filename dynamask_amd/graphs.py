@@ -4,7 +4,7 @@ The reference infers at most 100 detections per image, every exit run to 112x112
 (roi_heads/dynamask_roi_head.py:117-158; tools/benchmark.py:63-89 is the protocol).  At those sizes the mask path is
 ~60 dependent launches of 10-100 us each: the Python / ctypes issue of a launch costs about as much as the kernel, so the
 literal C-ABI launch sequence of ``simple_test_mask_logits`` is captured once per BUCKET of detection counts
-(16 / 32 / 64 / 100, RoIs padded with empty boxes, which the kernels turn into zero rows) and replayed.  No tracing
+(16 / 24 / 32 / 48 / 64 / 80 / 100, RoIs padded with empty boxes, which the kernels turn into zero rows) and replayed.  No tracing
 compiler: a graph holds exactly the launches the eager call makes.
 
 A graph is tied to the addresses it was captured with: the FPN maps' storage, the packed weights (``ops.WEIGHT_EPOCH``
@@ -17,7 +17,10 @@ import torch
 
 from . import ops
 
-BUCKETS = (16, 32, 64, 100)
+# (round 6: 24 / 48 / 80 added -- a call is padded up to its bucket, and the call time grows almost linearly with the RoI
+# count above 16: 0.61 / 0.79 / 0.90 / 1.21 / 1.39 / 1.93 ms at 16 / 24 / 32 / 48 / 64 / 100 detections, so 33 detections
+# in the 48-bucket cost 1.21 ms instead of the 64-bucket's 1.39)
+BUCKETS = (16, 24, 32, 48, 64, 80, 100)
 
 
 class GraphedMaskLogits:

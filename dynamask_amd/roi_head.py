@@ -521,7 +521,7 @@ class DynaMaskRoIHead(nn.Module):
                 and list(h.stage_sup_size) == [h.stage_sup_size[0] * k for k in (1, 2, 4, 8)])
 
     def enable_inference_graphs(self, on=True, buckets=None):
-        """Replay ``simple_test_mask_logits`` as a HIP graph per bucket of detection counts (16 / 32 / 64 / 100 by
+        """Replay ``simple_test_mask_logits`` as a HIP graph per bucket of detection counts (16 / 24 / 32 / 48 / 64 / 80 / 100 by
         default; see graphs.py for what a graph is tied to).  Off by default: the eager path is the reference one."""
         from .graphs import BUCKETS, GraphedMaskLogits
         self._mask_graphs = GraphedMaskLogits(self, buckets or BUCKETS) if on else None

@@ -850,7 +850,7 @@ def test_polygon_mask_targets_other_sizes(size):
 
 def test_bucketed_inference_graphs_replay_the_eager_launch_sequence(no_splitk):
     """DynaMaskRoIHead.enable_inference_graphs(): simple_test_mask_logits through a HIP graph per bucket of detection
-    counts (16 / 32 / 64 / 100, padded with empty boxes) gives the bits of the eager call (with split-K off: a bucket
+    counts (16 / 24 / 32 / 48 / 64 / 80 / 100, padded with empty boxes) gives the bits of the eager call (with split-K off: a bucket
     pads the RoI count, and the split of a launch depends on it -- ``no_splitk``), captures once per bucket
     and map storage, follows a parameter update, and leaves counts above the largest bucket to the eager path."""
     from dynamask_amd import ops, synth
@@ -865,7 +865,7 @@ def test_bucketed_inference_graphs_replay_the_eager_launch_sequence(no_splitk):
         for n in (1, 16, 17, 100):
             got = m.simple_test_mask_logits(feats, boxes[:n], labels[:n])
             assert got.shape == eager[n].shape and torch.equal(got, eager[n]), n
-        assert gl.captures == 3 and gl.replays == 4            # buckets 16 (n = 1, 16), 32 (17), 100
+        assert gl.captures == 3 and gl.replays == 4            # buckets 16 (n = 1, 16), 24 (17), 100
         assert torch.equal(m.simple_test_mask_logits(feats, boxes[:16], labels[:16]), eager[16]) and gl.captures == 3
         assert torch.equal(m.simple_test_mask_logits(feats, boxes, labels), eager[128]) and gl.replays == 5      # eager
         # a parameter update (the fused SGD step bumps the epoch) invalidates the packed weights the graph holds
