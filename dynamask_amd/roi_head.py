@@ -664,3 +664,80 @@ class DynaMaskRoIHead(nn.Module):
         for c, segm in zip(det_labels.tolist(), segs):
             segm_result[c].append(segm)
         return segm_result
+
+
+@HEADS.register_module()
+class StandardRoIHead(DynaMaskRoIHead):
+    """``StandardRoIHead`` -- mmdet/models/roi_heads/standard_roi_head.py:10-236 + ``MaskTestMixin.simple_test_mask``
+    (test_mixins.py:151-176): the RoI head of configs/mask_rcnn and configs/carafe (BASELINE configs[4]), whose mask head
+    is ``FCNMaskHead``.  The bbox branch, the assigner / sampler and ``simple_test`` are the parent's (the reference's
+    ``DynaMaskRoIHead`` is itself a ``StandardRoIHead``); the mask branch is the stock one: ``_mask_forward(x, rois)`` ->
+    ``{'mask_pred': [N, classes, 28, 28], 'mask_feats'}``, ``simple_test_mask`` -> ``FCNMaskHead.get_seg_masks``.
+    ``BaseRoIHead.__init__`` of the fork builds ``mask_predictor`` / ``semantic_roi_extractor`` for EVERY RoI head (Quirk
+    Q4), so the ``state_dict`` carries the ``mask_predictor.*`` keys here too, as the reference's does.
+    Training: ``forward_train`` follows standard_roi_head.py:70-134; its mask loss ends in ``FCNMaskHead.loss``, which
+    the fork broke (Quirk Q5) -- it raises here as it does there, the bbox losses and the mask targets are computed."""
+
+    def _mask_forward(self, x, rois=None, pos_inds=None, bbox_feats=None, **kw):
+        """standard_roi_head.py:199-215."""
+        assert (rois is not None) ^ (pos_inds is not None and bbox_feats is not None)
+        if rois is not None:
+            ext = self.mask_roi_extractor
+            mask_feats = ext(x[:ext.num_inputs], rois.contiguous())
+        else:
+            mask_feats = bbox_feats[pos_inds].contiguous()
+        return dict(mask_pred=self.mask_head(mask_feats), mask_feats=mask_feats)
+
+    def _mask_forward_train(self, x, sampling_results, bbox_feats, gt_masks, img_metas, **kw):
+        """standard_roi_head.py:162-197 (the mask branch with its own RoI extractor)."""
+        pos_rois = bbox2roi([res.pos_bboxes for res in sampling_results]).contiguous()
+        if pos_rois.shape[0] == 0:
+            return dict(loss_mask=None)
+        mask_results = self._mask_forward(x, pos_rois)
+        mask_targets = self.mask_head.get_targets(sampling_results, gt_masks, self.train_cfg)
+        pos_labels = torch.cat([res.pos_gt_labels for res in sampling_results])
+        loss_mask = self.mask_head.loss(mask_results['mask_pred'], mask_targets, pos_labels)
+        mask_results.update(loss_mask=loss_mask, mask_targets=mask_targets)
+        return mask_results
+
+    def forward_train(self, x, img_metas, proposal_list, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None):
+        """standard_roi_head.py:70-134."""
+        num_imgs = len(img_metas)
+        if gt_bboxes_ignore is None:
+            gt_bboxes_ignore = [None for _ in range(num_imgs)]
+        deferred = hasattr(self.bbox_sampler, 'sample_deferred')
+        do_sample = self.bbox_sampler.sample_deferred if deferred else self.bbox_sampler.sample
+        sampling_results = []
+        for i in range(num_imgs):
+            assign_result = self.bbox_assigner.assign(proposal_list[i], gt_bboxes[i], gt_bboxes_ignore[i], gt_labels[i])
+            sampling_results.append(do_sample(assign_result, proposal_list[i], gt_bboxes[i], gt_labels[i],
+                                              feats=[lvl_feat[i][None] for lvl_feat in x]))
+        if deferred:
+            sampling_results = self.bbox_sampler.finish_samples(sampling_results)
+        losses = dict()
+        bbox_results = None
+        if self.with_bbox:
+            bbox_results = self._bbox_forward_train(x, sampling_results, gt_bboxes, gt_labels, img_metas)
+            losses.update(bbox_results['loss_bbox'])
+        if self.with_mask:
+            mask_results = self._mask_forward_train(x, sampling_results, None if bbox_results is None else bbox_results['bbox_feats'],
+                                                    gt_masks, img_metas)
+            if mask_results['loss_mask'] is not None:
+                losses.update(mask_results['loss_mask'])
+        return losses
+
+    def simple_test_mask(self, x, img_metas, det_bboxes, det_labels, rescale=False, encode=False):
+        """test_mixins.py:151-176 -> ``cls_segms`` of ``FCNMaskHead.get_seg_masks`` (``encode``: COCO RLE dicts instead of
+        bitmaps, ``get_seg_rles``: the result after the caller's ``encode_mask_results``)."""
+        ori_shape = img_metas[0]['ori_shape']
+        scale_factor = img_metas[0]['scale_factor']
+        if det_bboxes.shape[0] == 0:
+            return [[] for _ in range(self.mask_head.num_classes)]
+        if rescale and not isinstance(scale_factor, float):
+            scale_factor = torch.from_numpy(scale_factor).to(det_bboxes.device)
+        _bboxes = det_bboxes[:, :4] * scale_factor if rescale else det_bboxes
+        mask_rois = bbox2roi([_bboxes]).contiguous()
+        with torch.no_grad():
+            mask_results = self._mask_forward(x, mask_rois)
+        to_segs = self.mask_head.get_seg_rles if encode else self.mask_head.get_seg_masks
+        return to_segs(mask_results['mask_pred'], _bboxes, det_labels, self.test_cfg, ori_shape, scale_factor, rescale)

@@ -125,6 +125,25 @@ def test_reference_config_is_consumed_unchanged():
     assert dict(cfg.model.roi_head.mask_head.loss_cfg) == dict(type='DynaCrossEntropyLoss', **gi.LOSS_CFG)
 
 
+def test_reference_carafe_config_builds_the_standard_roi_head_unchanged():
+    """configs/carafe/mask_rcnn_r50_fpn_carafe_1x_coco.py (BASELINE configs[4]: StandardRoIHead + FCNMaskHead with the
+    CARAFE upsample, two ``_base_`` levels deep) is consumed unchanged; the module tree has the reference's state_dict
+    keys, incl. the ``mask_predictor.*`` block the fork's BaseRoIHead gives every RoI head (Quirk Q4)."""
+    from dynamask_amd import registry, roi_head, losses, mask_heads, roi_extractors, bbox_heads  # noqa: F401
+    cfg = registry.Config.fromfile('/root/reference/configs/carafe/mask_rcnn_r50_fpn_carafe_1x_coco.py')
+    rh = dict(cfg.model.roi_head)
+    assert rh['type'] == 'StandardRoIHead' and rh['mask_head']['type'] == 'FCNMaskHead'
+    rh.update(train_cfg=cfg.train_cfg.rcnn, test_cfg=cfg.test_cfg.rcnn)
+    m = registry.build_head(rh)
+    assert type(m).__name__ == 'StandardRoIHead' and m.mask_head.upsample_method == 'carafe' and m.mask_head.num_classes == 80
+    assert m.train_cfg.mask_size == 28 and m.test_cfg.mask_thr_binary == 0.5 and m.with_bbox and m.with_mask
+    keys = set(m.state_dict())
+    ref = set(gi.fcn_state('carafe')) | {'bbox_head.' + k for k in ('shared_fcs.0.weight', 'shared_fcs.0.bias', 'shared_fcs.1.weight',
+                                                                   'shared_fcs.1.bias', 'fc_cls.weight', 'fc_cls.bias', 'fc_reg.weight', 'fc_reg.bias')}
+    assert ref <= keys
+    assert {k for k in keys if not (k in ref)} == {k for k in keys if k.startswith('mask_predictor.')} and 'mask_predictor.fc2.weight' in keys
+
+
 def test_fcn_head_state_dict_keys():
     from dynamask_amd import registry, mask_heads  # noqa: F401
     for up in ('deconv', 'carafe'):
