@@ -148,19 +148,16 @@ class SFMStage(nn.Module):
     def forward(self, instance_feats, semantic_feat, rois, roi_labels, upsample=True, sem=None, pred_out=None):
         return run_steps(self.steps(instance_feats, semantic_feat, rois, roi_labels, upsample, sem, pred_out))
 
-    def steps(self, instance_feats, semantic_feat, rois, roi_labels, upsample=True, sem=None, pred_out=None, sem_ready=None):
+    def steps(self, instance_feats, semantic_feat, rois, roi_labels, upsample=True, sem=None, pred_out=None):
         """``forward`` as a generator that yields after every launch (``run_steps`` exhausts it): a caller that runs
         several RoI chunks on several streams issues their launches in turn (roi_head._mask_forward_infer), so that
-        no stream waits for the host -- or for the graph's node order -- to get through another stream's whole chain.
-        ``sem_ready``: an event recorded behind the launch that produces ``sem`` on another stream."""
+        no stream waits for the host -- or for the graph's node order -- to get through another stream's whole chain."""
         n, c, s = instance_feats.shape[0], self.instance_in_channel, self.out_size
         co = self.instance_out_channel
         # instance-wise semantic feats: relu(conv1x1) on the whole FPN map, then point sample
         if sem is None:
             sem = self.semantic_map(semantic_feat)
             yield
-        elif sem_ready is not None:
-            torch.cuda.current_stream(instance_feats.device).wait_event(sem_ready)
         # [fused_feats(co-2) | sigmoid(ip) | sigmoid(dp)] is assembled in place
         tail = torch.empty((n, co, s, s), device=instance_feats.device, dtype=torch.float32)
         nc = self.num_classes
@@ -345,10 +342,9 @@ class DynaMaskHead(nn.Module):
         (``pred_sizes``) to write into -- the row slices of a chunked, multi-stream caller's buffers."""
         return run_steps(self.steps(instance_feats, semantic_feats, rois, roi_labels, last_stage, sems, pred_out))
 
-    def steps(self, instance_feats, semantic_feats, rois, roi_labels, last_stage=None, sems=None, pred_out=None, sem_ready=None,
-              extract=None, defer_final_up=False):
-        """``forward`` as a generator that yields after every launch (see ``SFMStage.steps``).  ``sem_ready``: per stage,
-        the event behind the launch that produces ``sems[idx]`` on another stream (None: same stream).  ``extract``: a
+    def steps(self, instance_feats, semantic_feats, rois, roi_labels, last_stage=None, sems=None, pred_out=None, extract=None,
+              defer_final_up=False):
+        """``forward`` as a generator that yields after every launch (see ``SFMStage.steps``).  ``extract``: a
         callable producing ``instance_feats`` -- the RoI extraction as the chain's first step.  ``defer_final_up``: hand
         back the last stage's logits at ITS resolution (2S) -- the caller folds their align_corners x2 upsample into the
         boundary merge (ops.boundary_merge_chain)."""
@@ -380,8 +376,7 @@ class DynaMaskHead(nn.Module):
                           and not torch.is_grad_enabled() and ops.class_logits_up2x_supported(instance_feats))
             ip, dp, instance_feats = yield from stage.steps(
                 instance_feats, semantic_feats[-idx - 3], rois, roi_labels, upsample_flag and not fused_exit,
-                sem=None if sems is None else sems[idx], pred_out=po(idx),
-                sem_ready=None if sem_ready is None else sem_ready[idx])
+                sem=None if sems is None else sems[idx], pred_out=po(idx))
             stage_instance_preds.append(ip)
             stage_detail_preds.append(dp)
         # (dynamask_head.py:236-237 clamps the labels to 0 for the class-agnostic last stage: the kernel clamps every

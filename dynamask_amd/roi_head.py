@@ -151,10 +151,6 @@ class DynaMaskRoIHead(nn.Module):
         # inference: RoI chunks on separate HIP streams (see _mask_forward)
         self.num_streams = 2
         self.stream_split_min = 64           # (100 detections to 112x112: 2.34 ms on one stream, 2.27 split over two; 32: no further gain)
-        # the FPN-wide semantic 1x1 convolutions on a stream of their own BESIDE the RoI chains instead of in front of them:
-        # measured (profiles/r06_infer_experiments.txt) neutral at 100 detections, +2 % at 16 and on the 512-RoI headline -- a
-        # fork inside a HIP graph costs more than the ~100 us it hides; off, and the maps are one grouped launch instead
-        self.overlap_semantic_maps = os.environ.get('DM_SEM_OVERLAP', '0') == '1'
 
     def init_assigner_sampler(self):
         """standard_roi_head.py:13-20."""
@@ -192,8 +188,9 @@ class DynaMaskRoIHead(nn.Module):
 
     def _mask_forward_infer(self, x, rois, roi_labels, last_stage=None, merge=False):
         """Inference.  The FPN-wide semantic maps (``relu(semantic_transform_in(P_l))``, which no RoI enters) are one
-        grouped launch in front of everything else (``overlap_semantic_maps``: on a stream of their own beside the
-        chains instead -- measured, not the default); the RoIs are independent, so from ``stream_split_min`` RoIs on they
+        grouped launch in front of everything else (on a stream of their own beside the chains they measured neutral at
+        100 detections and +2 % at 16 and on the 512-RoI headline -- a fork inside a HIP graph costs more than the ~100 us
+        it hides; profiles/r06_infer_experiments.txt; removed); the RoIs are independent, so from ``stream_split_min`` RoIs on they
         are split into chunks on separate HIP streams (the tail of every kernel -- its last, partially filled round of
         workgroups over the 256 CUs -- overlaps the other chunk's work) whose launches are issued in turn
         (``DynaMaskHead.steps``), every chunk writing its rows of the result tensors in place.
@@ -209,7 +206,7 @@ class DynaMaskRoIHead(nn.Module):
         cur = torch.cuda.current_stream(dev)
         n_streams = self.num_streams if n >= self.stream_split_min else 1
         head.prepack()                 # packs are cached by whoever asks first: before the fork, on this stream
-        sems, sem_ready, sem_stream = self._semantic_maps_for_chains(x, last_stage, n_streams, cur)
+        sems = head.semantic_maps(x, last_stage)
         if merge:
             assert last_stage is None and self._merged_tail_supported()
             s_out = head.stage_sup_size[-1]
@@ -224,8 +221,8 @@ class DynaMaskRoIHead(nn.Module):
         def chain(lo, hi):
             r, l = rois[lo:hi], roi_labels[lo:hi]
             out = None if merge else [(a[lo:hi], b[lo:hi]) for a, b in zip(ips, dps)]
-            got, _ = yield from head.steps(None, x, r, l, last_stage=last_stage, sems=sems, sem_ready=sem_ready, pred_out=out,
-                                           defer_final_up=merge, extract=lambda: ext(x[:ext.num_inputs], r))
+            got, _ = yield from head.steps(None, x, r, l, last_stage=last_stage, sems=sems, pred_out=out, defer_final_up=merge,
+                                           extract=lambda: ext(x[:ext.num_inputs], r))
             if merge:
                 ops.boundary_merge_chain(got[1], got[2], got[3], out=merged[lo:hi])
                 yield
@@ -252,31 +249,7 @@ class DynaMaskRoIHead(nn.Module):
                             chains.remove((st, gen))
             for st in streams:
                 cur.wait_stream(st)
-        if sem_stream is not cur:
-            cur.wait_stream(sem_stream)
         return merged if merge else dict(stage_instance_preds=ips, stage_detail_preds=dps)
-
-    def _semantic_maps_for_chains(self, x, last_stage, n_streams, cur):
-        """(maps, events, stream): the stages' semantic maps for the RoI chains of ``_mask_forward_infer`` -- one grouped
-        launch on the caller's stream (events None), or, with ``overlap_semantic_maps``, one launch each on the pool's
-        next stream with an event behind each that a chain waits for in front of that stage's point sample."""
-        head = self.mask_head
-        n_sem = len(head.stages) if last_stage is None else min(last_stage, len(head.stages))
-        if not self.overlap_semantic_maps:
-            return head.semantic_maps(x, last_stage), [None] * n_sem, cur
-        dev = x[0].device
-        sem_stream = self._side_streams(n_streams + 1, dev)[-1]
-        sem_stream.wait_stream(cur)
-        sems, sem_ready = [], []
-        for i in range(n_sem):
-            conv, f = head.stages[i].semantic_transform_in, x[-i - 3]
-            # (allocated on the caller's stream, which owns the memory; produced on the side stream)
-            out = torch.empty((f.shape[0], conv.out_channels, f.shape[2], f.shape[3]), device=dev, dtype=torch.float32)
-            with torch.cuda.stream(sem_stream), ops.overlapped_streams():
-                conv.run(f, relu=True, out=out)
-                sem_ready.append(sem_stream.record_event())
-            sems.append(out)
-        return sems, sem_ready, sem_stream
 
     def _side_streams(self, k, device):
         """k streams for k RoI chunks, from the package's shared pool (streams.py: hardware queues are few)."""

@@ -140,9 +140,6 @@ def test_fused_inference_launches_give_the_bits_of_the_unfused_sequence():
             m.enable_inference_graphs(True)
             outs[(split_min, 'graph')] = m.simple_test_mask_logits(feats, boxes, labels).clone()
             m.enable_inference_graphs(False)
-            m.overlap_semantic_maps = True           # the semantic maps on a stream of their own beside the chains (measured; not the default)
-            outs[(split_min, 'semantic maps on a side stream')] = m.simple_test_mask_logits(feats, boxes, labels).clone()
-            m.overlap_semantic_maps = False
         _ops.CONV_SPLITK[0] = split_was
         mask_heads.FUSED_STAGE_HEAD[0] = mask_heads.GROUPED_SEMANTIC_MAPS[0] = mask_heads.FUSED_DCN_TOUT[0] = roi_head.FUSED_MERGE_TAIL[0] = True
         m.stream_split_min = 64

@@ -50,9 +50,7 @@ python3 tools/small_n.py > $out/${tag}_small_n.txt 2>&1
 ROI_REPS=3 python3 tools/roi_cold.py > $out/${tag}_roi_cold.txt 2>&1
 { echo "# default (every fused launch of round 6 on)"; python3 tools/infer_bench.py;
   echo "# DM_FUSED_STAGE_HEAD=0 DM_FUSED_MERGE_TAIL=0 DM_GROUPED_SEM=0 DM_FUSED_DCN_TOUT=0: the launch sequence of round 5";
-  DM_FUSED_STAGE_HEAD=0 DM_FUSED_MERGE_TAIL=0 DM_GROUPED_SEM=0 DM_FUSED_DCN_TOUT=0 python3 tools/infer_bench.py;
-  echo "# DM_SEM_OVERLAP=1: the semantic maps on a stream of their own beside the chains (not the default)";
-  DM_SEM_OVERLAP=1 python3 tools/infer_bench.py; } > $out/${tag}_infer_experiments.txt 2>&1
+  DM_FUSED_STAGE_HEAD=0 DM_FUSED_MERGE_TAIL=0 DM_GROUPED_SEM=0 DM_FUSED_DCN_TOUT=0 python3 tools/infer_bench.py; } > $out/${tag}_infer_experiments.txt 2>&1
 echo "tables done"
 # ---- HBM traffic and MFMA busy of the roofline kernels: separate --pmc passes (gfx950), then the file bench.py reads
 PROBE_ITERS=6 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/traffic_fetch -- python3 tools/pmc_probe.py > /dev/null 2>&1
