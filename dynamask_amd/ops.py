@@ -93,7 +93,7 @@ def _float_array(vals):
 
 
 # ------------------------------------------------------------------ RoIAlign
-# 14x14 / 7x7 extractions of 192 RoIs or more go through dm_roi_align_fwd_ws with a scratch buffer (DM_ROI_WORKSPACE=0: never):
+# 14x14 / 7x7 extractions of 192 RoIs or more go through dm_roi_align_fwd_ws with a scratch buffer (ROI_WORKSPACE below):
 # the library orders the RoIs by level and position on the device first (DM_ROI_SORT, default on: 57 -> 50.7 us for 512 RoIs,
 # the same bits)
 ROI_WORKSPACE = True          # (tests compare with the unordered kernel by clearing it)
