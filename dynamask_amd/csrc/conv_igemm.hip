@@ -272,7 +272,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bx,
         b_off[0] = b_off32;
       }
       const float* rp = b_srcp + (size_t)cc0 * HW;
-      const int qw = __builtin_amdgcn_readfirstlane(tid / TN);
+      const int qw = (TN % 64 == 0) ? __builtin_amdgcn_readfirstlane(tid / TN) : tid / TN;      // (uniform per wave from 64 columns on)
 #pragma unroll
       for (int i = 0; i < B1_PER_T; ++i) {
         const float* rq = rp + (size_t)((qw + i * (NT / TN)) * 4) * HW;
@@ -998,7 +998,22 @@ static int conv2d_launch(const float* const* srcs, const int* src_channels, cons
     if (Cout > 32) return launch_conv<3, 1, 4, 2, 1, 8>(a, st);
     return launch_conv<3, 1, 4, 1, 1, 8>(a, st);
   }
-  if (Cout > 64) return launch_conv<1, 2, 2, 2, 2, 16>(a, st);
+  if (Cout > 64) {
+    // A launch of few 128 x 128 tiles (the <= 100-RoI inference calls: 25-307 workgroups for 256 CUs) is a chain of K
+    // chunks per workgroup, and next to another stream's 3x3 launch -- the two RoI chains of a 100-detection call -- each
+    // chunk's 32 MFMAs per wave queue behind the neighbour's.  Up to 1.25 tiles per CU the launch takes 128 couts x 32
+    // pixels instead: four times the workgroups, 8 MFMAs per wave and chunk.  Same products in the same order (a
+    // 32-channel chunk walks its quad pairs in the order two 16-channel chunks do), so rows do not depend on the launch
+    // size (tests/test_ops_gpu.py).  Measured (profiles/r06_infer_experiments.txt (5)): 100 / 64 / 32 / 16 detections
+    // 1.941 / 1.407 / 0.901 / 0.608 -> 1.879 / 1.360 / 0.884 / 0.584 ms; thresholds 100 / 160 / 320 / 640 / 1300 tiles:
+    // 1.923 / 1.896 / 1.879-1.891 / 1.883 / 1.887 at 100 detections; 128 x 64 tiles for the next 320-1300 and 64 x 64 tiles
+    // for the 64-cout build: inside the noise, not kept.  DM_CONV1_SMALL_WGS: the threshold in tiles (0: off), for A/B runs.
+    static const int small_env = getenv("DM_CONV1_SMALL_WGS") ? atoi(getenv("DM_CONV1_SMALL_WGS")) : -1;
+    const int small_wgs = small_env >= 0 ? small_env : (5 * dm_num_cus()) / 4;
+    if (!(relu & 2) && !mask && dm_ceil_div(a.CoutP, 128) * dm_ceil_div(a.Q, 128) <= small_wgs)
+      return launch_conv<1, 4, 1, 1, 1, 32>(a, st);
+    return launch_conv<1, 2, 2, 2, 2, 16>(a, st);
+  }
   if (Cout > 32) {
     // 64 couts x 128 px as 4 waves of 32 x 64: 0.437 -> 0.379 ms on 576 -> 64 @56^2 x 128 RoIs, 0.098 -> 0.089 ms on
     // 64 -> 64 x 256 (the other tilings tried: docs/HISTORY.md, round 3); one k order per output.

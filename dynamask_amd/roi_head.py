@@ -240,11 +240,14 @@ class DynaMaskRoIHead(nn.Module):
                 if hi > lo:
                     st.wait_stream(cur)
                     chains.append((st, chain(lo, hi)))
+            hook = getattr(self, '_launch_hook', None)      # tools/chain_probe.py: an event behind every launch of every chain
             while chains:                   # one launch of every chain in turn
                 for st, gen in list(chains):
                     with torch.cuda.stream(st), ops.overlapped_streams():
                         try:
                             next(gen)
+                            if hook is not None:
+                                hook(st)
                         except StopIteration:
                             chains.remove((st, gen))
             for st in streams:

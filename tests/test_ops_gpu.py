@@ -194,6 +194,20 @@ def test_conv2d_fused_concat_and_channel_slice_output(ops):
     assert torch.all(out[:, 0] == -7.0) and torch.all(out[:, C + 1] == -7.0)
 
 
+@pytest.mark.parametrize('cins,Cout,S,nbig', [([256, 256, 1, 1], 256, 14, 256), ([256], 126, 14, 440), ([128, 128, 1, 1], 128, 28, 64)])
+def test_conv1x1_rows_do_not_depend_on_launch_size(ops, cins, Cout, S, nbig):
+    # up to 1.25 tiles of 128 x 128 per CU a 1x1 launch takes 128 x 32 tiles with 32-channel chunks, above that 128 x 128
+    # tiles with 16-channel chunks (conv_igemm.hip: conv2d_launch): the same products in the same order -- the same bits
+    xs = [(torch.randn(nbig, c, S, S, generator=_g(140 + i)) * 0.7).cuda() for i, c in enumerate(cins)]
+    w = (torch.randn(Cout, sum(cins), 1, 1, generator=_g(145)) / sum(cins) ** 0.5).cuda()
+    b = torch.randn(Cout, generator=_g(146)).cuda()
+    wq = ops.pack_conv_weight(w, src_channels=cins)
+    big = ops.conv2d(xs, wq, b, Cout, 1, relu=True)
+    _close(big[:5], F.relu(F.conv2d(torch.cat([t[:5].cpu() for t in xs], 1), w.cpu(), b.cpu())))
+    for n in (1, 3, 16, 50):
+        assert torch.equal(ops.conv2d([t[:n].contiguous() for t in xs], wq, b, Cout, 1, relu=True), big[:n])
+
+
 def test_conv2d_on_fpn_map(ops):
     x = torch.randn(2, 256, 40, 56, generator=_g(40)) * 0.5
     w = torch.randn(128, 256, 1, 1, generator=_g(41)) / 16
