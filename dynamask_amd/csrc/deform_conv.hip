@@ -1130,7 +1130,13 @@ static int deform_conv_fwd_impl(const float* x, const float* offset, int NB, int
       const bool narrow = 8 * 16 * W / 4 <= 4 * 256;                        // band planes fit 4 float4 per thread
       // a handful of RoIs (real inference): the launch is bound by the time of one workgroup -- one cout tile per
       // wave, the waves sharing a pixel column (2-4 x the workgroups, 1/2-1/4 of the K-loop time each; same bits)
-      const bool few = (long long)NB * dm_ceil_div(a.HW, 128) * 4 < (long long)dm_num_cus() * 3;
+      bool few = (long long)NB * dm_ceil_div(a.HW, 128) * 4 < (long long)dm_num_cus() * 3;
+      // ... unless the caller brought a workspace: a workgroup's time is its number of chunks times a load round trip
+      // (~3.5 us) whatever it computes per chunk, so the full layout (every cout of 128 pixels: one gather per sample, four
+      // times the MFMAs per round trip) with the K loop split (dcn_choose_split's cost model, <= 24 RoIs) beats it:
+      // 16 / 24 detections 0.5845 / 0.733 -> 0.578 / 0.712 ms (DM_DCN_FEW_SPLIT=0: the A/B switch of that measurement)
+      static const int few_split = getenv("DM_DCN_FEW_SPLIT") ? atoi(getenv("DM_DCN_FEW_SPLIT")) : 1;
+      if (few && few_split && a.ws && NB <= 24 && !tout) few = false;
       if (a.CoutP == 64) {
         if (few) return narrow ? launch_dcn_band<1, 2, 4>(a, st) : launch_dcn_band<1, 2, 7>(a, st);
         return narrow ? launch_dcn_band<2, 1, 4>(a, st) : launch_dcn_band<2, 1, 7>(a, st);

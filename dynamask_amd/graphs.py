@@ -28,7 +28,7 @@ class GraphedMaskLogits:
         self.head = roi_head
         self.buckets = tuple(sorted(buckets))
         self.max_graphs = max_graphs
-        self._graphs = {}          # key -> (graph, rois_static, labels_static, out_static)
+        self._graphs = {}          # key -> (graph, rois_static, labels_static, out_static, [filled rows, column 0 dirty])
         self.captures = 0
         self.replays = 0
         self._params = None
@@ -91,23 +91,34 @@ class GraphedMaskLogits:
                 out = run()
         if len(self._graphs) >= self.max_graphs:
             self._graphs.pop(next(iter(self._graphs)))
-        self._graphs[key] = (g, rois, labels, out)
+        self._graphs[key] = (g, rois, labels, out, [0, False])
         self.captures += 1
         return self._graphs[key]
 
-    def __call__(self, x, mask_rois, det_labels):
-        """``mask_rois`` [n, 5], ``det_labels`` [n] -> merged logits [n, 1, 112, 112] (None: no bucket holds n)."""
-        n = mask_rois.shape[0]
+    def __call__(self, x, mask_rois, det_labels, boxes=None):
+        """``mask_rois`` [n, 5], ``det_labels`` [n] -> merged logits [n, 1, 112, 112] (None: no bucket holds n).
+        ``boxes`` [n, >= 4] instead of ``mask_rois`` (None): the boxes of ONE image -- written straight into columns 1..4 of
+        the graph's static RoI buffer (column 0, the batch index, stays 0), one strided copy instead of bbox2roi's fill + cat
+        and a copy of their result."""
+        src = mask_rois if boxes is None else boxes
+        n = src.shape[0]
         bucket = self.bucket_for(n)
-        if bucket is None or not mask_rois.is_cuda:
+        if bucket is None or not src.is_cuda:
             return None
         x = list(x)
         key = self._key(bucket, x)
         entry = self._graphs.get(key) or self._capture(key, bucket, x)
-        g, rois, labels, out = entry
-        rois[:n].copy_(mask_rois)
-        if n < bucket:
-            rois[n:].zero_()
+        g, rois, labels, out = entry[:4]
+        if boxes is None:
+            rois[:n].copy_(mask_rois)
+        else:
+            if entry[4][1]:                    # the last call left batch indices in column 0
+                rois[:, 0].zero_()
+            rois[:n, 1:5].copy_(boxes[:, :4])
+        filled = entry[4]                      # [rows that may hold a box, column 0 may be non-zero]
+        if n < filled[0]:
+            rois[n:filled[0]].zero_()          # empty boxes: zero rows (rows past `filled` are zero already)
+        filled[0], filled[1] = n, boxes is None
         labels[:n].copy_(det_labels)
         g.replay()
         self.replays += 1

@@ -474,12 +474,13 @@ class DynaMaskRoIHead(nn.Module):
         if det_bboxes.shape[0] == 0:
             return det_bboxes.new_zeros((0, 1, 112, 112))
         _bboxes = det_bboxes[:, :4] * scale_factor if rescale else det_bboxes
-        mask_rois = bbox2roi([_bboxes]).contiguous()
         graphs = getattr(self, '_mask_graphs', None)
         if graphs is not None and not torch.is_grad_enabled():
-            merged = graphs(x, mask_rois, det_labels)      # bucketed HIP-graph replay (graphs.py); None: too many RoIs
+            # bucketed HIP-graph replay (graphs.py); None: too many RoIs.  The boxes go straight into the graph's RoI buffer.
+            merged = graphs(x, None, det_labels, boxes=_bboxes)
             if merged is not None:
                 return merged
+        mask_rois = bbox2roi([_bboxes]).contiguous()
         return self._merged_logits(x, mask_rois, det_labels)
 
     def _merged_logits(self, x, mask_rois, det_labels):
