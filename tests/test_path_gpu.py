@@ -927,6 +927,16 @@ def test_bucketed_inference_graphs_replay_the_eager_launch_sequence(no_splitk):
             assert got.shape == eager[n].shape and torch.equal(got, eager[n]), n
         assert gl.captures == 3 and gl.replays == 4            # buckets 16 (n = 1, 16), 24 (17), 100
         assert torch.equal(m.simple_test_mask_logits(feats, boxes[:16], labels[:16]), eager[16]) and gl.captures == 3
+        # the graph's static RoI buffer: a call with fewer boxes than the last one zeroes the rows it leaves (empty boxes), and
+        # the [n, 5] form (batch index in column 0) followed by the boxes form leaves no batch index behind
+        assert torch.equal(m.simple_test_mask_logits(feats, boxes[:1], labels[:1]), eager[1])
+        static_rois = next(v[1] for k, v in gl._graphs.items() if k[0] == 16)
+        assert torch.equal(static_rois[0, 1:], boxes[0]) and not static_rois[1:].any() and not static_rois[:, 0].any()
+        rois5 = torch.cat([torch.zeros(16, 1, device=boxes.device), boxes[:16]], 1)
+        assert torch.equal(gl(feats, rois5, labels[:16]), eager[16])
+        static_rois[:, 0] = 7.0                                  # (as a multi-image caller of the [n, 5] form would leave it)
+        assert torch.equal(m.simple_test_mask_logits(feats, boxes[:16], labels[:16]), eager[16]) and not static_rois[:, 0].any()
+        gl.replays -= 3
         assert torch.equal(m.simple_test_mask_logits(feats, boxes, labels), eager[128]) and gl.replays == 5      # eager
         # a parameter update (the fused SGD step bumps the epoch) invalidates the packed weights the graph holds
         with torch.no_grad():
