@@ -150,7 +150,13 @@ class DynaMaskRoIHead(nn.Module):
         self.mask_predictor = MaskPre()
         # inference: RoI chunks on separate HIP streams (see _mask_forward)
         self.num_streams = 2
-        self.stream_split_min = 64           # (100 detections to 112x112: 2.34 ms on one stream, 2.27 split over two; 32: no further gain)
+        # RoI chunks on two streams from this many RoIs on (profiles/r06_infer_experiments.txt (12), 1 / 2 / 3 streams).  Replayed
+        # as a HIP graph: 24 detections 0.734 / 0.764 / 0.767, 32: 0.885 / 0.871 / 0.907, 48: 1.175 / 1.157 / 1.140, 64: 1.459 /
+        # 1.365 / 1.411, 80: 1.646 / 1.604 / 1.647, 100: 2.024 / 1.881 / 1.916 ms.  Eager, the host issues the two chains' launches
+        # one after the other and a call cannot take less than that (~1.6-1.7 ms): 1 / 2 streams at 32 detections 0.88 / 1.69,
+        # 48: 1.17 / 1.71, 64: 1.45 / 1.61, 80: 1.63 / 1.61, 100: 2.01 / 1.89 ms.
+        self.stream_split_min = 80           # eager launches
+        self.stream_split_min_graph = 32     # under HIP-graph capture (graphs.py)
 
     def init_assigner_sampler(self):
         """standard_roi_head.py:13-20."""
@@ -204,7 +210,8 @@ class DynaMaskRoIHead(nn.Module):
         head, ext = self.mask_head, self.mask_roi_extractor
         dev = rois.device
         cur = torch.cuda.current_stream(dev)
-        n_streams = self.num_streams if n >= self.stream_split_min else 1
+        capturing = torch.cuda.is_current_stream_capturing()
+        n_streams = self.num_streams if n >= (self.stream_split_min_graph if capturing else self.stream_split_min) else 1
         head.prepack()                 # packs are cached by whoever asks first: before the fork, on this stream
         sems = head.semantic_maps(x, last_stage)
         if merge:

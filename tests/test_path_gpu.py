@@ -130,7 +130,7 @@ def test_fused_inference_launches_give_the_bits_of_the_unfused_sequence():
     #                                  channel ranges in another association than the grouped launch, which never splits
     with torch.no_grad():
         for split_min in (64, 2):                 # one chain / two chains on two streams
-            m.stream_split_min = split_min
+            m.stream_split_min = m.stream_split_min_graph = split_min
             for fused in (False, True):
                 mask_heads.FUSED_STAGE_HEAD[0] = fused
                 mask_heads.GROUPED_SEMANTIC_MAPS[0] = fused
@@ -142,7 +142,7 @@ def test_fused_inference_launches_give_the_bits_of_the_unfused_sequence():
             m.enable_inference_graphs(False)
         _ops.CONV_SPLITK[0] = split_was
         mask_heads.FUSED_STAGE_HEAD[0] = mask_heads.GROUPED_SEMANTIC_MAPS[0] = mask_heads.FUSED_DCN_TOUT[0] = roi_head.FUSED_MERGE_TAIL[0] = True
-        m.stream_split_min = 64
+        m.stream_split_min = m.stream_split_min_graph = 64
         with_split = m.simple_test_mask_logits(feats, boxes, labels).clone()
     ref = outs[(64, False)]
     assert tuple(ref.shape) == (boxes.shape[0], 1, 112, 112)

@@ -28,7 +28,10 @@ with torch.no_grad():
         ref = call().clone()
         e = sorted(bench.time_kernel_median(call, iters=9, warmup=2) for _ in range(reps))
         head.enable_inference_graphs(True)
-        same = bool(torch.equal(ref, call()))
+        got = call()
+        # (eager calls split their RoIs over two streams from 80 detections on, captured ones from 32: where the chunking differs the
+        # split-K choices of the launches differ, and with them the association of the channel sums -- rounding only)
+        same = 'True' if bool(torch.equal(ref, got)) else f'no (max |d| {float((ref - got).abs().max()):.1e}: other chunking, other split-K sums)'
         gr = sorted(bench.time_kernel_median(call, iters=15, warmup=3) for _ in range(reps))
         head.enable_inference_graphs(False)
         print(f'infer_{nd}dets  eager {e[len(e) // 2]:.4f} ms   graph {gr[len(gr) // 2]:.4f} ms   graph==eager {same}   '
