@@ -11,9 +11,11 @@
  *     What the library does keep, per device and only as a cache: the device's
  *     compute-unit count and "this kernel's dynamic-LDS limit has been raised"
  *     flags (hipFuncSetAttribute once per device).  A few knobs are read from
- *     the environment on first use, six in all, none of which changes what is
+ *     the environment on first use, seven in all, none of which changes what is
  *     computed: DM_CONV_TAIL / DM_DCN_TAIL (0: no separate launch for the last,
- *     underfull round of workgroups), DM_WGRAD_WGS (split-K workgroups of the
+ *     underfull round of workgroups), DM_CONV1_SMALL_WGS (up to how many 128 x 128
+ *     tiles a 1x1 launch takes 128 x 32 tiles instead; default 1.25 per CU, 0: never),
+ *     DM_WGRAD_WGS (split-K workgroups of the
  *     weight gradients), DM_ROI_SORT / DM_ROI_SORT_MIN (the RoI ordering launch of
  *     dm_roi_align_fwd_ws; re-read by dm_reload_env_knobs()), DM_CONV_SPLITK is the
  *     host binding's.  (Rounds 2-4 had twenty more -- first-generation kernels and
