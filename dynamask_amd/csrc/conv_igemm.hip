@@ -1004,7 +1004,7 @@ static int conv2d_launch(const float* const* srcs, const int* src_channels, cons
     // chunk's 32 MFMAs per wave queue behind the neighbour's.  Up to 1.25 tiles per CU the launch takes 128 couts x 32
     // pixels instead: four times the workgroups, 8 MFMAs per wave and chunk.  Same products in the same order (a
     // 32-channel chunk walks its quad pairs in the order two 16-channel chunks do), so rows do not depend on the launch
-    // size (tests/test_ops_gpu.py).  Measured (profiles/r06_infer_experiments.txt (5)): 100 / 64 / 32 / 16 detections
+    // size (tests/test_ops_gpu.py).  Measured (profiles/r06_infer_notes.txt (5)): 100 / 64 / 32 / 16 detections
     // 1.941 / 1.407 / 0.901 / 0.608 -> 1.879 / 1.360 / 0.884 / 0.584 ms; thresholds 100 / 160 / 320 / 640 / 1300 tiles:
     // 1.923 / 1.896 / 1.879-1.891 / 1.883 / 1.887 at 100 detections; 128 x 64 tiles for the next 320-1300 and 64 x 64 tiles
     // for the 64-cout build: inside the noise, not kept.  DM_CONV1_SMALL_WGS: the threshold in tiles (0: off), for A/B runs.

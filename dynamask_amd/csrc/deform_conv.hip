@@ -1134,7 +1134,7 @@ static int deform_conv_fwd_impl(const float* x, const float* offset, int NB, int
       // ... unless the caller brought a workspace: a workgroup's time is its number of chunks times a load round trip
       // (~3.5 us) whatever it computes per chunk, so the full layout (every cout of 128 pixels: one gather per sample, four
       // times the MFMAs per round trip) with the K loop split (dcn_choose_split's cost model, <= 24 RoIs) beats it:
-      // 16 / 24 detections 0.5845 / 0.733 -> 0.578 / 0.712 ms (profiles/r06_infer_experiments.txt (6))
+      // 16 / 24 detections 0.5845 / 0.733 -> 0.578 / 0.712 ms (profiles/r06_infer_notes.txt (6))
       if (few && a.ws && NB <= 24 && !tout) few = false;
       if (a.CoutP == 64) {
         if (few) return narrow ? launch_dcn_band<1, 2, 4>(a, st) : launch_dcn_band<1, 2, 7>(a, st);

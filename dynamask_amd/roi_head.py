@@ -150,7 +150,7 @@ class DynaMaskRoIHead(nn.Module):
         self.mask_predictor = MaskPre()
         # inference: RoI chunks on separate HIP streams (see _mask_forward)
         self.num_streams = 2
-        # RoI chunks on two streams from this many RoIs on (profiles/r06_infer_experiments.txt (12), 1 / 2 / 3 streams).  Replayed
+        # RoI chunks on two streams from this many RoIs on (profiles/r06_infer_notes.txt (12), 1 / 2 / 3 streams).  Replayed
         # as a HIP graph: 24 detections 0.734 / 0.764 / 0.767, 32: 0.885 / 0.871 / 0.907, 48: 1.175 / 1.157 / 1.140, 64: 1.459 /
         # 1.365 / 1.411, 80: 1.646 / 1.604 / 1.647, 100: 2.024 / 1.881 / 1.916 ms.  Eager, the host issues the two chains' launches
         # one after the other and a call cannot take less than that (~1.6-1.7 ms): 1 / 2 streams at 32 detections 0.88 / 1.69,
@@ -196,7 +196,7 @@ class DynaMaskRoIHead(nn.Module):
         """Inference.  The FPN-wide semantic maps (``relu(semantic_transform_in(P_l))``, which no RoI enters) are one
         grouped launch in front of everything else (on a stream of their own beside the chains they measured neutral at
         100 detections and +2 % at 16 and on the 512-RoI headline -- a fork inside a HIP graph costs more than the ~100 us
-        it hides; profiles/r06_infer_experiments.txt; removed); the RoIs are independent, so from ``stream_split_min`` RoIs on they
+        it hides; profiles/r06_infer_notes.txt; removed); the RoIs are independent, so from ``stream_split_min`` RoIs on they
         are split into chunks on separate HIP streams (the tail of every kernel -- its last, partially filled round of
         workgroups over the 256 CUs -- overlaps the other chunk's work) whose launches are issued in turn
         (``DynaMaskHead.steps``), every chunk writing its rows of the result tensors in place.
